@@ -1,0 +1,68 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Vectors:
+    """Accessor for tests/golden/consensus_vectors.json + consensus_pool.bin
+    (converted from the reference's tests/**/data.yaml by make_consensus_fixtures.py)."""
+
+    def __init__(self):
+        with open(os.path.join(GOLDEN, "consensus_vectors.json")) as fh:
+            self.index = json.load(fh)
+        with open(os.path.join(GOLDEN, "consensus_pool.bin"), "rb") as fh:
+            self.pool = fh.read()
+
+    def val(self, x):
+        """decode one fixture value; returns bytes / int / bool / None / list, or the
+        marker BadHex for odd-length hex strings (unrepresentable as bytes)."""
+        if isinstance(x, dict):
+            if "ref" in x:
+                off, ln = x["ref"]
+                return self.pool[off:off + ln]
+            if "hex" in x:
+                return bytes.fromhex(x["hex"])
+            if "badhex" in x:
+                return BadHex(x["badhex"])
+            if "str" in x:
+                return BadHex(x["str"])
+            return {k: self.val(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [self.val(v) for v in x]
+        return x
+
+    def cases(self, api):
+        return self.index[api]
+
+
+class BadHex:
+    def __init__(self, s):
+        self.s = s
+
+    def __len__(self):
+        return -1
+
+
+@pytest.fixture(scope="session")
+def vectors():
+    return Vectors()
+
+
+@pytest.fixture(scope="session")
+def oracle_ctx():
+    import oracle
+    ctx = oracle.OracleContext()
+    yield ctx
+    ctx.close()

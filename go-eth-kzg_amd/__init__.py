@@ -1,0 +1,142 @@
+"""go-eth-kzg_amd -- MI355X-native KZG engine: thin ctypes binding over libmi355kzg.so.
+
+This module is plumbing for tests and bench.py only: the product is the C-ABI shared library
+(include/mi355kzg.h) that a cgo `Context` wrapper binds.  The directory name
+contains a hyphen, so load it with `importlib` (see `tests/conftest.py::load_product`) or via
+`__graft_entry__.load_product()`.
+
+There is NO CPU fallback here and nothing from oracle/ is imported: if the HIP library is
+missing, or no GPU is present, construction fails loudly.
+
+`Context` mirrors go-eth-kzg's Context method set (reference api.go:17-28, prove.go, verify.go,
+api_eip7594.go); methods return (rc, outputs...) with rc numbered as include/mi355kzg.h.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi355kzg.so")
+DEFAULT_SETUP = os.path.join(HERE, "trusted_setup.json")
+
+BYTES_PER_BLOB = 131072
+BYTES_PER_CELL = 2048
+CELLS_PER_EXT_BLOB = 128
+
+OK = 0
+VERIFY_FAILED = 1
+ERR_NON_CANONICAL_SCALAR = 3
+ERR_NIL_INPUT = 6
+ERR_TOO_MANY_GOROUTINES = 14
+ERR_INVALID_POLY_SIZE = 15
+ERR_BAD_ARGS = 17
+ERR_HIP = 100
+
+EXPORTED_SYMBOLS = [
+    "mkzg_ctx_new", "mkzg_ctx_free", "mkzg_ctx_set_option",
+    "mkzg_blob_to_kzg_commitment", "mkzg_blob_to_kzg_commitment_batch", "mkzg_blob_to_kzg_commitment_batch_device",
+    "mkzg_commit_lagrange", "mkzg_profile_enable", "mkzg_profile_read", "mkzg_version",
+]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("total_ms", C.c_double), ("launches", C.c_long)]
+
+
+_lib = None
+
+
+def lib():
+    """dlopen libmi355kzg.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python go-eth-kzg_amd/build.py` (hipcc, gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+        L.mkzg_ctx_new.argtypes = [C.c_char_p, sz, C.POINTER(i32), i32, C.POINTER(vp)]
+        L.mkzg_ctx_free.argtypes = [vp]
+        L.mkzg_ctx_free.restype = None
+        L.mkzg_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+        L.mkzg_blob_to_kzg_commitment.argtypes = [vp, C.c_char_p, i32, C.c_char_p]
+        L.mkzg_blob_to_kzg_commitment_batch.argtypes = [vp, C.POINTER(C.c_char_p), sz, C.c_char_p, C.POINTER(i32)]
+        L.mkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.mkzg_commit_lagrange.argtypes = [vp, C.c_char_p, sz, i32, C.c_char_p]
+        L.mkzg_profile_enable.argtypes = [vp, i32]
+        L.mkzg_profile_read.argtypes = [vp, C.POINTER(KernelTime), i32, i32]
+        L.mkzg_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+class Context:
+    """Mirror of goethkzg.Context backed by one MI355X."""
+
+    def __init__(self, setup_path=DEFAULT_SETUP, device=None):
+        L = lib()
+        with open(setup_path, "rb") as fh:
+            js = fh.read()
+        h = C.c_void_p()
+        if device is None:
+            rc = L.mkzg_ctx_new(js, len(js), None, 0, C.byref(h))
+        else:
+            ids = (C.c_int * 1)(device)
+            rc = L.mkzg_ctx_new(js, len(js), ids, 1, C.byref(h))
+        if rc:
+            raise RuntimeError(f"mkzg_ctx_new failed rc={rc} (HIP device required; no CPU fallback)")
+        self._h, self._L = h, L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mkzg_ctx_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        return self._L.mkzg_ctx_set_option(self._h, key.encode(), int(value))
+
+    # ---- EIP-4844 -------------------------------------------------------------------------
+    def BlobToKZGCommitment(self, blob, num_goroutines=0):
+        """reference prove.go:13"""
+        if blob is None:
+            return self._L.mkzg_blob_to_kzg_commitment(self._h, None, num_goroutines, C.create_string_buffer(48)), None
+        if len(blob) != BYTES_PER_BLOB:
+            return ERR_BAD_ARGS, None
+        out = C.create_string_buffer(48)
+        rc = self._L.mkzg_blob_to_kzg_commitment(self._h, bytes(blob), num_goroutines, out)
+        return rc, (out.raw if rc == 0 else None)
+
+    def BlobToKZGCommitmentBatch(self, blobs):
+        n = len(blobs)
+        if any(len(b) != BYTES_PER_BLOB for b in blobs):
+            return ERR_BAD_ARGS, None, None
+        keep = [bytes(b) for b in blobs]
+        arr = (C.c_char_p * max(1, n))(*keep)
+        out = C.create_string_buffer(48 * max(1, n))
+        st = (C.c_int * max(1, n))()
+        rc = self._L.mkzg_blob_to_kzg_commitment_batch(self._h, arr, n, out, st)
+        return rc, [out.raw[48 * i:48 * i + 48] for i in range(n)], list(st)[:n]
+
+    def blob_to_kzg_commitment_batch_device(self, d_blobs_ptr, n, d_out_ptr, d_status_ptr, stream=0):
+        """raw device pointers (ints) + hipStream_t handle; asynchronous"""
+        return self._L.mkzg_blob_to_kzg_commitment_batch_device(self._h, d_blobs_ptr, n, d_out_ptr, d_status_ptr, stream)
+
+    def CommitLagrange(self, scalars32, num_goroutines=0):
+        """kzg.CommitKey.Commit (reference internal/kzg/srs.go:56) on raw big-endian scalars"""
+        n = len(scalars32) // 32
+        out = C.create_string_buffer(48)
+        rc = self._L.mkzg_commit_lagrange(self._h, bytes(scalars32), n, num_goroutines, out)
+        return rc, (out.raw if rc == 0 else None)
+
+    # ---- profiling --------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        return self._L.mkzg_profile_enable(self._h, int(on))
+
+    def profile_read(self, reset=True):
+        recs = (KernelTime * 32)()
+        n = self._L.mkzg_profile_read(self._h, recs, 32, int(reset))
+        return {recs[i].name.decode(): (recs[i].total_ms, recs[i].launches) for i in range(n)}

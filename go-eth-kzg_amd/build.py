@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Build libmi355kzg.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box with the
+repository snapshot (it is git-ignored but not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmi355kzg.so")
+SOURCES = ["api.hip", "msm_kernels.hip"]
+HEADERS = ["mont29.hpp", "g1.hpp", "constants29.h", "msm_kernels.h", os.path.join("..", "..", "include", "mi355kzg.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    m = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > m for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(os.path.join(CSRC, "constants29.h")):
+        subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_constants.py")])
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            for cmd, rc in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=not verbose, text=True), jobs)):
+                if rc.returncode != 0:
+                    raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), (rc.stderr or "")[-4000:]))
+    if force or jobs or _stale(OUT, objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,320 @@
+// api.hip -- the C ABI of libmi355kzg.so (include/mi355kzg.h): context construction and the
+// host-side mirror of go-eth-kzg's Context methods for the hot path.  Host logic only: every
+// field/group operation happens in HIP kernels (msm_kernels.hip); there is no CPU fallback.
+//
+// Reference being mirrored (paths relative to crate-crypto/go-eth-kzg):
+//   NewContext4096            api.go:90-149   (+ trusted_setup.go:90-192 JSON / point decoding)
+//   Context.BlobToKZGCommitment  prove.go:13-33
+//   kzg.CommitKey.Commit      internal/kzg/srs.go:56-62
+//   multiexp.MultiExpG1       internal/multiexp/multiexp.go:20-50
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/mi355kzg.h"
+#include "msm_kernels.h"
+
+using namespace kzg;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            fprintf(stderr, "[mi355kzg] HIP error %s at %s:%d: %s\n", hipGetErrorName(e__), __FILE__, __LINE__, #expr); \
+            return MKZG_ERR_HIP;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+struct mkzg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;          // internal stream for host-pointer entry points
+    std::recursive_mutex mu;
+    // SRS
+    std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes
+    uint32_t* d_lagrange_aff = nullptr;    // 4096 affine rows, natural order of the JSON
+    // commit MSM
+    CommitPlan plan;
+    int opt_c = 13;
+    int opt_max_batch = 256;
+    bool plan_ready = false;
+    // staging
+    uint8_t* h_stage = nullptr;            // pinned
+    size_t h_stage_bytes = 0;
+    uint8_t* d_blobs = nullptr;
+    size_t d_blobs_bytes = 0;
+    uint8_t* d_out = nullptr;
+    int* d_status = nullptr;
+    size_t d_out_items = 0;
+    // profiling
+    bool profiling = false;
+    KernelTimer timer;
+};
+
+// ---------------------------------------------------------------------------------------------
+// trusted-setup JSON (reference trusted_setup.go:23-27): {"g1_monomial":[...], "g1_lagrange":[...],
+// "g2_monomial":[...]} with 0x-prefixed hex strings.  Minimal scanner, no allocation surprises.
+// ---------------------------------------------------------------------------------------------
+static int hexval(char c) {
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+}
+static bool parse_hex_array(const char* js, size_t len, const char* key, size_t item_bytes, std::vector<uint8_t>& out) {
+    std::string k = std::string("\"") + key + "\"";
+    const char* end = js + len;
+    const char* p = std::search(js, end, k.begin(), k.end());
+    if (p == end) return false;
+    p += k.size();
+    while (p < end && *p != '[') p++;
+    if (p == end) return false;
+    p++;
+    out.clear();
+    while (p < end) {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t' || *p == ',')) p++;
+        if (p == end) return false;
+        if (*p == ']') return true;
+        if (*p != '"') return false;
+        p++;
+        if (end - p < 2 || p[0] != '0' || (p[1] != 'x' && p[1] != 'X')) return false;   // trim0xPrefix panics otherwise
+        p += 2;
+        size_t n = 0;
+        while (p + 1 < end && *p != '"') {
+            int h = hexval(p[0]), l = hexval(p[1]);
+            if (h < 0 || l < 0) return false;
+            out.push_back((uint8_t)(h * 16 + l));
+            p += 2;
+            n++;
+        }
+        if (p >= end || *p != '"' || n != item_bytes) return false;
+        p++;
+    }
+    return false;
+}
+
+static int ensure_plan(mkzg_ctx* c) {
+    if (c->plan_ready) return MKZG_OK;
+    CommitPlanSizes sz;
+    commit_plan_sizes(c->opt_c, c->opt_max_batch, &sz);
+    c->plan.c = c->opt_c;
+    c->plan.max_batch = c->opt_max_batch;
+    HIPCHK(hipMalloc(&c->plan.d_table, sz.table_bytes));
+    HIPCHK(hipMalloc(&c->plan.d_entries, sz.entries_bytes));
+    HIPCHK(hipMalloc(&c->plan.d_offsets, sz.offsets_bytes));
+    HIPCHK(hipMalloc(&c->plan.d_buckets, sz.buckets_bytes));
+    HIPCHK(hipMalloc(&c->plan.d_partials, sz.partials_bytes));
+    // api.go:131: the commit key is the bit-reversed Lagrange SRS
+    build_table_device(c->plan.c, c->d_lagrange_aff, c->plan.d_table, 4096, 12, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->plan_ready = true;
+    return MKZG_OK;
+}
+static void free_plan(mkzg_ctx* c) {
+    if (c->plan.d_table) (void)hipFree(c->plan.d_table);
+    if (c->plan.d_entries) (void)hipFree(c->plan.d_entries);
+    if (c->plan.d_offsets) (void)hipFree(c->plan.d_offsets);
+    if (c->plan.d_buckets) (void)hipFree(c->plan.d_buckets);
+    if (c->plan.d_partials) (void)hipFree(c->plan.d_partials);
+    c->plan = CommitPlan();
+    c->plan_ready = false;
+}
+
+extern "C" {
+
+const char* mkzg_version(void) { return "mi355kzg 0.1 (gfx950)"; }
+
+void mkzg_ctx_free(mkzg_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_plan(c);
+    if (c->d_lagrange_aff) (void)hipFree(c->d_lagrange_aff);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->d_blobs) (void)hipFree(c->d_blobs);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, mkzg_ctx** out) {
+    if (!js || !out) return MKZG_ERR_BAD_ARGS;
+    *out = nullptr;
+    int ndev_present = 0;
+    if (hipGetDeviceCount(&ndev_present) != hipSuccess || ndev_present <= 0) {
+        fprintf(stderr, "[mi355kzg] no HIP device: this library has no CPU fallback\n");
+        return MKZG_ERR_HIP;
+    }
+    mkzg_ctx* c = new mkzg_ctx();
+    if (n_dev > 0 && device_ids) c->device = device_ids[0];
+    else (void)hipGetDevice(&c->device);
+    // reference api.go:93-95 (ErrMinSRSSize) and the fixed-size arrays of trusted_setup.go:23-27
+    if (!parse_hex_array(js, len, "g1_monomial", 48, c->g1_monomial) || !parse_hex_array(js, len, "g1_lagrange", 48, c->g1_lagrange) ||
+        !parse_hex_array(js, len, "g2_monomial", 96, c->g2_monomial) || c->g1_monomial.size() != 4096 * 48 || c->g1_lagrange.size() != 4096 * 48 ||
+        c->g2_monomial.size() < 2 * 96) {
+        delete c;
+        return MKZG_ERR_BAD_TRUSTED_SETUP;
+    }
+    int rc = [&]() -> int {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // decode the Lagrange SRS on the device (no subgroup check: trusted_setup.go:104-117)
+        uint8_t* d_raw = nullptr;
+        int* d_st = nullptr;
+        HIPCHK(hipMalloc(&d_raw, 4096 * 48));
+        HIPCHK(hipMalloc(&d_st, 4096 * sizeof(int)));
+        HIPCHK(hipMalloc(&c->d_lagrange_aff, 4096 * 128));
+        HIPCHK(hipMemcpyAsync(d_raw, c->g1_lagrange.data(), 4096 * 48, hipMemcpyHostToDevice, c->stream));
+        g1_decompress_device(d_raw, 4096, c->d_lagrange_aff, d_st, c->stream);
+        HIPCHK(hipGetLastError());
+        std::vector<int> st(4096);
+        HIPCHK(hipMemcpyAsync(st.data(), d_st, 4096 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(d_raw);
+        (void)hipFree(d_st);
+        for (int v : st) if (v) return MKZG_ERR_BAD_TRUSTED_SETUP;   // reference panics (trusted_setup.go:152-156)
+        return MKZG_OK;
+    }();
+    if (rc) { mkzg_ctx_free(c); return rc; }
+    *out = c;
+    return MKZG_OK;
+}
+
+int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
+    if (!c || !key) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    if (!strcmp(key, "msm_window")) {
+        if (value < 11 || value > 13) return MKZG_ERR_BAD_ARGS;
+        if (c->opt_c != (int)value) { c->opt_c = (int)value; free_plan(c); }
+        return MKZG_OK;
+    }
+    if (!strcmp(key, "max_batch")) {
+        if (value < 1 || value > 4096) return MKZG_ERR_BAD_ARGS;
+        if (c->opt_max_batch != (int)value) { c->opt_max_batch = (int)value; free_plan(c); }
+        return MKZG_OK;
+    }
+    return MKZG_ERR_BAD_ARGS;
+}
+
+// device-resident batch: the product's hot path
+int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, size_t n, void* d_out48n, int* d_status, void* stream) {
+    if (!c || (!d_blobs && n) || (!d_out48n && n) || (!d_status && n)) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_plan(c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    size_t done = 0;
+    while (done < n) {
+        int chunk = (int)std::min<size_t>(n - done, (size_t)c->plan.max_batch);
+        commit_batch_device(c->plan, (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB, MKZG_BYTES_PER_BLOB, 0, chunk, (uint8_t*)d_out48n + done * 48,
+                            d_status + done, s, c->profiling ? &c->timer : nullptr);
+        done += chunk;
+    }
+    HIPCHK(hipGetLastError());
+    return MKZG_OK;
+}
+
+static int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item) {
+    size_t need = n_items * in_bytes_per_item;
+    if (c->h_stage_bytes < need) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr; c->h_stage_bytes = 0;
+        HIPCHK(hipHostMalloc(&c->h_stage, need, hipHostMallocDefault));
+        c->h_stage_bytes = need;
+    }
+    if (c->d_blobs_bytes < need) {
+        if (c->d_blobs) (void)hipFree(c->d_blobs);
+        c->d_blobs = nullptr; c->d_blobs_bytes = 0;
+        HIPCHK(hipMalloc(&c->d_blobs, need));
+        c->d_blobs_bytes = need;
+    }
+    if (c->d_out_items < n_items) {
+        if (c->d_out) (void)hipFree(c->d_out);
+        if (c->d_status) (void)hipFree(c->d_status);
+        c->d_out = nullptr; c->d_status = nullptr; c->d_out_items = 0;
+        HIPCHK(hipMalloc(&c->d_out, n_items * 48));
+        HIPCHK(hipMalloc(&c->d_status, n_items * sizeof(int)));
+        c->d_out_items = n_items;
+    }
+    return MKZG_OK;
+}
+
+int mkzg_blob_to_kzg_commitment_batch(mkzg_ctx* c, const uint8_t* const* blobs, size_t n, uint8_t* out48n, int* per_item_status) {
+    if (!c || (n && (!blobs || !out48n))) return MKZG_ERR_BAD_ARGS;
+    if (n == 0) return MKZG_OK;
+    for (size_t i = 0; i < n; i++) if (!blobs[i]) return MKZG_ERR_NIL_INPUT;      // serialization.go:135-137
+    int first = MKZG_OK;
+    size_t done = 0;
+    while (done < n) {
+        std::lock_guard<std::recursive_mutex> g(c->mu);
+        HIPCHK(hipSetDevice(c->device));
+        size_t chunk = std::min<size_t>(n - done, (size_t)c->opt_max_batch);
+        int rc = ensure_staging(c, chunk, MKZG_BYTES_PER_BLOB);
+        if (rc) return rc;
+        for (size_t i = 0; i < chunk; i++) memcpy(c->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[done + i], MKZG_BYTES_PER_BLOB);
+        HIPCHK(hipMemcpyAsync(c->d_blobs, c->h_stage, chunk * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, c->stream));
+        rc = mkzg_blob_to_kzg_commitment_batch_device(c, c->d_blobs, chunk, c->d_out, c->d_status, c->stream);
+        if (rc) return rc;
+        std::vector<int> st(chunk);
+        HIPCHK(hipMemcpyAsync(out48n + done * 48, c->d_out, chunk * 48, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(st.data(), c->d_status, chunk * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < chunk; i++) {
+            if (per_item_status) per_item_status[done + i] = st[i];
+            if (st[i] && !first) first = st[i];
+        }
+        done += chunk;
+    }
+    return first;
+}
+
+int mkzg_blob_to_kzg_commitment(mkzg_ctx* c, const uint8_t* blob, int num_threads, uint8_t out48[48]) {
+    if (!c || !out48) return MKZG_ERR_BAD_ARGS;
+    if (!blob) return MKZG_ERR_NIL_INPUT;
+    const uint8_t* one[1] = {blob};
+    int st = 0;
+    int rc = mkzg_blob_to_kzg_commitment_batch(c, one, 1, out48, &st);
+    if (rc) return rc;
+    if (num_threads >= 1024) return MKZG_ERR_TOO_MANY_GOROUTINES;                  // multiexp.go:45-50
+    return MKZG_OK;
+}
+
+int mkzg_commit_lagrange(mkzg_ctx* c, const uint8_t* scalars32, size_t n, int num_threads, uint8_t out48[48]) {
+    if (!c || !out48 || (!scalars32 && n)) return MKZG_ERR_BAD_ARGS;
+    if (n == 0 || n > 4096) return MKZG_ERR_INVALID_POLY_SIZE;                     // srs.go:57-59
+    if (num_threads >= 1024) return MKZG_ERR_TOO_MANY_GOROUTINES;
+    std::vector<uint8_t> padded(MKZG_BYTES_PER_BLOB, 0);                             // zero scalars contribute nothing
+    memcpy(padded.data(), scalars32, n * 32);
+    const uint8_t* one[1] = {padded.data()};
+    int st = 0;
+    return mkzg_blob_to_kzg_commitment_batch(c, one, 1, out48, &st);
+}
+
+int mkzg_profile_enable(mkzg_ctx* c, int on) {
+    if (!c) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    c->profiling = on != 0;
+    return MKZG_OK;
+}
+int mkzg_profile_read(mkzg_ctx* c, mkzg_kernel_time* out, int cap, int reset) {
+    if (!c) return 0;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    c->timer.collect();
+    for (int i = 0; i < KT_COUNT && i < cap; i++) {
+        out[i].name = kKernelNames[i];
+        out[i].total_ms = c->timer.total_ms[i];
+        out[i].launches = c->timer.launches[i];
+    }
+    if (reset) c->timer.reset();
+    return KT_COUNT;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// msm_kernels.h -- host-visible launch interface of msm_kernels.hip (internal to libmi355kzg.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+#include "../../include/mi355kzg.h"
+
+namespace kzg {
+
+enum KernelKind { KT_DIGITS_SORT = 0, KT_BUCKET_ACC, KT_REDUCE1, KT_REDUCE2, KT_COUNT };
+static const char* const kKernelNames[KT_COUNT] = {"k_digits_sort", "k_bucket_accumulate", "k_bucket_reduce1", "k_bucket_reduce2"};
+
+// hipEvent bracket around each kernel launch, on the stream the kernel is launched on.
+struct KernelTimer {
+    struct Rec { hipEvent_t e0, e1; int kind; };
+    std::vector<Rec> pending;
+    double total_ms[KT_COUNT] = {0};
+    long launches[KT_COUNT] = {0};
+    hipEvent_t cur0 = nullptr;
+    void begin(int kind, hipStream_t s) {
+        (void)kind;
+        (void)hipEventCreate(&cur0);
+        (void)hipEventRecord(cur0, s);
+    }
+    void end(int kind, hipStream_t s) {
+        hipEvent_t e1;
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e1, s);
+        pending.push_back({cur0, e1, kind});
+        cur0 = nullptr;
+    }
+    void collect() {   // caller has synchronised the stream(s)
+        for (auto& r : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { total_ms[r.kind] += ms; launches[r.kind]++; }
+            (void)hipEventDestroy(r.e0);
+            (void)hipEventDestroy(r.e1);
+        }
+        pending.clear();
+    }
+    void reset() {
+        for (int i = 0; i < KT_COUNT; i++) { total_ms[i] = 0; launches[i] = 0; }
+    }
+};
+
+struct CommitPlanSizes { int nwin, nbucket; size_t table_bytes, entries_bytes, offsets_bytes, buckets_bytes, partials_bytes; };
+struct CommitPlan {
+    int c = 13;                 // window bits
+    int max_batch = 0;
+    uint32_t* d_table = nullptr;    // [nwin][4096] affine rows
+    uint32_t* d_entries = nullptr;
+    uint32_t* d_offsets = nullptr;
+    uint32_t* d_buckets = nullptr;
+    uint32_t* d_partials = nullptr;
+};
+
+void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz);
+// scalars: input_kind 0 = 32-byte big-endian scalars, 4096 per item, items `stride` bytes apart
+void commit_batch_device(const CommitPlan& pl, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt);
+void g1_decompress_device(const uint8_t* d_in48, int n, uint32_t* d_out_aff, int* d_status, hipStream_t s);
+void build_table_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s);
+
+}  // namespace kzg

@@ -1,0 +1,475 @@
+// msm_kernels.hip -- fixed-base multi-scalar multiplication over BLS12-381 G1 for MI355X (gfx950).
+//
+// Hot path of BlobToKZGCommitment (reference prove.go:13-33 -> internal/kzg/srs.go:56-62 ->
+// internal/multiexp/multiexp.go:20-26 -> gnark G1Affine.MultiExp): for every blob b of a batch,
+//     C_b = sum_i  s_{b,i} * L_i          (4096 scalars, the bit-reversed Lagrange SRS L)
+//
+// MI355X-first design (not gnark's per-window goroutine Pippenger):
+//   * the base is FIXED for the life of the Context, so the table T[j][i] = 2^(c j) L_i is
+//     precomputed once (k_build_table) and all NWIN windows of a scalar fall into ONE set of
+//     2^(c-1) signed-digit buckets: no per-window doublings, one bucket reduction per blob;
+//   * k_digits_sort: one workgroup per blob streams the 128 KiB of big-endian scalars with
+//     16-byte coalesced loads (this IS the HBM read of the path), checks canonicity, recodes
+//     signed c-bit digits and counting-sorts the (point, window) pairs by bucket in LDS
+//     (ds_add histograms), so that no atomics on 224-byte group elements are ever needed;
+//   * k_bucket_accumulate: one lane per (blob, bucket) walks its sorted run and performs mixed
+//     XYZZ additions against table rows (128-byte rows, L2 / Infinity-Cache resident);
+//   * k_bucket_reduce1 / k_bucket_reduce2: work-efficient weighted sum  sum_k (k+1) B_k  by
+//     lane-serial running sums over 16-bucket chunks, then a wavefront-level (64-lane DPP/
+//     bpermute) scan + tree per blob, one field inversion and the 48-byte compressed output.
+// Integer modular arithmetic only -- no MFMA.  Field representation: mont29.hpp.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "g1.hpp"
+#include "msm_kernels.h"
+
+namespace kzg {
+
+// ------------------------------------------------------------------------------------------
+// record layouts in HBM
+//   affine point : 32 words  = x[14] y[14] inf pad[3]            (128 B, one cache line)
+//   XYZZ point   : 64 words  = x[14] y[14] zz[14] zzz[14] pad[8] (256 B)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_affine(G1Aff& p, const uint32_t* rec) {
+    const uint4* q = reinterpret_cast<const uint4*>(rec);
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) { p.x.l[i] = w[i]; p.y.l[i] = w[14 + i]; }
+    p.inf = w[28];
+}
+__device__ __forceinline__ void store_affine(uint32_t* rec, const G1Aff& p) {
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 14; i++) { w[i] = p.x.l[i]; w[14 + i] = p.y.l[i]; }
+    w[28] = p.inf; w[29] = 0; w[30] = 0; w[31] = 0;
+    uint4* q = reinterpret_cast<uint4*>(rec);
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ void load_xyzz(G1X& p, const uint32_t* rec) {
+    const uint4* q = reinterpret_cast<const uint4*>(rec);
+    uint32_t w[56];
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) { p.x.l[i] = w[i]; p.y.l[i] = w[14 + i]; p.zz.l[i] = w[28 + i]; p.zzz.l[i] = w[42 + i]; }
+}
+__device__ __forceinline__ void store_xyzz(uint32_t* rec, const G1X& p) {
+    uint32_t w[56];
+#pragma unroll
+    for (int i = 0; i < 14; i++) { w[i] = p.x.l[i]; w[14 + i] = p.y.l[i]; w[28 + i] = p.zz.l[i]; w[42 + i] = p.zzz.l[i]; }
+    uint4* q = reinterpret_cast<uint4*>(rec);
+#pragma unroll
+    for (int i = 0; i < 14; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// out-of-line group operations for the low-arithmetic-intensity kernels (keeps code size sane)
+__device__ __noinline__ void g1x_add_ni(G1X& r, const G1X& a, const G1X& b) { g1x_add(r, a, b); }
+__device__ __noinline__ void g1x_dbl_ni(G1X& r, const G1X& a) { g1x_dbl(r, a); }
+
+// ------------------------------------------------------------------------------------------
+// scalar decoding + signed-digit recoding
+// ------------------------------------------------------------------------------------------
+// 32 big-endian bytes at p (16-byte aligned) -> 8 little-endian words
+__device__ __forceinline__ void load_scalar_be(uint32_t w[8], const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 hi = q[0], lo = q[1];
+    w[7] = __builtin_bswap32(hi.x); w[6] = __builtin_bswap32(hi.y); w[5] = __builtin_bswap32(hi.z); w[4] = __builtin_bswap32(hi.w);
+    w[3] = __builtin_bswap32(lo.x); w[2] = __builtin_bswap32(lo.y); w[1] = __builtin_bswap32(lo.z); w[0] = __builtin_bswap32(lo.w);
+}
+// canonical check of reference serialization.go:141 / internal/utils/utils.go:45-50: value < r
+__device__ __forceinline__ bool scalar_is_canonical(const uint32_t w[8]) { return !Fr::words32_geq_mod(w); }
+
+template <int C>
+struct Recode {
+    static constexpr int NWIN = (255 + C - 1) / C;
+    static constexpr int NBUCKET = 1 << (C - 1);
+    // digit j of the signed recoding of w (value < 2^255): d in [-2^(C-1), 2^(C-1)], sum d_j 2^(C j) = w
+    template <class F>
+    static __device__ __forceinline__ void for_each_digit(const uint32_t w[8], F&& f) {
+        int carry = 0;
+#pragma unroll
+        for (int j = 0; j < NWIN; j++) {
+            const int bit = C * j, wi = bit >> 5, off = bit & 31;
+            uint32_t v = w[wi] >> off;
+            if (off + C > 32 && wi + 1 < 8) v |= w[wi + 1] << (32 - off);
+            int d = (int)(v & ((1u << C) - 1)) + carry;
+            carry = 0;
+            if (d > NBUCKET) { d -= (1 << C); carry = 1; }
+            f(j, d);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// kernel A: decode scalars, recode digits, counting sort by bucket.  One 1024-thread workgroup
+// per blob (4096 scalars -> 4 per thread).
+//   entries[b][slot] = table index (j*4096 + i) | sign << 31, grouped by bucket
+//   offsets[b][k]    = first slot of bucket k (k = |digit| - 1), offsets[b][NBUCKET] = total
+//   status[b]        = 0 or MKZG_ERR_NON_CANONICAL_SCALAR
+// INPUT_KIND 0: 32-byte big-endian scalars (blob bytes).  1: Fr elements in Montgomery radix-2^29
+// form (9 words each, as produced by the on-device quotient kernel).
+// ------------------------------------------------------------------------------------------
+template <int C, int INPUT_KIND>
+__global__ void __launch_bounds__(1024) k_digits_sort(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, uint32_t* __restrict__ entries,
+                                                      uint32_t* __restrict__ offsets, int* __restrict__ status) {
+    using RC = Recode<C>;
+    constexpr int NB = RC::NBUCKET;
+    constexpr int PER_THREAD = NB / 1024 > 0 ? NB / 1024 : 1;
+    __shared__ uint32_t hist[NB];
+    __shared__ uint32_t wave_tot[16];
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int k = t; k < NB; k += 1024) hist[k] = 0;
+    __syncthreads();
+
+    uint32_t sc[4][8];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = t + 1024 * k;
+        if (INPUT_KIND == 0) {
+            load_scalar_be(sc[k], scalars + (size_t)b * scalar_stride_bytes + (size_t)i * 32);
+            bad |= !scalar_is_canonical(sc[k]);
+        } else {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(scalars + (size_t)b * scalar_stride_bytes) + (size_t)i * 9;
+            fr_t m, pl;
+#pragma unroll
+            for (int q = 0; q < 9; q++) m.l[q] = src[q];
+            Fr::to_plain(pl, m);
+            Fr::to_words32(sc[k], pl);
+        }
+    }
+    if (__syncthreads_or(bad)) {
+        if (t == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
+        // leave a well-formed (empty) bucket layout behind so the later kernels are harmless
+        for (int k = t; k <= NB; k += 1024) offsets[(size_t)b * (NB + 1) + k] = 0;
+        return;
+    }
+    if (t == 0) status[b] = 0;
+
+    // pass 1: histogram
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        RC::for_each_digit(sc[k], [&](int, int d) {
+            if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+        });
+    }
+    __syncthreads();
+
+    // exclusive scan of hist[NB] (thread t owns PER_THREAD consecutive counters when NB >= 1024)
+    uint32_t local[PER_THREAD];
+    uint32_t sum = 0;
+    if (t * PER_THREAD < NB) {
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; q++) { local[q] = hist[t * PER_THREAD + q]; sum += local[q]; }
+    }
+    uint32_t incl = sum;
+    const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wave_tot[w];
+    uint32_t excl = base + incl - sum;
+    __syncthreads();   // everyone has read hist; now overwrite it with the running cursors
+    if (t * PER_THREAD < NB) {
+        uint32_t run = excl;
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; q++) {
+            hist[t * PER_THREAD + q] = run;
+            offsets[(size_t)b * (NB + 1) + t * PER_THREAD + q] = run;
+            run += local[q];
+        }
+        if (t * PER_THREAD + PER_THREAD == NB) offsets[(size_t)b * (NB + 1) + NB] = run;
+    }
+    __syncthreads();
+
+    // pass 2: scatter
+    uint32_t* ent = entries + (size_t)b * (4096 * RC::NWIN);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = t + 1024 * k;
+        RC::for_each_digit(sc[k], [&](int j, int d) {
+            if (d != 0) {
+                uint32_t slot = atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+                ent[slot] = (uint32_t)(j * 4096 + i) | (d < 0 ? 0x80000000u : 0u);
+            }
+        });
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel B: one lane per (blob, bucket): mixed additions of table rows into an XYZZ accumulator.
+// ------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) k_bucket_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries,
+                                                           const uint32_t* __restrict__ offsets, uint32_t* __restrict__ buckets) {
+    using RC = Recode<C>;
+    constexpr int NB = RC::NBUCKET;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t b = gid / NB;
+    const int k = (int)(gid % NB);
+    const uint32_t* off = offsets + b * (NB + 1);
+    const uint32_t start = off[k], end = off[k + 1];
+    const uint32_t* ent = entries + b * (size_t)(4096 * RC::NWIN);
+    G1X acc;
+    g1x_set_inf(acc);
+    for (uint32_t e = start; e < end; e++) {
+        const uint32_t v = ent[e];
+        G1Aff p;
+        load_affine(p, table + (size_t)(v & 0x7fffffffu) * 32);
+        if (p.inf) continue;
+        if (v >> 31) Fp::template neg<0>(p.y, p.y);     // p - y  (table rows are canonical)
+        g1x_madd(acc, p.x, p.y);
+    }
+    store_xyzz(buckets + gid * 64, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel R1: lane-serial running sums over chunks of 16 buckets:
+//   S_t = sum_{k in chunk} B_k ,   T_t = sum_{k in chunk} (k - 16 t + 1) B_k
+// partials[b][t] = (S_t, T_t)
+// ------------------------------------------------------------------------------------------
+constexpr int CHUNK = 16;
+template <int C>
+__global__ void __launch_bounds__(64) k_bucket_reduce1(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ partials, int n_chunks_total) {
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= n_chunks_total) return;
+    const uint32_t* src = buckets + (size_t)gid * CHUNK * 64;
+    G1X run, sum, bk;
+    g1x_set_inf(run);
+    g1x_set_inf(sum);
+    for (int q = CHUNK - 1; q >= 0; q--) {
+        load_xyzz(bk, src + q * 64);
+        g1x_add_ni(run, run, bk);
+        g1x_add_ni(sum, sum, run);
+    }
+    store_xyzz(partials + (size_t)gid * 128, run);
+    store_xyzz(partials + (size_t)gid * 128 + 64, sum);
+}
+
+// wave-wide helpers on whole XYZZ points (56 words through ds_bpermute)
+__device__ __forceinline__ void shfl_down_xyzz(G1X& r, const G1X& a, int d) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.x.l[i] = __shfl_down(a.x.l[i], d);
+        r.y.l[i] = __shfl_down(a.y.l[i], d);
+        r.zz.l[i] = __shfl_down(a.zz.l[i], d);
+        r.zzz.l[i] = __shfl_down(a.zzz.l[i], d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel R2: one wavefront per blob finishes  sum_k (k+1) B_k = sum_t T_t + 16 sum_t t S_t,
+// converts to affine and writes the 48-byte compressed commitment.
+// Lane j owns chunks t = M j .. M j + M - 1 (M = chunks per blob / 64).
+// ------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(64) k_bucket_reduce2(const uint32_t* __restrict__ partials, const int* __restrict__ status, uint8_t* __restrict__ out48) {
+    using RC = Recode<C>;
+    constexpr int NCHUNK = RC::NBUCKET / CHUNK;
+    constexpr int M = NCHUNK / 64;
+    static_assert(M >= 1 && (M & (M - 1)) == 0, "bucket count must give a power-of-two number of chunks per lane");
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (status[b] != 0) return;
+    const uint32_t* src = partials + ((size_t)b * NCHUNK + (size_t)lane * M) * 128;
+    // per lane: U = sum_i T_i ; SS = sum_i S_i ; Wt = sum_i i S_i   (i = 0..M-1)
+    G1X U, run, wsum, t;
+    g1x_set_inf(U);
+    g1x_set_inf(run);
+    g1x_set_inf(wsum);
+    for (int i = M - 1; i >= 0; i--) {
+        load_xyzz(t, src + i * 128 + 64);
+        g1x_add_ni(U, U, t);
+        load_xyzz(t, src + i * 128);
+        g1x_add_ni(run, run, t);
+        if (i > 0) g1x_add_ni(wsum, wsum, run);
+    }
+    // X = U + 16 * Wt
+    for (int q = 0; q < 4; q++) g1x_dbl_ni(wsum, wsum);
+    G1X X;
+    g1x_add_ni(X, U, wsum);
+    // suffix scan of SS over lanes, then sum over lanes 1..63  ->  sum_j j SS_j
+    G1X P = run, o;
+    for (int d = 1; d < 64; d <<= 1) {
+        shfl_down_xyzz(o, P, d);
+        if (lane + d < 64) g1x_add_ni(P, P, o);
+    }
+    if (lane == 0) g1x_set_inf(P);
+    for (int d = 32; d >= 1; d >>= 1) {
+        shfl_down_xyzz(o, P, d);
+        if (lane < d) g1x_add_ni(P, P, o);
+        shfl_down_xyzz(o, X, d);
+        if (lane < d) g1x_add_ni(X, X, o);
+    }
+    if (lane == 0) {
+        // total = X + (16 M) * P
+        int sh = 4;
+        for (int m = M; m > 1; m >>= 1) sh++;
+        for (int q = 0; q < sh; q++) g1x_dbl_ni(P, P);
+        g1x_add_ni(X, X, P);
+        G1Aff a;
+        g1x_to_affine(a, X);
+        uint32_t w[12];
+        g1_compress_words(w, a);
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(out48 + (size_t)b * 48);
+#pragma unroll
+        for (int i = 0; i < 12; i++) o32[i] = __builtin_bswap32(w[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// set-up kernels
+// ------------------------------------------------------------------------------------------
+// zcash-compressed G1 -> affine record.  Checks of gnark's SetBytes (reference
+// serialization.go:108-115): flag bits, x < p, on curve; the r-torsion check is a separate
+// kernel (k_subgroup_check) because trusted-setup points are decoded without it
+// (reference trusted_setup.go:104-117).
+__global__ void __launch_bounds__(64) k_g1_decompress(const uint8_t* __restrict__ in48, int n, uint32_t* __restrict__ out_aff, int* __restrict__ st) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(in48 + (size_t)i * 48);
+    uint32_t w[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) w[11 - q] = __builtin_bswap32(p[q]);
+    const uint32_t flags = w[11] >> 29;
+    G1Aff a;
+    Fp::set_zero(a.x);
+    Fp::set_zero(a.y);
+    a.inf = 1;
+    int rc = 0;
+    if (!(flags & 4) || flags == 7) {
+        rc = MKZG_ERR_G1_BAD_ENCODING;
+    } else if (flags & 2) {
+        uint32_t any = w[11] & 0x1fffffffu;
+#pragma unroll
+        for (int q = 0; q < 11; q++) any |= w[q];
+        if (any) rc = MKZG_ERR_G1_BAD_ENCODING;
+    } else {
+        w[11] &= 0x1fffffffu;
+        if (Fp::words32_geq_mod(w)) {
+            rc = MKZG_ERR_G1_BAD_ENCODING;
+        } else {
+            fp_t xp, x, rhs, y, four, chk;
+            Fp::from_words32(xp, w);
+            Fp::from_plain(x, xp);
+            Fp::sqr(rhs, x);
+            Fp::mul(rhs, rhs, x);
+            Fp::set(four, FP_FOUR);
+            Fp::add(rhs, rhs, four);
+            Fp::pow_words(y, rhs, FpParams::EXP_SQRT, FpParams::BITS);
+            Fp::sqr(chk, y);
+            if (!Fp::eq_mod(chk, rhs)) {
+                rc = MKZG_ERR_G1_NOT_ON_CURVE;
+            } else {
+                fp_t yc, ypl;
+                uint32_t yw[12];
+                Fp::canon(yc, y);
+                Fp::to_plain(ypl, yc);
+                Fp::to_words32(yw, ypl);
+                bool gt = false, lt = false;
+#pragma unroll
+                for (int j = 11; j >= 0; j--) {
+                    if (!gt && !lt) {
+                        if (yw[j] > FpParams::HALF[j]) gt = true;
+                        else if (yw[j] < FpParams::HALF[j]) lt = true;
+                    }
+                }
+                if (gt != ((flags & 1) != 0)) { Fp::template neg<0>(yc, yc); Fp::reduce_once(yc, yc); }
+                Fp::canon(a.x, x);
+                a.y = yc;
+                a.inf = 0;
+            }
+        }
+    }
+    st[i] = rc;
+    store_affine(out_aff + (size_t)i * 32, a);
+}
+
+// table[j][i] = 2^(C j) * src[perm(i)], canonical affine rows.  perm = bit reversal over 4096 when
+// bitrev != 0 (reference api.go:131 commitKeyLagrange.ReversePoints()).
+template <int C>
+__global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__ src_aff, uint32_t* __restrict__ table, int n, int bitrev_bits) {
+    using RC = Recode<C>;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    int s = i;
+    if (bitrev_bits) s = (int)(__brev((uint32_t)i) >> (32 - bitrev_bits));
+    G1Aff a;
+    load_affine(a, src_aff + (size_t)s * 32);
+    G1X acc;
+    if (a.inf) g1x_set_inf(acc); else g1x_from_affine(acc, a.x, a.y);
+    for (int j = 0; j < RC::NWIN; j++) {
+        if (j > 0) {
+            for (int q = 0; q < C; q++) g1x_dbl_ni(acc, acc);
+            g1x_to_affine(a, acc);
+            if (!a.inf) g1x_from_affine(acc, a.x, a.y);   // restart from Z = 1 (keeps values tight)
+        }
+        store_affine(table + ((size_t)j * n + i) * 32, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+template <int C>
+static void launch_commit(const CommitPlan& pl, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
+    using RC = Recode<C>;
+    if (n <= 0) return;
+    if (kt) kt->begin(KT_DIGITS_SORT, s);
+    if (input_kind == 0) hipLaunchKernelGGL((k_digits_sort<C, 0>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_offsets, d_status);
+    else hipLaunchKernelGGL((k_digits_sort<C, 1>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_offsets, d_status);
+    if (kt) kt->end(KT_DIGITS_SORT, s);
+    if (kt) kt->begin(KT_BUCKET_ACC, s);
+    hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((unsigned)((size_t)n * RC::NBUCKET / 256)), dim3(256), 0, s, pl.d_table, pl.d_entries, pl.d_offsets, pl.d_buckets);
+    if (kt) kt->end(KT_BUCKET_ACC, s);
+    const int n_chunks = n * (RC::NBUCKET / CHUNK);
+    if (kt) kt->begin(KT_REDUCE1, s);
+    hipLaunchKernelGGL((k_bucket_reduce1<C>), dim3((n_chunks + 63) / 64), dim3(64), 0, s, pl.d_buckets, pl.d_partials, n_chunks);
+    if (kt) kt->end(KT_REDUCE1, s);
+    if (kt) kt->begin(KT_REDUCE2, s);
+    hipLaunchKernelGGL((k_bucket_reduce2<C>), dim3(n), dim3(64), 0, s, pl.d_partials, d_status, d_out48);
+    if (kt) kt->end(KT_REDUCE2, s);
+}
+
+void commit_batch_device(const CommitPlan& pl, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
+    switch (pl.c) {
+        case 11: launch_commit<11>(pl, d_scalars, stride, input_kind, n, d_out48, d_status, s, kt); break;
+        case 12: launch_commit<12>(pl, d_scalars, stride, input_kind, n, d_out48, d_status, s, kt); break;
+        default: launch_commit<13>(pl, d_scalars, stride, input_kind, n, d_out48, d_status, s, kt); break;
+    }
+}
+void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz) {
+    const int nwin = (255 + c - 1) / c, nb = 1 << (c - 1);
+    sz->nwin = nwin;
+    sz->nbucket = nb;
+    sz->table_bytes = (size_t)nwin * 4096 * 128;
+    sz->entries_bytes = (size_t)max_batch * 4096 * nwin * 4;
+    sz->offsets_bytes = (size_t)max_batch * (nb + 1) * 4;
+    sz->buckets_bytes = (size_t)max_batch * nb * 256;
+    sz->partials_bytes = (size_t)max_batch * (nb / CHUNK) * 512;
+}
+void g1_decompress_device(const uint8_t* d_in48, int n, uint32_t* d_out_aff, int* d_status, hipStream_t s) {
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in48, n, d_out_aff, d_status);
+}
+void build_table_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s) {
+    switch (c) {
+        case 11: hipLaunchKernelGGL((k_build_table<11>), dim3((n + 63) / 64), dim3(64), 0, s, d_src_aff, d_table, n, bitrev_bits); break;
+        case 12: hipLaunchKernelGGL((k_build_table<12>), dim3((n + 63) / 64), dim3(64), 0, s, d_src_aff, d_table, n, bitrev_bits); break;
+        default: hipLaunchKernelGGL((k_build_table<13>), dim3((n + 63) / 64), dim3(64), 0, s, d_src_aff, d_table, n, bitrev_bits); break;
+    }
+}
+
+}  // namespace kzg

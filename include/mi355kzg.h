@@ -1,0 +1,97 @@
+/*
+ * mi355kzg.h -- C ABI of the MI355X-native KZG engine (libmi355kzg.so).
+ *
+ * Drop-in boundary: the byte-level method set of go-eth-kzg's `Context`
+ * (reference api.go:17-28).  Every entry point below names the reference method it replaces
+ * (file:line relative to crate-crypto/go-eth-kzg); a cgo `Context` wrapper binds them 1:1
+ * (INTEGRATION.md).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - blobs are 131072 bytes, cells 2048, commitments/proofs 48, scalars 32 (big-endian),
+ *     exactly reference serialization.go:56-95.
+ *   - "host" entry points take host pointers and copy; "_device" entry points take device
+ *     (HBM) pointers + a hipStream_t (as void*) and enqueue asynchronously on that stream.
+ *   - return value: MKZG_OK, MKZG_VERIFY_FAILED (<-> kzg.ErrVerifyOpeningProof), or one code per
+ *     reference error sentinel; MKZG_ERR_HIP for a runtime failure.  Never aborts.
+ *   - a context is immutable after construction and may be shared by threads (calls that use
+ *     the context's workspace are serialised internally).
+ *   - there is NO CPU fallback: without a HIP device mkzg_ctx_new fails with MKZG_ERR_HIP.
+ */
+#ifndef MI355KZG_H
+#define MI355KZG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKZG_BYTES_PER_BLOB 131072        /* reference serialization.go:33,80 */
+#define MKZG_BYTES_PER_CELL 2048          /* reference serialization.go:36 */
+#define MKZG_CELLS_PER_EXT_BLOB 128       /* reference serialization.go:39 */
+#define MKZG_BYTES_PER_G1 48              /* reference serialization.go:14 */
+#define MKZG_BYTES_PER_SCALAR 32          /* reference serialization.go:25 */
+
+enum {
+    MKZG_OK = 0,
+    MKZG_VERIFY_FAILED = 1,                /* kzg.ErrVerifyOpeningProof       internal/kzg/errors.go:8 */
+    MKZG_ERR_BATCH_LENGTH = 2,             /* ErrBatchLengthCheck             errors.go:6 */
+    MKZG_ERR_NON_CANONICAL_SCALAR = 3,     /* ErrNonCanonicalScalar           errors.go:7 */
+    MKZG_ERR_INVALID_CELL_ID = 4,          /* ErrInvalidCellID                errors.go:8 */
+    MKZG_ERR_INVALID_ROW_INDEX = 5,        /* ErrInvalidRowIndex              errors.go:9 */
+    MKZG_ERR_NIL_INPUT = 6,                /* ErrDeserializeNilInput          errors.go:10 */
+    MKZG_ERR_NUM_CELL_IDS = 7,             /* ErrNumCellIDsNotEqualNumCells   errors.go:12 */
+    MKZG_ERR_CELL_IDS_NOT_ORDERED = 8,     /* ErrCellIDsNotOrdered            errors.go:13 */
+    MKZG_ERR_FOUND_INVALID_CELL_ID = 9,    /* ErrFoundInvalidCellID           errors.go:14 */
+    MKZG_ERR_NOT_ENOUGH_CELLS = 10,        /* ErrNotEnoughCellsForReconstruction errors.go:15 */
+    MKZG_ERR_G1_BAD_ENCODING = 11,         /* gnark G1Affine.SetBytes errors reached from serialization.go:110 */
+    MKZG_ERR_G1_NOT_ON_CURVE = 12,
+    MKZG_ERR_G1_NOT_IN_SUBGROUP = 13,
+    MKZG_ERR_TOO_MANY_GOROUTINES = 14,     /* multiexp.ErrTooManyGoRoutines   internal/multiexp/errors.go:5 */
+    MKZG_ERR_INVALID_POLY_SIZE = 15,       /* kzg.ErrInvalidPolynomialSize */
+    MKZG_ERR_BAD_TRUSTED_SETUP = 16,       /* panics / kzg.ErrMinSRSSize of api.go:90-117, trusted_setup.go */
+    MKZG_ERR_BAD_ARGS = 17,
+    MKZG_ERR_HIP = 100                     /* HIP / RCCL runtime failure (no reference analogue) */
+};
+
+typedef struct mkzg_ctx mkzg_ctx;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* NewContext4096 (reference api.go:90-149) from the JSON of trusted_setup.go:23-27
+ * (`g1_monomial`, `g1_lagrange`, `g2_monomial` hex strings).  device_ids/n_dev select the HIP
+ * device (n_dev == 0: current device).  One context drives one GPU; multi-GPU jobs create one
+ * context per process/rank (DESIGN.md "multi-GPU"). */
+int mkzg_ctx_new(const char* trusted_setup_json, size_t len, const int* device_ids, int n_dev, mkzg_ctx** out);
+void mkzg_ctx_free(mkzg_ctx* ctx);
+/* tuning knobs before first use: key "msm_window" (11..13), "max_batch" (blobs per launch). */
+int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
+
+/* ---- EIP-4844 ------------------------------------------------------------------------------ */
+/* Context.BlobToKZGCommitment (reference prove.go:13-33).  num_threads mirrors numGoRoutines:
+ * ignored by the GPU path but >= 1024 still returns MKZG_ERR_TOO_MANY_GOROUTINES
+ * (reference internal/multiexp/multiexp.go:45-50). */
+int mkzg_blob_to_kzg_commitment(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint8_t out48[48]);
+/* batch of independent blobs given as an array of host pointers (Go's []*Blob); per_item_status
+ * (may be NULL) receives one code per blob; the return value is the first non-zero item code. */
+int mkzg_blob_to_kzg_commitment_batch(mkzg_ctx* ctx, const uint8_t* const* blobs, size_t n, uint8_t* out48n, int* per_item_status);
+/* same, blobs contiguous in HBM (n x 131072 B), outputs to HBM; asynchronous on `stream`. */
+int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n, void* d_out48n, int* d_status, void* stream);
+
+/* fine seam: multiexp.MultiExpG1 (reference internal/multiexp/multiexp.go:20-26) against the
+ * context's commit key: n <= 4096 scalars (32-byte big-endian, canonical) -> compressed point.
+ * Mirrors kzg.CommitKey.Commit's length check (reference internal/kzg/srs.go:56-62). */
+int mkzg_commit_lagrange(mkzg_ctx* ctx, const uint8_t* scalars32, size_t n, int num_threads, uint8_t out48[48]);
+
+/* ---- profiling hooks (bench.py's roofline section) ------------------------------------------ */
+/* When enabled, every kernel launch of the hot path is bracketed by hipEvents on its stream. */
+int mkzg_profile_enable(mkzg_ctx* ctx, int on);
+/* Synchronises, then writes up to `cap` records; returns the number of kernel kinds. */
+typedef struct { const char* name; double total_ms; long launches; } mkzg_kernel_time;
+int mkzg_profile_read(mkzg_ctx* ctx, mkzg_kernel_time* out, int cap, int reset);
+
+const char* mkzg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -55,6 +55,32 @@ class BadHex:
         return -1
 
 
+def load_product():
+    """import the hyphen-named product package (go-eth-kzg_amd/) as module `goethkzg_amd`"""
+    import importlib.util
+    if "goethkzg_amd" in sys.modules:
+        return sys.modules["goethkzg_amd"]
+    path = os.path.join(ROOT, "go-eth-kzg_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("goethkzg_amd", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["goethkzg_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def product():
+    return load_product()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(product):
+    """product Context on cuda:0 -- fails loudly (no fallback) if the HIP library or GPU is missing"""
+    ctx = product.Context()
+    yield ctx
+    ctx.close()
+
+
 @pytest.fixture(scope="session")
 def vectors():
     return Vectors()

@@ -1,0 +1,36 @@
+// tests/host_shim/mont29_shim.cpp -- exposes the product's header-only field / curve code
+// (go-eth-kzg_amd/csrc/mont29.hpp, g1.hpp) to Python so that it can be unit-tested on the CPU
+// against big-integer arithmetic (tests/test_mont29_host.py).  Host logic test only; the
+// kernels use the very same templates on the device.
+#include "../../go-eth-kzg_amd/csrc/g1.hpp"
+#include <cstring>
+using namespace kzg;
+extern "C" {
+void shim_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { fp_t x, y, r; Fp::set(x, a); Fp::set(y, b); Fp::mul(r, x, y); memcpy(o, r.l, 56); }
+void shim_fp_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { fp_t x, y, r; Fp::set(x, a); Fp::set(y, b); Fp::add(r, x, y); memcpy(o, r.l, 56); }
+void shim_fp_sub(int klog, const uint32_t* a, const uint32_t* b, uint32_t* o) {
+    fp_t x, y, r; Fp::set(x, a); Fp::set(y, b);
+    switch (klog) { case 0: Fp::sub<0>(r, x, y); break; case 1: Fp::sub<1>(r, x, y); break; case 2: Fp::sub<2>(r, x, y); break; case 3: Fp::sub<3>(r, x, y); break; default: Fp::sub<4>(r, x, y); }
+    memcpy(o, r.l, 56);
+}
+void shim_fp_canon(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp::canon(r, x); memcpy(o, r.l, 56); }
+void shim_fp_to_plain(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp::to_plain(r, x); memcpy(o, r.l, 56); }
+void shim_fp_from_plain(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp::from_plain(r, x); memcpy(o, r.l, 56); }
+int shim_fp_is_zero16(const uint32_t* a) { fp_t x; Fp::set(x, a); return Fp::is_zero_mod<16>(x); }
+void shim_fp_inv(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp::pow_words(r, x, FpParams::EXP_INV, FpParams::BITS); memcpy(o, r.l, 56); }
+void shim_fp_words(const uint32_t* w12, uint32_t* o14, uint32_t* back12) { fp_t x; Fp::from_words32(x, w12); memcpy(o14, x.l, 56); Fp::to_words32(back12, x); }
+void shim_fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { fr_t x, y, r; Fr::set(x, a); Fr::set(y, b); FrC::mul(r, x, y); memcpy(o, r.l, 36); }
+void shim_fr_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { fr_t x, y, r; Fr::set(x, a); Fr::set(y, b); FrC::add(r, x, y); memcpy(o, r.l, 36); }
+void shim_fr_sub(const uint32_t* a, const uint32_t* b, uint32_t* o) { fr_t x, y, r; Fr::set(x, a); Fr::set(y, b); FrC::sub(r, x, y); memcpy(o, r.l, 36); }
+// points: acc = 4 x 14 limbs (x, y, zz, zzz)
+void shim_g1_madd(uint32_t* acc, const uint32_t* x, const uint32_t* y) { G1X a; memcpy(&a, acc, 224); fp_t px, py; Fp::set(px, x); Fp::set(py, y); g1x_madd(a, px, py); memcpy(acc, &a, 224); }
+void shim_g1_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { G1X x, y, r; memcpy(&x, a, 224); memcpy(&y, b, 224); g1x_add(r, x, y); memcpy(o, &r, 224); }
+void shim_g1_dbl(const uint32_t* a, uint32_t* o) { G1X x, r; memcpy(&x, a, 224); g1x_dbl(r, x); memcpy(o, &r, 224); }
+void shim_g1_set_inf(uint32_t* o) { G1X r; g1x_set_inf(r); memcpy(o, &r, 224); }
+// returns compressed 48 bytes
+void shim_g1_compress(const uint32_t* a, uint8_t* out48) {
+    G1X x; memcpy(&x, a, 224); G1Aff aff; g1x_to_affine(aff, x);
+    uint32_t w[12]; g1_compress_words(w, aff);
+    for (int i = 0; i < 12; i++) { out48[4 * i] = w[i] >> 24; out48[4 * i + 1] = w[i] >> 16; out48[4 * i + 2] = w[i] >> 8; out48[4 * i + 3] = w[i]; }
+}
+}

@@ -1,0 +1,101 @@
+"""GPU parity tests for BlobToKZGCommitment (config 2 of BASELINE.json), through the C ABI.
+
+Bar: bit-exact.  Compared against (a) the reference's consensus-spec vectors
+(tests/blob_to_kzg_commitment, consensus_specs_test.go:32-70) and (b) the CPU oracle on seeded
+GetRandBlob inputs (reference bench_test.go:38-46) and edge cases.
+"""
+import hashlib
+import struct
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+def rand_blob(seed):
+    """GetRandBlob (reference bench_test.go:17-46), product-side generator (hashlib)"""
+    out = bytearray()
+    for i in range(0, 131072, 32):
+        v = int.from_bytes(hashlib.sha256(struct.pack(">q", seed + i)).digest(), "big") % R
+        out += v.to_bytes(32, "big")
+    return bytes(out)
+
+
+def test_consensus_vectors(vectors, gpu_ctx):
+    from conftest import BadHex
+    n_ok = 0
+    for c in vectors.cases("blob_to_kzg_commitment"):
+        blob = vectors.val(c["input"]["blob"])
+        exp = vectors.val(c["output"])
+        if isinstance(blob, BadHex) or len(blob) != 131072:
+            assert exp is None
+            continue
+        rc, out = gpu_ctx.BlobToKZGCommitment(blob)
+        if exp is None:
+            assert rc == 3, c["name"]          # ErrNonCanonicalScalar
+        else:
+            assert rc == 0 and out == exp, c["name"]
+            n_ok += 1
+    assert n_ok == 7
+
+
+def test_batch_vs_oracle(gpu_ctx, oracle_ctx):
+    import oracle
+    blobs = [rand_blob(s) for s in range(12)]
+    assert blobs[3] == oracle.rand_blob(3)      # the two GetRandBlob restatements agree
+    blobs.append(bytes(131072))                                       # zero polynomial -> infinity
+    blobs.append((1).to_bytes(32, "big") * 4096)                      # constant polynomial 1
+    blobs.append((R - 1).to_bytes(32, "big") * 4096)                  # all scalars r-1 (max canonical)
+    blobs.append(bytes(32) * 4095 + (5).to_bytes(32, "big"))          # single non-zero scalar
+    rc, outs, st = gpu_ctx.BlobToKZGCommitmentBatch(blobs)
+    assert rc == 0 and all(s == 0 for s in st)
+    for b, o in zip(blobs, outs):
+        rco, exp = oracle_ctx.blob_to_kzg_commitment(b)
+        assert rco == 0 and o == exp
+    assert outs[12] == bytes([0xC0] + [0] * 47)
+
+
+def test_batch_with_invalid_items(gpu_ctx, oracle_ctx):
+    good = rand_blob(100)
+    bad = bytearray(rand_blob(101))
+    bad[2111 * 32:2111 * 32 + 32] = R.to_bytes(32, "big")             # scalar #2111 == r (non canonical)
+    allbad = b"\xff" * 131072
+    rc, outs, st = gpu_ctx.BlobToKZGCommitmentBatch([good, bytes(bad), allbad, good])
+    assert rc == 3 and st == [0, 3, 3, 0]
+    exp = oracle_ctx.blob_to_kzg_commitment(good)[1]
+    assert outs[0] == exp and outs[3] == exp
+
+
+def test_api_edges(gpu_ctx):
+    blob = rand_blob(7)
+    rc, _ = gpu_ctx.BlobToKZGCommitment(blob, num_goroutines=1024)    # multiexp_test.go:68-76
+    assert rc == 14
+    rc, _ = gpu_ctx.BlobToKZGCommitment(None)
+    assert rc == 6
+    rc, _, _ = gpu_ctx.BlobToKZGCommitmentBatch([])
+    assert rc == 0
+    rc, _ = gpu_ctx.CommitLagrange(b"")                               # srs.go:57 zero length
+    assert rc == 15
+
+
+def test_commit_lagrange_prefix(gpu_ctx, oracle_ctx):
+    """Commit on a short polynomial == commitment of the zero-padded blob (srs.go:61 G1[:len(p)])"""
+    blob = rand_blob(9)
+    rc, out = gpu_ctx.CommitLagrange(blob[:32 * 100])
+    exp = oracle_ctx.blob_to_kzg_commitment(blob[:3200] + bytes(131072 - 3200))[1]
+    assert rc == 0 and out == exp
+
+
+def test_windows_agree(product, oracle_ctx):
+    """every supported window size gives the same bytes"""
+    blob = rand_blob(11)
+    exp = oracle_ctx.blob_to_kzg_commitment(blob)[1]
+    for c in (11, 12, 13):
+        ctx = product.Context()
+        assert ctx.set_option("msm_window", c) == 0
+        assert ctx.set_option("max_batch", 4) == 0
+        rc, out = ctx.BlobToKZGCommitment(blob)
+        ctx.close()
+        assert rc == 0 and out == exp, c

@@ -1,0 +1,235 @@
+"""Host-side unit tests of the product's radix-2^29 field / G1 templates
+(go-eth-kzg_amd/csrc/mont29.hpp, g1.hpp) against Python big-integer arithmetic.
+
+The kernels instantiate exactly these templates on the device; testing them on the CPU (g++)
+catches arithmetic and bound mistakes without a GPU.  The G1 results are also compared with
+the CPU oracle (compressed encodings are canonical, so any correct implementation agrees).
+"""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM_DIR = os.path.join(ROOT, "tests", "host_shim")
+P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+RP = 1 << (29 * 14)
+RF = 1 << (29 * 9)
+G1X = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
+G1Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(SHIM_DIR, "libmont29_shim.so")
+    src = os.path.join(SHIM_DIR, "mont29_shim.cpp")
+    hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("mont29.hpp", "g1.hpp", "constants29.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    return C.CDLL(so)
+
+
+def limbs(v, n=14):
+    assert 0 <= v < 1 << (29 * n)
+    return (C.c_uint32 * n)(*[(v >> (29 * i)) & ((1 << 29) - 1) for i in range(n)])
+
+
+def val(arr):
+    return sum(int(x) << (29 * i) for i, x in enumerate(arr))
+
+
+def out(n=14):
+    return (C.c_uint32 * n)()
+
+
+def normalized(arr):
+    return all(int(x) < (1 << 29) for x in arr[:-1])
+
+
+def test_fp_mul_add_sub(shim):
+    rng = random.Random(1)
+    for it in range(300):
+        # loose inputs up to 2^392
+        a = rng.randrange(0, 1 << rng.choice([381, 385, 390, 392]))
+        b = rng.randrange(0, 1 << rng.choice([381, 385, 390, 392]))
+        o = out()
+        shim.shim_fp_mul(limbs(a), limbs(b), o)
+        v = val(o)
+        assert normalized(o)
+        assert (v * RP - a * b) % P == 0
+        assert v < a * b // RP + P + 1
+        shim.shim_fp_add(limbs(a), limbs(b), o)
+        assert val(o) == a + b and normalized(o)
+        for klog in range(5):
+            bb = rng.randrange(0, (1 << klog) * P + 1)
+            shim.shim_fp_sub(klog, limbs(a), limbs(bb), o)
+            assert val(o) == a - bb + (1 << klog) * P and normalized(o)
+
+
+def test_fp_canon_plain_inv(shim):
+    rng = random.Random(2)
+    for it in range(100):
+        a = rng.randrange(0, 1 << 392)
+        o = out()
+        shim.shim_fp_canon(limbs(a), o)
+        assert val(o) == a % P
+        shim.shim_fp_to_plain(limbs(a), o)
+        assert val(o) == a * pow(RP, -1, P) % P
+        x = rng.randrange(0, P)
+        shim.shim_fp_from_plain(limbs(x), o)
+        assert val(o) % P == x * RP % P
+    for k in range(16):
+        assert shim.shim_fp_is_zero16(limbs(k * P)) == 1
+        assert shim.shim_fp_is_zero16(limbs(k * P + 1)) == 0
+    assert shim.shim_fp_is_zero16(limbs(5 * P + (1 << 29) * 12345)) == 0
+    for it in range(5):
+        a = rng.randrange(1, P)
+        o = out()
+        shim.shim_fp_inv(limbs(a * RP % P), o)
+        assert val(o) % P == pow(a, -1, P) * RP % P
+
+
+def test_fp_words(shim):
+    rng = random.Random(3)
+    for it in range(50):
+        a = rng.randrange(0, P)
+        w = (C.c_uint32 * 12)(*[(a >> (32 * i)) & 0xFFFFFFFF for i in range(12)])
+        o, back = out(), (C.c_uint32 * 12)()
+        shim.shim_fp_words(w, o, back)
+        assert val(o) == a
+        assert list(back) == list(w)
+
+
+def test_fr_ops(shim):
+    rng = random.Random(4)
+    for it in range(300):
+        a, b = rng.randrange(0, R), rng.randrange(0, R)
+        if it == 0:
+            a, b = R - 1, R - 1
+        o = out(9)
+        shim.shim_fr_mul(limbs(a, 9), limbs(b, 9), o)
+        assert val(o) == a * b * pow(RF, -1, R) % R
+        shim.shim_fr_add(limbs(a, 9), limbs(b, 9), o)
+        assert val(o) == (a + b) % R
+        shim.shim_fr_sub(limbs(a, 9), limbs(b, 9), o)
+        assert val(o) == (a - b) % R
+
+
+# ---- G1: affine big-int reference
+def ec_add(p1, p2):
+    if p1 is None:
+        return p2
+    if p2 is None:
+        return p1
+    (x1, y1), (x2, y2) = p1, p2
+    if x1 == x2:
+        if (y1 + y2) % P == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, P) % P
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, P) % P
+    x3 = (lam * lam - x1 - x2) % P
+    return x3, (lam * (x1 - x3) - y1) % P
+
+
+def ec_mul(k, p):
+    acc = None
+    while k:
+        if k & 1:
+            acc = ec_add(acc, p)
+        p = ec_add(p, p)
+        k >>= 1
+    return acc
+
+
+def compress(pt):
+    if pt is None:
+        return bytes([0xC0] + [0] * 47)
+    x, y = pt
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80 | (0x20 if y > (P - 1) // 2 else 0)
+    return bytes(b)
+
+
+def xyzz_from_affine(pt):
+    arr = (C.c_uint32 * 56)()
+    x, y = pt
+    for j, v in enumerate([x * RP % P, y * RP % P, RP % P, RP % P]):
+        for i in range(14):
+            arr[14 * j + i] = (v >> (29 * i)) & ((1 << 29) - 1)
+    return arr
+
+
+def shim_compress(shim, acc):
+    b = C.create_string_buffer(48)
+    shim.shim_g1_compress(acc, b)
+    return b.raw
+
+
+def test_g1_ops(shim):
+    G = (G1X, G1Y)
+    rng = random.Random(5)
+    pts = [ec_mul(rng.randrange(1, R), G) for _ in range(6)]
+    # madd chain incl. start from infinity, doubling and cancellation
+    acc = (C.c_uint32 * 56)()
+    shim.shim_g1_set_inf(acc)
+    ref = None
+    assert shim_compress(shim, acc) == compress(None)
+    seq = [pts[0], pts[1], pts[2], pts[0], pts[3]]
+    for pt in seq:
+        shim.shim_g1_madd(acc, limbs(pt[0] * RP % P), limbs(pt[1] * RP % P))
+        ref = ec_add(ref, pt)
+        assert shim_compress(shim, acc) == compress(ref)
+    # P + P through madd (acc == point)
+    acc = xyzz_from_affine(pts[4])
+    shim.shim_g1_madd(acc, limbs(pts[4][0] * RP % P), limbs(pts[4][1] * RP % P))
+    assert shim_compress(shim, acc) == compress(ec_add(pts[4], pts[4]))
+    # P - P through madd
+    acc = xyzz_from_affine(pts[4])
+    shim.shim_g1_madd(acc, limbs(pts[4][0] * RP % P), limbs((P - pts[4][1]) * RP % P))
+    assert shim_compress(shim, acc) == compress(None)
+    # full add / dbl, including non-trivial ZZ on both sides
+    a = xyzz_from_affine(pts[0])
+    shim.shim_g1_madd(a, limbs(pts[1][0] * RP % P), limbs(pts[1][1] * RP % P))    # a = p0+p1
+    b = xyzz_from_affine(pts[2])
+    shim.shim_g1_madd(b, limbs(pts[3][0] * RP % P), limbs(pts[3][1] * RP % P))    # b = p2+p3
+    o = (C.c_uint32 * 56)()
+    shim.shim_g1_add(a, b, o)
+    r_ab = ec_add(ec_add(pts[0], pts[1]), ec_add(pts[2], pts[3]))
+    assert shim_compress(shim, o) == compress(r_ab)
+    shim.shim_g1_add(a, a, o)                                                     # add -> doubling path
+    assert shim_compress(shim, o) == compress(ec_mul(2, ec_add(pts[0], pts[1])))
+    shim.shim_g1_dbl(a, o)
+    assert shim_compress(shim, o) == compress(ec_mul(2, ec_add(pts[0], pts[1])))
+    inf = (C.c_uint32 * 56)()
+    shim.shim_g1_set_inf(inf)
+    shim.shim_g1_add(a, inf, o)
+    assert shim_compress(shim, o) == compress(ec_add(pts[0], pts[1]))
+    shim.shim_g1_add(inf, a, o)
+    assert shim_compress(shim, o) == compress(ec_add(pts[0], pts[1]))
+    # long chain: bounds stay valid over many operations
+    acc = (C.c_uint32 * 56)()
+    shim.shim_g1_set_inf(acc)
+    ref = None
+    for i in range(40):
+        pt = pts[i % 6]
+        shim.shim_g1_madd(acc, limbs(pt[0] * RP % P), limbs(pt[1] * RP % P))
+        ref = ec_add(ref, pt)
+        if i % 7 == 3:
+            shim.shim_g1_dbl(acc, acc)
+            ref = ec_add(ref, ref)
+        if i % 5 == 4:
+            shim.shim_g1_add(acc, a, acc)
+            ref = ec_add(ref, ec_add(pts[0], pts[1]))
+    assert shim_compress(shim, acc) == compress(ref)
+
+
+def test_g1_matches_oracle(shim):
+    """cross-check with the CPU oracle on k*G"""
+    import oracle
+    G = (G1X, G1Y)
+    for k in (1, 2, 3, 0xDEADBEEF, R - 1):
+        assert compress(ec_mul(k, G)) == oracle.g1_gen_mul(k)

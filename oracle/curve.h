@@ -68,8 +68,25 @@ static inline void g1j_add(g1j_t *o, const g1j_t *p, const g1j_t *q) {
     fp_add(&z3, &p->z, &q->z); fp_sqr(&z3, &z3); fp_sub(&z3, &z3, &z1z1); fp_sub(&z3, &z3, &z2z2); fp_mul(&z3, &z3, &h);
     o->x = x3; o->y = y3; o->z = z3;
 }
+/* mixed addition Jacobian + affine (madd-2007-bl), exceptional cases routed to the general code */
 static inline void g1j_add_affine(g1j_t *o, const g1j_t *p, const g1a_t *q) {
-    g1j_t qj; g1j_from_affine(&qj, q); g1j_add(o, p, &qj);
+    if (g1a_is_inf(q)) { *o = *p; return; }
+    if (g1j_is_inf(p)) { g1j_from_affine(o, q); return; }
+    fp_t z1z1, u2, s2, h, hh, i, j, rr, v, t, x3, y3, z3;
+    fp_sqr(&z1z1, &p->z);
+    fp_mul(&u2, &q->x, &z1z1);
+    fp_mul(&s2, &q->y, &p->z); fp_mul(&s2, &s2, &z1z1);
+    if (fp_eq(&u2, &p->x)) { g1j_t qj; g1j_from_affine(&qj, q); g1j_add(o, p, &qj); return; }
+    fp_sub(&h, &u2, &p->x);
+    fp_sqr(&hh, &h);
+    fp_dbl(&i, &hh); fp_dbl(&i, &i);
+    fp_mul(&j, &h, &i);
+    fp_sub(&rr, &s2, &p->y); fp_dbl(&rr, &rr);
+    fp_mul(&v, &p->x, &i);
+    fp_sqr(&x3, &rr); fp_sub(&x3, &x3, &j); fp_sub(&x3, &x3, &v); fp_sub(&x3, &x3, &v);
+    fp_sub(&t, &v, &x3); fp_mul(&y3, &rr, &t); fp_mul(&t, &p->y, &j); fp_dbl(&t, &t); fp_sub(&y3, &y3, &t);
+    fp_add(&z3, &p->z, &h); fp_sqr(&z3, &z3); fp_sub(&z3, &z3, &z1z1); fp_sub(&z3, &z3, &hh);
+    o->x = x3; o->y = y3; o->z = z3;
 }
 static inline void g1j_sub(g1j_t *o, const g1j_t *p, const g1j_t *q) { g1j_t n; g1j_neg(&n, q); g1j_add(o, p, &n); }
 /* scalar as plain little-endian limbs */

@@ -50,30 +50,39 @@ static inline void mod_sub(int n, u64 *o, const u64 *a, const u64 *b, const u64 
     if (br) { u64 c = 0; for (int i = 0; i < n; i++) t[i] = kz_adc(t[i], m[i], &c); }
     for (int i = 0; i < n; i++) o[i] = t[i];
 }
-/* Montgomery product a*b*R^-1 mod m (coarsely integrated operand scanning) */
-static inline void mont_mul(int n, u64 *o, const u64 *a, const u64 *b, const u64 *m, u64 inv) {
-    u64 t[8] = {0};
-    for (int i = 0; i < n; i++) {
-        u64 c = 0;
-        for (int j = 0; j < n; j++) t[j] = kz_mac(t[j], a[j], b[i], &c);
-        t[n] = kz_adc(t[n], 0, &c);
-        t[n + 1] = c;
-        u64 q = t[0] * inv;
-        c = 0;
-        (void)kz_mac(t[0], q, m[0], &c);
-        for (int j = 1; j < n; j++) t[j - 1] = kz_mac(t[j], q, m[j], &c);
-        t[n - 1] = kz_adc(t[n], 0, &c);
-        t[n] = t[n + 1] + c;
+/* Montgomery product a*b*R^-1 mod m (coarsely integrated operand scanning, "no-carry" variant:
+ * valid because the top bit of both moduli is clear).  Generated per field by macro so that the
+ * limb count is a literal and gcc fully unrolls the loops. */
+#define KZ_DEFINE_MONT_MUL(NAME, NL, MOD, INV)                                                   \
+    static inline void NAME(u64 *o, const u64 *a, const u64 *b) {                                \
+        u64 t[NL] = {0};                                                                         \
+        _Pragma("GCC unroll 8") for (int i = 0; i < NL; i++) {                                   \
+            u64 A = 0, C = 0, bi = b[i];                                                         \
+            u128 x = (u128)a[0] * bi + t[0];                                                     \
+            A = (u64)(x >> 64);                                                                  \
+            u64 q = (u64)x * INV;                                                                \
+            u128 y = (u128)q * MOD[0] + (u64)x;                                                  \
+            C = (u64)(y >> 64);                                                                  \
+            _Pragma("GCC unroll 8") for (int j = 1; j < NL; j++) {                               \
+                x = (u128)a[j] * bi + t[j] + A;                                                  \
+                A = (u64)(x >> 64);                                                              \
+                y = (u128)q * MOD[j] + (u64)x + C;                                               \
+                C = (u64)(y >> 64);                                                              \
+                t[j - 1] = (u64)y;                                                               \
+            }                                                                                    \
+            t[NL - 1] = C + A;                                                                   \
+        }                                                                                        \
+        if (bn_geq(NL, t, MOD)) { u64 br = 0; for (int i = 0; i < NL; i++) t[i] = kz_sbb(t[i], MOD[i], &br); } \
+        for (int i = 0; i < NL; i++) o[i] = t[i];                                                \
     }
-    if (t[n] || bn_geq(n, t, m)) { u64 br = 0; for (int i = 0; i < n; i++) t[i] = kz_sbb(t[i], m[i], &br); }
-    for (int i = 0; i < n; i++) o[i] = t[i];
-}
+KZ_DEFINE_MONT_MUL(fp_mont_mul, 6, FP_MOD, FP_INV)
+KZ_DEFINE_MONT_MUL(fr_mont_mul, 4, FR_MOD, FR_INV)
 
 /* ---------- Fp ---------- */
 static inline void fp_add(fp_t *o, const fp_t *a, const fp_t *b) { mod_add(6, o->l, a->l, b->l, FP_MOD); }
 static inline void fp_sub(fp_t *o, const fp_t *a, const fp_t *b) { mod_sub(6, o->l, a->l, b->l, FP_MOD); }
-static inline void fp_mul(fp_t *o, const fp_t *a, const fp_t *b) { mont_mul(6, o->l, a->l, b->l, FP_MOD, FP_INV); }
-static inline void fp_sqr(fp_t *o, const fp_t *a) { mont_mul(6, o->l, a->l, a->l, FP_MOD, FP_INV); }
+static inline void fp_mul(fp_t *o, const fp_t *a, const fp_t *b) { fp_mont_mul(o->l, a->l, b->l); }
+static inline void fp_sqr(fp_t *o, const fp_t *a) { fp_mont_mul(o->l, a->l, a->l); }
 static inline int fp_is_zero(const fp_t *a) { return bn_is_zero(6, a->l); }
 static inline int fp_eq(const fp_t *a, const fp_t *b) { return bn_eq(6, a->l, b->l); }
 static inline void fp_zero(fp_t *o) { memset(o, 0, sizeof *o); }
@@ -118,8 +127,8 @@ static inline int fp_lex_largest(const fp_t *a) {
 /* ---------- Fr ---------- */
 static inline void fr_add(fr_t *o, const fr_t *a, const fr_t *b) { mod_add(4, o->l, a->l, b->l, FR_MOD); }
 static inline void fr_sub(fr_t *o, const fr_t *a, const fr_t *b) { mod_sub(4, o->l, a->l, b->l, FR_MOD); }
-static inline void fr_mul(fr_t *o, const fr_t *a, const fr_t *b) { mont_mul(4, o->l, a->l, b->l, FR_MOD, FR_INV); }
-static inline void fr_sqr(fr_t *o, const fr_t *a) { mont_mul(4, o->l, a->l, a->l, FR_MOD, FR_INV); }
+static inline void fr_mul(fr_t *o, const fr_t *a, const fr_t *b) { fr_mont_mul(o->l, a->l, b->l); }
+static inline void fr_sqr(fr_t *o, const fr_t *a) { fr_mont_mul(o->l, a->l, a->l); }
 static inline int fr_is_zero(const fr_t *a) { return bn_is_zero(4, a->l); }
 static inline int fr_eq(const fr_t *a, const fr_t *b) { return bn_eq(4, a->l, b->l); }
 static inline void fr_zero(fr_t *o) { memset(o, 0, sizeof *o); }

@@ -104,8 +104,10 @@ static int ensure_plan(mkzg_ctx* c) {
     c->plan.max_batch = c->opt_max_batch;
     HIPCHK(hipMalloc(&c->plan.d_table, sz.table_bytes));
     HIPCHK(hipMalloc(&c->plan.d_entries, sz.entries_bytes));
-    HIPCHK(hipMalloc(&c->plan.d_offsets, sz.offsets_bytes));
-    HIPCHK(hipMalloc(&c->plan.d_buckets, sz.buckets_bytes));
+    HIPCHK(hipMalloc(&c->plan.d_task_off, sz.task_off_bytes));
+    HIPCHK(hipMalloc(&c->plan.d_tasks, sz.tasks_bytes));
+    HIPCHK(hipMalloc(&c->plan.d_ntasks, sz.ntasks_bytes));
+    HIPCHK(hipMalloc(&c->plan.d_parts, sz.parts_bytes));
     HIPCHK(hipMalloc(&c->plan.d_partials, sz.partials_bytes));
     // api.go:131: the commit key is the bit-reversed Lagrange SRS
     build_table_device(c->plan.c, c->d_lagrange_aff, c->plan.d_table, 4096, 12, c->stream);
@@ -117,8 +119,10 @@ static int ensure_plan(mkzg_ctx* c) {
 static void free_plan(mkzg_ctx* c) {
     if (c->plan.d_table) (void)hipFree(c->plan.d_table);
     if (c->plan.d_entries) (void)hipFree(c->plan.d_entries);
-    if (c->plan.d_offsets) (void)hipFree(c->plan.d_offsets);
-    if (c->plan.d_buckets) (void)hipFree(c->plan.d_buckets);
+    if (c->plan.d_task_off) (void)hipFree(c->plan.d_task_off);
+    if (c->plan.d_tasks) (void)hipFree(c->plan.d_tasks);
+    if (c->plan.d_ntasks) (void)hipFree(c->plan.d_ntasks);
+    if (c->plan.d_parts) (void)hipFree(c->plan.d_parts);
     if (c->plan.d_partials) (void)hipFree(c->plan.d_partials);
     c->plan = CommitPlan();
     c->plan_ready = false;

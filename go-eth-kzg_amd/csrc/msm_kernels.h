@@ -44,15 +44,17 @@ struct KernelTimer {
     }
 };
 
-struct CommitPlanSizes { int nwin, nbucket; size_t table_bytes, entries_bytes, offsets_bytes, buckets_bytes, partials_bytes; };
+struct CommitPlanSizes { int nwin, nbucket, max_tasks; size_t table_bytes, entries_bytes, task_off_bytes, tasks_bytes, ntasks_bytes, parts_bytes, partials_bytes; };
 struct CommitPlan {
     int c = 13;                 // window bits
     int max_batch = 0;
     uint32_t* d_table = nullptr;    // [nwin][4096] affine rows
-    uint32_t* d_entries = nullptr;
-    uint32_t* d_offsets = nullptr;
-    uint32_t* d_buckets = nullptr;
-    uint32_t* d_partials = nullptr;
+    uint32_t* d_entries = nullptr;   // [batch][4096*nwin] sorted (point, window, sign) entries
+    uint32_t* d_task_off = nullptr;  // [batch][nbucket+1] first task id of each bucket
+    uint32_t* d_tasks = nullptr;     // [batch][max_tasks] uint2 task descriptors, longest first
+    uint32_t* d_ntasks = nullptr;    // [batch]
+    uint32_t* d_parts = nullptr;     // [batch][max_tasks] XYZZ partial bucket sums, bucket-major
+    uint32_t* d_partials = nullptr;  // [batch][nbucket/16][2] XYZZ chunk sums
 };
 
 void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz);

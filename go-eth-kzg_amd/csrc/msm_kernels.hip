@@ -110,23 +110,39 @@ struct Recode {
 };
 
 // ------------------------------------------------------------------------------------------
-// kernel A: decode scalars, recode digits, counting sort by bucket.  One 1024-thread workgroup
-// per blob (4096 scalars -> 4 per thread).
+// kernel A: decode scalars, recode digits, counting sort by bucket, build the task list.
+// One 1024-thread workgroup per blob (4096 scalars -> 4 per thread).
 //   entries[b][slot] = table index (j*4096 + i) | sign << 31, grouped by bucket
-//   offsets[b][k]    = first slot of bucket k (k = |digit| - 1), offsets[b][NBUCKET] = total
-//   status[b]        = 0 or MKZG_ERR_NON_CANONICAL_SCALAR
+//   task_off[b][k]   = id of the first task of bucket k (k = |digit| - 1); a bucket with n entries
+//                      is cut into ceil(n / PIECE) tasks, so degenerate inputs (constant
+//                      polynomials, the short top window) cannot serialise a lane
+//   tasks[b][i]      = {first entry, task id << 8 | length}, sorted by length (descending) so
+//                      that the 64 lanes of a wavefront run the same number of additions
+//   ntasks[b], status[b] (0 or MKZG_ERR_NON_CANONICAL_SCALAR)
 // INPUT_KIND 0: 32-byte big-endian scalars (blob bytes).  1: Fr elements in Montgomery radix-2^29
 // form (9 words each, as produced by the on-device quotient kernel).
 // ------------------------------------------------------------------------------------------
+constexpr int PIECE = 64;
+template <int C>
+struct TaskGeom {
+    using RC = Recode<C>;
+    static constexpr int NENT = 4096 * RC::NWIN;
+    static constexpr int MAXT = ((RC::NBUCKET + NENT / PIECE + 255) / 256) * 256;
+};
+
 template <int C, int INPUT_KIND>
 __global__ void __launch_bounds__(1024) k_digits_sort(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, uint32_t* __restrict__ entries,
-                                                      uint32_t* __restrict__ offsets, int* __restrict__ status) {
+                                                      uint32_t* __restrict__ task_off, uint2* __restrict__ tasks, uint32_t* __restrict__ ntasks,
+                                                      int* __restrict__ status) {
     using RC = Recode<C>;
+    using TG = TaskGeom<C>;
     constexpr int NB = RC::NBUCKET;
     constexpr int PER_THREAD = NB / 1024 > 0 ? NB / 1024 : 1;
     __shared__ uint32_t hist[NB];
     __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t len_pos[PIECE + 1];
     const int b = blockIdx.x, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
     for (int k = t; k < NB; k += 1024) hist[k] = 0;
     __syncthreads();
 
@@ -148,9 +164,9 @@ __global__ void __launch_bounds__(1024) k_digits_sort(const uint8_t* __restrict_
         }
     }
     if (__syncthreads_or(bad)) {
-        if (t == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
-        // leave a well-formed (empty) bucket layout behind so the later kernels are harmless
-        for (int k = t; k <= NB; k += 1024) offsets[(size_t)b * (NB + 1) + k] = 0;
+        if (t == 0) { status[b] = MKZG_ERR_NON_CANONICAL_SCALAR; ntasks[b] = 0; }
+        // leave a well-formed (empty) layout behind so the later kernels are harmless
+        for (int k = t; k <= NB; k += 1024) task_off[(size_t)b * (NB + 1) + k] = 0;
         return;
     }
     if (t == 0) status[b] = 0;
@@ -164,40 +180,39 @@ __global__ void __launch_bounds__(1024) k_digits_sort(const uint8_t* __restrict_
     }
     __syncthreads();
 
-    // exclusive scan of hist[NB] (thread t owns PER_THREAD consecutive counters when NB >= 1024)
-    uint32_t local[PER_THREAD];
+    // exclusive scan of hist[NB] (thread t owns PER_THREAD consecutive counters)
+    const bool owner = t * PER_THREAD < NB;
+    uint32_t cnt[PER_THREAD], first[PER_THREAD];
     uint32_t sum = 0;
-    if (t * PER_THREAD < NB) {
+    if (owner) {
 #pragma unroll
-        for (int q = 0; q < PER_THREAD; q++) { local[q] = hist[t * PER_THREAD + q]; sum += local[q]; }
+        for (int q = 0; q < PER_THREAD; q++) { cnt[q] = hist[t * PER_THREAD + q]; sum += cnt[q]; }
     }
-    uint32_t incl = sum;
-    const int lane = t & 63, wave = t >> 6;
+    auto block_excl_scan = [&](uint32_t v) -> uint32_t {   // exclusive prefix of v over the 1024 threads
+        uint32_t incl = v;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; w++) base += wave_tot[w];
-    uint32_t excl = base + incl - sum;
-    __syncthreads();   // everyone has read hist; now overwrite it with the running cursors
-    if (t * PER_THREAD < NB) {
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        __syncthreads();
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; w++) base += wave_tot[w];
+        return base + incl - v;
+    };
+    uint32_t excl = block_excl_scan(sum);
+    __syncthreads();   // everyone has read hist; overwrite it with the running cursors
+    if (owner) {
         uint32_t run = excl;
 #pragma unroll
-        for (int q = 0; q < PER_THREAD; q++) {
-            hist[t * PER_THREAD + q] = run;
-            offsets[(size_t)b * (NB + 1) + t * PER_THREAD + q] = run;
-            run += local[q];
-        }
-        if (t * PER_THREAD + PER_THREAD == NB) offsets[(size_t)b * (NB + 1) + NB] = run;
+        for (int q = 0; q < PER_THREAD; q++) { first[q] = run; hist[t * PER_THREAD + q] = run; run += cnt[q]; }
     }
     __syncthreads();
 
     // pass 2: scatter
-    uint32_t* ent = entries + (size_t)b * (4096 * RC::NWIN);
+    uint32_t* ent = entries + (size_t)b * TG::NENT;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int i = t + 1024 * k;
@@ -208,56 +223,121 @@ __global__ void __launch_bounds__(1024) k_digits_sort(const uint8_t* __restrict_
             }
         });
     }
+
+    // task ids: bucket k owns ceil(cnt/PIECE) consecutive ids
+    uint32_t np = 0;
+    if (owner) {
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; q++) np += (cnt[q] + PIECE - 1) / PIECE;
+    }
+    uint32_t tbase = block_excl_scan(np);
+    if (owner) {
+        uint32_t run = tbase;
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; q++) {
+            task_off[(size_t)b * (NB + 1) + t * PER_THREAD + q] = run;
+            run += (cnt[q] + PIECE - 1) / PIECE;
+        }
+        if (t * PER_THREAD + PER_THREAD == NB) { task_off[(size_t)b * (NB + 1) + NB] = run; ntasks[b] = run; }
+    }
+    // counting sort of the tasks by length, longest first
+    __syncthreads();   // pass 2 is done with hist; reuse hist[0..PIECE] as the length histogram
+    if (t <= PIECE) hist[t] = 0;
+    __syncthreads();
+    if (owner) {
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; q++) {
+            uint32_t full = cnt[q] / PIECE, rem = cnt[q] % PIECE;
+            if (full) atomicAdd(&hist[PIECE], full);
+            if (rem) atomicAdd(&hist[rem], 1u);
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int l = PIECE; l >= 1; l--) { len_pos[l] = run; run += hist[l]; }
+    }
+    __syncthreads();
+    if (owner) {
+        uint2* tk = tasks + (size_t)b * TG::MAXT;
+        uint32_t id = tbase;
+#pragma unroll
+        for (int q = 0; q < PER_THREAD; q++) {
+            uint32_t start = first[q], left = cnt[q];
+            while (left) {
+                uint32_t len = left < PIECE ? left : PIECE;
+                uint32_t slot = atomicAdd(&len_pos[len], 1u);
+                tk[slot] = make_uint2(start, (id << 8) | len);
+                start += len; left -= len; id++;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-// kernel B: one lane per (blob, bucket): mixed additions of table rows into an XYZZ accumulator.
+// kernel B: one lane per task: mixed additions of table rows into an XYZZ accumulator.  The
+// next table row is fetched while the current addition runs.
 // ------------------------------------------------------------------------------------------
 template <int C>
-__global__ void __launch_bounds__(256) k_bucket_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries,
-                                                           const uint32_t* __restrict__ offsets, uint32_t* __restrict__ buckets) {
-    using RC = Recode<C>;
-    constexpr int NB = RC::NBUCKET;
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t b = gid / NB;
-    const int k = (int)(gid % NB);
-    const uint32_t* off = offsets + b * (NB + 1);
-    const uint32_t start = off[k], end = off[k + 1];
-    const uint32_t* ent = entries + b * (size_t)(4096 * RC::NWIN);
+__global__ void __launch_bounds__(256) k_bucket_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries, const uint2* __restrict__ tasks,
+                                                           const uint32_t* __restrict__ ntasks, uint32_t* __restrict__ parts) {
+    using TG = TaskGeom<C>;
+    const int b = blockIdx.y;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntasks[b]) return;
+    const uint2 d = tasks[(size_t)b * TG::MAXT + i];
+    const uint32_t len = d.y & 0xffu, tid = d.y >> 8;
+    const uint32_t* ent = entries + (size_t)b * TG::NENT + d.x;
     G1X acc;
     g1x_set_inf(acc);
-    for (uint32_t e = start; e < end; e++) {
-        const uint32_t v = ent[e];
-        G1Aff p;
-        load_affine(p, table + (size_t)(v & 0x7fffffffu) * 32);
-        if (p.inf) continue;
-        if (v >> 31) Fp::template neg<0>(p.y, p.y);     // p - y  (table rows are canonical)
-        g1x_madd(acc, p.x, p.y);
+    uint32_t v = ent[0];
+    G1Aff p;
+    load_affine(p, table + (size_t)(v & 0x7fffffffu) * 32);
+    for (uint32_t e = 0; e < len; e++) {
+        const uint32_t vn = ent[e + 1 < len ? e + 1 : e];
+        G1Aff pn;
+        load_affine(pn, table + (size_t)(vn & 0x7fffffffu) * 32);
+        if (!p.inf) {
+            if (v >> 31) Fp::template neg<0>(p.y, p.y);     // p - y  (table rows are canonical)
+            g1x_madd(acc, p.x, p.y);
+        }
+        p = pn;
+        v = vn;
     }
-    store_xyzz(buckets + gid * 64, acc);
+    store_xyzz(parts + ((size_t)b * TG::MAXT + tid) * 64, acc);
 }
 
 // ------------------------------------------------------------------------------------------
-// kernel R1: lane-serial running sums over chunks of 16 buckets:
+// kernel R1: lane-serial running sums over chunks of 16 buckets (a bucket = its task pieces):
 //   S_t = sum_{k in chunk} B_k ,   T_t = sum_{k in chunk} (k - 16 t + 1) B_k
 // partials[b][t] = (S_t, T_t)
 // ------------------------------------------------------------------------------------------
 constexpr int CHUNK = 16;
 template <int C>
-__global__ void __launch_bounds__(64) k_bucket_reduce1(const uint32_t* __restrict__ buckets, uint32_t* __restrict__ partials, int n_chunks_total) {
-    const int gid = blockIdx.x * 64 + threadIdx.x;
-    if (gid >= n_chunks_total) return;
-    const uint32_t* src = buckets + (size_t)gid * CHUNK * 64;
+__global__ void __launch_bounds__(64) k_bucket_reduce1(const uint32_t* __restrict__ parts, const uint32_t* __restrict__ task_off, const int* __restrict__ status,
+                                                       uint32_t* __restrict__ partials) {
+    using RC = Recode<C>;
+    using TG = TaskGeom<C>;
+    constexpr int NCHUNK = RC::NBUCKET / CHUNK;
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= NCHUNK || status[b] != 0) return;
+    const uint32_t* off = task_off + (size_t)b * (RC::NBUCKET + 1) + t * CHUNK;
+    const uint32_t* src = parts + (size_t)b * TG::MAXT * 64;
     G1X run, sum, bk;
     g1x_set_inf(run);
     g1x_set_inf(sum);
     for (int q = CHUNK - 1; q >= 0; q--) {
-        load_xyzz(bk, src + q * 64);
-        g1x_add_ni(run, run, bk);
+        const uint32_t p0 = off[q], p1 = off[q + 1];
+        for (uint32_t p = p0; p < p1; p++) {
+            load_xyzz(bk, src + (size_t)p * 64);
+            g1x_add_ni(run, run, bk);
+        }
         g1x_add_ni(sum, sum, run);
     }
-    store_xyzz(partials + (size_t)gid * 128, run);
-    store_xyzz(partials + (size_t)gid * 128 + 64, sum);
+    uint32_t* dst = partials + ((size_t)b * NCHUNK + t) * 128;
+    store_xyzz(dst, run);
+    store_xyzz(dst + 64, sum);
 }
 
 // wave-wide helpers on whole XYZZ points (56 words through ds_bpermute)
@@ -427,17 +507,19 @@ __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__
 template <int C>
 static void launch_commit(const CommitPlan& pl, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
     using RC = Recode<C>;
+    using TG = TaskGeom<C>;
     if (n <= 0) return;
+    uint2* tasks = reinterpret_cast<uint2*>(pl.d_tasks);
     if (kt) kt->begin(KT_DIGITS_SORT, s);
-    if (input_kind == 0) hipLaunchKernelGGL((k_digits_sort<C, 0>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_offsets, d_status);
-    else hipLaunchKernelGGL((k_digits_sort<C, 1>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_offsets, d_status);
+    if (input_kind == 0) hipLaunchKernelGGL((k_digits_sort<C, 0>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_task_off, tasks, pl.d_ntasks, d_status);
+    else hipLaunchKernelGGL((k_digits_sort<C, 1>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_task_off, tasks, pl.d_ntasks, d_status);
     if (kt) kt->end(KT_DIGITS_SORT, s);
     if (kt) kt->begin(KT_BUCKET_ACC, s);
-    hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3((unsigned)((size_t)n * RC::NBUCKET / 256)), dim3(256), 0, s, pl.d_table, pl.d_entries, pl.d_offsets, pl.d_buckets);
+    hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3(TG::MAXT / 256, n), dim3(256), 0, s, pl.d_table, pl.d_entries, tasks, pl.d_ntasks, pl.d_parts);
     if (kt) kt->end(KT_BUCKET_ACC, s);
-    const int n_chunks = n * (RC::NBUCKET / CHUNK);
+    constexpr int NCHUNK = RC::NBUCKET / CHUNK;
     if (kt) kt->begin(KT_REDUCE1, s);
-    hipLaunchKernelGGL((k_bucket_reduce1<C>), dim3((n_chunks + 63) / 64), dim3(64), 0, s, pl.d_buckets, pl.d_partials, n_chunks);
+    hipLaunchKernelGGL((k_bucket_reduce1<C>), dim3((NCHUNK + 63) / 64, n), dim3(64), 0, s, pl.d_parts, pl.d_task_off, d_status, pl.d_partials);
     if (kt) kt->end(KT_REDUCE1, s);
     if (kt) kt->begin(KT_REDUCE2, s);
     hipLaunchKernelGGL((k_bucket_reduce2<C>), dim3(n), dim3(64), 0, s, pl.d_partials, d_status, d_out48);
@@ -453,12 +535,17 @@ void commit_batch_device(const CommitPlan& pl, const uint8_t* d_scalars, size_t 
 }
 void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz) {
     const int nwin = (255 + c - 1) / c, nb = 1 << (c - 1);
+    const int nent = 4096 * nwin;
+    const int maxt = ((nb + nent / PIECE + 255) / 256) * 256;
     sz->nwin = nwin;
     sz->nbucket = nb;
+    sz->max_tasks = maxt;
     sz->table_bytes = (size_t)nwin * 4096 * 128;
-    sz->entries_bytes = (size_t)max_batch * 4096 * nwin * 4;
-    sz->offsets_bytes = (size_t)max_batch * (nb + 1) * 4;
-    sz->buckets_bytes = (size_t)max_batch * nb * 256;
+    sz->entries_bytes = (size_t)max_batch * nent * 4;
+    sz->task_off_bytes = (size_t)max_batch * (nb + 1) * 4;
+    sz->tasks_bytes = (size_t)max_batch * maxt * 8;
+    sz->ntasks_bytes = (size_t)max_batch * 4;
+    sz->parts_bytes = (size_t)max_batch * maxt * 256;
     sz->partials_bytes = (size_t)max_batch * (nb / CHUNK) * 512;
 }
 void g1_decompress_device(const uint8_t* d_in48, int n, uint32_t* d_out_aff, int* d_status, hipStream_t s) {

@@ -35,6 +35,8 @@ EXPORTED_SYMBOLS = [
     "mkzg_ctx_new", "mkzg_ctx_free", "mkzg_ctx_set_option",
     "mkzg_blob_to_kzg_commitment", "mkzg_blob_to_kzg_commitment_batch", "mkzg_blob_to_kzg_commitment_batch_device",
     "mkzg_commit_lagrange", "mkzg_profile_enable", "mkzg_profile_read", "mkzg_version",
+    "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
+    "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
 ]
 
 
@@ -61,6 +63,13 @@ def lib():
         L.mkzg_blob_to_kzg_commitment_batch.argtypes = [vp, C.POINTER(C.c_char_p), sz, C.c_char_p, C.POINTER(i32)]
         L.mkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.mkzg_commit_lagrange.argtypes = [vp, C.c_char_p, sz, i32, C.c_char_p]
+        L.mkzg_compute_kzg_proof.argtypes = [vp, C.c_char_p, C.c_char_p, i32, C.c_char_p, C.c_char_p]
+        L.mkzg_compute_blob_kzg_proof.argtypes = [vp, C.c_char_p, C.c_char_p, i32, C.c_char_p]
+        L.mkzg_compute_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+        L.mkzg_verify_kzg_proof.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.mkzg_verify_blob_kzg_proof.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
+        L.mkzg_verify_blob_kzg_proof_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, sz, sz, sz]
+        L.mkzg_verify_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, vp, sz, vp]
         L.mkzg_profile_enable.argtypes = [vp, i32]
         L.mkzg_profile_read.argtypes = [vp, C.POINTER(KernelTime), i32, i32]
         L.mkzg_version.restype = C.c_char_p
@@ -131,6 +140,48 @@ class Context:
         out = C.create_string_buffer(48)
         rc = self._L.mkzg_commit_lagrange(self._h, bytes(scalars32), n, num_goroutines, out)
         return rc, (out.raw if rc == 0 else None)
+
+    def ComputeKZGProof(self, blob, z, num_goroutines=0):
+        """reference prove.go:85 -> (rc, proof, y)"""
+        if blob is not None and len(blob) != BYTES_PER_BLOB or len(z) != 32:
+            return ERR_BAD_ARGS, None, None
+        proof, y = C.create_string_buffer(48), C.create_string_buffer(32)
+        rc = self._L.mkzg_compute_kzg_proof(self._h, None if blob is None else bytes(blob), bytes(z), num_goroutines, proof, y)
+        return (rc, proof.raw, y.raw) if rc == 0 else (rc, None, None)
+
+    def ComputeBlobKZGProof(self, blob, commitment, num_goroutines=0):
+        """reference prove.go:46"""
+        if blob is not None and len(blob) != BYTES_PER_BLOB or len(commitment) != 48:
+            return ERR_BAD_ARGS, None
+        out = C.create_string_buffer(48)
+        rc = self._L.mkzg_compute_blob_kzg_proof(self._h, None if blob is None else bytes(blob), bytes(commitment), num_goroutines, out)
+        return rc, (out.raw if rc == 0 else None)
+
+    def compute_blob_kzg_proof_batch_device(self, d_blobs_ptr, d_commitments_ptr, n, d_proofs_ptr, d_status_ptr, stream=0):
+        return self._L.mkzg_compute_blob_kzg_proof_batch_device(self._h, d_blobs_ptr, d_commitments_ptr, n, d_proofs_ptr, d_status_ptr, stream)
+
+    def VerifyKZGProof(self, commitment, z, y, proof):
+        """reference verify.go:12"""
+        if len(commitment) != 48 or len(z) != 32 or len(y) != 32 or len(proof) != 48:
+            return ERR_BAD_ARGS
+        return self._L.mkzg_verify_kzg_proof(self._h, bytes(commitment), bytes(z), bytes(y), bytes(proof))
+
+    def VerifyBlobKZGProof(self, blob, commitment, proof):
+        """reference verify.go:48"""
+        if blob is not None and len(blob) != BYTES_PER_BLOB or len(commitment) != 48 or len(proof) != 48:
+            return ERR_BAD_ARGS
+        return self._L.mkzg_verify_blob_kzg_proof(self._h, None if blob is None else bytes(blob), bytes(commitment), bytes(proof))
+
+    def VerifyBlobKZGProofBatch(self, blobs, commitments, proofs):
+        """reference verify.go:88 (lengths of the three lists may differ -> ErrBatchLengthCheck)"""
+        if any(b is not None and len(b) != BYTES_PER_BLOB for b in blobs) or any(len(x) != 48 for x in commitments) or any(len(x) != 48 for x in proofs):
+            return ERR_BAD_ARGS
+        keep = [None if b is None else bytes(b) for b in blobs]
+        arr = (C.c_char_p * max(1, len(blobs)))(*keep)
+        return self._L.mkzg_verify_blob_kzg_proof_batch(self._h, arr, b"".join(commitments), b"".join(proofs), len(blobs), len(commitments), len(proofs))
+
+    def verify_blob_kzg_proof_batch_device(self, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n, stream=0):
+        return self._L.mkzg_verify_blob_kzg_proof_batch_device(self._h, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n, stream)
 
     # ---- profiling --------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -7,52 +7,7 @@
 //   Context.BlobToKZGCommitment  prove.go:13-33
 //   kzg.CommitKey.Commit      internal/kzg/srs.go:56-62
 //   multiexp.MultiExpG1       internal/multiexp/multiexp.go:20-50
-#include <hip/hip_runtime.h>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <algorithm>
-#include <mutex>
-#include <string>
-#include <vector>
-#include "../../include/mi355kzg.h"
-#include "msm_kernels.h"
-
-using namespace kzg;
-
-#define HIPCHK(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e__ = (expr);                                                                       \
-        if (e__ != hipSuccess) {                                                                       \
-            fprintf(stderr, "[mi355kzg] HIP error %s at %s:%d: %s\n", hipGetErrorName(e__), __FILE__, __LINE__, #expr); \
-            return MKZG_ERR_HIP;                                                                       \
-        }                                                                                              \
-    } while (0)
-
-struct mkzg_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;          // internal stream for host-pointer entry points
-    std::recursive_mutex mu;
-    // SRS
-    std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes
-    uint32_t* d_lagrange_aff = nullptr;    // 4096 affine rows, natural order of the JSON
-    // commit MSM
-    CommitPlan plan;
-    int opt_c = 13;
-    int opt_max_batch = 256;
-    bool plan_ready = false;
-    // staging
-    uint8_t* h_stage = nullptr;            // pinned
-    size_t h_stage_bytes = 0;
-    uint8_t* d_blobs = nullptr;
-    size_t d_blobs_bytes = 0;
-    uint8_t* d_out = nullptr;
-    int* d_status = nullptr;
-    size_t d_out_items = 0;
-    // profiling
-    bool profiling = false;
-    KernelTimer timer;
-};
+#include "ctx.h"
 
 // ---------------------------------------------------------------------------------------------
 // trusted-setup JSON (reference trusted_setup.go:23-27): {"g1_monomial":[...], "g1_lagrange":[...],
@@ -96,7 +51,7 @@ static bool parse_hex_array(const char* js, size_t len, const char* key, size_t 
     return false;
 }
 
-static int ensure_plan(mkzg_ctx* c) {
+int ensure_plan(mkzg_ctx* c) {
     if (c->plan_ready) return MKZG_OK;
     CommitPlanSizes sz;
     commit_plan_sizes(c->opt_c, c->opt_max_batch, &sz);
@@ -137,10 +92,13 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     (void)hipSetDevice(c->device);
     free_plan(c);
     if (c->d_lagrange_aff) (void)hipFree(c->d_lagrange_aff);
+    if (c->d_roots_brp) (void)hipFree(c->d_roots_brp);
+    if (c->d_inv_roots_brp) (void)hipFree(c->d_inv_roots_brp);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_blobs) (void)hipFree(c->d_blobs);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_status) (void)hipFree(c->d_status);
+    free_verify_ws(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -181,6 +139,17 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
         (void)hipFree(d_raw);
         (void)hipFree(d_st);
         for (int v : st) if (v) return MKZG_ERR_BAD_TRUSTED_SETUP;   // reference panics (trusted_setup.go:152-156)
+        // domain of the blob polynomial, bit-reversed (api.go:127-132)
+        HIPCHK(hipMalloc(&c->d_roots_brp, 4096 * 48));
+        HIPCHK(hipMalloc(&c->d_inv_roots_brp, 4096 * 48));
+        build_roots_device(c->d_roots_brp, c->d_inv_roots_brp, 12, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        // opening key (api.go:104-123): G2 generator and [alpha]G2, Miller-loop lines prepared once
+        G2Aff q0, q1;
+        if (!g2_decompress(q0, c->g2_monomial.data()) || !g2_decompress(q1, c->g2_monomial.data() + 96)) return MKZG_ERR_BAD_TRUSTED_SETUP;
+        g2_prepare(c->g2_gen, q0);
+        g2_prepare(c->g2_alpha, q1);
         return MKZG_OK;
     }();
     if (rc) { mkzg_ctx_free(c); return rc; }
@@ -224,7 +193,7 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, s
     return MKZG_OK;
 }
 
-static int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item) {
+int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item) {
     size_t need = n_items * in_bytes_per_item;
     if (c->h_stage_bytes < need) {
         if (c->h_stage) (void)hipHostFree(c->h_stage);

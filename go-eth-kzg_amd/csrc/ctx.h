@@ -1,0 +1,79 @@
+// ctx.h -- the context object behind the C ABI (internal to libmi355kzg.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/mi355kzg.h"
+#include "msm_kernels.h"
+#include "verify_kernels.h"
+#include "host_g1.hpp"
+
+using namespace kzg;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            fprintf(stderr, "[mi355kzg] HIP error %s at %s:%d: %s\n", hipGetErrorName(e__), __FILE__, __LINE__, #expr); \
+            return MKZG_ERR_HIP;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+struct mkzg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;          // internal stream for host-pointer entry points
+    std::recursive_mutex mu;
+    // SRS
+    std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes
+    uint32_t* d_lagrange_aff = nullptr;    // 4096 affine rows, natural order of the JSON
+    // commit MSM
+    CommitPlan plan;
+    int opt_c = 13;
+    int opt_max_batch = 256;
+    bool plan_ready = false;
+    // staging
+    uint8_t* h_stage = nullptr;            // pinned
+    size_t h_stage_bytes = 0;
+    uint8_t* d_blobs = nullptr;
+    size_t d_blobs_bytes = 0;
+    uint8_t* d_out = nullptr;
+    int* d_status = nullptr;
+    size_t d_out_items = 0;
+    // profiling
+    bool profiling = false;
+    KernelTimer timer;
+    // ---- EIP-4844 proofs / verification
+    uint32_t* d_roots_brp = nullptr;       // 4096 Fr rows (12 words), bit-reversed domain (api.go:132)
+    uint32_t* d_inv_roots_brp = nullptr;
+    G2Prepared g2_gen, g2_alpha;           // prepared [1]G2, [alpha]G2 (kzg.OpeningKey, internal/kzg/srs.go:10-20)
+    // verify workspace, sized for v_cap proofs
+    size_t v_cap = 0;
+    uint8_t* d_v_raw = nullptr;            // 2 v_cap x 48 B   (commitments | proofs)
+    uint32_t* d_v_aff = nullptr;           // 2 v_cap affine rows
+    int* d_v_st = nullptr;                 // 3 v_cap ints (commitments | proofs | blobs)
+    uint32_t* d_v_z = nullptr;             // v_cap Fr rows
+    uint32_t* d_v_y = nullptr;
+    uint32_t* d_v_s1 = nullptr;            // v_cap x 8 words
+    uint32_t* d_v_s3 = nullptr;
+    uint32_t* d_v_misc = nullptr;          // [0..8) r, [8..16) e, [16 .. 16+3*32*48) window sums
+    uint8_t* h_v = nullptr;                // pinned: statuses + misc
+    size_t h_v_bytes = 0;
+    // quotient workspace (proof computation), q_cap blobs
+    size_t q_cap = 0;
+    uint32_t* d_quot = nullptr;            // q_cap x 4096 Fr rows
+    uint32_t* d_q_z = nullptr;
+    uint32_t* d_q_y = nullptr;
+    int* d_q_st = nullptr;
+};
+
+int ensure_plan(mkzg_ctx* c);
+extern "C" int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item);   // defined inside api.hip's extern "C" block
+int ensure_verify_ws(mkzg_ctx* c, size_t n);
+int ensure_quot_ws(mkzg_ctx* c, size_t n);
+void free_verify_ws(mkzg_ctx* c);
+

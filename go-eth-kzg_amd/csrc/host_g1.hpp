@@ -1,0 +1,87 @@
+// host_g1.hpp -- product host code: G1 helpers over HostFp for the verifiers' finishing steps
+// (window-sum Horner combination, [e]G, point negation/addition, affine conversion) -- the
+// handful of group operations per *batch* that reference internal/kzg/kzg_verify.go:160-188
+// performs after its MSMs.  Shares the group law with the device through g1.hpp.
+#pragma once
+#include "g1.hpp"
+#include "host_pairing.hpp"
+
+namespace kzg {
+
+using G1H = G1T<HostFp>;
+using G1HX = G1H::XYZZ;
+
+// device export format: 4 coordinates (X, Y, ZZ, ZZZ) as canonical plain integers, 12 LE 32-bit words each
+inline void g1h_from_plain_words(G1HX& r, const uint32_t* w48) {
+    fe* dst[4] = {&r.x, &r.y, &r.zz, &r.zzz};
+    for (int c = 0; c < 4; c++) {
+        uint64_t v[6];
+        for (int i = 0; i < 6; i++) v[i] = (uint64_t)w48[12 * c + 2 * i] | ((uint64_t)w48[12 * c + 2 * i + 1] << 32);
+        HostFp::from_plain(*dst[c], v);
+    }
+}
+inline void g1h_generator(G1HX& r) {
+    fe x, y;
+    HostFp::set(x, HostFpParams::GEN_X);
+    HostFp::set(y, HostFpParams::GEN_Y);
+    G1H::from_affine(r, x, y);
+}
+// r = [k]p, k as 4 little-endian 64-bit words
+inline void g1h_mul(G1HX& r, const G1HX& p, const uint64_t k[4]) {
+    G1HX acc;
+    G1H::set_inf(acc);
+    for (int i = 255; i >= 0; i--) {
+        G1H::dbl(acc, acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) G1H::add(acc, acc, p);
+    }
+    r = acc;
+}
+inline void g1h_to_affine(G1AffH& r, const G1HX& p) {
+    G1H::Aff a;
+    G1H::to_affine(a, p);
+    r.x = a.x;
+    r.y = a.y;
+    r.inf = a.inf != 0;
+}
+// sum_w 2^(c w) S_w  (Horner from the top window)
+inline void g1h_horner(G1HX& r, const G1HX* sums, int nwin, int c) {
+    G1HX acc;
+    G1H::set_inf(acc);
+    for (int w = nwin - 1; w >= 0; w--) {
+        for (int q = 0; q < c; q++) G1H::dbl(acc, acc);
+        G1H::add(acc, acc, sums[w]);
+    }
+    r = acc;
+}
+// compressed 48 bytes -> affine, curve check only (test helper and G1 inputs of host-only paths)
+inline bool g1h_decompress(G1AffH& o, const uint8_t in[48]) {
+    uint8_t flags = in[0] & 0xe0;
+    if (!(flags & 0x80) || flags == 0xe0) return false;
+    if (flags & 0x40) {
+        if (in[0] & 0x1f) return false;
+        for (int i = 1; i < 48; i++) if (in[i]) return false;
+        HostFp::set_zero(o.x);
+        HostFp::set_zero(o.y);
+        o.inf = true;
+        return true;
+    }
+    uint8_t xb[48];
+    memcpy(xb, in, 48);
+    xb[0] &= 0x1f;
+    fe x, y, rhs, four;
+    if (!HostFp::from_be48(x, xb)) return false;
+    HostFp::sqr(rhs, x);
+    HostFp::mul(rhs, rhs, x);
+    HostFp::set_one(four);
+    HostFp::dbl(four, four);
+    HostFp::dbl(four, four);
+    HostFp::add(rhs, rhs, four);
+    if (!HostFp::sqrt(y, rhs)) return false;
+    if (HostFp::lex_largest(y) != ((flags & 0x20) != 0)) HostFp::neg<0>(y, y);
+    o.x = x;
+    o.y = y;
+    o.inf = false;
+    return true;
+}
+
+}  // namespace kzg

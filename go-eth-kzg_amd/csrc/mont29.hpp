@@ -240,6 +240,7 @@ struct Mont29 {
         }
         r = acc;
     }
+    static KZ_HD void inv(El& r, const El& a) { pow_words(r, a, P::EXP_INV, P::BITS); }   // Fermat; 0 -> 0
 };
 
 using Fp = Mont29<FpParams>;

@@ -120,7 +120,7 @@ struct Recode {
 //                      that the 64 lanes of a wavefront run the same number of additions
 //   ntasks[b], status[b] (0 or MKZG_ERR_NON_CANONICAL_SCALAR)
 // INPUT_KIND 0: 32-byte big-endian scalars (blob bytes).  1: Fr elements in Montgomery radix-2^29
-// form (9 words each, as produced by the on-device quotient kernel).
+// form (rows of 12 words, as produced by the on-device quotient kernel).
 // ------------------------------------------------------------------------------------------
 constexpr int PIECE = 64;
 template <int C>
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(1024) k_digits_sort(const uint8_t* __restrict_
             load_scalar_be(sc[k], scalars + (size_t)b * scalar_stride_bytes + (size_t)i * 32);
             bad |= !scalar_is_canonical(sc[k]);
         } else {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(scalars + (size_t)b * scalar_stride_bytes) + (size_t)i * 9;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(scalars + (size_t)b * scalar_stride_bytes) + (size_t)i * 12;   // 12-word Fr rows
             fr_t m, pl;
 #pragma unroll
             for (int q = 0; q < 9; q++) m.l[q] = src[q];

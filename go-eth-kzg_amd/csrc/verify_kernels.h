@@ -1,0 +1,23 @@
+// verify_kernels.h -- host-visible launch interface of verify_kernels.hip (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mi355kzg.h"
+
+namespace kzg {
+
+// Fr rows are 12 words (9 limbs + padding), affine G1 rows 32 words, as in msm_kernels.hip.
+void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s);
+void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s);
+void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
+                          int* d_status, hipStream_t s);
+void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s);
+void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e, hipStream_t s);
+// n_msm <= 4 jobs of n <= 8192 (scalar, point) pairs; d_out[msm][32 windows][48 words]
+int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, int n_msm, int n, uint32_t* d_out, hipStream_t s);
+void build_roots_device(uint32_t* d_roots_brp, uint32_t* d_inv_roots_brp, int log_n, hipStream_t s);
+void scalars_to_fr_device(const uint8_t* d_in32, int n, uint32_t* d_out12, int* d_status, hipStream_t s);
+void fr_to_scalars_device(const uint32_t* d_in12, int n, uint8_t* d_out32, hipStream_t s);
+constexpr int VMSM_WINDOWS = 32, VMSM_WINDOW_BITS = 8, VMSM_MAX_N = 8192;
+
+}  // namespace kzg

@@ -1,0 +1,680 @@
+// verify_kernels.hip -- device side of the EIP-4844 proof paths on MI355X (gfx950):
+//   VerifyBlobKZGProofBatch  reference verify.go:88-143 + internal/kzg/kzg_verify.go:111-202
+//   ComputeBlobKZGProof / ComputeKZGProof   reference prove.go:46-111 + internal/kzg/kzg_prove.go
+//
+//   k_challenge_sha256   compute_challenge (fiatshamir.go:22-33): one lane per blob streams its
+//                        131,152-byte transcript through SHA-256 (inherently serial per blob;
+//                        blobs are the parallel axis) and reduces the digest mod r.
+//   k_blob_eval          DeserializeBlob + EvaluateLagrangePolynomial (serialization.go:134-146,
+//                        internal/domain/domain.go:193-235): one workgroup per blob, barycentric
+//                        formula over the bit-reversed 4096-domain, batch inversion per lane.
+//   k_blob_quotient      computeQuotientPoly (kzg_prove.go:53-180), both the off-domain and the
+//                        on-domain branch; output feeds the fixed-base MSM of msm_kernels.hip.
+//   k_g1_subgroup_check  the r-torsion test of gnark's SetBytes (serialization.go:108-115) as
+//                        phi(P) == -[x^2]P (Scott 2021), one lane per point.
+//   k_rlc_scalars        utils.ComputePowers + the scalar folds of kzg_verify.go:141-179.
+//   k_vmsm_window        variable-base Pippenger, one workgroup per (MSM, 8-bit window): LDS
+//                        counting sort of Booth digits, one lane per bucket, wavefront-level
+//                        weighted bucket reduction; the per-window sums go to the host, which
+//                        does the 255 serial doublings of the Horner combination.
+// Integer modular arithmetic only -- no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "g1.hpp"
+#include "verify_kernels.h"
+
+namespace kzg {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_affine_v(G1Aff& p, const uint32_t* rec) {
+    const uint4* q = reinterpret_cast<const uint4*>(rec);
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) { p.x.l[i] = w[i]; p.y.l[i] = w[14 + i]; }
+    p.inf = w[28];
+}
+__device__ __noinline__ void g1x_add_nv(G1X& r, const G1X& a, const G1X& b) { g1x_add(r, a, b); }
+__device__ __noinline__ void g1x_dbl_nv(G1X& r, const G1X& a) { g1x_dbl(r, a); }
+__device__ __noinline__ void g1x_madd_nv(G1X& acc, const fp_t& x, const fp_t& y) { g1x_madd(acc, x, y); }
+
+// Fr table rows are padded to 12 words (48 B) for 16-byte loads
+__device__ __forceinline__ void load_fr12(fr_t& r, const uint32_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1], c = q[2];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
+}
+__device__ __forceinline__ void store_fr12(uint32_t* p, const fr_t& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]);
+    q[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
+    q[2] = make_uint4(r.l[8], 0, 0, 0);
+}
+__device__ __forceinline__ void load_be32_words(uint32_t w[8], const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 hi = q[0], lo = q[1];
+    w[7] = __builtin_bswap32(hi.x); w[6] = __builtin_bswap32(hi.y); w[5] = __builtin_bswap32(hi.z); w[4] = __builtin_bswap32(hi.w);
+    w[3] = __builtin_bswap32(lo.x); w[2] = __builtin_bswap32(lo.y); w[1] = __builtin_bswap32(lo.z); w[0] = __builtin_bswap32(lo.w);
+}
+// canonical words (value < r) -> Montgomery
+__device__ __forceinline__ void fr_from_words(fr_t& r, const uint32_t w[8]) {
+    fr_t pl;
+    Fr::from_words32(pl, w);
+    fr_t t;
+    Fr::from_plain(t, pl);
+    Fr::reduce_once(r, t);
+}
+__device__ __noinline__ void fr_mul_n(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
+__device__ __noinline__ void fr_inv_n(fr_t& r, const fr_t& a) {
+    fr_t t;
+    Fr::pow_words(t, a, FrParams::EXP_INV, FrParams::BITS);
+    Fr::reduce_once(r, t);
+}
+
+// ------------------------------------------------------------------------------------------
+// SHA-256 (FIPS 180-4), one lane per message
+// ------------------------------------------------------------------------------------------
+__device__ __constant__ uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe,
+    0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7,
+    0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b,
+    0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3,
+    0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+            uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25);
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t t1 = hh + S1 + ch + SHA_K[i] + w[i & 15];
+        uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22);
+        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+__device__ __forceinline__ void load16_be(uint32_t* w, const uint8_t* p) {   // 16 bytes -> 4 big-endian words
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    w[0] = __builtin_bswap32(v.x); w[1] = __builtin_bswap32(v.y); w[2] = __builtin_bswap32(v.z); w[3] = __builtin_bswap32(v.w);
+}
+
+// z_b = SHA256("FSBLOBVERIFY_V1_" || u128be(4096) || blob_b || commitment_b) mod r   (Montgomery rows)
+__global__ void __launch_bounds__(64) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n) return;
+    const uint8_t* blob = blobs + (size_t)b * 131072;
+    const uint8_t* cm = commitments48 + (size_t)b * 48;
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    uint32_t w[16];
+    // block 0: domain separator, degree, blob[0..32)
+    w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;   // "FSBLOBVERIFY_V1_"
+    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = 4096;
+    load16_be(w + 8, blob);
+    load16_be(w + 12, blob + 16);
+    sha256_compress(h, w);
+    // blocks 1..2047: blob[64k-32 .. 64k+32)
+    for (int k = 1; k < 2048; k++) {
+        const uint8_t* p = blob + 64 * k - 32;
+        load16_be(w, p);
+        load16_be(w + 4, p + 16);
+        load16_be(w + 8, p + 32);
+        load16_be(w + 12, p + 48);
+        sha256_compress(h, w);
+    }
+    // block 2048: blob[131040..131072) || commitment[0..32)
+    load16_be(w, blob + 131040);
+    load16_be(w + 4, blob + 131056);
+    load16_be(w + 8, cm);
+    load16_be(w + 12, cm + 16);
+    sha256_compress(h, w);
+    // block 2049: commitment[32..48) || 0x80 || zeros || bit length (131152 * 8)
+    load16_be(w, cm + 32);
+    w[4] = 0x80000000u;
+#pragma unroll
+    for (int i = 5; i < 15; i++) w[i] = 0;
+    w[15] = 131152u * 8u;
+    sha256_compress(h, w);
+    // digest (big-endian h[0..7]) as little-endian words, reduced mod r (2^256 < 3r: at most two subtractions)
+    uint32_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = h[7 - i];
+    for (int rep = 0; rep < 2; rep++) {
+        if (Fr::words32_geq_mod(v)) {
+            uint64_t br = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                uint64_t t = (uint64_t)v[i] - FrParams::MOD32[i] - br;
+                v[i] = (uint32_t)t;
+                br = (t >> 32) & 1;
+            }
+        }
+    }
+    fr_t z;
+    fr_from_words(z, v);
+    store_fr12(z_out + (size_t)b * 12, z);
+}
+
+// ------------------------------------------------------------------------------------------
+// barycentric evaluation / quotient: one 256-thread workgroup per blob, 16 scalars per lane
+// ------------------------------------------------------------------------------------------
+constexpr int EV_T = 256, EV_PER = 16;
+
+// block-wide sum of one Fr per thread (result valid in thread 0)
+__device__ __forceinline__ void block_sum_fr(fr_t& v, uint32_t* sh /* EV_T*9 words */) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 9; q++) sh[q * EV_T + t] = v.l[q];
+    __syncthreads();
+    for (int s = EV_T / 2; s >= 1; s >>= 1) {
+        if (t < s) {
+            fr_t a, b2;
+#pragma unroll
+            for (int q = 0; q < 9; q++) { a.l[q] = sh[q * EV_T + t]; b2.l[q] = sh[q * EV_T + t + s]; }
+            FrC::add(a, a, b2);
+#pragma unroll
+            for (int q = 0; q < 9; q++) sh[q * EV_T + t] = a.l[q];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) v.l[q] = sh[q * EV_T];
+    __syncthreads();
+}
+
+// MODE 0: y_b = f_b(z_b)                                  -> y_out
+// MODE 1: q_b = (f_b - y_b)/(X - z_b) in evaluation form   -> quot_out (4096 rows of 12 words), also y_out
+// z comes from z_in (rows of 12 words); if y_given != nullptr MODE 1 trusts it (not used).
+template <int MODE>
+__global__ void __launch_bounds__(EV_T) k_blob_eval(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ z_in, const uint32_t* __restrict__ roots_brp,
+                                                    const uint32_t* __restrict__ inv_roots_brp, uint32_t* __restrict__ y_out, uint32_t* __restrict__ quot_out,
+                                                    int* __restrict__ status) {
+    __shared__ uint32_t sh[EV_T * 9];
+    __shared__ int sh_found;
+    __shared__ int sh_bad;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint8_t* blob = blobs + (size_t)b * 131072;
+    if (t == 0) { sh_found = -1; sh_bad = 0; }
+    __syncthreads();
+    fr_t z;
+    load_fr12(z, z_in + (size_t)b * 12);
+
+    // pass 1: canonical check, d_i = z - w_i, per-lane prefix products (zeros skipped)
+    fr_t pre[EV_PER];
+    fr_t acc;
+    Fr::set_one(acc);
+    bool bad = false;
+    int found = -1;
+#pragma unroll
+    for (int k = 0; k < EV_PER; k++) {
+        const int i = t + EV_T * k;
+        uint32_t w[8];
+        load_be32_words(w, blob + (size_t)i * 32);
+        bad |= Fr::words32_geq_mod(w);
+        fr_t wi, d;
+        load_fr12(wi, roots_brp + (size_t)i * 12);
+        FrC::sub(d, z, wi);
+        if (Fr::limbs_all_zero(d)) found = i;
+        else fr_mul_n(acc, acc, d);
+        pre[k] = acc;
+    }
+    if (bad) sh_bad = 1;
+    if (found >= 0) sh_found = found;
+    __syncthreads();
+    if (sh_bad) {
+        if (t == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
+        return;
+    }
+    const int fidx = sh_found;
+    if (t == 0) status[b] = 0;
+
+    if (MODE == 0 && fidx >= 0) {
+        // z is a domain point: the value is the corresponding evaluation (domain.go:204-207)
+        if (t == 0) {
+            uint32_t w[8];
+            load_be32_words(w, blob + (size_t)fidx * 32);
+            fr_t f;
+            fr_from_words(f, w);
+            store_fr12(y_out + (size_t)b * 12, f);
+        }
+        return;
+    }
+
+    fr_t inv;
+    fr_inv_n(inv, acc);   // 1 / prod d_i over this lane's non-zero d_i
+
+    if (MODE == 0 || fidx < 0) {
+        // sum_i f_i w_i / (z - w_i)
+        fr_t part;
+        Fr::set_zero(part);
+#pragma unroll
+        for (int k = EV_PER - 1; k >= 0; k--) {
+            const int i = t + EV_T * k;
+            fr_t wi, d, di, f, term;
+            load_fr12(wi, roots_brp + (size_t)i * 12);
+            FrC::sub(d, z, wi);
+            if (k > 0) fr_mul_n(di, inv, pre[k - 1]); else di = inv;
+            fr_mul_n(inv, inv, d);
+            uint32_t w[8];
+            load_be32_words(w, blob + (size_t)i * 32);
+            fr_from_words(f, w);
+            fr_mul_n(term, f, wi);
+            fr_mul_n(term, term, di);
+            FrC::add(part, part, term);
+            if (MODE == 1) pre[k] = di;   // keep 1/(z - w_i) for the quotient
+        }
+        block_sum_fr(part, sh);
+        // y = (z^4096 - 1)/4096 * sum
+        fr_t y;
+        {
+            fr_t zp = z, one, c;
+#pragma unroll 1
+            for (int s = 0; s < 12; s++) fr_mul_n(zp, zp, zp);
+            Fr::set_one(one);
+            FrC::sub(zp, zp, one);
+            Fr::set(c, FR_INV_4096);
+            fr_mul_n(zp, zp, c);
+            fr_mul_n(y, zp, part);
+        }
+        if (t == 0) store_fr12(y_out + (size_t)b * 12, y);
+        if (MODE == 1) {
+            // q_i = (f_i - y) / (w_i - z) = (y - f_i) * 1/(z - w_i)          (kzg_prove.go:81-112)
+#pragma unroll
+            for (int k = 0; k < EV_PER; k++) {
+                const int i = t + EV_T * k;
+                uint32_t w[8];
+                load_be32_words(w, blob + (size_t)i * 32);
+                fr_t f, q;
+                fr_from_words(f, w);
+                FrC::sub(f, y, f);
+                fr_mul_n(q, f, pre[k]);
+                store_fr12(quot_out + ((size_t)b * 4096 + i) * 12, q);
+            }
+        }
+        return;
+    }
+
+    // MODE 1 and z = w_m is in the domain (kzg_prove.go:118-180): y = f_m,
+    //   q_j = (f_j - y)/(w_j - w_m) (j != m),   q_m = sum_{j != m} -q_j w_j / w_m
+    {
+        fr_t y;
+        {
+            uint32_t w[8];
+            load_be32_words(w, blob + (size_t)fidx * 32);
+            fr_from_words(y, w);
+        }
+        if (t == 0) store_fr12(y_out + (size_t)b * 12, y);
+        fr_t part;
+        Fr::set_zero(part);
+#pragma unroll
+        for (int k = EV_PER - 1; k >= 0; k--) {
+            const int i = t + EV_T * k;
+            fr_t wi, d, di, f, q, term;
+            load_fr12(wi, roots_brp + (size_t)i * 12);
+            FrC::sub(d, z, wi);
+            const bool self = (i == fidx);
+            if (!self) {
+                // pre[] skipped the zero, so the chain is consistent: previous prefix is pre[k-1]
+                if (k > 0) fr_mul_n(di, inv, pre[k - 1]); else di = inv;
+                fr_mul_n(inv, inv, d);
+                uint32_t w[8];
+                load_be32_words(w, blob + (size_t)i * 32);
+                fr_from_words(f, w);
+                FrC::sub(f, y, f);               // y - f_i
+                fr_mul_n(q, f, di);              // (y - f_i)/(z - w_i) = (f_i - y)/(w_i - z)
+                store_fr12(quot_out + ((size_t)b * 4096 + i) * 12, q);
+                fr_mul_n(term, q, wi);
+                FrC::sub(part, part, term);      // accumulate -q_j w_j
+            }
+        }
+        block_sum_fr(part, sh);
+        if (t == 0) {
+            fr_t iw, qm;
+            load_fr12(iw, inv_roots_brp + (size_t)fidx * 12);
+            fr_mul_n(qm, part, iw);
+            store_fr12(quot_out + ((size_t)b * 4096 + fidx) * 12, qm);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// G1 subgroup membership: phi(P) == -[x^2]P, one lane per affine row; st[i] |= NOT_IN_SUBGROUP
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __restrict__ aff, int n, int* __restrict__ st) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    if (st[i] != 0) return;
+    G1Aff p;
+    load_affine_v(p, aff + (size_t)i * 32);
+    if (p.inf) return;
+    // T = [|x|]P, Q = [|x|]T   (|x| = 0xd201000000010000, top bit at 63)
+    G1X T, Q;
+    g1x_from_affine(T, p.x, p.y);
+    for (int bit = 62; bit >= 0; bit--) {
+        g1x_dbl_nv(T, T);
+        if ((BLS_X_ABS >> bit) & 1) g1x_madd_nv(T, p.x, p.y);
+    }
+    Q = T;
+    for (int bit = 62; bit >= 0; bit--) {
+        g1x_dbl_nv(Q, Q);
+        if ((BLS_X_ABS >> bit) & 1) g1x_add_nv(Q, Q, T);
+    }
+    // phi(P) = (beta x, y) must equal -Q = (X, -Y, ZZ, ZZZ):   beta x ZZ == X  and  y ZZZ == -Y
+    bool ok;
+    if (g1x_is_inf(Q)) {
+        ok = false;
+    } else {
+        fp_t beta, l, r;
+        Fp::set(beta, FP_BETA);
+        Fp::mul(l, beta, p.x);
+        Fp::mul(l, l, Q.zz);
+        ok = Fp::eq_mod(l, Q.x);
+        Fp::mul(l, p.y, Q.zzz);
+        Fp::template neg<2>(r, Q.y);
+        ok = ok && Fp::eq_mod(l, r);
+    }
+    if (!ok) st[i] = MKZG_ERR_G1_NOT_IN_SUBGROUP;
+}
+
+// ------------------------------------------------------------------------------------------
+// RLC scalars (single workgroup): r -> r^i ; s1_i = r^i ; s3_i = r^i z_i ; e = sum r^i y_i
+// outputs as plain little-endian 8-word scalars
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(EV_T) k_rlc_scalars(const uint32_t* __restrict__ r_words8, const uint32_t* __restrict__ z_in, const uint32_t* __restrict__ y_in, int n,
+                                                      uint32_t* __restrict__ s1, uint32_t* __restrict__ s3, uint32_t* __restrict__ e_out) {
+    __shared__ uint32_t sh[EV_T * 9];
+    const int t = threadIdx.x;
+    uint32_t rw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rw[i] = r_words8[i];
+    for (int rep = 0; rep < 2; rep++) {
+        if (Fr::words32_geq_mod(rw)) {
+            uint64_t br = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { uint64_t v = (uint64_t)rw[i] - FrParams::MOD32[i] - br; rw[i] = (uint32_t)v; br = (v >> 32) & 1; }
+        }
+    }
+    fr_t r;
+    fr_from_words(r, rw);
+    fr_t part;
+    Fr::set_zero(part);
+    for (int i = t; i < n; i += EV_T) {
+        // r^i by square-and-multiply on the (small) exponent i
+        fr_t rp, base = r;
+        Fr::set_one(rp);
+        Fr::reduce_once(rp, rp);
+        for (uint32_t e = (uint32_t)i; e; e >>= 1) {
+            if (e & 1) fr_mul_n(rp, rp, base);
+            fr_mul_n(base, base, base);
+        }
+        fr_t z, y, rz, ry, pl;
+        load_fr12(z, z_in + (size_t)i * 12);
+        load_fr12(y, y_in + (size_t)i * 12);
+        fr_mul_n(rz, rp, z);
+        fr_mul_n(ry, rp, y);
+        FrC::add(part, part, ry);
+        uint32_t w[8];
+        Fr::to_plain(pl, rp);
+        Fr::to_words32(w, pl);
+#pragma unroll
+        for (int q = 0; q < 8; q++) s1[(size_t)i * 8 + q] = w[q];
+        Fr::to_plain(pl, rz);
+        Fr::to_words32(w, pl);
+#pragma unroll
+        for (int q = 0; q < 8; q++) s3[(size_t)i * 8 + q] = w[q];
+    }
+    block_sum_fr(part, sh);
+    if (t == 0) {
+        fr_t pl;
+        uint32_t w[8];
+        Fr::to_plain(pl, part);
+        Fr::to_words32(w, pl);
+#pragma unroll
+        for (int q = 0; q < 8; q++) e_out[q] = w[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// variable-base MSM: one 128-thread workgroup per (window, msm).  8-bit Booth windows, 128 signed
+// buckets.  scalars: n x 8 plain words; points: n affine rows.  Output: per-window sum as 4
+// canonical plain coordinates (X, Y, ZZ, ZZZ; 12 words each) -> 48 words.
+// ------------------------------------------------------------------------------------------
+constexpr int VC = 8, VNB = 128, VNWIN = 32, VMAXN = 8192;
+
+__device__ __forceinline__ void shfl_down_xyzz_v(G1X& r, const G1X& a, int d) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.x.l[i] = __shfl_down(a.x.l[i], d);
+        r.y.l[i] = __shfl_down(a.y.l[i], d);
+        r.zz.l[i] = __shfl_down(a.zz.l[i], d);
+        r.zzz.l[i] = __shfl_down(a.zzz.l[i], d);
+    }
+}
+
+struct VmsmJob {
+    const uint32_t* scalars;   // n x 8 words
+    const uint32_t* points;    // n affine rows (32 words)
+};
+struct VmsmJobs { VmsmJob j[4]; };
+
+__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, int n, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
+    __shared__ uint32_t ent[VMAXN];
+    __shared__ uint32_t hist[VNB + 1];
+    __shared__ uint32_t cursor[VNB];
+    __shared__ uint32_t xchg[2 * 56];
+    const int w = blockIdx.x, m = blockIdx.y, t = threadIdx.x;
+    const uint32_t* sc = jobs.j[m].scalars;
+    const uint32_t* pts = jobs.j[m].points;
+    hist[t] = 0;
+    if (t == 0) hist[VNB] = 0;
+    __syncthreads();
+    // Booth digit of window w: v = bits [8w-1, 8w+8) ; d = ((v+1)>>1) - (v>>8 ? 256 : 0)
+    auto digit = [&](int i) -> int {
+        const uint32_t* s = sc + (size_t)i * 8;
+        const int bit = VC * w - 1;
+        uint32_t v;
+        if (bit < 0) {
+            v = (s[0] << 1) & 0x1ffu;
+        } else {
+            const int wi = bit >> 5, off = bit & 31;
+            v = s[wi] >> off;
+            if (off + VC + 1 > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - off);
+            v &= 0x1ffu;
+        }
+        int d = (int)((v + 1) >> 1);
+        if (v >> VC) d -= (1 << VC);
+        return d;
+    };
+    for (int i = t; i < n; i += VNB) {
+        int d = digit(i);
+        if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < VNB; k++) { uint32_t c = hist[k]; hist[k] = run; cursor[k] = run; run += c; }
+        hist[VNB] = run;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += VNB) {
+        int d = digit(i);
+        if (d != 0) {
+            uint32_t slot = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
+            ent[slot] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+    __syncthreads();
+    // bucket t
+    G1X acc;
+    g1x_set_inf(acc);
+    for (uint32_t e = hist[t]; e < hist[t + 1]; e++) {
+        const uint32_t v = ent[e];
+        G1Aff p;
+        load_affine_v(p, pts + (size_t)(v & 0x7fffffffu) * 32);
+        if (p.inf) continue;
+        if (v >> 31) Fp::template neg<0>(p.y, p.y);
+        g1x_madd_nv(acc, p.x, p.y);
+    }
+    // per wave (64 buckets): S = sum B_l ; Q = sum l B_l  via suffix scan + tree
+    const int lane = t & 63, wave = t >> 6;
+    G1X Pf = acc, o;
+    for (int d = 1; d < 64; d <<= 1) {
+        shfl_down_xyzz_v(o, Pf, d);
+        if (lane + d < 64) g1x_add_nv(Pf, Pf, o);
+    }
+    G1X S = Pf;                    // lane 0: sum of the wave's buckets
+    if (lane == 0) g1x_set_inf(Pf);
+    for (int d = 32; d >= 1; d >>= 1) {
+        shfl_down_xyzz_v(o, Pf, d);
+        if (lane < d) g1x_add_nv(Pf, Pf, o);
+    }
+    // lane 0 of each wave now holds S_w (in S) and Q_w (in Pf)
+    if (wave == 1 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            xchg[i] = S.x.l[i]; xchg[14 + i] = S.y.l[i]; xchg[28 + i] = S.zz.l[i]; xchg[42 + i] = S.zzz.l[i];
+            xchg[56 + i] = Pf.x.l[i]; xchg[70 + i] = Pf.y.l[i]; xchg[84 + i] = Pf.zz.l[i]; xchg[98 + i] = Pf.zzz.l[i];
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        // total = sum_k (k+1) B_k = (S_0 + Q_0) + (65 S_1 + Q_1)
+        G1X S1, Q1, tot;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            S1.x.l[i] = xchg[i]; S1.y.l[i] = xchg[14 + i]; S1.zz.l[i] = xchg[28 + i]; S1.zzz.l[i] = xchg[42 + i];
+            Q1.x.l[i] = xchg[56 + i]; Q1.y.l[i] = xchg[70 + i]; Q1.zz.l[i] = xchg[84 + i]; Q1.zzz.l[i] = xchg[98 + i];
+        }
+        g1x_add_nv(tot, S, Pf);
+        g1x_add_nv(tot, tot, Q1);
+        g1x_add_nv(tot, tot, S1);
+        for (int q = 0; q < 6; q++) g1x_dbl_nv(S1, S1);
+        g1x_add_nv(tot, tot, S1);
+        // export canonical plain coordinates
+        uint32_t* dst = out + ((size_t)m * VNWIN + w) * 48;
+        fp_t c;
+        uint32_t ww[12];
+        const fp_t* src[4] = {&tot.x, &tot.y, &tot.zz, &tot.zzz};
+        for (int k = 0; k < 4; k++) {
+            if (g1x_is_inf(tot)) {
+                for (int q = 0; q < 12; q++) dst[12 * k + q] = 0;
+            } else {
+                Fp::to_plain(c, *src[k]);
+                Fp::to_words32(ww, c);
+                for (int q = 0; q < 12; q++) dst[12 * k + q] = ww[q];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// set-up: bit-reversed 4096-domain roots and their inverses (Montgomery rows of 12 words)
+// (reference internal/domain/domain.go:51-98 + ReverseRoots, api.go:132)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_build_roots(uint32_t* __restrict__ roots_brp, uint32_t* __restrict__ inv_roots_brp, int log_n) {
+    const int n = 1 << log_n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // generator of the order-n subgroup: root_2^32 ^ (2^(32-log_n))
+    fr_t g;
+    Fr::set(g, FR_ROOT_2_32);
+    Fr::reduce_once(g, g);
+    for (int s = 0; s < 32 - log_n; s++) fr_mul_n(g, g, g);
+    // w^i
+    fr_t acc, base = g;
+    Fr::set_one(acc);
+    Fr::reduce_once(acc, acc);
+    for (uint32_t e = (uint32_t)i; e; e >>= 1) {
+        if (e & 1) fr_mul_n(acc, acc, base);
+        fr_mul_n(base, base, base);
+    }
+    const int pos = (int)(__brev((uint32_t)i) >> (32 - log_n));
+    store_fr12(roots_brp + (size_t)pos * 12, acc);
+    // inverse = w^(n-i)
+    fr_t inv, b2 = g;
+    Fr::set_one(inv);
+    Fr::reduce_once(inv, inv);
+    for (uint32_t e = (uint32_t)((n - i) & (n - 1)); e; e >>= 1) {
+        if (e & 1) fr_mul_n(inv, inv, b2);
+        fr_mul_n(b2, b2, b2);
+    }
+    store_fr12(inv_roots_brp + (size_t)pos * 12, inv);
+}
+
+// 32-byte big-endian scalars -> Montgomery rows (canonical check); used for caller-supplied z, y
+__global__ void __launch_bounds__(64) k_scalars_to_fr(const uint8_t* __restrict__ in32, int n, uint32_t* __restrict__ out12, int* __restrict__ st) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[8];
+    load_be32_words(w, in32 + (size_t)i * 32);
+    if (Fr::words32_geq_mod(w)) { st[i] = MKZG_ERR_NON_CANONICAL_SCALAR; return; }
+    st[i] = 0;
+    fr_t f;
+    fr_from_words(f, w);
+    store_fr12(out12 + (size_t)i * 12, f);
+}
+// Montgomery rows -> 32-byte big-endian scalars
+__global__ void __launch_bounds__(64) k_fr_to_scalars(const uint32_t* __restrict__ in12, int n, uint8_t* __restrict__ out32) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    fr_t f, pl;
+    load_fr12(f, in12 + (size_t)i * 12);
+    Fr::to_plain(pl, f);
+    uint32_t w[8];
+    Fr::to_words32(w, pl);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out32 + (size_t)i * 32);
+#pragma unroll
+    for (int q = 0; q < 8; q++) o[q] = __builtin_bswap32(w[7 - q]);
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(64), 0, s, d_blobs, d_commitments, n, d_z);
+}
+void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EV_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);
+}
+void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
+                          int* d_status, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL((k_blob_eval<1>), dim3(n), dim3(EV_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, d_quot, d_status);
+}
+void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_g1_subgroup_check, dim3((n + 63) / 64), dim3(64), 0, s, d_aff, n, d_status);
+}
+void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e, hipStream_t s) {
+    hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, d_s1, d_s3, d_e);
+}
+int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, int n_msm, int n, uint32_t* d_out, hipStream_t s) {
+    if (n_msm < 1 || n_msm > 4 || n < 0 || n > VMAXN) return -1;
+    VmsmJobs jobs;
+    for (int m = 0; m < 4; m++) { jobs.j[m].scalars = d_scalars[m < n_msm ? m : 0]; jobs.j[m].points = d_points[m < n_msm ? m : 0]; }
+    hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm), dim3(VNB), 0, s, jobs, n, d_out);
+    return 0;
+}
+void build_roots_device(uint32_t* d_roots_brp, uint32_t* d_inv_roots_brp, int log_n, hipStream_t s) {
+    int n = 1 << log_n;
+    hipLaunchKernelGGL(k_build_roots, dim3((n + 255) / 256), dim3(256), 0, s, d_roots_brp, d_inv_roots_brp, log_n);
+}
+void scalars_to_fr_device(const uint8_t* d_in32, int n, uint32_t* d_out12, int* d_status, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_scalars_to_fr, dim3((n + 63) / 64), dim3(64), 0, s, d_in32, n, d_out12, d_status);
+}
+void fr_to_scalars_device(const uint32_t* d_in12, int n, uint8_t* d_out32, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_fr_to_scalars, dim3((n + 63) / 64), dim3(64), 0, s, d_in12, n, d_out32);
+}
+
+}  // namespace kzg

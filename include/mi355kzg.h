@@ -82,6 +82,24 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* ctx, const void* d_blobs,
  * Mirrors kzg.CommitKey.Commit's length check (reference internal/kzg/srs.go:56-62). */
 int mkzg_commit_lagrange(mkzg_ctx* ctx, const uint8_t* scalars32, size_t n, int num_threads, uint8_t out48[48]);
 
+/* Context.ComputeKZGProof (reference prove.go:85-111): proof and claimed value y = f(z). */
+int mkzg_compute_kzg_proof(mkzg_ctx* ctx, const uint8_t* blob, const uint8_t z32[32], int num_threads, uint8_t proof48[48], uint8_t y32[32]);
+/* Context.ComputeBlobKZGProof (reference prove.go:46-77). */
+int mkzg_compute_blob_kzg_proof(mkzg_ctx* ctx, const uint8_t* blob, const uint8_t commitment48[48], int num_threads, uint8_t out48[48]);
+/* same for a device-resident batch (blobs n x 131072 B, commitments n x 48 B -> proofs n x 48 B, per-item status) */
+int mkzg_compute_blob_kzg_proof_batch_device(mkzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, size_t n, void* d_proofs48, int* d_status, void* stream);
+/* Context.VerifyKZGProof (reference verify.go:12-43). */
+int mkzg_verify_kzg_proof(mkzg_ctx* ctx, const uint8_t commitment48[48], const uint8_t z32[32], const uint8_t y32[32], const uint8_t proof48[48]);
+/* Context.VerifyBlobKZGProof (reference verify.go:48-83). */
+int mkzg_verify_blob_kzg_proof(mkzg_ctx* ctx, const uint8_t* blob, const uint8_t commitment48[48], const uint8_t proof48[48]);
+/* Context.VerifyBlobKZGProofBatch (reference verify.go:88-143; also covers ...BatchPar, verify.go:152-169,
+ * which must return the same verdict).  blobs: array of host pointers; the three counts mirror the
+ * three Go slices (mismatch -> MKZG_ERR_BATCH_LENGTH).  At most 8192 proofs per call. */
+int mkzg_verify_blob_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n_blobs, size_t n_comm,
+                                     size_t n_proofs);
+/* same, inputs contiguous in HBM; synchronises `stream` internally (the verdict needs the host pairing). */
+int mkzg_verify_blob_kzg_proof_batch_device(mkzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n, void* stream);
+
 /* ---- profiling hooks (bench.py's roofline section) ------------------------------------------ */
 /* When enabled, every kernel launch of the hot path is bracketed by hipEvents on its stream. */
 int mkzg_profile_enable(mkzg_ctx* ctx, int on);

@@ -1,0 +1,37 @@
+// tests/host_shim/pairing_shim.cpp -- exposes the product's HOST pairing / G1 code
+// (go-eth-kzg_amd/csrc/host_pairing.hpp, host_g1.hpp) to Python for CPU-side unit tests.
+#include "../../go-eth-kzg_amd/csrc/host_g1.hpp"
+using namespace kzg;
+extern "C" {
+// prod e(P_i, Q_i) == 1 ?  P: n x 48 B compressed, Q: n x 96 B compressed.  -1 on decode error.
+int shim_pairing_check(const uint8_t* p48, const uint8_t* q96, int n) {
+    std::vector<G1AffH> ps(n);
+    std::vector<G2Prepared> prep(n);
+    std::vector<const G2Prepared*> qp(n);
+    for (int i = 0; i < n; i++) {
+        if (!g1h_decompress(ps[i], p48 + 48 * i)) return -1;
+        G2Aff q;
+        if (!g2_decompress(q, q96 + 96 * i)) return -2;
+        g2_prepare(prep[i], q);
+        qp[i] = &prep[i];
+    }
+    return pairing_check_prepared(ps.data(), qp.data(), n) ? 1 : 0;
+}
+// [k]P for compressed P, k = 32-byte little-endian words; returns affine x,y as 2x48 big-endian + inf flag
+int shim_g1_mul(const uint8_t* p48, const uint64_t* k, uint8_t* out_xy96) {
+    G1AffH a;
+    if (!g1h_decompress(a, p48)) return -1;
+    G1HX p, r;
+    if (a.inf) G1H::set_inf(p); else G1H::from_affine(p, a.x, a.y);
+    g1h_mul(r, p, k);
+    G1AffH o;
+    g1h_to_affine(o, r);
+    if (o.inf) return 1;
+    uint64_t v[6];
+    HostFp::to_plain(v, o.x);
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 8; j++) out_xy96[(5 - i) * 8 + j] = (uint8_t)(v[i] >> (56 - 8 * j));
+    HostFp::to_plain(v, o.y);
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 8; j++) out_xy96[48 + (5 - i) * 8 + j] = (uint8_t)(v[i] >> (56 - 8 * j));
+    return 0;
+}
+}

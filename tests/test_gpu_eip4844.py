@@ -1,0 +1,150 @@
+"""GPU parity tests of the EIP-4844 proof paths through the C ABI: ComputeKZGProof,
+ComputeBlobKZGProof, VerifyKZGProof, VerifyBlobKZGProof, VerifyBlobKZGProofBatch.
+
+Rules restated from the reference's consensus_specs_test.go:72-359: compute outputs byte-for-byte;
+verifiers: output true <=> rc == 0, false <=> rc == MKZG_VERIFY_FAILED (1), null <=> input error.
+"""
+import pytest
+
+from test_gpu_commit import rand_blob
+
+pytestmark = pytest.mark.gpu
+VERIFY_FAILED = 1
+
+
+def _bad(*vals):
+    from conftest import BadHex
+    return any(isinstance(v, BadHex) for v in vals)
+
+
+def _wrong_len(val, n):
+    return not _bad(val) and len(val) != n
+
+
+def _check_verifier(rc, expected, name):
+    if expected is None:
+        assert rc not in (0, VERIFY_FAILED), f"{name}: expected input error, got rc={rc}"
+    elif expected is True:
+        assert rc == 0, f"{name}: expected accept, got rc={rc}"
+    else:
+        assert rc == VERIFY_FAILED, f"{name}: expected reject, got rc={rc}"
+
+
+def test_compute_kzg_proof(vectors, gpu_ctx):
+    n_ok = 0
+    for c in vectors.cases("compute_kzg_proof"):
+        blob, z = vectors.val(c["input"]["blob"]), vectors.val(c["input"]["z"])
+        exp = vectors.val(c["output"])
+        if _bad(blob, z) or len(blob) != 131072 or len(z) != 32:
+            assert exp is None
+            continue
+        rc, proof, y = gpu_ctx.ComputeKZGProof(blob, z)
+        if exp is None:
+            assert rc != 0, c["name"]
+        else:
+            assert rc == 0 and proof == exp[0] and y == exp[1], c["name"]
+            n_ok += 1
+    assert n_ok > 30
+
+
+def test_compute_blob_kzg_proof(vectors, gpu_ctx):
+    n_ok = 0
+    for c in vectors.cases("compute_blob_kzg_proof"):
+        blob, cm = vectors.val(c["input"]["blob"]), vectors.val(c["input"]["commitment"])
+        exp = vectors.val(c["output"])
+        if _bad(blob, cm) or len(blob) != 131072 or len(cm) != 48:
+            assert exp is None
+            continue
+        rc, proof = gpu_ctx.ComputeBlobKZGProof(blob, cm)
+        if exp is None:
+            assert rc != 0, c["name"]
+        else:
+            assert rc == 0 and proof == exp, c["name"]
+            n_ok += 1
+    assert n_ok == 7
+
+
+def test_verify_kzg_proof(vectors, gpu_ctx):
+    n = 0
+    for c in vectors.cases("verify_kzg_proof"):
+        i = c["input"]
+        cm, z, y, pr = (vectors.val(i[k]) for k in ("commitment", "z", "y", "proof"))
+        exp = vectors.val(c["output"])
+        if _bad(cm, z, y, pr) or len(cm) != 48 or len(pr) != 48 or len(z) != 32 or len(y) != 32:
+            assert exp is None
+            continue
+        _check_verifier(gpu_ctx.VerifyKZGProof(cm, z, y, pr), exp, c["name"])
+        n += 1
+    assert n > 100
+
+
+def test_verify_blob_kzg_proof(vectors, gpu_ctx):
+    for c in vectors.cases("verify_blob_kzg_proof"):
+        i = c["input"]
+        blob, cm, pr = (vectors.val(i[k]) for k in ("blob", "commitment", "proof"))
+        exp = vectors.val(c["output"])
+        if _bad(blob, cm, pr) or len(blob) != 131072 or len(cm) != 48 or len(pr) != 48:
+            assert exp is None
+            continue
+        _check_verifier(gpu_ctx.VerifyBlobKZGProof(blob, cm, pr), exp, c["name"])
+
+
+def test_verify_blob_kzg_proof_batch(vectors, gpu_ctx):
+    for c in vectors.cases("verify_blob_kzg_proof_batch"):
+        i = c["input"]
+        blobs, cms, prs = (vectors.val(i[k]) for k in ("blobs", "commitments", "proofs"))
+        exp = vectors.val(c["output"])
+        if _bad(*blobs, *cms, *prs) or any(len(b) != 131072 for b in blobs) or any(len(x) != 48 for x in cms) or any(len(x) != 48 for x in prs):
+            assert exp is None
+            continue
+        _check_verifier(gpu_ctx.VerifyBlobKZGProofBatch(blobs, cms, prs), exp, c["name"])
+
+
+def test_roundtrip_vs_oracle(gpu_ctx, oracle_ctx):
+    """commit -> prove -> verify on GetRandBlob inputs (reference examples_test.go:13-53), each step
+    bit-compared with the oracle; then a corrupted batch must be rejected."""
+    blobs = [rand_blob(s) for s in range(5)]
+    cms, prs = [], []
+    for b in blobs:
+        rc, cm = gpu_ctx.BlobToKZGCommitment(b)
+        assert rc == 0 and cm == oracle_ctx.blob_to_kzg_commitment(b)[1]
+        rc, pr = gpu_ctx.ComputeBlobKZGProof(b, cm)
+        assert rc == 0 and pr == oracle_ctx.compute_blob_kzg_proof(b, cm)[1]
+        cms.append(cm)
+        prs.append(pr)
+        assert gpu_ctx.VerifyBlobKZGProof(b, cm, pr) == 0
+    assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, cms, prs) == 0
+    assert oracle_ctx.verify_blob_kzg_proof_batch(blobs, cms, prs) == 0
+    swapped = [prs[1], prs[0]] + prs[2:]
+    assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, cms, swapped) == VERIFY_FAILED
+    assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, cms, prs[:4]) == 2            # ErrBatchLengthCheck
+    assert gpu_ctx.VerifyBlobKZGProofBatch([], [], []) == 0
+    # z inside the domain (compute_kzg_proof on-domain branch) vs oracle
+    import oracle
+    rc, ext = oracle.fr_fft((1).to_bytes(32, "big") + bytes(32 * 4095))         # all-ones: not roots; build a root explicitly
+    root = 10238227357739495823651030575849232062558860180284477541189508159991286009131
+    R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    w = pow(root, (1 << 32) // 4096, R)
+    for k in (0, 1, 5, 4095):
+        z = pow(w, k, R).to_bytes(32, "big")
+        rc, pr, y = gpu_ctx.ComputeKZGProof(blobs[0], z)
+        rco, pro, yo = oracle_ctx.compute_kzg_proof(blobs[0], z)
+        assert rc == 0 and rco == 0 and pr == pro and y == yo
+        assert gpu_ctx.VerifyKZGProof(cms[0], z, y, pr) == 0
+
+
+def test_batch_64_device_generated(gpu_ctx, oracle_ctx):
+    """larger batch: proofs produced on the device, verified on the device, spot-checked vs oracle"""
+    blobs = [rand_blob(1000 + s) for s in range(24)]
+    rc, cms, st = gpu_ctx.BlobToKZGCommitmentBatch(blobs)
+    assert rc == 0
+    prs = []
+    for b, cm in zip(blobs, cms):
+        rc, pr = gpu_ctx.ComputeBlobKZGProof(b, cm)
+        assert rc == 0
+        prs.append(pr)
+    assert prs[7] == oracle_ctx.compute_blob_kzg_proof(blobs[7], cms[7])[1]
+    assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, cms, prs) == 0
+    bad = list(prs)
+    bad[13] = prs[12]
+    assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, cms, bad) == VERIFY_FAILED

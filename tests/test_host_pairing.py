@@ -1,0 +1,87 @@
+"""CPU unit tests of the product's host-side pairing and G1 code
+(go-eth-kzg_amd/csrc/host_pairing.hpp, host_g1.hpp) -- bilinearity on the trusted-setup powers
+[tau^i]G1 / [tau^i]G2 and the identities the final exponentiation relies on."""
+import ctypes as C
+import json
+import os
+import subprocess
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM_DIR = os.path.join(ROOT, "tests", "host_shim")
+P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+X = -0xD201000000010000
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(SHIM_DIR, "libpairing_shim.so")
+    src = os.path.join(SHIM_DIR, "pairing_shim.cpp")
+    hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("host_pairing.hpp", "host_field.hpp", "host_g1.hpp", "g1.hpp", "mont29.hpp", "constants29.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    with open(os.path.join(ROOT, "tests", "golden", "trusted_setup.json")) as fh:
+        js = json.load(fh)
+    g1 = [bytes.fromhex(x[2:]) for x in js["g1_monomial"][:16]]
+    g2 = [bytes.fromhex(x[2:]) for x in js["g2_monomial"][:16]]
+    return g1, g2
+
+
+def neg(p48):
+    b = bytearray(p48)
+    if not (b[0] & 0x40):
+        b[0] ^= 0x20
+    return bytes(b)
+
+
+def check(shim, ps, qs):
+    return shim.shim_pairing_check(b"".join(ps), b"".join(qs), len(ps))
+
+
+def test_hard_part_identity():
+    h = (P**4 - P**2 + 1) // R
+    assert (X - 1) ** 2 * (X + P) * (X * X + P * P - 1) + 3 == 3 * h
+    assert (P - 1) % 6 == 0
+
+
+def test_bilinearity(shim, setup):
+    g1, g2 = setup
+    # e(tau^a G1, tau^b G2) e(-tau^c G1, tau^d G2) == 1  <=>  a+b == c+d
+    t0 = time.time()
+    assert check(shim, [g1[1], neg(g1[0])], [g2[0], g2[1]]) == 1
+    dt = time.time() - t0
+    assert check(shim, [g1[5], neg(g1[7])], [g2[3], g2[1]]) == 1
+    assert check(shim, [g1[2], neg(g1[0])], [g2[0], g2[1]]) == 0
+    assert check(shim, [g1[0]], [g2[0]]) == 0
+    assert check(shim, [g1[3], g1[3]], [g2[2], g2[2]]) == 0
+    # three factors: tau^(1+2) * tau^(0+4) * tau^-(...)
+    assert check(shim, [g1[1], neg(g1[3])], [g2[2], g2[0]]) == 1
+    assert check(shim, [g1[1], g1[2], neg(g1[3]), neg(g1[5])], [g2[2], g2[3], g2[0], g2[0]]) == 1
+    # infinity members contribute 1
+    inf = bytes([0xC0] + [0] * 47)
+    assert check(shim, [inf, g1[1], neg(g1[0])], [g2[5], g2[0], g2[1]]) == 1
+    assert check(shim, [inf], [g2[0]]) == 1
+    print("2-pairing check incl. line preparation: %.1f ms" % (dt * 1e3))
+
+
+def test_g1_mul_matches_oracle(shim, setup):
+    import oracle
+    g1, _ = setup
+    for k in (1, 2, 0xDEADBEEFCAFE, R - 1):
+        karr = (C.c_uint64 * 4)(*[(k >> (64 * i)) & (2**64 - 1) for i in range(4)])
+        out = C.create_string_buffer(96)
+        rc = shim.shim_g1_mul(g1[0], karr, out)
+        assert rc == 0
+        x = int.from_bytes(out.raw[:48], "big")
+        y = int.from_bytes(out.raw[48:], "big")
+        exp = bytearray(x.to_bytes(48, "big"))
+        exp[0] |= 0x80 | (0x20 if y > (P - 1) // 2 else 0)
+        assert bytes(exp) == oracle.g1_gen_mul(k)

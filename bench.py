@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="blobs per GPU per step (config 2: 256)")
     ap.add_argument("--window", type=int, default=0, help="MSM window bits override (11..13)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-batch", type=int, default=1024, help="config 3: proofs per VerifyBlobKZGProofBatch call (0 = skip)")
+    ap.add_argument("--verify-steps", type=int, default=3)
     args = ap.parse_args()
 
     import torch
@@ -121,6 +123,10 @@ def main():
     ctx.profile_enable(False)
     assert int(d_status.abs().sum().item()) == 0, "some blobs were rejected"
 
+    verify = None
+    if args.verify_batch > 0:
+        verify = bench_verify(ctx, torch, dist, world, rank, args, d_blobs, B)
+
     if rank == 0:
         total_blobs = B * world * args.steps
         value = total_blobs / elapsed
@@ -141,12 +147,69 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"blob-sharded x{world}, no collective"},
             "roofline": roofline,
         }
+        if verify is not None:
+            out["verify_blob_kzg_proof_batch"] = verify
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+
+
+def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
+    """config 3: VerifyBlobKZGProofBatch on N synthetic (blob, commitment, proof) triples per GPU.
+    Commitments and proofs are produced on the device by the product itself; one corrupted run
+    must be rejected."""
+    N = args.verify_batch
+    reps = (N + B - 1) // B
+    # N distinct blobs: seeds beyond the commitment batch
+    extra = [rand_blob(100000 + rank * N + s) for s in range(N - B)] if N > B else []
+    if N > B:
+        d_blobs = torch.cat([d_blobs256, torch.frombuffer(bytearray(b"".join(extra)), dtype=torch.uint8).cuda()])
+    else:
+        d_blobs = d_blobs256[: N * BLOB]
+    d_cm = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
+    d_pr = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(N, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), N, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
+    assert ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), N, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0
+    rc = ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st)     # warm-up + correctness
+    assert rc == 0, f"valid batch rejected rc={rc}"
+    d_bad = d_pr.clone()
+    d_bad[0:48] = d_pr[48:96]
+    assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_bad.data_ptr(), N, st) == 1, "corrupted batch accepted"
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    host_us = 0.0
+    for _ in range(args.verify_steps):
+        assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st) == 0
+        host_us += ctx.last_host_finish_us()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    ms = dt / args.verify_steps * 1e3
+    kern = {k: round(v[0] / args.verify_steps, 4) for k, v in prof.items() if v[1]}
+    dom = max(kern.items(), key=lambda kv: kv[1])
+    algo = (131072 + 48 + 48) * N          # SURVEY.md 8(d): bytes read per blob
+    return {"metric": "blobs/sec VerifyBlobKZGProofBatch", "value": round(N * world / dt * args.verify_steps, 2), "unit": "blobs/s", "batch_per_gpu": N,
+            "ms_per_call": round(ms, 3), "host_finish_ms": round(host_us / args.verify_steps / 1e3, 3), "kernels_ms_per_call": kern,
+            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(algo / (dom[1] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(algo / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None}}
 
 
 def cpu_baseline():

@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_commit_lagrange", "mkzg_profile_enable", "mkzg_profile_read", "mkzg_version",
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
+    "mkzg_last_host_finish_us",
 ]
 
 
@@ -73,6 +74,8 @@ def lib():
         L.mkzg_profile_enable.argtypes = [vp, i32]
         L.mkzg_profile_read.argtypes = [vp, C.POINTER(KernelTime), i32, i32]
         L.mkzg_version.restype = C.c_char_p
+        L.mkzg_last_host_finish_us.argtypes = [vp]
+        L.mkzg_last_host_finish_us.restype = C.c_double
         _lib = L
     return _lib
 
@@ -182,6 +185,9 @@ class Context:
 
     def verify_blob_kzg_proof_batch_device(self, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n, stream=0):
         return self._L.mkzg_verify_blob_kzg_proof_batch_device(self._h, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n, stream)
+
+    def last_host_finish_us(self):
+        return self._L.mkzg_last_host_finish_us(self._h)
 
     # ---- profiling --------------------------------------------------------------------------
     def profile_enable(self, on=True):

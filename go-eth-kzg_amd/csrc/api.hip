@@ -100,6 +100,9 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     if (c->d_status) (void)hipFree(c->d_status);
     free_verify_ws(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -124,6 +127,9 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
     int rc = [&]() -> int {
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         // decode the Lagrange SRS on the device (no subgroup check: trusted_setup.go:104-117)
         uint8_t* d_raw = nullptr;
         int* d_st = nullptr;

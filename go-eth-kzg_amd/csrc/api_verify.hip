@@ -7,12 +7,19 @@
 // fixed-base scalar multiplication, and the 2-pairing product check with prepared G2 lines
 // (reference internal/kzg/kzg_verify.go:160-199).
 #include <sys/random.h>
+#include <chrono>
 #include "ctx.h"
 
 // ---------------------------------------------------------------------------------------------
 // workspaces
 // ---------------------------------------------------------------------------------------------
 static const size_t V_MISC_WORDS = 16 + 3 * VMSM_WINDOWS * 48;
+#define KT(kind, s, call)                                  \
+    do {                                                   \
+        if (c->profiling) c->timer.begin(kind, s);         \
+        call;                                              \
+        if (c->profiling) c->timer.end(kind, s);           \
+    } while (0)
 
 void free_verify_ws(mkzg_ctx* c) {
     void* ptrs[] = {c->d_v_raw, c->d_v_aff, c->d_v_st, c->d_v_z, c->d_v_y, c->d_v_s1, c->d_v_s3, c->d_v_misc, c->d_quot, c->d_q_z, c->d_q_y, c->d_q_st};
@@ -74,14 +81,19 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     int* st_q = c->d_v_st + cap;
     int* st_b = c->d_v_st + 2 * cap;
     // 1. decode + validate the points (serialization.go:108-115)
-    g1_decompress_device(d_commitments, (int)n, aff_c, st_c, s);
-    g1_decompress_device(d_proofs, (int)n, aff_q, st_q, s);
-    g1_subgroup_check_device(aff_c, (int)n, st_c, s);
-    g1_subgroup_check_device(aff_q, (int)n, st_q, s);
+    //    on the side stream, beside the (longer, latency-bound) SHA-256 + evaluation chain
+    hipStream_t s2 = c->side;
+    HIPCHK(hipEventRecord(c->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    KT(KT_DECOMPRESS, s2, g1_decompress_device(d_commitments, (int)n, aff_c, st_c, s2));
+    KT(KT_DECOMPRESS, s2, g1_decompress_device(d_proofs, (int)n, aff_q, st_q, s2));
+    KT(KT_SUBGROUP, s2, g1_subgroup_check_device(aff_c, (int)n, st_c, s2));
+    KT(KT_SUBGROUP, s2, g1_subgroup_check_device(aff_q, (int)n, st_q, s2));
+    HIPCHK(hipEventRecord(c->ev_join, s2));
     // 2. challenge and claimed value per blob, or caller-supplied z / y
     if (d_blobs) {
-        challenge_device(d_blobs, d_commitments, (int)n, c->d_v_z, s);
-        blob_eval_device(d_blobs, c->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, c->d_v_y, st_b, s);
+        KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, c->d_v_z, s));
+        KT(KT_EVAL, s, blob_eval_device(d_blobs, c->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, c->d_v_y, st_b, s));
     } else {
         // VerifyKZGProof checks y before z (verify.go:15-23); st_b ends up non-zero if either fails
         scalars_to_fr_device(d_z32, (int)n, c->d_v_z, st_b, s);
@@ -89,6 +101,7 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
         scalars_to_fr_device(d_y32, (int)n, c->d_v_y, st_y, s);
         // merge: handled on the host below through a second copy
     }
+    HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     // 3. random linear combination scalars (kzg_verify.go:136-141)
     uint32_t* h_misc = (uint32_t*)(c->h_v + 3 * cap * sizeof(int));
     uint8_t rbytes[32];
@@ -103,11 +116,13 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
         for (int v : sty) if (v) y_bad = v;
     }
     HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
-    rlc_scalars_device(c->d_v_misc, c->d_v_z, c->d_v_y, (int)n, c->d_v_s1, c->d_v_s3, c->d_v_misc + 8, s);
+    KT(KT_RLC, s, rlc_scalars_device(c->d_v_misc, c->d_v_z, c->d_v_y, (int)n, c->d_v_s1, c->d_v_s3, c->d_v_misc + 8, s));
     // 4. the three MSMs of kzg_verify.go:150,225,179: sum r^i Q_i, sum r^i C_i, sum r^i z_i Q_i
     const uint32_t* scal[3] = {c->d_v_s1, c->d_v_s1, c->d_v_s3};
     const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
-    if (vmsm_windows_device(scal, pts, 3, (int)n, c->d_v_misc + 16, s)) return MKZG_ERR_BAD_ARGS;
+    int vrc = 0;
+    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, 3, (int)n, c->d_v_misc + 16, s));
+    if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     // 5. one round trip: statuses, e, window sums
     int* h_st = (int*)c->h_v;
@@ -129,6 +144,7 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
         }
     }
     // 6. host finish (kzg_verify.go:160-199)
+    auto t_h0 = std::chrono::steady_clock::now();
     G1HX win[VMSM_WINDOWS], A, Cc, D, eG, gen, Fsum, negA;
     const uint32_t* wsum = h_misc + 16;
     auto horner = [&](int m, G1HX& out) {
@@ -155,7 +171,9 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     g1h_to_affine(ps[0], Fsum);
     g1h_to_affine(ps[1], negA);
     const G2Prepared* qs[2] = {&c->g2_gen, &c->g2_alpha};
-    return pairing_check_prepared(ps, qs, 2) ? MKZG_OK : MKZG_VERIFY_FAILED;
+    bool ok = pairing_check_prepared(ps, qs, 2);
+    c->last_host_finish_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
+    return ok ? MKZG_OK : MKZG_VERIFY_FAILED;
 }
 
 // upload helper: gather n host items of `bytes` each into the context staging area and copy to `dst`
@@ -270,8 +288,8 @@ int mkzg_compute_blob_kzg_proof_batch_device(mkzg_ctx* c, const void* d_blobs, c
         // commitment must be a valid subgroup point (prove.go:56-62)
         g1_decompress_device(cms, (int)chunk, c->d_v_aff, c->d_q_st + c->q_cap, s);
         g1_subgroup_check_device(c->d_v_aff, (int)chunk, c->d_q_st + c->q_cap, s);
-        challenge_device(blobs, cms, (int)chunk, c->d_q_z, s);
-        blob_quotient_device(blobs, c->d_q_z, c->d_roots_brp, c->d_inv_roots_brp, (int)chunk, c->d_q_y, c->d_quot, c->d_q_st, s);
+        KT(KT_SHA256, s, challenge_device(blobs, cms, (int)chunk, c->d_q_z, s));
+        KT(KT_QUOTIENT, s, blob_quotient_device(blobs, c->d_q_z, c->d_roots_brp, c->d_inv_roots_brp, (int)chunk, c->d_q_y, c->d_quot, c->d_q_st, s));
         commit_batch_device(c->plan, (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, (int)chunk, (uint8_t*)d_proofs48 + done * 48, d_status + done, s,
                             c->profiling ? &c->timer : nullptr);
         // merge statuses: blob error first, then commitment error (prove.go:49-62)
@@ -345,5 +363,8 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     if (num_threads >= 1024) return MKZG_ERR_TOO_MANY_GOROUTINES;
     return MKZG_OK;
 }
+
+// host-side share of the last verification (microseconds): Horner + [e]G + pairing
+double mkzg_last_host_finish_us(mkzg_ctx* c) { return c ? c->last_host_finish_us : 0.0; }
 
 }  // extern "C"

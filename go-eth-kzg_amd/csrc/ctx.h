@@ -27,6 +27,8 @@ using namespace kzg;
 struct mkzg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;          // internal stream for host-pointer entry points
+    hipStream_t side = nullptr;            // side stream: point validation runs beside SHA-256 / evaluation
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::recursive_mutex mu;
     // SRS
     std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes
@@ -69,6 +71,8 @@ struct mkzg_ctx {
     uint32_t* d_q_z = nullptr;
     uint32_t* d_q_y = nullptr;
     int* d_q_st = nullptr;
+    // host finish timing (last call), microseconds
+    double last_host_finish_us = 0, last_verify_total_us = 0;
 };
 
 int ensure_plan(mkzg_ctx* c);

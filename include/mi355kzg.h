@@ -107,6 +107,9 @@ int mkzg_profile_enable(mkzg_ctx* ctx, int on);
 typedef struct { const char* name; double total_ms; long launches; } mkzg_kernel_time;
 int mkzg_profile_read(mkzg_ctx* ctx, mkzg_kernel_time* out, int cap, int reset);
 
+/* host-side share (Horner + [e]G + pairing) of the last verification call, in microseconds */
+double mkzg_last_host_finish_us(mkzg_ctx* ctx);
+
 const char* mkzg_version(void);
 
 #ifdef __cplusplus

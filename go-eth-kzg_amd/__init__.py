@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_commit_lagrange", "mkzg_profile_enable", "mkzg_profile_read", "mkzg_version",
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
-    "mkzg_last_host_finish_us",
+    "mkzg_last_host_finish_us", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
 ]
 
 
@@ -71,6 +71,8 @@ def lib():
         L.mkzg_verify_blob_kzg_proof.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p]
         L.mkzg_verify_blob_kzg_proof_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, sz, sz, sz]
         L.mkzg_verify_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.mkzg_compute_cells.argtypes = [vp, C.c_char_p, i32, C.c_char_p]
+        L.mkzg_compute_cells_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.mkzg_profile_enable.argtypes = [vp, i32]
         L.mkzg_profile_read.argtypes = [vp, C.POINTER(KernelTime), i32, i32]
         L.mkzg_version.restype = C.c_char_p
@@ -185,6 +187,17 @@ class Context:
 
     def verify_blob_kzg_proof_batch_device(self, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n, stream=0):
         return self._L.mkzg_verify_blob_kzg_proof_batch_device(self._h, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n, stream)
+
+    # ---- EIP-7594 -------------------------------------------------------------------------
+    def ComputeCells(self, blob, num_goroutines=0):
+        """reference api_eip7594.go:12 -> (rc, [128 cells])"""
+        if blob is not None and len(blob) != BYTES_PER_BLOB:
+            return ERR_BAD_ARGS, None
+        out = C.create_string_buffer(CELLS_PER_EXT_BLOB * BYTES_PER_CELL)
+        rc = self._L.mkzg_compute_cells(self._h, None if blob is None else bytes(blob), num_goroutines, out)
+        if rc:
+            return rc, None
+        return 0, [out.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)]
 
     def last_host_finish_us(self):
         return self._L.mkzg_last_host_finish_us(self._h)

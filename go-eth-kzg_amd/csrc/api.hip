@@ -99,6 +99,7 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_status) (void)hipFree(c->d_status);
     free_verify_ws(c);
+    free_cells(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

@@ -1,0 +1,76 @@
+// api_cells.hip -- C ABI entry points of the EIP-7594 cell paths (include/mi355kzg.h):
+//   Context.ComputeCells                  reference api_eip7594.go:12-26
+//   Context.ComputeCellsAndKZGProofs      reference api_eip7594.go:28-52
+// All field work happens in cells_kernels.hip / fk20_kernels.hip; the host only stages bytes.
+#include "ctx.h"
+
+void free_cells(mkzg_ctx* c) {
+    void* ptrs[] = {c->d_tw_fwd, c->d_tw_inv, c->d_g1tw_fwd, c->d_g1tw_inv, c->d_coeffs, c->d_cells, c->d_cell_st};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    c->d_tw_fwd = c->d_tw_inv = c->d_g1tw_fwd = c->d_g1tw_inv = c->d_coeffs = nullptr;
+    c->d_cells = nullptr;
+    c->d_cell_st = nullptr;
+    c->cells_ready = false;
+    c->cell_cap = 0;
+}
+int ensure_cells(mkzg_ctx* c, size_t n) {
+    if (!c->cells_ready) {
+        HIPCHK(hipMalloc(&c->d_tw_fwd, 4096 * 48));
+        HIPCHK(hipMalloc(&c->d_tw_inv, 4096 * 48));
+        HIPCHK(hipMalloc(&c->d_g1tw_fwd, 64 * 32));
+        HIPCHK(hipMalloc(&c->d_g1tw_inv, 64 * 32));
+        build_twiddles_device(c->d_tw_fwd, c->d_tw_inv, c->d_g1tw_fwd, c->d_g1tw_inv, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->cells_ready = true;
+    }
+    if (n > c->cell_cap) {
+        if (c->d_coeffs) (void)hipFree(c->d_coeffs);
+        if (c->d_cells) (void)hipFree(c->d_cells);
+        if (c->d_cell_st) (void)hipFree(c->d_cell_st);
+        c->cell_cap = 0;
+        HIPCHK(hipMalloc(&c->d_coeffs, n * 4096 * 48));
+        HIPCHK(hipMalloc(&c->d_cells, n * 262144));
+        HIPCHK(hipMalloc(&c->d_cell_st, n * sizeof(int)));
+        c->cell_cap = n;
+    }
+    return MKZG_OK;
+}
+
+extern "C" {
+
+// Context.ComputeCells for a device-resident batch: blobs n x 131072 B -> cells n x 128 x 2048 B
+int mkzg_compute_cells_batch_device(mkzg_ctx* c, const void* d_blobs, size_t n, void* d_cells, int* d_status, void* stream) {
+    if (!c || (n && (!d_blobs || !d_cells || !d_status))) return MKZG_ERR_BAD_ARGS;
+    if (n == 0) return MKZG_OK;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_cells(c, 1);
+    if (rc) return rc;
+    cells_from_blobs_device((const uint8_t*)d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, nullptr, (uint8_t*)d_cells, d_status, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return MKZG_OK;
+}
+
+int mkzg_compute_cells(mkzg_ctx* c, const uint8_t* blob, int num_threads, uint8_t* cells_out) {
+    (void)num_threads;                                            // ignored by the reference too (api_eip7594.go:54)
+    if (!c || !cells_out) return MKZG_ERR_BAD_ARGS;
+    if (!blob) return MKZG_ERR_NIL_INPUT;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_cells(c, 1);
+    if (rc) return rc;
+    rc = ensure_staging(c, 1, MKZG_BYTES_PER_BLOB);
+    if (rc) return rc;
+    memcpy(c->h_stage, blob, MKZG_BYTES_PER_BLOB);
+    HIPCHK(hipMemcpyAsync(c->d_blobs, c->h_stage, MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, c->stream));
+    rc = mkzg_compute_cells_batch_device(c, c->d_blobs, 1, c->d_cells, c->d_cell_st, c->stream);
+    if (rc) return rc;
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(&st, c->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(cells_out, c->d_cells, 262144, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return st;
+}
+
+}  // extern "C"

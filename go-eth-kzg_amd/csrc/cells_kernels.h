@@ -1,0 +1,19 @@
+// cells_kernels.h -- host-visible launch interface of cells_kernels.hip (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mi355kzg.h"
+
+namespace kzg {
+
+// tw_fwd / tw_inv: 4096 Fr rows (12 words) of w_8192^(+-j); g1tw_*: 64 x 8 plain words of w_128^(+-j)
+void build_twiddles_device(uint32_t* d_tw_fwd, uint32_t* d_tw_inv, uint32_t* d_g1tw_fwd, uint32_t* d_g1tw_inv, hipStream_t s);
+// blobs (n x 131072 B) -> coefficient rows (n x 4096 x 12 words, may be null) + extended blob bytes (n x 262144 B) + status
+void cells_from_blobs_device(const uint8_t* d_blobs, int n, const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint32_t* d_coeffs, uint8_t* d_cells, int* d_status,
+                             hipStream_t s);
+// coefficient rows -> extended blob bytes (items with status != 0 are skipped)
+void cells_from_coeffs_device(const uint32_t* d_coeffs, int n, const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint8_t* d_cells, int* d_status, hipStream_t s);
+// coefficient rows -> FK20 scalars [n][128][64][8 words]
+void fk20_scalars_device(const uint32_t* d_coeffs, int n, const uint32_t* d_tw_fwd, const int* d_status, uint32_t* d_scalars, hipStream_t s);
+
+}  // namespace kzg

@@ -1,0 +1,367 @@
+// cells_kernels.hip -- EIP-7594 (PeerDAS) device kernels for MI355X (gfx950): the radix-2 Fr NTT
+// and everything built on it.
+//
+//   k_cells_ntt     ComputeCells (reference api_eip7594.go:12-26,54-58 -> fk20.go:58-74 ->
+//                   internal/domain/fft.go:95-144): one workgroup per blob keeps the whole
+//                   4096-point polynomial in LDS (147 KB of the CU's 160 KB): inverse NTT
+//                   (decimation in time on the blob's bit-reversed order, so no permutation
+//                   pass), then the 8192-point extension.  Because the upper half of the padded
+//                   input is zero the 8192-NTT splits into the blob itself (cells 0..63 are the
+//                   input evaluations) and ONE coset NTT-4096 (shift w_8192) whose decimation-
+//                   in-frequency output order is exactly the bit-reversed order the cells use.
+//   k_fk20_scalars  the 64 circulant-row NTT-128s of FK20 (reference fk20.go:100-124,
+//                   toeplitz.go:17-29,95-107), transposed, scaled by 1/128 and exported as plain
+//                   scalars for the fixed-base MSMs.
+// Twiddles come from precomputed tables (the reference recomputes them by running products,
+// internal/domain/fft.go:118-137).  Integer modular arithmetic only -- no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mont29.hpp"
+#include "cells_kernels.h"
+
+namespace kzg {
+
+__device__ __forceinline__ void c_load_fr12(fr_t& r, const uint32_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1], c = q[2];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w; r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w; r.l[8] = c.x;
+}
+__device__ __forceinline__ void c_store_fr12(uint32_t* p, const fr_t& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]);
+    q[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
+    q[2] = make_uint4(r.l[8], 0, 0, 0);
+}
+__device__ __noinline__ void c_fr_mul(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
+
+// LDS element access, structure-of-arrays: word q of element e at sh[q * N + e]
+template <int N>
+__device__ __forceinline__ void lds_get(fr_t& r, const uint32_t* sh, int e) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) r.l[q] = sh[q * N + e];
+}
+template <int N>
+__device__ __forceinline__ void lds_put(uint32_t* sh, int e, const fr_t& r) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) sh[q * N + e] = r.l[q];
+}
+
+// ------------------------------------------------------------------------------------------
+// twiddle tables: tw_fwd[j] = w_8192^j, tw_inv[j] = w_8192^-j for j < 4096 (Montgomery rows),
+// plus the plain-integer forms of w_128^(+-j), j < 64, used as scalars by the G1 FFT.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_build_twiddles(uint32_t* __restrict__ tw_fwd, uint32_t* __restrict__ tw_inv, uint32_t* __restrict__ g1tw_fwd,
+                                                        uint32_t* __restrict__ g1tw_inv) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= 4096) return;
+    fr_t g;
+    Fr::set(g, FR_ROOT_2_32);
+    for (int s = 0; s < 32 - 13; s++) c_fr_mul(g, g, g);      // generator of the 8192-domain
+    auto pw = [&](uint32_t e, fr_t& out) {
+        fr_t acc, base = g;
+        Fr::set_one(acc);
+        for (; e; e >>= 1) {
+            if (e & 1) c_fr_mul(acc, acc, base);
+            c_fr_mul(base, base, base);
+        }
+        Fr::reduce_once(out, acc);
+    };
+    fr_t f, inv;
+    pw((uint32_t)j, f);
+    pw((uint32_t)((8192 - j) & 8191), inv);
+    c_store_fr12(tw_fwd + (size_t)j * 12, f);
+    c_store_fr12(tw_inv + (size_t)j * 12, inv);
+    if ((j & 63) == 0) {                                       // w_128^(j/64)
+        const int m = j >> 6;
+        fr_t pl;
+        uint32_t w[8];
+        Fr::to_plain(pl, f);
+        Fr::to_words32(w, pl);
+        for (int q = 0; q < 8; q++) g1tw_fwd[m * 8 + q] = w[q];
+        Fr::to_plain(pl, inv);
+        Fr::to_words32(w, pl);
+        for (int q = 0; q < 8; q++) g1tw_inv[m * 8 + q] = w[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_cells_ntt: one 1024-thread workgroup per blob.
+//   in : blob (4096 x 32 B big-endian, evaluations in bit-reversed order)
+//   out: coeffs[b] (4096 Montgomery rows, natural order)           -- consumed by FK20
+//        cells[b]  (8192 x 32 B big-endian; first half = the blob, second half = coset NTT)
+// ------------------------------------------------------------------------------------------
+constexpr int NT = 1024;
+__device__ __forceinline__ void c_load_be32(uint32_t w[8], const uint8_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 hi = q[0], lo = q[1];
+    w[7] = __builtin_bswap32(hi.x); w[6] = __builtin_bswap32(hi.y); w[5] = __builtin_bswap32(hi.z); w[4] = __builtin_bswap32(hi.w);
+    w[3] = __builtin_bswap32(lo.x); w[2] = __builtin_bswap32(lo.y); w[1] = __builtin_bswap32(lo.z); w[0] = __builtin_bswap32(lo.w);
+}
+__device__ __forceinline__ void c_store_be32(uint8_t* p, const uint32_t w[8]) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(__builtin_bswap32(w[7]), __builtin_bswap32(w[6]), __builtin_bswap32(w[5]), __builtin_bswap32(w[4]));
+    q[1] = make_uint4(__builtin_bswap32(w[3]), __builtin_bswap32(w[2]), __builtin_bswap32(w[1]), __builtin_bswap32(w[0]));
+}
+
+// INPUT 0: blob bytes (evaluation form).  INPUT 1: coefficient rows already on the device (recovery).
+template <int INPUT>
+__global__ void __launch_bounds__(NT) k_cells_ntt(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ coeffs_in, const uint32_t* __restrict__ tw_fwd,
+                                                  const uint32_t* __restrict__ tw_inv, uint32_t* __restrict__ coeffs_out, uint8_t* __restrict__ cells,
+                                                  int* __restrict__ status) {
+    extern __shared__ uint32_t sh[];   // [9][4096]
+    constexpr int N = 4096;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (INPUT == 0) {
+        const uint8_t* blob = blobs + (size_t)b * 131072;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < N / NT; k++) {
+            const int i = t + NT * k;
+            uint32_t w[8];
+            c_load_be32(w, blob + (size_t)i * 32);
+            bad |= Fr::words32_geq_mod(w);
+            fr_t pl, m;
+            Fr::from_words32(pl, w);
+            Fr::from_plain(m, pl);
+            Fr::reduce_once(m, m);
+            lds_put<N>(sh, i, m);
+        }
+        if (__syncthreads_or(bad)) {
+            if (t == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
+            return;
+        }
+        if (t == 0) status[b] = 0;
+        // inverse NTT, decimation in time: the blob holds evaluations in bit-reversed order, which
+        // is the input order DIT wants; output = coefficients in natural order
+        for (int h = 1; h < N; h <<= 1) {
+#pragma unroll
+            for (int r = 0; r < N / 2 / NT; r++) {
+                const int p = t + NT * r;
+                const int k = p & (h - 1);
+                const int i0 = ((p - k) << 1) + k, i1 = i0 + h;
+                fr_t a, bb, w, tt;
+                lds_get<N>(a, sh, i0);
+                lds_get<N>(bb, sh, i1);
+                c_load_fr12(w, tw_inv + (size_t)(k * (N / h)) * 12);
+                c_fr_mul(tt, bb, w);
+                FrC::add(bb, a, tt);
+                FrC::sub(a, a, tt);
+                lds_put<N>(sh, i0, bb);
+                lds_put<N>(sh, i1, a);
+            }
+            __syncthreads();
+        }
+    } else {
+        if (status[b] != 0) return;
+#pragma unroll
+        for (int k = 0; k < N / NT; k++) {
+            const int i = t + NT * k;
+            fr_t m;
+            c_load_fr12(m, coeffs_in + ((size_t)b * N + i) * 12);
+            lds_put<N>(sh, i, m);
+        }
+        __syncthreads();
+    }
+    // (INPUT 0) scale by 1/4096 and publish the coefficients; then shift to the coset w_8192
+    fr_t ninv;
+    Fr::set(ninv, FR_INV_4096);
+#pragma unroll
+    for (int k = 0; k < N / NT; k++) {
+        const int i = t + NT * k;
+        fr_t c, w;
+        lds_get<N>(c, sh, i);
+        if (INPUT == 0) {
+            c_fr_mul(c, c, ninv);
+            if (coeffs_out) c_store_fr12(coeffs_out + ((size_t)b * N + i) * 12, c);
+        }
+        c_load_fr12(w, tw_fwd + (size_t)i * 12);
+        c_fr_mul(c, c, w);
+        lds_put<N>(sh, i, c);
+    }
+    __syncthreads();
+    // forward NTT-4096, decimation in frequency: natural in, bit-reversed out
+    for (int h = N / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int r = 0; r < N / 2 / NT; r++) {
+            const int p = t + NT * r;
+            const int k = p & (h - 1);
+            const int i0 = ((p - k) << 1) + k, i1 = i0 + h;
+            fr_t a, bb, w, s, d;
+            lds_get<N>(a, sh, i0);
+            lds_get<N>(bb, sh, i1);
+            FrC::add(s, a, bb);
+            FrC::sub(d, a, bb);
+            c_load_fr12(w, tw_fwd + (size_t)(k * (N / h)) * 12);
+            c_fr_mul(d, d, w);
+            lds_put<N>(sh, i0, s);
+            lds_put<N>(sh, i1, d);
+        }
+        __syncthreads();
+    }
+    // serialise: second half of the extended blob; the first half is the blob itself
+    uint8_t* out = cells + (size_t)b * 262144;
+#pragma unroll
+    for (int k = 0; k < N / NT; k++) {
+        const int i = t + NT * k;
+        fr_t v, pl;
+        uint32_t w[8];
+        lds_get<N>(v, sh, i);
+        Fr::to_plain(pl, v);
+        Fr::to_words32(w, pl);
+        c_store_be32(out + 131072 + (size_t)i * 32, w);
+        if (INPUT == 0) {
+            const uint4* src = reinterpret_cast<const uint4*>(blobs + (size_t)b * 131072 + (size_t)i * 32);
+            uint4* dst = reinterpret_cast<uint4*>(out + (size_t)i * 32);
+            dst[0] = src[0];
+            dst[1] = src[1];
+        }
+    }
+}
+
+// first half of the cells from coefficients (recovery path): plain NTT-4096 (no coset), DIF order
+__global__ void __launch_bounds__(NT) k_cells_first_half(const uint32_t* __restrict__ coeffs_in, const uint32_t* __restrict__ tw_fwd, uint8_t* __restrict__ cells,
+                                                         const int* __restrict__ status) {
+    extern __shared__ uint32_t sh[];
+    constexpr int N = 4096;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (status[b] != 0) return;
+#pragma unroll
+    for (int k = 0; k < N / NT; k++) {
+        const int i = t + NT * k;
+        fr_t m;
+        c_load_fr12(m, coeffs_in + ((size_t)b * N + i) * 12);
+        lds_put<N>(sh, i, m);
+    }
+    __syncthreads();
+    for (int h = N / 2; h >= 1; h >>= 1) {
+#pragma unroll
+        for (int r = 0; r < N / 2 / NT; r++) {
+            const int p = t + NT * r;
+            const int k = p & (h - 1);
+            const int i0 = ((p - k) << 1) + k, i1 = i0 + h;
+            fr_t a, bb, w, s, d;
+            lds_get<N>(a, sh, i0);
+            lds_get<N>(bb, sh, i1);
+            FrC::add(s, a, bb);
+            FrC::sub(d, a, bb);
+            c_load_fr12(w, tw_fwd + (size_t)(k * (N / h)) * 12);
+            c_fr_mul(d, d, w);
+            lds_put<N>(sh, i0, s);
+            lds_put<N>(sh, i1, d);
+        }
+        __syncthreads();
+    }
+    uint8_t* out = cells + (size_t)b * 262144;
+#pragma unroll
+    for (int k = 0; k < N / NT; k++) {
+        const int i = t + NT * k;
+        fr_t v, pl;
+        uint32_t w[8];
+        lds_get<N>(v, sh, i);
+        Fr::to_plain(pl, v);
+        Fr::to_words32(w, pl);
+        c_store_be32(out + (size_t)i * 32, w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fk20_scalars: per blob, the 64 circulant rows of FK20 and their NTT-128s.
+//   row i (i < 64):  circ_i[0] = c[4095 - i];  circ_i[64 + j] = c[64 j - i - 1] (j = 1..63); else 0
+//   V_i = NTT_128(circ_i) / 128    (the 1/128 of the later G1 inverse FFT is folded in here)
+//   out: scalars[b][k][i] as 8 plain little-endian words   (k < 128 outputs, i < 64 rows)
+// One 1024-thread workgroup per blob; all 64 x 128 elements live in LDS (64 transforms side by side).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) k_fk20_scalars(const uint32_t* __restrict__ coeffs, const uint32_t* __restrict__ tw_fwd, const int* __restrict__ status,
+                                                     uint32_t* __restrict__ scalars) {
+    extern __shared__ uint32_t sh[];   // [9][4096] : 32 rows at a time; element (row r, pos p) at index r*128 + p
+    constexpr int N = 4096;
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (status[b] != 0) return;
+    const uint32_t* c = coeffs + (size_t)b * 4096 * 12;
+    fr_t inv128;
+    {
+        // 1/128 = 32 * (1/4096)
+        fr_t x;
+        Fr::set(x, FR_INV_4096);
+        for (int s = 0; s < 5; s++) FrC::add(x, x, x);
+        inv128 = x;
+    }
+    uint32_t* out = scalars + (size_t)b * 128 * 64 * 8;
+    for (int half = 0; half < 2; half++) {
+        for (int e = t; e < N; e += NT) {
+            const int i = (e >> 7) + 32 * half, p = e & 127;
+            fr_t v;
+            Fr::set_zero(v);
+            if (p == 0) c_load_fr12(v, c + (size_t)(4095 - i) * 12);
+            else if (p > 64) c_load_fr12(v, c + (size_t)(64 * (p - 64) - i - 1) * 12);
+            lds_put<N>(sh, e, v);
+        }
+        __syncthreads();
+        // 32 independent NTT-128s (DIF), w_128 = w_8192^64
+        for (int h = 64; h >= 1; h >>= 1) {
+            for (int pr = t; pr < N / 2; pr += NT) {
+                const int row = pr >> 6, q = pr & 63;
+                const int k = q & (h - 1);
+                const int i0 = row * 128 + ((q - k) << 1) + k, i1 = i0 + h;
+                fr_t a, bb, w, s, d;
+                lds_get<N>(a, sh, i0);
+                lds_get<N>(bb, sh, i1);
+                FrC::add(s, a, bb);
+                FrC::sub(d, a, bb);
+                c_load_fr12(w, tw_fwd + (size_t)(k * (64 / h) * 64) * 12);
+                c_fr_mul(d, d, w);
+                lds_put<N>(sh, i0, s);
+                lds_put<N>(sh, i1, d);
+            }
+            __syncthreads();
+        }
+        // DIF left the outputs bit-reversed within each row: V_i[k] sits at position brev7(k)
+        for (int e = t; e < N; e += NT) {
+            const int k = e >> 5, r = e & 31;                  // output index [k][i], i = r + 32*half
+            const int pos = (int)(__brev((uint32_t)k) >> 25);
+            fr_t v, pl;
+            uint32_t w[8];
+            lds_get<N>(v, sh, r * 128 + pos);
+            c_fr_mul(v, v, inv128);
+            Fr::to_plain(pl, v);
+            Fr::to_words32(w, pl);
+            uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)k * 64 + r + 32 * half) * 8);
+            dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static bool g_attr_set = false;
+static void set_lds_attrs() {
+    if (g_attr_set) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cells_ntt<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 4096 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cells_ntt<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 4096 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cells_first_half), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 4096 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fk20_scalars), hipFuncAttributeMaxDynamicSharedMemorySize, 9 * 4096 * 4);
+    g_attr_set = true;
+}
+void build_twiddles_device(uint32_t* d_tw_fwd, uint32_t* d_tw_inv, uint32_t* d_g1tw_fwd, uint32_t* d_g1tw_inv, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_twiddles, dim3(16), dim3(256), 0, s, d_tw_fwd, d_tw_inv, d_g1tw_fwd, d_g1tw_inv);
+}
+void cells_from_blobs_device(const uint8_t* d_blobs, int n, const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint32_t* d_coeffs, uint8_t* d_cells, int* d_status,
+                             hipStream_t s) {
+    set_lds_attrs();
+    if (n > 0) hipLaunchKernelGGL((k_cells_ntt<0>), dim3(n), dim3(NT), 9 * 4096 * 4, s, d_blobs, (const uint32_t*)nullptr, d_tw_fwd, d_tw_inv, d_coeffs, d_cells, d_status);
+}
+void cells_from_coeffs_device(const uint32_t* d_coeffs, int n, const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint8_t* d_cells, int* d_status, hipStream_t s) {
+    set_lds_attrs();
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_cells_first_half, dim3(n), dim3(NT), 9 * 4096 * 4, s, d_coeffs, d_tw_fwd, d_cells, d_status);
+    hipLaunchKernelGGL((k_cells_ntt<1>), dim3(n), dim3(NT), 9 * 4096 * 4, s, (const uint8_t*)nullptr, d_coeffs, d_tw_fwd, d_tw_inv, (uint32_t*)nullptr, d_cells, d_status);
+}
+void fk20_scalars_device(const uint32_t* d_coeffs, int n, const uint32_t* d_tw_fwd, const int* d_status, uint32_t* d_scalars, hipStream_t s) {
+    set_lds_attrs();
+    if (n > 0) hipLaunchKernelGGL(k_fk20_scalars, dim3(n), dim3(NT), 9 * 4096 * 4, s, d_coeffs, d_tw_fwd, d_status, d_scalars);
+}
+
+}  // namespace kzg

@@ -11,6 +11,7 @@
 #include "../../include/mi355kzg.h"
 #include "msm_kernels.h"
 #include "verify_kernels.h"
+#include "cells_kernels.h"
 #include "host_g1.hpp"
 
 using namespace kzg;
@@ -71,6 +72,16 @@ struct mkzg_ctx {
     uint32_t* d_q_z = nullptr;
     uint32_t* d_q_y = nullptr;
     int* d_q_st = nullptr;
+    // ---- EIP-7594
+    uint32_t* d_tw_fwd = nullptr;          // 4096 Fr rows: w_8192^j
+    uint32_t* d_tw_inv = nullptr;          // 4096 Fr rows: w_8192^-j
+    uint32_t* d_g1tw_fwd = nullptr;        // 64 x 8 words: w_128^j as plain scalars
+    uint32_t* d_g1tw_inv = nullptr;
+    bool cells_ready = false;
+    size_t cell_cap = 0;                   // blobs per launch for the cell paths
+    uint32_t* d_coeffs = nullptr;          // cell_cap x 4096 Fr rows
+    uint8_t* d_cells = nullptr;            // cell_cap x 262144 B
+    int* d_cell_st = nullptr;
     // host finish timing (last call), microseconds
     double last_host_finish_us = 0, last_verify_total_us = 0;
 };
@@ -80,4 +91,6 @@ extern "C" int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_i
 int ensure_verify_ws(mkzg_ctx* c, size_t n);
 int ensure_quot_ws(mkzg_ctx* c, size_t n);
 void free_verify_ws(mkzg_ctx* c);
+int ensure_cells(mkzg_ctx* c, size_t n);
+void free_cells(mkzg_ctx* c);
 

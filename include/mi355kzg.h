@@ -100,6 +100,11 @@ int mkzg_verify_blob_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* const* blobs,
 /* same, inputs contiguous in HBM; synchronises `stream` internally (the verdict needs the host pairing). */
 int mkzg_verify_blob_kzg_proof_batch_device(mkzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n, void* stream);
 
+/* ---- EIP-7594 ------------------------------------------------------------------------------ */
+/* Context.ComputeCells (reference api_eip7594.go:12-26): 128 cells of 2048 bytes, contiguous. */
+int mkzg_compute_cells(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint8_t* cells_out /* 128 x 2048 */);
+int mkzg_compute_cells_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n, void* d_cells, int* d_status, void* stream);
+
 /* ---- profiling hooks (bench.py's roofline section) ------------------------------------------ */
 /* When enabled, every kernel launch of the hot path is bracketed by hipEvents on its stream. */
 int mkzg_profile_enable(mkzg_ctx* ctx, int on);

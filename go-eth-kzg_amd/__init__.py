@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
     "mkzg_last_host_finish_us", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
+    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device",
 ]
 
 
@@ -73,6 +74,8 @@ def lib():
         L.mkzg_verify_blob_kzg_proof_batch_device.argtypes = [vp, vp, vp, vp, sz, vp]
         L.mkzg_compute_cells.argtypes = [vp, C.c_char_p, i32, C.c_char_p]
         L.mkzg_compute_cells_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
+        L.mkzg_compute_cells_and_kzg_proofs.argtypes = [vp, C.c_char_p, i32, C.c_char_p, C.c_char_p]
+        L.mkzg_compute_cells_and_kzg_proofs_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.mkzg_profile_enable.argtypes = [vp, i32]
         L.mkzg_profile_read.argtypes = [vp, C.POINTER(KernelTime), i32, i32]
         L.mkzg_version.restype = C.c_char_p
@@ -198,6 +201,21 @@ class Context:
         if rc:
             return rc, None
         return 0, [out.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)]
+
+    def ComputeCellsAndKZGProofs(self, blob, num_goroutines=0):
+        """reference api_eip7594.go:28 -> (rc, [128 cells], [128 proofs])"""
+        if blob is not None and len(blob) != BYTES_PER_BLOB:
+            return ERR_BAD_ARGS, None, None
+        cells = C.create_string_buffer(CELLS_PER_EXT_BLOB * BYTES_PER_CELL)
+        proofs = C.create_string_buffer(CELLS_PER_EXT_BLOB * 48)
+        rc = self._L.mkzg_compute_cells_and_kzg_proofs(self._h, None if blob is None else bytes(blob), num_goroutines, cells, proofs)
+        if rc:
+            return rc, None, None
+        return (0, [cells.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)],
+                [proofs.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
+
+    def compute_cells_and_kzg_proofs_batch_device(self, d_blobs_ptr, n, d_cells_ptr, d_proofs_ptr, d_status_ptr, stream=0):
+        return self._L.mkzg_compute_cells_and_kzg_proofs_batch_device(self._h, d_blobs_ptr, n, d_cells_ptr, d_proofs_ptr, d_status_ptr, stream)
 
     def last_host_finish_us(self):
         return self._L.mkzg_last_host_finish_us(self._h)

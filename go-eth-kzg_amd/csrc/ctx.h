@@ -12,6 +12,7 @@
 #include "msm_kernels.h"
 #include "verify_kernels.h"
 #include "cells_kernels.h"
+#include "fk20_kernels.h"
 #include "host_g1.hpp"
 
 using namespace kzg;
@@ -82,6 +83,15 @@ struct mkzg_ctx {
     uint32_t* d_coeffs = nullptr;          // cell_cap x 4096 Fr rows
     uint8_t* d_cells = nullptr;            // cell_cap x 262144 B
     int* d_cell_st = nullptr;
+    // FK20
+    bool fk_ready = false;
+    uint32_t* d_monomial_aff = nullptr;    // 4096 affine rows
+    uint32_t* d_fk_t_aff = nullptr;        // 8192 affine rows T[k][i]
+    uint32_t* d_fk_table = nullptr;        // direct window table (4.3 GB)
+    size_t fk_cap = 0;
+    uint32_t* d_fk_scalars = nullptr;      // fk_cap x 128 x 64 x 8 words
+    uint32_t* d_fk_results = nullptr;      // fk_cap x 128 XYZZ rows
+    uint8_t* d_fk_proofs = nullptr;        // fk_cap x 128 x 48 B
     // host finish timing (last call), microseconds
     double last_host_finish_us = 0, last_verify_total_us = 0;
 };
@@ -93,4 +103,5 @@ int ensure_quot_ws(mkzg_ctx* c, size_t n);
 void free_verify_ws(mkzg_ctx* c);
 int ensure_cells(mkzg_ctx* c, size_t n);
 void free_cells(mkzg_ctx* c);
+int ensure_fk20(mkzg_ctx* c, size_t n);
 

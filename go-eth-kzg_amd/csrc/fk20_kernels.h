@@ -1,0 +1,21 @@
+// fk20_kernels.h -- host-visible launch interface of fk20_kernels.hip (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/mi355kzg.h"
+
+namespace kzg {
+
+constexpr int FK_C = 8;          // window bits of the direct table
+constexpr int FK_NWIN = 32;      // byte windows of a 255-bit scalar
+constexpr int FK_NMULT = 128;    // multiples 1..128 (signed Booth digits)
+
+size_t fk20_table_bytes();
+// monomial SRS (4096 affine rows) -> T (8192 affine rows, [k][i]) -> direct table (fk20_table_bytes())
+void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fwd, uint32_t* d_t_aff, uint32_t* d_table, hipStream_t s);
+// scalars [n][128][64][8 words] -> results [n][128] XYZZ rows (scratch) -> proofs [n][128][48 B]
+void fk20_proofs_device(const uint32_t* d_scalars, const uint32_t* d_table, const uint32_t* d_g1tw_fwd, const uint32_t* d_g1tw_inv, int n, const int* d_status,
+                        uint32_t* d_results, uint8_t* d_proofs48, hipStream_t s);
+
+}  // namespace kzg

@@ -1,0 +1,320 @@
+// fk20_kernels.hip -- FK20 amortised multi-proofs for EIP-7594 on MI355X (gfx950).
+//
+// Reference: internal/kzg_multi/fk20/fk20.go:23-124 + toeplitz.go:42-125 (+ the G1 FFT of
+// internal/domain/fft.go:23-92).  Per blob:
+//     V[k][i]  = NTT_128(circulant row i)[k] / 128                 (cells_kernels.hip)
+//     R[k]     = sum_{i<64} V[k][i] * T[k][i]                      128 fixed-base MSMs of 64 points
+//     h        = IFFT_128^{G1}(R)[0..63], zero-padded to 128
+//     proofs   = bitrev(FFT_128^{G1}(h))
+// MI355X-first choices:
+//   * the 8192 fixed bases T[k][i] get a DIRECT window table in HBM: D[k][i][w][m] = m 2^(8w) T
+//     for the 32 byte-windows w and m = 1..128 (signed Booth digits) -- 4.3 GB, sized for a
+//     288 GB part -- so an MSM-64 is 64 x 32 mixed additions with no bucket reduction at all and
+//     no sort; 16 lanes share one MSM and combine with a 4-level wavefront tree.
+//   * each G1 FFT-128 runs in ONE wavefront (64 butterflies = 64 lanes) with the 128 points in
+//     LDS (28 KB, structure-of-arrays); inverse transform by decimation in frequency, forward by
+//     decimation in time, so the truncation/zero-padding between them is "clear the odd slots"
+//     and no permutation pass exists.  Twiddle multiplications are 255-bit double-and-add.
+// Integer modular arithmetic only -- no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "g1.hpp"
+#include "fk20_kernels.h"
+
+namespace kzg {
+
+__device__ __noinline__ void f_add(G1X& r, const G1X& a, const G1X& b) { g1x_add(r, a, b); }
+__device__ __noinline__ void f_dbl(G1X& r, const G1X& a) { g1x_dbl(r, a); }
+__device__ __noinline__ void f_madd(G1X& acc, const fp_t& x, const fp_t& y) { g1x_madd(acc, x, y); }
+__device__ __noinline__ void f_to_affine(G1Aff& r, const G1X& p) { g1x_to_affine(r, p); }
+
+__device__ __forceinline__ void f_load_affine(G1Aff& p, const uint32_t* rec) {
+    const uint4* q = reinterpret_cast<const uint4*>(rec);
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) { p.x.l[i] = w[i]; p.y.l[i] = w[14 + i]; }
+    p.inf = w[28];
+}
+__device__ __forceinline__ void f_store_affine(uint32_t* rec, const G1Aff& p) {
+    uint32_t w[32];
+#pragma unroll
+    for (int i = 0; i < 14; i++) { w[i] = p.x.l[i]; w[14 + i] = p.y.l[i]; }
+    w[28] = p.inf; w[29] = 0; w[30] = 0; w[31] = 0;
+    uint4* q = reinterpret_cast<uint4*>(rec);
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+__device__ __forceinline__ void f_load_xyzz(G1X& p, const uint32_t* rec) {
+    const uint4* q = reinterpret_cast<const uint4*>(rec);
+    uint32_t w[56];
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) { p.x.l[i] = w[i]; p.y.l[i] = w[14 + i]; p.zz.l[i] = w[28 + i]; p.zzz.l[i] = w[42 + i]; }
+}
+__device__ __forceinline__ void f_store_xyzz(uint32_t* rec, const G1X& p) {
+    uint32_t w[56];
+#pragma unroll
+    for (int i = 0; i < 14; i++) { w[i] = p.x.l[i]; w[14 + i] = p.y.l[i]; w[28 + i] = p.zz.l[i]; w[42 + i] = p.zzz.l[i]; }
+    uint4* q = reinterpret_cast<uint4*>(rec);
+#pragma unroll
+    for (int i = 0; i < 14; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// r = [k]p, k = 8 little-endian words (plain integer < r)
+__device__ __noinline__ void f_mul_words(G1X& r, const G1X& p, const uint32_t* k) {
+    G1X acc;
+    g1x_set_inf(acc);
+    int top = 255;
+    while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1)) top--;
+    for (int i = top; i >= 0; i--) {
+        f_dbl(acc, acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) f_add(acc, acc, p);
+    }
+    r = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// G1 FFT-128 in one wavefront.  LDS: structure of arrays, word q of point e at sh[q*128 + e].
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lp_get(G1X& p, const uint32_t* sh, int e) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        p.x.l[i] = sh[i * 128 + e];
+        p.y.l[i] = sh[(14 + i) * 128 + e];
+        p.zz.l[i] = sh[(28 + i) * 128 + e];
+        p.zzz.l[i] = sh[(42 + i) * 128 + e];
+    }
+}
+__device__ __forceinline__ void lp_put(uint32_t* sh, int e, const G1X& p) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        sh[i * 128 + e] = p.x.l[i];
+        sh[(14 + i) * 128 + e] = p.y.l[i];
+        sh[(28 + i) * 128 + e] = p.zz.l[i];
+        sh[(42 + i) * 128 + e] = p.zzz.l[i];
+    }
+}
+// decimation in frequency: natural order in, bit-reversed order out.  tw: 64 x 8 words of w^j.
+__device__ __forceinline__ void g1_fft128_dif(uint32_t* sh, const uint32_t* __restrict__ tw, int lane) {
+    for (int h = 64; h >= 1; h >>= 1) {
+        const int k = lane & (h - 1);
+        const int i0 = ((lane - k) << 1) + k, i1 = i0 + h;
+        G1X a, b, s, d, nb;
+        lp_get(a, sh, i0);
+        lp_get(b, sh, i1);
+        f_add(s, a, b);
+        g1x_neg(nb, b);
+        f_add(d, a, nb);
+        const int e = k * (64 / h);
+        if (e != 0) {
+            uint32_t kw[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) kw[q] = tw[e * 8 + q];
+            f_mul_words(d, d, kw);
+        }
+        lp_put(sh, i0, s);
+        lp_put(sh, i1, d);
+        __syncthreads();
+    }
+}
+// decimation in time: bit-reversed order in, natural order out
+__device__ __forceinline__ void g1_fft128_dit(uint32_t* sh, const uint32_t* __restrict__ tw, int lane) {
+    for (int h = 1; h <= 64; h <<= 1) {
+        const int k = lane & (h - 1);
+        const int i0 = ((lane - k) << 1) + k, i1 = i0 + h;
+        G1X a, b, s, d, nb;
+        lp_get(a, sh, i0);
+        lp_get(b, sh, i1);
+        const int e = k * (64 / h);
+        if (e != 0) {
+            uint32_t kw[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) kw[q] = tw[e * 8 + q];
+            f_mul_words(b, b, kw);
+        }
+        f_add(s, a, b);
+        g1x_neg(nb, b);
+        f_add(d, a, nb);
+        lp_put(sh, i0, s);
+        lp_put(sh, i1, d);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// set-up, step 1: T[k][i] = FFT_128(vec_i)[k], vec_i = (reversed monomial SRS without its first 64
+// points, stride 64 from offset i, padded with the identity)        reference fk20.go:28-35,
+// toeplitz.go:50-93.  One wavefront per i; output affine rows t_aff[k*64 + i].
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fk20_setup_fft(const uint32_t* __restrict__ monomial_aff, const uint32_t* __restrict__ g1tw_fwd, uint32_t* __restrict__ t_aff) {
+    __shared__ uint32_t sh[56 * 128];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    for (int j = lane; j < 128; j += 64) {
+        G1X p;
+        g1x_set_inf(p);
+        if (j < 63) {
+            G1Aff a;
+            f_load_affine(a, monomial_aff + (size_t)(4031 - i - 64 * j) * 32);
+            if (!a.inf) g1x_from_affine(p, a.x, a.y);
+        }
+        lp_put(sh, j, p);
+    }
+    __syncthreads();
+    g1_fft128_dif(sh, g1tw_fwd, lane);
+    for (int k = lane; k < 128; k += 64) {
+        G1X p;
+        lp_get(p, sh, (int)(__brev((uint32_t)k) >> 25));
+        G1Aff a;
+        f_to_affine(a, p);
+        f_store_affine(t_aff + ((size_t)k * 64 + i) * 32, a);
+    }
+}
+
+// set-up, step 2: D[(k*64+i)][w][m-1] = m * 2^(8w) * T[k][i], affine rows.  One lane per (point, window).
+__global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restrict__ t_aff, uint32_t* __restrict__ table, int n_points) {
+    const size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= (size_t)n_points * FK_NWIN) return;
+    const int pt = (int)(gid / FK_NWIN), w = (int)(gid % FK_NWIN);
+    G1Aff base;
+    f_load_affine(base, t_aff + (size_t)pt * 32);
+    uint32_t* dst = table + ((size_t)pt * FK_NWIN + w) * FK_NMULT * 32;
+    if (base.inf) {
+        for (int m = 0; m < FK_NMULT; m++) f_store_affine(dst + (size_t)m * 32, base);
+        return;
+    }
+    G1X b;
+    g1x_from_affine(b, base.x, base.y);
+    for (int q = 0; q < FK_C * w; q++) f_dbl(b, b);
+    f_to_affine(base, b);
+    G1X acc;
+    g1x_set_inf(acc);
+    for (int m = 0; m < FK_NMULT; m++) {
+        f_madd(acc, base.x, base.y);
+        G1Aff a;
+        f_to_affine(a, acc);
+        f_store_affine(dst + (size_t)m * 32, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fk20_msm: R[b][k] = sum_i V[b][k][i] * T[k][i] through the direct table.  16 lanes per MSM,
+// lane l handles windows 2l, 2l+1 for all 64 points; 4 MSMs per wavefront.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void f_shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.x.l[i] = __shfl_xor(a.x.l[i], m);
+        r.y.l[i] = __shfl_xor(a.y.l[i], m);
+        r.zz.l[i] = __shfl_xor(a.zz.l[i], m);
+        r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
+    }
+}
+__global__ void __launch_bounds__(64) k_fk20_msm(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ table, const int* __restrict__ status,
+                                                 uint32_t* __restrict__ results) {
+    const int b = blockIdx.y;
+    if (status[b] != 0) return;
+    const int lane = threadIdx.x, sub = lane & 15;
+    const int k = blockIdx.x * 4 + (lane >> 4);
+    const uint32_t* sc = scalars + ((size_t)b * 128 + k) * 64 * 8;
+    G1X acc;
+    g1x_set_inf(acc);
+    for (int i = 0; i < 64; i++) {
+        const uint32_t* s = sc + i * 8;
+#pragma unroll
+        for (int ww = 0; ww < 2; ww++) {
+            const int w = 2 * sub + ww;
+            const int bit = FK_C * w - 1;
+            uint32_t v;
+            if (bit < 0) {
+                v = (s[0] << 1) & 0x1ffu;
+            } else {
+                const int wi = bit >> 5, off = bit & 31;
+                v = s[wi] >> off;
+                if (off + FK_C + 1 > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - off);
+                v &= 0x1ffu;
+            }
+            int d = (int)((v + 1) >> 1);
+            if (v >> FK_C) d -= (1 << FK_C);
+            if (d != 0) {
+                const int m = d < 0 ? -d : d;
+                G1Aff p;
+                f_load_affine(p, table + (((size_t)(k * 64 + i) * FK_NWIN + w) * FK_NMULT + (m - 1)) * 32);
+                if (!p.inf) {
+                    if (d < 0) Fp::template neg<0>(p.y, p.y);
+                    f_madd(acc, p.x, p.y);
+                }
+            }
+        }
+    }
+    // combine the 16 partial sums
+    G1X o;
+    for (int m = 8; m >= 1; m >>= 1) {
+        f_shfl_xor_xyzz(o, acc, m);
+        f_add(acc, acc, o);
+    }
+    if (sub == 0) f_store_xyzz(results + ((size_t)b * 128 + k) * 64, acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fk20_ffts: one wavefront per blob: IFFT_128 (1/128 already folded into the scalars), keep
+// h[0..63], FFT_128, bit-reverse, compress.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fk20_ffts(const uint32_t* __restrict__ results, const uint32_t* __restrict__ g1tw_fwd, const uint32_t* __restrict__ g1tw_inv,
+                                                  const int* __restrict__ status, uint8_t* __restrict__ proofs48) {
+    __shared__ uint32_t sh[56 * 128];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (status[b] != 0) return;
+    for (int j = lane; j < 128; j += 64) {
+        G1X p;
+        f_load_xyzz(p, results + ((size_t)b * 128 + j) * 64);
+        lp_put(sh, j, p);
+    }
+    __syncthreads();
+    g1_fft128_dif(sh, g1tw_inv, lane);
+    // slot p now holds h[brev7(p)]; h[j] for j >= 64 lives in the odd slots: drop it (toeplitz.go:124, fk20.go:83-86)
+    {
+        G1X z;
+        g1x_set_inf(z);
+        lp_put(sh, 2 * lane + 1, z);
+    }
+    __syncthreads();
+    g1_fft128_dit(sh, g1tw_fwd, lane);
+    for (int i = lane; i < 128; i += 64) {
+        G1X p;
+        lp_get(p, sh, (int)(__brev((uint32_t)i) >> 25));          // proofs[i] = X[brev(i)]  (fk20.go:90)
+        G1Aff a;
+        f_to_affine(a, p);
+        uint32_t w[12];
+        g1_compress_words(w, a);
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(proofs48 + ((size_t)b * 128 + i) * 48);
+#pragma unroll
+        for (int q = 0; q < 12; q++) o32[q] = __builtin_bswap32(w[q]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fwd, uint32_t* d_t_aff, uint32_t* d_table, hipStream_t s) {
+    hipLaunchKernelGGL(k_fk20_setup_fft, dim3(64), dim3(64), 0, s, d_monomial_aff, d_g1tw_fwd, d_t_aff);
+    const size_t n = (size_t)8192 * FK_NWIN;
+    hipLaunchKernelGGL(k_fk20_setup_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_t_aff, d_table, 8192);
+}
+void fk20_proofs_device(const uint32_t* d_scalars, const uint32_t* d_table, const uint32_t* d_g1tw_fwd, const uint32_t* d_g1tw_inv, int n, const int* d_status,
+                        uint32_t* d_results, uint8_t* d_proofs48, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fk20_msm, dim3(32, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_results);
+    hipLaunchKernelGGL(k_fk20_ffts, dim3(n), dim3(64), 0, s, d_results, d_g1tw_fwd, d_g1tw_inv, d_status, d_proofs48);
+}
+size_t fk20_table_bytes() { return (size_t)8192 * FK_NWIN * FK_NMULT * 128; }
+
+}  // namespace kzg

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
     "mkzg_last_host_finish_us", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
-    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device",
+    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch",
 ]
 
 
@@ -76,6 +76,7 @@ def lib():
         L.mkzg_compute_cells_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
         L.mkzg_compute_cells_and_kzg_proofs.argtypes = [vp, C.c_char_p, i32, C.c_char_p, C.c_char_p]
         L.mkzg_compute_cells_and_kzg_proofs_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+        L.mkzg_verify_cell_kzg_proof_batch.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, C.c_char_p, sz]
         L.mkzg_profile_enable.argtypes = [vp, i32]
         L.mkzg_profile_read.argtypes = [vp, C.POINTER(KernelTime), i32, i32]
         L.mkzg_version.restype = C.c_char_p
@@ -216,6 +217,16 @@ class Context:
 
     def compute_cells_and_kzg_proofs_batch_device(self, d_blobs_ptr, n, d_cells_ptr, d_proofs_ptr, d_status_ptr, stream=0):
         return self._L.mkzg_compute_cells_and_kzg_proofs_batch_device(self._h, d_blobs_ptr, n, d_cells_ptr, d_proofs_ptr, d_status_ptr, stream)
+
+    def VerifyCellKZGProofBatch(self, commitments, cell_indices, cells, proofs):
+        """reference api_eip7594.go:163"""
+        if any(len(x) != 48 for x in commitments) or any(x is not None and len(x) != BYTES_PER_CELL for x in cells) or any(len(x) != 48 for x in proofs):
+            return ERR_BAD_ARGS
+        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        keep = [None if x is None else bytes(x) for x in cells]
+        arr = (C.c_char_p * max(1, len(cells)))(*keep)
+        return self._L.mkzg_verify_cell_kzg_proof_batch(self._h, b"".join(commitments), len(commitments), idx, len(cell_indices), arr, len(cells),
+                                                        b"".join(proofs), len(proofs))
 
     def last_host_finish_us(self):
         return self._L.mkzg_last_host_finish_us(self._h)

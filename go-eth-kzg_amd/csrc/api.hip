@@ -157,6 +157,14 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
         if (!g2_decompress(q0, c->g2_monomial.data()) || !g2_decompress(q1, c->g2_monomial.data() + 96)) return MKZG_ERR_BAD_TRUSTED_SETUP;
         g2_prepare(c->g2_gen, q0);
         g2_prepare(c->g2_alpha, q1);
+        // EIP-7594 opening key needs [alpha^64]G2 (api.go:113-115 panics below 64 points; we degrade: cell verify unavailable)
+        if (c->g2_monomial.size() >= 65 * 96) {
+            G2Aff q64, nq0;
+            if (!g2_decompress(q64, c->g2_monomial.data() + 64 * 96)) return MKZG_ERR_BAD_TRUSTED_SETUP;
+            g2_neg(nq0, q0);
+            g2_prepare(c->g2_alpha64, q64);
+            g2_prepare(c->g2_neg_gen, nq0);
+        }
         return MKZG_OK;
     }();
     if (rc) { mkzg_ctx_free(c); return rc; }

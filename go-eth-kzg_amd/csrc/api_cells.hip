@@ -2,42 +2,76 @@
 //   Context.ComputeCells                  reference api_eip7594.go:12-26
 //   Context.ComputeCellsAndKZGProofs      reference api_eip7594.go:28-52
 // All field work happens in cells_kernels.hip / fk20_kernels.hip; the host only stages bytes.
+#include <sys/random.h>
+#include <string>
+#include <unordered_map>
 #include "ctx.h"
+
+static const size_t V_MISC_WORDS_C = 16 + 4 * VMSM_WINDOWS * 48;
 
 void free_cells(mkzg_ctx* c) {
     void* ptrs[] = {c->d_tw_fwd, c->d_tw_inv, c->d_g1tw_fwd, c->d_g1tw_inv, c->d_coeffs, c->d_cells, c->d_cell_st,
-                    c->d_monomial_aff, c->d_fk_t_aff, c->d_fk_table, c->d_fk_scalars, c->d_fk_results, c->d_fk_proofs};
+                    c->d_monomial_aff, c->d_fk_t_aff, c->d_fk_table, c->d_fk_scalars, c->d_fk_results, c->d_fk_proofs,
+                    c->d_cv_cells, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_rp, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->d_tw_fwd = c->d_tw_inv = c->d_g1tw_fwd = c->d_g1tw_inv = c->d_coeffs = nullptr;
     c->d_cells = nullptr;
     c->d_cell_st = nullptr;
     c->d_monomial_aff = c->d_fk_t_aff = c->d_fk_table = c->d_fk_scalars = c->d_fk_results = nullptr;
     c->d_fk_proofs = nullptr;
+    c->d_cv_cells = nullptr; c->d_cv_cell_idx = nullptr; c->d_cv_row_idx = nullptr; c->d_cv_rp = nullptr; c->d_cv_weights = nullptr;
+    c->d_cv_partials = nullptr; c->d_cv_interp = nullptr; c->d_cv_st = nullptr; c->cv_cap = 0;
     c->cells_ready = false;
     c->cell_cap = 0;
     c->fk_ready = false;
     c->fk_cap = 0;
+}
+// monomial G1 SRS on the device (decoded without subgroup checks, trusted_setup.go:104-117)
+int ensure_monomial(mkzg_ctx* c) {
+    if (c->d_monomial_aff) return MKZG_OK;
+    uint8_t* d_raw = nullptr;
+    int* d_st = nullptr;
+    uint32_t* d_aff = nullptr;
+    HIPCHK(hipMalloc(&d_raw, 4096 * 48));
+    HIPCHK(hipMalloc(&d_st, 4096 * sizeof(int)));
+    HIPCHK(hipMalloc(&d_aff, 4096 * 128));
+    HIPCHK(hipMemcpyAsync(d_raw, c->g1_monomial.data(), 4096 * 48, hipMemcpyHostToDevice, c->stream));
+    g1_decompress_device(d_raw, 4096, d_aff, d_st, c->stream);
+    std::vector<int> st(4096);
+    HIPCHK(hipMemcpyAsync(st.data(), d_st, 4096 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_raw);
+    (void)hipFree(d_st);
+    for (int v : st) if (v) { (void)hipFree(d_aff); return MKZG_ERR_BAD_TRUSTED_SETUP; }
+    c->d_monomial_aff = d_aff;
+    return MKZG_OK;
+}
+static int ensure_cv_ws(mkzg_ctx* c, size_t n) {
+    if (n <= c->cv_cap) return MKZG_OK;
+    void* ptrs[] = {c->d_cv_cells, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_rp, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    c->cv_cap = 0;
+    size_t cap = std::max<size_t>(n, 128);
+    HIPCHK(hipMalloc(&c->d_cv_cells, cap * 2048));
+    HIPCHK(hipMalloc(&c->d_cv_cell_idx, cap * 8));
+    HIPCHK(hipMalloc(&c->d_cv_row_idx, cap * 4));
+    HIPCHK(hipMalloc(&c->d_cv_rp, cap * 48));
+    HIPCHK(hipMalloc(&c->d_cv_weights, cap * 32));
+    HIPCHK(hipMalloc(&c->d_cv_partials, (size_t)CELL_INTERP_BLOCKS * 64 * 48));
+    HIPCHK(hipMalloc(&c->d_cv_interp, 64 * 32));
+    HIPCHK(hipMalloc(&c->d_cv_st, cap * sizeof(int)));
+    c->cv_cap = cap;
+    return MKZG_OK;
 }
 // fk20.NewFK20 (reference fk20.go:23-52, called from api.go:137): done lazily on first use
 int ensure_fk20(mkzg_ctx* c, size_t n) {
     int rc = ensure_cells(c, n);
     if (rc) return rc;
     if (!c->fk_ready) {
-        uint8_t* d_raw = nullptr;
-        int* d_st = nullptr;
-        HIPCHK(hipMalloc(&d_raw, 4096 * 48));
-        HIPCHK(hipMalloc(&d_st, 4096 * sizeof(int)));
-        HIPCHK(hipMalloc(&c->d_monomial_aff, 4096 * 128));
+        rc = ensure_monomial(c);
+        if (rc) return rc;
         HIPCHK(hipMalloc(&c->d_fk_t_aff, 8192 * 128));
         HIPCHK(hipMalloc(&c->d_fk_table, fk20_table_bytes()));
-        HIPCHK(hipMemcpyAsync(d_raw, c->g1_monomial.data(), 4096 * 48, hipMemcpyHostToDevice, c->stream));
-        g1_decompress_device(d_raw, 4096, c->d_monomial_aff, d_st, c->stream);
-        std::vector<int> st(4096);
-        HIPCHK(hipMemcpyAsync(st.data(), d_st, 4096 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(d_raw);
-        (void)hipFree(d_st);
-        for (int v : st) if (v) return MKZG_ERR_BAD_TRUSTED_SETUP;
         fk20_setup_device(c->d_monomial_aff, c->d_g1tw_fwd, c->d_fk_t_aff, c->d_fk_table, c->stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -160,6 +194,113 @@ int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* c, const uint8_t* blob, int num_
     HIPCHK(hipMemcpyAsync(proofs_out, c->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return st;
+}
+
+// Context.VerifyCellKZGProofBatch (reference api_eip7594.go:163-214 + internal/kzg_multi/kzg_verify.go:16-105).
+// commitments: n_c x 48 B (one per cell, duplicates allowed); cell_indices: n_i; cells: n_cells host pointers;
+// proofs: n_p x 48 B.  At most 8192 cells per call.
+int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
+                                     size_t n_cells, const uint8_t* proofs48n, size_t n_p) {
+    if (!c) return MKZG_ERR_BAD_ARGS;
+    // deduplicateKZGCommitments (api_eip7594.go:238-265)
+    std::unordered_map<std::string, uint32_t> seen;
+    std::vector<uint32_t> row_idx(n_c);
+    std::vector<uint8_t> rows;
+    for (size_t i = 0; i < n_c; i++) {
+        std::string key((const char*)commitments48n + 48 * i, 48);
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            it = seen.emplace(key, (uint32_t)seen.size()).first;
+            rows.insert(rows.end(), commitments48n + 48 * i, commitments48n + 48 * i + 48);
+        }
+        row_idx[i] = it->second;
+    }
+    const size_t n = n_c, n_rows = seen.size();
+    if (n != n_i || n != n_cells || n != n_p) return MKZG_ERR_BATCH_LENGTH;          // api_eip7594.go:166-171
+    if (n == 0) return MKZG_OK;                                                        // :173-175
+    if (!cell_indices || !cells || !proofs48n) return MKZG_ERR_BAD_ARGS;
+    for (size_t i = 0; i < n; i++) if (cell_indices[i] >= MKZG_CELLS_PER_EXT_BLOB) return MKZG_ERR_INVALID_CELL_ID;   // :184-188
+    if (n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
+    if (c->g2_alpha64.lines.empty()) return MKZG_ERR_BAD_TRUSTED_SETUP;
+    size_t first_nil = n;
+    for (size_t i = 0; i < n; i++) if (!cells[i]) { first_nil = i; break; }
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = ensure_cells(c, 1);
+    if (!rc) rc = ensure_monomial(c);
+    if (!rc) rc = ensure_verify_ws(c, n);
+    if (!rc) rc = ensure_cv_ws(c, n);
+    if (!rc) rc = ensure_staging(c, 1, n * 2048);
+    if (rc) return rc;
+    const size_t cap = c->v_cap;
+    // uploads
+    std::vector<uint8_t> zero_cell;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* src = cells[i];
+        if (!src) { if (zero_cell.empty()) zero_cell.assign(2048, 0); src = zero_cell.data(); }
+        memcpy(c->h_stage + i * 2048, src, 2048);
+    }
+    HIPCHK(hipMemcpyAsync(c->d_cv_cells, c->h_stage, n * 2048, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_v_raw, rows.data(), n_rows * 48, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_v_raw + cap * 48, proofs48n, n * 48, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_cv_cell_idx, cell_indices, n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_cv_row_idx, row_idx.data(), n * 4, hipMemcpyHostToDevice, s));
+    uint32_t* h_misc = (uint32_t*)(c->h_v + 3 * cap * sizeof(int));
+    if (getrandom(h_misc, 32, 0) != 32) return MKZG_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
+    // points
+    uint32_t* aff_rows = c->d_v_aff;
+    uint32_t* aff_q = c->d_v_aff + cap * 32;
+    int* st_rows = c->d_v_st;
+    int* st_q = c->d_v_st + cap;
+    g1_decompress_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, s);
+    g1_decompress_device(c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s);
+    g1_subgroup_check_device(aff_rows, (int)n_rows, st_rows, s);
+    g1_subgroup_check_device(aff_q, (int)n, st_q, s);
+    // scalars
+    cell_verify_scalars_device(c->d_v_misc, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, c->d_cv_rp, c->d_v_s1,
+                               c->d_v_s3, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st, s);
+    // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
+    const uint32_t* scal[4] = {c->d_v_s1, c->d_cv_weights, c->d_cv_interp, c->d_v_s3};
+    const uint32_t* pts[4] = {aff_q, aff_rows, c->d_monomial_aff, aff_q};
+    const int njob[4] = {(int)n, (int)n_rows, 64, (int)n};
+    if (vmsm_windows_device(scal, pts, njob, 4, c->d_v_misc + 16, s)) return MKZG_ERR_BAD_ARGS;
+    HIPCHK(hipGetLastError());
+    int* h_st = (int*)c->h_v;
+    std::vector<int> st_cells(n);
+    HIPCHK(hipMemcpyAsync(h_st, c->d_v_st, 2 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(st_cells.data(), c->d_cv_st, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_misc, c->d_v_misc, V_MISC_WORDS_C * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    // error precedence of api_eip7594.go:190-213: all commitments, then all proofs, then all cells
+    for (size_t i = 0; i < n_rows; i++) if (h_st[i]) return h_st[i];
+    for (size_t i = 0; i < n; i++) if (h_st[cap + i]) return h_st[cap + i];
+    for (size_t i = 0; i < n; i++) {
+        if (i == first_nil) return MKZG_ERR_NIL_INPUT;
+        if (st_cells[i]) return st_cells[i];
+    }
+    // host finish (kzg_verify.go:85-104)
+    G1HX win[VMSM_WINDOWS], sums[4];
+    const uint32_t* wsum = h_misc + 16;
+    for (int m = 0; m < 4; m++) {
+        for (int w = 0; w < VMSM_WINDOWS; w++) {
+            const uint32_t* p = wsum + ((size_t)m * VMSM_WINDOWS + w) * 48;
+            bool zero = true;
+            for (int q = 24; q < 36; q++) zero = zero && p[q] == 0;
+            if (zero) G1H::set_inf(win[w]); else g1h_from_plain_words(win[w], p);
+        }
+        g1h_horner(sums[m], win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
+    }
+    G1HX rl, t;
+    G1H::neg(t, sums[2]);
+    G1H::add(rl, sums[1], t);
+    G1H::add(rl, rl, sums[3]);
+    G1AffH ps[2];
+    g1h_to_affine(ps[0], sums[0]);
+    g1h_to_affine(ps[1], rl);
+    const G2Prepared* qs[2] = {&c->g2_alpha64, &c->g2_neg_gen};
+    return pairing_check_prepared(ps, qs, 2) ? MKZG_OK : MKZG_VERIFY_FAILED;
 }
 
 }  // extern "C"

@@ -13,7 +13,7 @@
 // ---------------------------------------------------------------------------------------------
 // workspaces
 // ---------------------------------------------------------------------------------------------
-static const size_t V_MISC_WORDS = 16 + 3 * VMSM_WINDOWS * 48;
+static const size_t V_MISC_WORDS = 16 + 4 * VMSM_WINDOWS * 48;
 #define KT(kind, s, call)                                  \
     do {                                                   \
         if (c->profiling) c->timer.begin(kind, s);         \
@@ -121,7 +121,8 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     const uint32_t* scal[3] = {c->d_v_s1, c->d_v_s1, c->d_v_s3};
     const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
     int vrc = 0;
-    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, 3, (int)n, c->d_v_misc + 16, s));
+    const int njob[3] = {(int)n, (int)n, (int)n};
+    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, c->d_v_misc + 16, s));
     if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     // 5. one round trip: statuses, e, window sums

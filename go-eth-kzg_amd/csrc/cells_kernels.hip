@@ -334,6 +334,151 @@ __global__ void __launch_bounds__(NT) k_fk20_scalars(const uint32_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// VerifyCellKZGProofBatch (reference internal/kzg_multi/kzg_verify.go:16-105), device side of the
+// scalar work.  w_8192^e for any e in [0, 8192): the tables hold e < 4096, the rest is -w^(e-4096).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tw_any(fr_t& r, const uint32_t* __restrict__ tw, uint32_t e) {
+    e &= 8191u;
+    if (e < 4096u) {
+        c_load_fr12(r, tw + (size_t)e * 12);
+    } else {
+        fr_t t;
+        c_load_fr12(t, tw + (size_t)(e - 4096u) * 12);
+        FrC::neg(r, t);
+    }
+}
+__device__ __forceinline__ void fr_reduce_words(uint32_t v[8]) {   // value < 2^256 -> value mod r
+    for (int rep = 0; rep < 2; rep++) {
+        if (Fr::words32_geq_mod(v)) {
+            uint64_t br = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)v[i] - FrParams::MOD32[i] - br; v[i] = (uint32_t)t; br = (t >> 32) & 1; }
+        }
+    }
+}
+__device__ __forceinline__ void fr_store_plain8(uint32_t* dst, const fr_t& m) {
+    fr_t pl;
+    uint32_t w[8];
+    Fr::to_plain(pl, m);
+    Fr::to_words32(w, pl);
+#pragma unroll
+    for (int q = 0; q < 8; q++) dst[q] = w[q];
+}
+// r^k rows, s1_k = r^k, s4_k = r^k * h_{cell_k}^64   (kzg_verify.go:28, 73-79; srs.go:75-78)
+__global__ void __launch_bounds__(256) k_cell_rpowers(const uint32_t* __restrict__ r_words8, const uint64_t* __restrict__ cell_idx, int n, const uint32_t* __restrict__ tw_fwd,
+                                                      uint32_t* __restrict__ rp_rows, uint32_t* __restrict__ s1, uint32_t* __restrict__ s4) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    uint32_t rw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rw[i] = r_words8[i];
+    fr_reduce_words(rw);
+    fr_t r, pl;
+    Fr::from_words32(pl, rw);
+    Fr::from_plain(r, pl);
+    Fr::reduce_once(r, r);
+    fr_t rp, base = r;
+    Fr::set_one(rp);
+    for (uint32_t e = (uint32_t)k; e; e >>= 1) {
+        if (e & 1) c_fr_mul(rp, rp, base);
+        c_fr_mul(base, base, base);
+    }
+    Fr::reduce_once(rp, rp);
+    c_store_fr12(rp_rows + (size_t)k * 12, rp);
+    fr_store_plain8(s1 + (size_t)k * 8, rp);
+    const uint32_t c = (uint32_t)cell_idx[k] & 127u;
+    fr_t hp, v;
+    tw_any(hp, tw_fwd, 64u * (__brev(c) >> 25));                 // h_c^64 = w_8192^(64 brev7(c))
+    c_fr_mul(v, rp, hp);
+    fr_store_plain8(s4 + (size_t)k * 8, v);
+}
+// weights[row] = sum_{k : row_idx[k] == row} r^k   (kzg_verify.go:36-40)
+__global__ void __launch_bounds__(64) k_cell_weights(const uint32_t* __restrict__ rp_rows, const uint32_t* __restrict__ row_idx, int n, int n_rows, uint32_t* __restrict__ weights8) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= n_rows) return;
+    fr_t acc;
+    Fr::set_zero(acc);
+    for (int k = 0; k < n; k++) {
+        if ((int)row_idx[k] == row) {
+            fr_t v;
+            c_load_fr12(v, rp_rows + (size_t)k * 12);
+            FrC::add(acc, acc, v);
+        }
+    }
+    fr_store_plain8(weights8 + (size_t)row * 8, acc);
+}
+// per cell: canonical check, coset IFFT-64 on the bit-reversed evaluations, times r^k, summed per
+// workgroup into partials[block][64]   (kzg_verify.go:50-66, coset_fft.go:55-70)
+__global__ void __launch_bounds__(64) k_cell_interp(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_idx, const uint32_t* __restrict__ rp_rows, int n,
+                                                    const uint32_t* __restrict__ tw_inv, uint32_t* __restrict__ partials, int* __restrict__ cell_status) {
+    __shared__ uint32_t sh[9 * 64];
+    const int lane = threadIdx.x;
+    fr_t acc, inv64;
+    Fr::set_zero(acc);
+    {
+        fr_t x;
+        Fr::set(x, FR_INV_4096);
+        for (int s = 0; s < 6; s++) FrC::add(x, x, x);           // 64/4096
+        inv64 = x;
+    }
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        uint32_t w[8];
+        c_load_be32(w, cells + (size_t)k * 2048 + (size_t)lane * 32);
+        const bool bad = Fr::words32_geq_mod(w);
+        if (__syncthreads_or(bad)) {
+            if (lane == 0) cell_status[k] = MKZG_ERR_NON_CANONICAL_SCALAR;
+            continue;
+        }
+        if (lane == 0) cell_status[k] = 0;
+        fr_t pl, m;
+        Fr::from_words32(pl, w);
+        Fr::from_plain(m, pl);
+        Fr::reduce_once(m, m);
+        lds_put<64>(sh, lane, m);
+        __syncthreads();
+        // DIT with inverse twiddles: the cell is the bit-reversed natural-order input (kzg_verify.go:52)
+        for (int h = 1; h < 64; h <<= 1) {
+            if (lane < 32) {
+                const int kk = lane & (h - 1);
+                const int i0 = ((lane - kk) << 1) + kk, i1 = i0 + h;
+                fr_t a, bb, tw, tt;
+                lds_get<64>(a, sh, i0);
+                lds_get<64>(bb, sh, i1);
+                c_load_fr12(tw, tw_inv + (size_t)(kk * (32 / h) * 128) * 12);
+                c_fr_mul(tt, bb, tw);
+                FrC::add(bb, a, tt);
+                FrC::sub(a, a, tt);
+                lds_put<64>(sh, i0, bb);
+                lds_put<64>(sh, i1, a);
+            }
+            __syncthreads();
+        }
+        fr_t v, hs, rp;
+        lds_get<64>(v, sh, lane);
+        const uint32_t c = (uint32_t)cell_idx[k] & 127u;
+        tw_any(hs, tw_inv, (uint32_t)lane * (__brev(c) >> 25));  // (h_c^-1)^lane
+        c_load_fr12(rp, rp_rows + (size_t)k * 12);
+        c_fr_mul(v, v, inv64);
+        c_fr_mul(v, v, hs);
+        c_fr_mul(v, v, rp);
+        FrC::add(acc, acc, v);
+        __syncthreads();
+    }
+    c_store_fr12(partials + ((size_t)blockIdx.x * 64 + lane) * 12, acc);
+}
+__global__ void __launch_bounds__(64) k_cell_interp_reduce(const uint32_t* __restrict__ partials, int n_blocks, uint32_t* __restrict__ interp8) {
+    const int lane = threadIdx.x;
+    fr_t acc;
+    Fr::set_zero(acc);
+    for (int b = 0; b < n_blocks; b++) {
+        fr_t v;
+        c_load_fr12(v, partials + ((size_t)b * 64 + lane) * 12);
+        FrC::add(acc, acc, v);
+    }
+    fr_store_plain8(interp8 + (size_t)lane * 8, acc);
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 static bool g_attr_set = false;
@@ -362,6 +507,17 @@ void cells_from_coeffs_device(const uint32_t* d_coeffs, int n, const uint32_t* d
 void fk20_scalars_device(const uint32_t* d_coeffs, int n, const uint32_t* d_tw_fwd, const int* d_status, uint32_t* d_scalars, hipStream_t s) {
     set_lds_attrs();
     if (n > 0) hipLaunchKernelGGL(k_fk20_scalars, dim3(n), dim3(NT), 9 * 4096 * 4, s, d_coeffs, d_tw_fwd, d_status, d_scalars);
+}
+
+void cell_verify_scalars_device(const uint32_t* d_r8, const uint64_t* d_cell_idx, const uint32_t* d_row_idx, const uint8_t* d_cells, int n, int n_rows,
+                                const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint32_t* d_rp_rows, uint32_t* d_s1, uint32_t* d_s4, uint32_t* d_weights8,
+                                uint32_t* d_partials, uint32_t* d_interp8, int* d_cell_status, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_cell_rpowers, dim3((n + 255) / 256), dim3(256), 0, s, d_r8, d_cell_idx, n, d_tw_fwd, d_rp_rows, d_s1, d_s4);
+    hipLaunchKernelGGL(k_cell_weights, dim3((n_rows + 63) / 64), dim3(64), 0, s, d_rp_rows, d_row_idx, n, n_rows, d_weights8);
+    const int nb = n < CELL_INTERP_BLOCKS ? n : CELL_INTERP_BLOCKS;
+    hipLaunchKernelGGL(k_cell_interp, dim3(nb), dim3(64), 0, s, d_cells, d_cell_idx, d_rp_rows, n, d_tw_inv, d_partials, d_cell_status);
+    hipLaunchKernelGGL(k_cell_interp_reduce, dim3(1), dim3(64), 0, s, d_partials, nb, d_interp8);
 }
 
 }  // namespace kzg

@@ -55,6 +55,7 @@ struct mkzg_ctx {
     uint32_t* d_roots_brp = nullptr;       // 4096 Fr rows (12 words), bit-reversed domain (api.go:132)
     uint32_t* d_inv_roots_brp = nullptr;
     G2Prepared g2_gen, g2_alpha;           // prepared [1]G2, [alpha]G2 (kzg.OpeningKey, internal/kzg/srs.go:10-20)
+    G2Prepared g2_neg_gen, g2_alpha64;     // prepared -[1]G2, [alpha^64]G2 (kzgmulti.OpeningKey, internal/kzg_multi/kzg_verify.go:89-92)
     // verify workspace, sized for v_cap proofs
     size_t v_cap = 0;
     uint8_t* d_v_raw = nullptr;            // 2 v_cap x 48 B   (commitments | proofs)
@@ -83,6 +84,16 @@ struct mkzg_ctx {
     uint32_t* d_coeffs = nullptr;          // cell_cap x 4096 Fr rows
     uint8_t* d_cells = nullptr;            // cell_cap x 262144 B
     int* d_cell_st = nullptr;
+    // VerifyCellKZGProofBatch workspace, cv_cap cells
+    size_t cv_cap = 0;
+    uint8_t* d_cv_cells = nullptr;         // cv_cap x 2048 B
+    uint64_t* d_cv_cell_idx = nullptr;
+    uint32_t* d_cv_row_idx = nullptr;
+    uint32_t* d_cv_rp = nullptr;           // cv_cap Fr rows
+    uint32_t* d_cv_weights = nullptr;      // cv_cap x 8 words
+    uint32_t* d_cv_partials = nullptr;     // CELL_INTERP_BLOCKS x 64 Fr rows
+    uint32_t* d_cv_interp = nullptr;       // 64 x 8 words
+    int* d_cv_st = nullptr;                // cv_cap
     // FK20
     bool fk_ready = false;
     uint32_t* d_monomial_aff = nullptr;    // 4096 affine rows
@@ -104,4 +115,5 @@ void free_verify_ws(mkzg_ctx* c);
 int ensure_cells(mkzg_ctx* c, size_t n);
 void free_cells(mkzg_ctx* c);
 int ensure_fk20(mkzg_ctx* c, size_t n);
+int ensure_monomial(mkzg_ctx* c);
 

@@ -467,10 +467,11 @@ __device__ __forceinline__ void shfl_down_xyzz_v(G1X& r, const G1X& a, int d) {
 struct VmsmJob {
     const uint32_t* scalars;   // n x 8 words
     const uint32_t* points;    // n affine rows (32 words)
+    int n;
 };
 struct VmsmJobs { VmsmJob j[4]; };
 
-__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, int n, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
+__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
     __shared__ uint32_t ent[VMAXN];
     __shared__ uint32_t hist[VNB + 1];
     __shared__ uint32_t cursor[VNB];
@@ -478,6 +479,7 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, int n, uint3
     const int w = blockIdx.x, m = blockIdx.y, t = threadIdx.x;
     const uint32_t* sc = jobs.j[m].scalars;
     const uint32_t* pts = jobs.j[m].points;
+    const int n = jobs.j[m].n;
     hist[t] = 0;
     if (t == 0) hist[VNB] = 0;
     __syncthreads();
@@ -659,11 +661,17 @@ void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipSt
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e, hipStream_t s) {
     hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, d_s1, d_s3, d_e);
 }
-int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, int n_msm, int n, uint32_t* d_out, hipStream_t s) {
-    if (n_msm < 1 || n_msm > 4 || n < 0 || n > VMAXN) return -1;
+int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_out, hipStream_t s) {
+    if (n_msm < 1 || n_msm > 4) return -1;
     VmsmJobs jobs;
-    for (int m = 0; m < 4; m++) { jobs.j[m].scalars = d_scalars[m < n_msm ? m : 0]; jobs.j[m].points = d_points[m < n_msm ? m : 0]; }
-    hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm), dim3(VNB), 0, s, jobs, n, d_out);
+    for (int m = 0; m < 4; m++) {
+        const int q = m < n_msm ? m : 0;
+        if (n_per_job[q] < 0 || n_per_job[q] > VMAXN) return -1;
+        jobs.j[m].scalars = d_scalars[q];
+        jobs.j[m].points = d_points[q];
+        jobs.j[m].n = n_per_job[q];
+    }
+    hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm), dim3(VNB), 0, s, jobs, d_out);
     return 0;
 }
 void build_roots_device(uint32_t* d_roots_brp, uint32_t* d_inv_roots_brp, int log_n, hipStream_t s) {

@@ -110,6 +110,11 @@ int mkzg_compute_cells_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n
 int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint8_t* cells_out, uint8_t* proofs_out);
 int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n, void* d_cells, void* d_proofs, int* d_status, void* stream);
 
+/* Context.VerifyCellKZGProofBatch (reference api_eip7594.go:163-214): one commitment, cell index, cell and
+ * proof per entry; the four counts mirror the four Go slices.  At most 8192 cells per call. */
+int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* commitments48n, size_t n_commitments, const uint64_t* cell_indices, size_t n_indices,
+                                     const uint8_t* const* cells, size_t n_cells, const uint8_t* proofs48n, size_t n_proofs);
+
 /* ---- profiling hooks (bench.py's roofline section) ------------------------------------------ */
 /* When enabled, every kernel launch of the hot path is bracketed by hipEvents on its stream. */
 int mkzg_profile_enable(mkzg_ctx* ctx, int on);

@@ -60,3 +60,41 @@ def test_compute_cells_and_kzg_proofs_vs_oracle(gpu_ctx, oracle_ctx):
     rco, ec, ep = oracle_ctx.compute_cells_and_kzg_proofs(blob)
     assert rc == 0 and rco == 0
     assert b"".join(cells) == ec and b"".join(proofs) == ep
+
+
+def _check_verifier(rc, expected, name):
+    if expected is None:
+        assert rc not in (0, 1), f"{name}: expected input error, got rc={rc}"
+    elif expected is True:
+        assert rc == 0, f"{name}: expected accept, got rc={rc}"
+    else:
+        assert rc == 1, f"{name}: expected reject, got rc={rc}"
+
+
+def test_verify_cell_kzg_proof_batch_vectors(vectors, gpu_ctx):
+    for c in vectors.cases("verify_cell_kzg_proof_batch"):
+        i = c["input"]
+        cms, idx, cells, prs = (vectors.val(i[k]) for k in ("commitments", "cell_indices", "cells", "proofs"))
+        exp = vectors.val(c["output"])
+        if _bad(*cms, *cells, *prs) or any(len(x) != 48 for x in cms) or any(len(x) != 2048 for x in cells) or any(len(x) != 48 for x in prs):
+            assert exp is None
+            continue
+        _check_verifier(gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs), exp, c["name"])
+
+
+def test_verify_cells_two_blobs(gpu_ctx):
+    """cells of two blobs, interleaved (dedup path), then a wrong cell must be rejected"""
+    items = []
+    for seed in (5, 6):
+        blob = rand_blob(seed)
+        rc, cm = gpu_ctx.BlobToKZGCommitment(blob)
+        rc2, cells, proofs = gpu_ctx.ComputeCellsAndKZGProofs(blob)
+        assert rc == 0 and rc2 == 0
+        items += [(cm, i, cells[i], proofs[i]) for i in range(0, 128, 3)]
+    items = items[::2] + items[1::2]
+    cms, idx, cells, prs = map(list, zip(*items))
+    assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs) == 0
+    cells[5], cells[6] = cells[6], cells[5]
+    assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs) == 1
+    assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx[:-1], cells, prs) == 2
+    assert gpu_ctx.VerifyCellKZGProofBatch([], [], [], []) == 0

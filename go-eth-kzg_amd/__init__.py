@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
     "mkzg_last_host_finish_us", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
     "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch",
+    "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
 ]
 
 
@@ -77,6 +78,8 @@ def lib():
         L.mkzg_compute_cells_and_kzg_proofs.argtypes = [vp, C.c_char_p, i32, C.c_char_p, C.c_char_p]
         L.mkzg_compute_cells_and_kzg_proofs_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.mkzg_verify_cell_kzg_proof_batch.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, C.c_char_p, sz]
+        L.mkzg_recover_cells_and_kzg_proofs.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p, C.c_char_p]
+        L.mkzg_recover_cells.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p]
         L.mkzg_profile_enable.argtypes = [vp, i32]
         L.mkzg_profile_read.argtypes = [vp, C.POINTER(KernelTime), i32, i32]
         L.mkzg_version.restype = C.c_char_p
@@ -227,6 +230,33 @@ class Context:
         arr = (C.c_char_p * max(1, len(cells)))(*keep)
         return self._L.mkzg_verify_cell_kzg_proof_batch(self._h, b"".join(commitments), len(commitments), idx, len(cell_indices), arr, len(cells),
                                                         b"".join(proofs), len(proofs))
+
+    def RecoverCellsAndComputeKZGProofs(self, cell_ids, cells, num_goroutines=0):
+        """reference api_eip7594.go:144 -> (rc, [128 cells], [128 proofs])"""
+        if any(x is not None and len(x) != BYTES_PER_CELL for x in cells):
+            return ERR_BAD_ARGS, None, None
+        ids = (C.c_uint64 * max(1, len(cell_ids)))(*cell_ids)
+        keep = [None if x is None else bytes(x) for x in cells]
+        arr = (C.c_char_p * max(1, len(cells)))(*keep)
+        oc = C.create_string_buffer(CELLS_PER_EXT_BLOB * BYTES_PER_CELL)
+        op = C.create_string_buffer(CELLS_PER_EXT_BLOB * 48)
+        rc = self._L.mkzg_recover_cells_and_kzg_proofs(self._h, ids, len(cell_ids), arr, len(cells), num_goroutines, oc, op)
+        if rc:
+            return rc, None, None
+        return (0, [oc.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)], [op.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
+
+    def RecoverCells(self, cell_ids, cells, num_goroutines=0):
+        """reference api_eip.go:8 -> (rc, [128 cells])"""
+        if any(x is not None and len(x) != BYTES_PER_CELL for x in cells):
+            return ERR_BAD_ARGS, None
+        ids = (C.c_uint64 * max(1, len(cell_ids)))(*cell_ids)
+        keep = [None if x is None else bytes(x) for x in cells]
+        arr = (C.c_char_p * max(1, len(cells)))(*keep)
+        oc = C.create_string_buffer(CELLS_PER_EXT_BLOB * BYTES_PER_CELL)
+        rc = self._L.mkzg_recover_cells(self._h, ids, len(cell_ids), arr, len(cells), num_goroutines, oc)
+        if rc:
+            return rc, None
+        return 0, [oc.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)]
 
     def last_host_finish_us(self):
         return self._L.mkzg_last_host_finish_us(self._h)

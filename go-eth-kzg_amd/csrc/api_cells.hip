@@ -12,7 +12,8 @@ static const size_t V_MISC_WORDS_C = 16 + 4 * VMSM_WINDOWS * 48;
 void free_cells(mkzg_ctx* c) {
     void* ptrs[] = {c->d_tw_fwd, c->d_tw_inv, c->d_g1tw_fwd, c->d_g1tw_inv, c->d_coeffs, c->d_cells, c->d_cell_st,
                     c->d_monomial_aff, c->d_fk_t_aff, c->d_fk_table, c->d_fk_scalars, c->d_fk_results, c->d_fk_proofs,
-                    c->d_cv_cells, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_rp, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st};
+                    c->d_cv_cells, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_rp, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st,
+                    c->d_pow7, c->d_ipow7, c->d_rec_scratch, c->d_rec_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->d_tw_fwd = c->d_tw_inv = c->d_g1tw_fwd = c->d_g1tw_inv = c->d_coeffs = nullptr;
     c->d_cells = nullptr;
@@ -21,6 +22,7 @@ void free_cells(mkzg_ctx* c) {
     c->d_fk_proofs = nullptr;
     c->d_cv_cells = nullptr; c->d_cv_cell_idx = nullptr; c->d_cv_row_idx = nullptr; c->d_cv_rp = nullptr; c->d_cv_weights = nullptr;
     c->d_cv_partials = nullptr; c->d_cv_interp = nullptr; c->d_cv_st = nullptr; c->cv_cap = 0;
+    c->d_pow7 = c->d_ipow7 = c->d_rec_scratch = nullptr; c->d_rec_pos = nullptr; c->rec_ready = false;
     c->cells_ready = false;
     c->cell_cap = 0;
     c->fk_ready = false;
@@ -301,6 +303,80 @@ int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n,
     g1h_to_affine(ps[1], rl);
     const G2Prepared* qs[2] = {&c->g2_alpha64, &c->g2_neg_gen};
     return pairing_check_prepared(ps, qs, 2) ? MKZG_OK : MKZG_VERIFY_FAILED;
+}
+
+// shared front end of RecoverCells / RecoverCellsAndComputeKZGProofs: reference api_eip7594.go:93-142
+static int recover_front(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, bool with_proofs) {
+    if (n_ids != n_cells) return MKZG_ERR_NUM_CELL_IDS;                                  // :94-96
+    for (size_t i = 1; i < n_ids; i++) if (cell_ids[i] <= cell_ids[i - 1]) return MKZG_ERR_CELL_IDS_NOT_ORDERED;   // :99-101
+    for (size_t i = 0; i < n_ids; i++) if (cell_ids[i] >= MKZG_CELLS_PER_EXT_BLOB) return MKZG_ERR_FOUND_INVALID_CELL_ID;   // :104-108
+    if (n_ids < 64) return MKZG_ERR_NOT_ENOUGH_CELLS;                                    // :111-113
+    for (size_t i = 0; i < n_cells; i++) if (!cells[i]) return MKZG_ERR_NIL_INPUT;       // serialization.go:197-199
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = with_proofs ? ensure_fk20(c, 1) : ensure_cells(c, 1);
+    if (!rc) rc = ensure_staging(c, 1, n_cells * 2048);
+    if (rc) return rc;
+    if (!c->rec_ready) {
+        HIPCHK(hipMalloc(&c->d_pow7, 8192 * 48));
+        HIPCHK(hipMalloc(&c->d_ipow7, 4096 * 48));
+        HIPCHK(hipMalloc(&c->d_rec_scratch, recover_scratch_words() * 4));
+        HIPCHK(hipMalloc(&c->d_rec_pos, (128 + 64) * sizeof(int)));
+        recover_tables_device(c->d_pow7, c->d_ipow7, s);
+        c->rec_ready = true;
+    }
+    int pos[128 + 64];
+    for (int i = 0; i < 128; i++) pos[i] = -1;
+    for (size_t i = 0; i < n_ids; i++) pos[cell_ids[i]] = (int)i;
+    int nm = 0;
+    for (uint32_t cid = 0; cid < 128; cid++) {
+        if (pos[cid] < 0) {
+            uint32_t r = 0;
+            for (int b = 0; b < 7; b++) if (cid & (1u << b)) r |= 1u << (6 - b);             // BitReverseInt(cellID, 128)  (:117-122)
+            pos[128 + nm++] = (int)r;
+        }
+    }
+    for (size_t i = 0; i < n_cells; i++) memcpy(c->h_stage + i * 2048, cells[i], 2048);
+    HIPCHK(hipMemcpyAsync(c->d_blobs, c->h_stage, n_cells * 2048, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_rec_pos, pos, sizeof(pos), hipMemcpyHostToDevice, s));
+    recover_coeffs_device(c->d_blobs, c->d_rec_pos, (const uint32_t*)(c->d_rec_pos + 128), nm, c->d_tw_fwd, c->d_tw_inv, c->d_pow7, c->d_ipow7, c->d_rec_scratch, c->d_coeffs,
+                          c->d_cell_st, s);
+    cells_from_coeffs_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_tw_inv, c->d_cells, c->d_cell_st, s);
+    if (with_proofs) {
+        fk20_scalars_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_cell_st, c->d_fk_scalars, s);
+        fk20_proofs_device(c->d_fk_scalars, c->d_fk_table, c->d_g1tw_fwd, c->d_g1tw_inv, 1, c->d_cell_st, c->d_fk_results, c->d_fk_proofs, s);
+    }
+    HIPCHK(hipGetLastError());
+    return MKZG_OK;
+}
+
+// Context.RecoverCellsAndComputeKZGProofs (reference api_eip7594.go:144-161)
+int mkzg_recover_cells_and_kzg_proofs(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads, uint8_t* cells_out,
+                                      uint8_t* proofs_out) {
+    (void)num_threads;
+    if (!c || !cells_out || !proofs_out || (n_ids && !cell_ids) || (n_cells && !cells)) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    int rc = recover_front(c, cell_ids, n_ids, cells, n_cells, true);
+    if (rc) return rc;
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(&st, c->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(cells_out, c->d_cells, 262144, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(proofs_out, c->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return st;
+}
+// Context.RecoverCells (reference api_eip.go:8-15)
+int mkzg_recover_cells(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads, uint8_t* cells_out) {
+    (void)num_threads;
+    if (!c || !cells_out || (n_ids && !cell_ids) || (n_cells && !cells)) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    int rc = recover_front(c, cell_ids, n_ids, cells, n_cells, false);
+    if (rc) return rc;
+    int st = 0;
+    HIPCHK(hipMemcpyAsync(&st, c->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(cells_out, c->d_cells, 262144, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return st;
 }
 
 }  // extern "C"

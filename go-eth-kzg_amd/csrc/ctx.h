@@ -13,6 +13,7 @@
 #include "verify_kernels.h"
 #include "cells_kernels.h"
 #include "fk20_kernels.h"
+#include "recover_kernels.h"
 #include "host_g1.hpp"
 
 using namespace kzg;
@@ -94,6 +95,12 @@ struct mkzg_ctx {
     uint32_t* d_cv_partials = nullptr;     // CELL_INTERP_BLOCKS x 64 Fr rows
     uint32_t* d_cv_interp = nullptr;       // 64 x 8 words
     int* d_cv_st = nullptr;                // cv_cap
+    // recovery
+    bool rec_ready = false;
+    uint32_t* d_pow7 = nullptr;
+    uint32_t* d_ipow7 = nullptr;
+    uint32_t* d_rec_scratch = nullptr;
+    int* d_rec_pos = nullptr;              // 128 ints + 64 missing ids
     // FK20
     bool fk_ready = false;
     uint32_t* d_monomial_aff = nullptr;    // 4096 affine rows

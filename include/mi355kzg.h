@@ -115,6 +115,13 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* ctx, const void* d_
 int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* commitments48n, size_t n_commitments, const uint64_t* cell_indices, size_t n_indices,
                                      const uint8_t* const* cells, size_t n_cells, const uint8_t* proofs48n, size_t n_proofs);
 
+/* Context.RecoverCellsAndComputeKZGProofs (reference api_eip7594.go:144-161): cell_ids strictly ascending, < 128,
+ * at least 64 of them; cells are host pointers in the same order. */
+int mkzg_recover_cells_and_kzg_proofs(mkzg_ctx* ctx, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads,
+                                      uint8_t* cells_out, uint8_t* proofs_out);
+/* Context.RecoverCells (reference api_eip.go:8-15). */
+int mkzg_recover_cells(mkzg_ctx* ctx, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads, uint8_t* cells_out);
+
 /* ---- profiling hooks (bench.py's roofline section) ------------------------------------------ */
 /* When enabled, every kernel launch of the hot path is bracketed by hipEvents on its stream. */
 int mkzg_profile_enable(mkzg_ctx* ctx, int on);

@@ -98,3 +98,41 @@ def test_verify_cells_two_blobs(gpu_ctx):
     assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs) == 1
     assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx[:-1], cells, prs) == 2
     assert gpu_ctx.VerifyCellKZGProofBatch([], [], [], []) == 0
+
+
+def test_recover_cells_and_kzg_proofs_vectors(vectors, gpu_ctx):
+    n_ok = 0
+    for c in vectors.cases("recover_cells_and_kzg_proofs"):
+        i = c["input"]
+        ids, cells = vectors.val(i["cell_indices"]), vectors.val(i["cells"])
+        exp = vectors.val(c["output"])
+        if _bad(*cells) or any(len(x) != 2048 for x in cells):
+            assert exp is None
+            continue
+        rc, oc, op = gpu_ctx.RecoverCellsAndComputeKZGProofs(ids, cells)
+        rc2, oc2 = gpu_ctx.RecoverCells(ids, cells)
+        if exp is None:
+            assert rc != 0 and rc2 != 0, c["name"]
+        else:
+            assert rc == 0 and oc == exp[0] and op == exp[1], c["name"]
+            assert rc2 == 0 and oc2 == oc
+            n_ok += 1
+    assert n_ok >= 4
+
+
+def test_recover_patterns_vs_oracle(gpu_ctx, oracle_ctx):
+    """the reference bench pattern (even cells, bench_eip7594_test.go:64-69) and ragged subsets"""
+    import random
+    blob = rand_blob(42)
+    rc, cells, proofs = gpu_ctx.ComputeCellsAndKZGProofs(blob)
+    assert rc == 0
+    rng = random.Random(3)
+    subsets = [list(range(0, 128, 2)), list(range(64)), list(range(64, 128)), sorted(rng.sample(range(128), 64)), sorted(rng.sample(range(128), 100)), list(range(128))]
+    for ids in subsets:
+        rc, oc, op = gpu_ctx.RecoverCellsAndComputeKZGProofs(ids, [cells[i] for i in ids])
+        assert rc == 0 and oc == cells and op == proofs, ids[:4]
+    ids = subsets[0]
+    assert gpu_ctx.RecoverCells(ids[:63], [cells[i] for i in ids[:63]])[0] == 10          # ErrNotEnoughCellsForReconstruction
+    assert gpu_ctx.RecoverCells(ids[::-1], [cells[i] for i in ids[::-1]])[0] == 8          # ErrCellIDsNotOrdered
+    assert gpu_ctx.RecoverCells(ids, [cells[i] for i in ids[:-1]])[0] == 7                 # ErrNumCellIDsNotEqualNumCells
+    assert gpu_ctx.RecoverCells(ids[:-1] + [128], [cells[i] for i in ids])[0] == 9         # ErrFoundInvalidCellID

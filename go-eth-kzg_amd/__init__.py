@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_last_host_finish_us", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
     "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch",
     "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
+    "mkzg_verify_blob_kzg_proof_batch_partial_device", "mkzg_verify_blob_kzg_proof_batch_finish",
 ]
 
 
@@ -80,6 +81,8 @@ def lib():
         L.mkzg_verify_cell_kzg_proof_batch.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, C.c_char_p, sz]
         L.mkzg_recover_cells_and_kzg_proofs.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p, C.c_char_p]
         L.mkzg_recover_cells.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p]
+        L.mkzg_verify_blob_kzg_proof_batch_partial_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
+        L.mkzg_verify_blob_kzg_proof_batch_finish.argtypes = [vp, C.c_char_p, sz]
         L.mkzg_profile_enable.argtypes = [vp, i32]
         L.mkzg_profile_read.argtypes = [vp, C.POINTER(KernelTime), i32, i32]
         L.mkzg_version.restype = C.c_char_p
@@ -257,6 +260,15 @@ class Context:
         if rc:
             return rc, None
         return 0, [oc.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)]
+
+    # ---- sharded batch verification (see distributed.py)
+    def verify_blob_batch_partial_device(self, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n_local, offset, r32, stream=0):
+        rec = C.create_string_buffer(512)
+        rc = self._L.mkzg_verify_blob_kzg_proof_batch_partial_device(self._h, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n_local, offset, bytes(r32), rec, stream)
+        return rc, rec.raw
+
+    def verify_blob_batch_finish(self, records):
+        return self._L.mkzg_verify_blob_kzg_proof_batch_finish(self._h, b"".join(records), len(records))
 
     def last_host_finish_us(self):
         return self._L.mkzg_last_host_finish_us(self._h)

@@ -68,9 +68,11 @@ int ensure_quot_ws(mkzg_ctx* c, size_t n) {
 //   either d_blobs (n x 131072 B; z and y are derived) or d_z32/d_y32 (n x 32 B big-endian scalars)
 // Error precedence mirrors the reference loops (verify.go:102-140, verify.go:15-33).
 // ---------------------------------------------------------------------------------------------
-static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
-                       hipStream_t s) {
-    if (n == 0) return MKZG_OK;                                   // kzg_verify.go:121-123
+struct VerifyFold { G1HX A, Cc, D; uint32_t e[8]; };
+// device work + Horner: A = sum r^i Q_i, Cc = sum r^i C_i, D = sum r^i z_i Q_i, e = sum r^i y_i with i = exp_offset + local index;
+// r32 == nullptr: draw r here.
+static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
+                       uint32_t exp_offset, const uint8_t* r32, hipStream_t s, VerifyFold* out) {
     if (n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
     int rc = ensure_verify_ws(c, n);
     if (rc) return rc;
@@ -105,7 +107,11 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     // 3. random linear combination scalars (kzg_verify.go:136-141)
     uint32_t* h_misc = (uint32_t*)(c->h_v + 3 * cap * sizeof(int));
     uint8_t rbytes[32];
-    if (getrandom(rbytes, 32, 0) != 32) return MKZG_ERR_HIP;
+    if (r32) {
+        for (int i = 0; i < 32; i++) rbytes[i] = r32[31 - i];        // big-endian bytes -> little-endian words
+    } else if (getrandom(rbytes, 32, 0) != 32) {
+        return MKZG_ERR_HIP;
+    }
     memcpy(h_misc, rbytes, 32);
     int y_bad = 0;
     if (!d_blobs) {
@@ -116,7 +122,7 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
         for (int v : sty) if (v) y_bad = v;
     }
     HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
-    KT(KT_RLC, s, rlc_scalars_device(c->d_v_misc, c->d_v_z, c->d_v_y, (int)n, c->d_v_s1, c->d_v_s3, c->d_v_misc + 8, s));
+    KT(KT_RLC, s, rlc_scalars_device(c->d_v_misc, c->d_v_z, c->d_v_y, (int)n, exp_offset, c->d_v_s1, c->d_v_s3, c->d_v_misc + 8, s));
     // 4. the three MSMs of kzg_verify.go:150,225,179: sum r^i Q_i, sum r^i C_i, sum r^i z_i Q_i
     const uint32_t* scal[3] = {c->d_v_s1, c->d_v_s1, c->d_v_s3};
     const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
@@ -144,9 +150,9 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
             if (h_st[cap + i]) return h_st[cap + i];
         }
     }
-    // 6. host finish (kzg_verify.go:160-199)
+    // 6. Horner over the window sums (the 255 serial doublings stay on the host)
     auto t_h0 = std::chrono::steady_clock::now();
-    G1HX win[VMSM_WINDOWS], A, Cc, D, eG, gen, Fsum, negA;
+    G1HX win[VMSM_WINDOWS];
     const uint32_t* wsum = h_misc + 16;
     auto horner = [&](int m, G1HX& out) {
         for (int w = 0; w < VMSM_WINDOWS; w++) {
@@ -157,25 +163,42 @@ static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
         }
         g1h_horner(out, win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
     };
-    horner(0, A);
-    horner(1, Cc);
-    horner(2, D);
+    horner(0, out->A);
+    horner(1, out->Cc);
+    horner(2, out->D);
+    memcpy(out->e, h_misc + 8, 32);
+    c->last_host_finish_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
+    return MKZG_OK;
+}
+// kzg_verify.go:160-199: F = Cc - [e]G + D ; e(F, G2) e(-A, [alpha]G2) == 1
+static int verify_finish(mkzg_ctx* c, const VerifyFold& f) {
+    auto t_h0 = std::chrono::steady_clock::now();
+    G1HX eG, gen, Fsum, negA;
     uint64_t e64[4];
-    for (int i = 0; i < 4; i++) e64[i] = (uint64_t)h_misc[8 + 2 * i] | ((uint64_t)h_misc[8 + 2 * i + 1] << 32);
+    for (int i = 0; i < 4; i++) e64[i] = (uint64_t)f.e[2 * i] | ((uint64_t)f.e[2 * i + 1] << 32);
     g1h_generator(gen);
     g1h_mul(eG, gen, e64);
     G1H::neg(eG, eG);
-    G1H::add(Fsum, Cc, eG);
-    G1H::add(Fsum, Fsum, D);
-    G1H::neg(negA, A);
+    G1H::add(Fsum, f.Cc, eG);
+    G1H::add(Fsum, Fsum, f.D);
+    G1H::neg(negA, f.A);
     G1AffH ps[2];
     g1h_to_affine(ps[0], Fsum);
     g1h_to_affine(ps[1], negA);
     const G2Prepared* qs[2] = {&c->g2_gen, &c->g2_alpha};
     bool ok = pairing_check_prepared(ps, qs, 2);
-    c->last_host_finish_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
+    c->last_host_finish_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
     return ok ? MKZG_OK : MKZG_VERIFY_FAILED;
 }
+static int verify_core(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
+                       hipStream_t s) {
+    if (n == 0) return MKZG_OK;                                   // kzg_verify.go:121-123
+    VerifyFold f;
+    int rc = verify_fold(c, d_blobs, d_z32, d_y32, d_commitments, d_proofs, n, 0, nullptr, s, &f);
+    if (rc) return rc;
+    return verify_finish(c, f);
+}
+
 
 // upload helper: gather n host items of `bytes` each into the context staging area and copy to `dst`
 static int upload_items(mkzg_ctx* c, const uint8_t* const* items, size_t n, size_t bytes, uint8_t* d_dst, hipStream_t s) {
@@ -363,6 +386,72 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     if (stz) return stz;
     if (num_threads >= 1024) return MKZG_ERR_TOO_MANY_GOROUTINES;
     return MKZG_OK;
+}
+
+// ---- sharded batch verification (multi-GPU): each rank folds its shard with the GLOBAL exponents
+// r^(offset + i) and publishes one 512-byte record; any rank adds the records and runs the pairing.
+// Record: [0..4) status (LE int) | [16..64) A | [64..112) Cc | [112..160) D (compressed G1) | [160..192) e (32 B big-endian) | zero padding
+int mkzg_verify_blob_kzg_proof_batch_partial_device(mkzg_ctx* c, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n_local, uint64_t offset,
+                                                    const uint8_t r32[32], uint8_t record512[512], void* stream) {
+    if (!c || !r32 || !record512 || (n_local && (!d_blobs || !d_commitments48 || !d_proofs48))) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    memset(record512, 0, 512);
+    VerifyFold f;
+    G1H::set_inf(f.A);
+    G1H::set_inf(f.Cc);
+    G1H::set_inf(f.D);
+    memset(f.e, 0, 32);
+    int rc = MKZG_OK;
+    if (n_local) rc = verify_fold(c, (const uint8_t*)d_blobs, nullptr, nullptr, (const uint8_t*)d_commitments48, (const uint8_t*)d_proofs48, n_local, (uint32_t)offset, r32,
+                                  (hipStream_t)stream, &f);
+    int32_t st = rc;
+    memcpy(record512, &st, 4);
+    if (rc == MKZG_OK) {
+        G1AffH a;
+        g1h_to_affine(a, f.A);
+        g1h_compress(record512 + 16, a);
+        g1h_to_affine(a, f.Cc);
+        g1h_compress(record512 + 64, a);
+        g1h_to_affine(a, f.D);
+        g1h_compress(record512 + 112, a);
+        for (int i = 0; i < 8; i++) {
+            uint32_t w = f.e[7 - i];
+            record512[160 + 4 * i] = (uint8_t)(w >> 24); record512[161 + 4 * i] = (uint8_t)(w >> 16); record512[162 + 4 * i] = (uint8_t)(w >> 8); record512[163 + 4 * i] = (uint8_t)w;
+        }
+    }
+    return rc;
+}
+int mkzg_verify_blob_kzg_proof_batch_finish(mkzg_ctx* c, const uint8_t* records512, size_t n_records) {
+    if (!c || (n_records && !records512)) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    VerifyFold f;
+    G1H::set_inf(f.A);
+    G1H::set_inf(f.Cc);
+    G1H::set_inf(f.D);
+    memset(f.e, 0, 32);
+    for (size_t k = 0; k < n_records; k++) {                       // first failing rank (lowest indices) decides the error
+        int32_t st;
+        memcpy(&st, records512 + 512 * k, 4);
+        if (st) return st;
+    }
+    for (size_t k = 0; k < n_records; k++) {
+        const uint8_t* rec = records512 + 512 * k;
+        G1AffH a;
+        G1HX t;
+        G1HX* dst[3] = {&f.A, &f.Cc, &f.D};
+        for (int q = 0; q < 3; q++) {
+            if (!g1h_decompress(a, rec + 16 + 48 * q)) return MKZG_ERR_BAD_ARGS;
+            if (a.inf) continue;
+            G1H::from_affine(t, a.x, a.y);
+            G1H::add(*dst[q], *dst[q], t);
+        }
+        uint32_t ew[8];
+        for (int i = 0; i < 8; i++) ew[7 - i] = ((uint32_t)rec[160 + 4 * i] << 24) | ((uint32_t)rec[161 + 4 * i] << 16) | ((uint32_t)rec[162 + 4 * i] << 8) | rec[163 + 4 * i];
+        fr_words_add(f.e, f.e, ew);
+    }
+    c->last_host_finish_us = 0;
+    return verify_finish(c, f);
 }
 
 // host-side share of the last verification (microseconds): Horner + [e]G + pairing

@@ -84,4 +84,33 @@ inline bool g1h_decompress(G1AffH& o, const uint8_t in[48]) {
     return true;
 }
 
+// affine -> zcash compressed 48 bytes
+inline void g1h_compress(uint8_t out[48], const G1AffH& a) {
+    if (a.inf) { memset(out, 0, 48); out[0] = 0xc0; return; }
+    uint64_t v[6];
+    HostFp::to_plain(v, a.x);
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 8; j++) out[(5 - i) * 8 + j] = (uint8_t)(v[i] >> (56 - 8 * j));
+    out[0] |= 0x80;
+    if (HostFp::lex_largest(a.y)) out[0] |= 0x20;
+}
+// (a + b) mod r on 8-word little-endian plain scalars
+inline void fr_words_add(uint32_t out[8], const uint32_t a[8], const uint32_t b[8]) {
+    uint64_t c = 0;
+    uint32_t t[8];
+    for (int i = 0; i < 8; i++) { uint64_t s = (uint64_t)a[i] + b[i] + c; t[i] = (uint32_t)s; c = s >> 32; }
+    bool geq = c != 0;
+    if (!geq) {
+        geq = true;
+        for (int i = 7; i >= 0; i--) {
+            if (t[i] > FrParams::MOD32[i]) break;
+            if (t[i] < FrParams::MOD32[i]) { geq = false; break; }
+        }
+    }
+    if (geq) {
+        uint64_t br = 0;
+        for (int i = 0; i < 8; i++) { uint64_t s = (uint64_t)t[i] - FrParams::MOD32[i] - br; t[i] = (uint32_t)s; br = (s >> 32) & 1; }
+    }
+    memcpy(out, t, 32);
+}
+
 }  // namespace kzg

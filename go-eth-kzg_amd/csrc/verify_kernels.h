@@ -12,7 +12,9 @@ void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_
 void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
                           int* d_status, hipStream_t s);
 void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s);
-void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e, hipStream_t s);
+// r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)
+void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
+                        hipStream_t s);
 // n_msm <= 4 jobs of n_per_job[m] <= 8192 (scalar, point) pairs; d_out[msm][32 windows][48 words]
 int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_out, hipStream_t s);
 void build_roots_device(uint32_t* d_roots_brp, uint32_t* d_inv_roots_brp, int log_n, hipStream_t s);

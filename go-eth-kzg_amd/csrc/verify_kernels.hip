@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __rest
 // outputs as plain little-endian 8-word scalars
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(EV_T) k_rlc_scalars(const uint32_t* __restrict__ r_words8, const uint32_t* __restrict__ z_in, const uint32_t* __restrict__ y_in, int n,
-                                                      uint32_t* __restrict__ s1, uint32_t* __restrict__ s3, uint32_t* __restrict__ e_out) {
+                                                      uint32_t exp_offset, uint32_t* __restrict__ s1, uint32_t* __restrict__ s3, uint32_t* __restrict__ e_out) {
     __shared__ uint32_t sh[EV_T * 9];
     const int t = threadIdx.x;
     uint32_t rw[8];
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(EV_T) k_rlc_scalars(const uint32_t* __restrict
         fr_t rp, base = r;
         Fr::set_one(rp);
         Fr::reduce_once(rp, rp);
-        for (uint32_t e = (uint32_t)i; e; e >>= 1) {
+        for (uint32_t e = exp_offset + (uint32_t)i; e; e >>= 1) {
             if (e & 1) fr_mul_n(rp, rp, base);
             fr_mul_n(base, base, base);
         }
@@ -658,8 +658,9 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
 void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_g1_subgroup_check, dim3((n + 63) / 64), dim3(64), 0, s, d_aff, n, d_status);
 }
-void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e, hipStream_t s) {
-    hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, d_s1, d_s3, d_e);
+void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, exp_offset, d_s1, d_s3, d_e);
 }
 int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_out, hipStream_t s) {
     if (n_msm < 1 || n_msm > 4) return -1;

@@ -100,6 +100,14 @@ int mkzg_verify_blob_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* const* blobs,
 /* same, inputs contiguous in HBM; synchronises `stream` internally (the verdict needs the host pairing). */
 int mkzg_verify_blob_kzg_proof_batch_device(mkzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n, void* stream);
 
+/* Sharded VerifyBlobKZGProofBatch for multi-GPU jobs (one context/process per GPU): every rank folds its
+ * shard (global indices offset .. offset+n_local) with the batch-wide scalar r32 (32 bytes big-endian, chosen by
+ * rank 0 and broadcast) into a 512-byte record; after an all-gather any rank combines the records and runs the
+ * single pairing check.  Equivalent to reference internal/kzg/kzg_verify.go:111-202 on the concatenated batch. */
+int mkzg_verify_blob_kzg_proof_batch_partial_device(mkzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n_local,
+                                                    uint64_t offset, const uint8_t r32[32], uint8_t record512[512], void* stream);
+int mkzg_verify_blob_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* records512, size_t n_records);
+
 /* ---- EIP-7594 ------------------------------------------------------------------------------ */
 /* Context.ComputeCells (reference api_eip7594.go:12-26): 128 cells of 2048 bytes, contiguous. */
 int mkzg_compute_cells(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint8_t* cells_out /* 128 x 2048 */);

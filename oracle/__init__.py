@@ -58,6 +58,8 @@ def lib():
         L.kzgo_recover_cells_and_kzg_proofs.argtypes = [vp, vp, sz, u8p, sz, u8p, u8p]
         L.kzgo_recover_cells.argtypes = [vp, vp, sz, u8p, sz, u8p]
         L.kzgo_verify_cell_kzg_proof_batch.argtypes = [vp, u8p, sz, vp, sz, u8p, sz, u8p, sz]
+        L.kzgo_verify_blob_batch_partial.argtypes = [vp, u8p, u8p, u8p, sz, C.c_uint64, u8p, u8p]
+        L.kzgo_verify_blob_batch_finish.argtypes = [vp, u8p, sz]
         L.kzgo_fr_fft.argtypes = [u8p, sz, i32]
         L.kzgo_fr_coset_fft.argtypes = [u8p, sz, u8p, i32]
         L.kzgo_g1_msm.argtypes = [u8p, u8p, sz, u8p]
@@ -155,6 +157,15 @@ class OracleContext:
             return 17
         return self._L.kzgo_verify_blob_kzg_proof_batch(
             self._h, b"".join(blobs), len(blobs), b"".join(commitments), len(commitments), b"".join(proofs), len(proofs))
+
+    # ---- sharded batch verification (mirror of the product's partial/finish pair)
+    def verify_blob_batch_partial(self, blobs, commitments, proofs, offset, r32):
+        rec = _buf(512)
+        rc = self._L.kzgo_verify_blob_batch_partial(self._h, b"".join(blobs), b"".join(commitments), b"".join(proofs), len(blobs), offset, bytes(r32), rec)
+        return rc, rec.raw
+
+    def verify_blob_batch_finish(self, records):
+        return self._L.kzgo_verify_blob_batch_finish(self._h, b"".join(records), len(records))
 
     # ---- EIP-7594 (reference api_eip7594.go, api_eip.go)
     def compute_cells(self, blob):

@@ -467,6 +467,69 @@ KZGO_EXPORT int kzgo_verify_blob_kzg_proof_batch(const kzgo_ctx *c, const uint8_
     return rc;
 }
 
+/* Sharded form of BatchVerifyMultiPoints for multi-GPU jobs: a rank folds the proofs with global indices
+ * offset..offset+n with the batch-wide r into (A, C, D, e); records are added and checked by one pairing.
+ * Same algebra as internal/kzg/kzg_verify.go:141-199 split at the sums.  Record layout as
+ * include/mi355kzg.h (mkzg_verify_blob_kzg_proof_batch_partial_device). */
+KZGO_EXPORT int kzgo_verify_blob_batch_partial(const kzgo_ctx *c, const uint8_t *blobs, const uint8_t *commitments48, const uint8_t *proofs48, size_t n, uint64_t offset,
+                                               const uint8_t r32[32], uint8_t record[512]) {
+    memset(record, 0, 512);
+    g1a_t *cms = malloc((n + 1) * sizeof(g1a_t)), *prs = malloc((n + 1) * sizeof(g1a_t));
+    fr_t *zs = malloc((n + 1) * sizeof(fr_t)), *ys = malloc((n + 1) * sizeof(fr_t)), *poly = malloc(N_BLOB * sizeof(fr_t));
+    fr_t *rp = malloc((n + 1) * sizeof(fr_t)), *rz = malloc((n + 1) * sizeof(fr_t));
+    int rc = KZG_OK;
+    for (size_t i = 0; i < n && !rc; i++) {
+        int64_t idx;
+        if ((rc = deserialize_g1(&cms[i], commitments48 + 48 * i))) break;
+        if ((rc = deserialize_g1(&prs[i], proofs48 + 48 * i))) break;
+        if ((rc = deserialize_blob(poly, blobs + i * BLOB_BYTES))) break;
+        compute_challenge(&zs[i], blobs + i * BLOB_BYTES, commitments48 + 48 * i);
+        eval_lagrange(&ys[i], &idx, &c->dom, poly, &zs[i]);
+    }
+    int32_t st = rc;
+    memcpy(record, &st, 4);
+    if (!rc) {
+        fr_t r, fe, t;
+        fr_from_be32_reduce(&r, r32);
+        fr_pow_u64(&rp[0], &r, offset);
+        for (size_t i = 1; i < n; i++) fr_mul(&rp[i], &rp[i - 1], &r);
+        fr_zero(&fe);
+        for (size_t i = 0; i < n; i++) { fr_mul(&t, &ys[i], &rp[i]); fr_add(&fe, &fe, &t); fr_mul(&rz[i], &rp[i], &zs[i]); }
+        g1j_t A, Cc, D;
+        msm_g1(&A, rp, prs, n);
+        msm_g1(&Cc, rp, cms, n);
+        msm_g1(&D, rz, prs, n);
+        serialize_g1j(record + 16, &A);
+        serialize_g1j(record + 64, &Cc);
+        serialize_g1j(record + 112, &D);
+        fr_to_be32(record + 160, &fe);
+    }
+    free(cms); free(prs); free(zs); free(ys); free(poly); free(rp); free(rz);
+    return rc;
+}
+KZGO_EXPORT int kzgo_verify_blob_batch_finish(const kzgo_ctx *c, const uint8_t *records, size_t n_records) {
+    g1j_t A, Cc, D, gen, ye; fr_t e;
+    g1j_set_inf(&A); g1j_set_inf(&Cc); g1j_set_inf(&D); fr_zero(&e);
+    for (size_t k = 0; k < n_records; k++) { int32_t st; memcpy(&st, records + 512 * k, 4); if (st) return st; }
+    for (size_t k = 0; k < n_records; k++) {
+        const uint8_t *rec = records + 512 * k;
+        g1a_t p; fr_t t;
+        if (g1a_decompress(&p, rec + 16, 0)) return KZG_ERR_BAD_ARGS;
+        g1j_add_affine(&A, &A, &p);
+        if (g1a_decompress(&p, rec + 64, 0)) return KZG_ERR_BAD_ARGS;
+        g1j_add_affine(&Cc, &Cc, &p);
+        if (g1a_decompress(&p, rec + 112, 0)) return KZG_ERR_BAD_ARGS;
+        g1j_add_affine(&D, &D, &p);
+        if (!fr_from_be32_canonical(&t, rec + 160)) return KZG_ERR_BAD_ARGS;
+        fr_add(&e, &e, &t);
+    }
+    fp_from_plain(&gen.x, G1_GEN_X); fp_from_plain(&gen.y, G1_GEN_Y); fp_one(&gen.z);
+    g1j_mul_fr(&ye, &gen, &e); g1j_sub(&Cc, &Cc, &ye); g1j_add(&Cc, &Cc, &D); g1j_neg(&A, &A);
+    g1a_t ps[2]; g2a_t qs[2];
+    g1j_to_affine(&ps[0], &Cc); g1j_to_affine(&ps[1], &A); qs[0] = c->g2[0]; qs[1] = c->g2[1];
+    return pairing_check(ps, qs, 2) ? KZG_OK : KZG_VERIFY_FAILED;
+}
+
 /* ------------------------------------------------------------------ EIP-7594 */
 /* reference internal/kzg_multi/fk20/fk20.go:58-74: pad, FFT-8192, bit-reverse */
 static void compute_extended(const kzgo_ctx *c, const fr_t *coeff, fr_t *ext /*8192*/) {

@@ -76,6 +76,11 @@ def product():
 @pytest.fixture(scope="session")
 def gpu_ctx(product):
     """product Context on cuda:0 -- fails loudly (no fallback) if the HIP library or GPU is missing"""
+    # torch ships its own HIP runtime: initialise it first so that both it and libmi355kzg.so share one
+    # runtime instance in this process (tests use torch tensors as device buffers)
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     ctx = product.Context()
     yield ctx
     ctx.close()

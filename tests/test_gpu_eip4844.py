@@ -148,3 +148,44 @@ def test_batch_64_device_generated(gpu_ctx, oracle_ctx):
     bad = list(prs)
     bad[13] = prs[12]
     assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, cms, bad) == VERIFY_FAILED
+
+
+def test_sharded_verify_records_match_oracle(gpu_ctx, oracle_ctx, product):
+    """The partial-sum records of the sharded verifier are deterministic once r is fixed, so the GPU fold
+    can be compared byte-for-byte with the oracle's -- a parity check INSIDE the batch verifier that the
+    random r normally hides.  Also: GPU records finish on the oracle and vice versa."""
+    import torch
+    n = 7
+    blobs = [rand_blob(500 + s) for s in range(n)]
+    rc, cms, _ = gpu_ctx.BlobToKZGCommitmentBatch(blobs)
+    prs = [gpu_ctx.ComputeBlobKZGProof(b, c)[1] for b, c in zip(blobs, cms)]
+    r32 = bytes(range(7, 39))
+    d_b = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_c = torch.frombuffer(bytearray(b"".join(cms)), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(b"".join(prs)), dtype=torch.uint8).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    recs_gpu, recs_cpu = [], []
+    for lo, hi in ((0, 4), (4, 7)):
+        rc, rec = gpu_ctx.verify_blob_batch_partial_device(d_b.data_ptr() + lo * 131072, d_c.data_ptr() + lo * 48, d_p.data_ptr() + lo * 48, hi - lo, lo, r32, st)
+        assert rc == 0
+        rco, reco = oracle_ctx.verify_blob_batch_partial(blobs[lo:hi], cms[lo:hi], prs[lo:hi], lo, r32)
+        assert rco == 0 and rec == reco
+        recs_gpu.append(rec)
+        recs_cpu.append(reco)
+    assert gpu_ctx.verify_blob_batch_finish(recs_gpu) == 0
+    assert oracle_ctx.verify_blob_batch_finish(recs_gpu) == 0
+    # a shard folded with the wrong offset must break the batch
+    rc, rec_bad = gpu_ctx.verify_blob_batch_partial_device(d_b.data_ptr() + 4 * 131072, d_c.data_ptr() + 4 * 48, d_p.data_ptr() + 4 * 48, 3, 5, r32, st)
+    assert gpu_ctx.verify_blob_batch_finish([recs_gpu[0], rec_bad]) == 0   # offsets only relabel r^i: still a valid RLC
+    # corrupted proof in shard 1
+    d_p2 = d_p.clone()
+    d_p2[5 * 48:6 * 48] = d_p[6 * 48:7 * 48]
+    rc, rec2 = gpu_ctx.verify_blob_batch_partial_device(d_b.data_ptr() + 4 * 131072, d_c.data_ptr() + 4 * 48, d_p2.data_ptr() + 4 * 48, 3, 4, r32, st)
+    assert rc == 0 and gpu_ctx.verify_blob_batch_finish([recs_gpu[0], rec2]) == VERIFY_FAILED
+    # through the orchestration helper, single process
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("kzg_distributed", os.path.join(os.path.dirname(product.__file__), "distributed.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    eng = D.ProductEngine(gpu_ctx)
+    assert D.verify_blob_kzg_proof_batch_sharded(eng, (d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, st), n) == 0

@@ -37,6 +37,9 @@ constexpr int W29 = 29;
 constexpr uint32_t MASK29 = (1u << 29) - 1;
 
 template <class P>
+struct ModInv30;   // modinv30.hpp (included at the end of this header)
+
+template <class P>
 struct Mont29 {
     static constexpr int N = P::N;
     struct El {
@@ -240,7 +243,8 @@ struct Mont29 {
         }
         r = acc;
     }
-    static KZ_HD void inv(El& r, const El& a) { pow_words(r, a, P::EXP_INV, P::BITS); }   // Fermat; 0 -> 0
+    static KZ_HD void inv_fermat(El& r, const El& a) { pow_words(r, a, P::EXP_INV, P::BITS); }   // a^(M-2); 0 -> 0
+    static KZ_HD void inv(El& r, const El& a) { ModInv30<P>::inv_mont(r, a); }                      // divsteps; 0 -> 0
 };
 
 using Fp = Mont29<FpParams>;
@@ -273,3 +277,5 @@ struct FrC {
 };
 
 }  // namespace kzg
+
+#include "modinv30.hpp"

@@ -73,7 +73,7 @@ __device__ __forceinline__ void fr_from_words(fr_t& r, const uint32_t w[8]) {
 __device__ __noinline__ void fr_mul_n(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
 __device__ __noinline__ void fr_inv_n(fr_t& r, const fr_t& a) {
     fr_t t;
-    Fr::pow_words(t, a, FrParams::EXP_INV, FrParams::BITS);
+    Fr::inv(t, a);             // divsteps (modinv30.hpp)
     Fr::reduce_once(r, t);
 }
 

@@ -3,6 +3,7 @@
 // against big-integer arithmetic (tests/test_mont29_host.py).  Host logic test only; the
 // kernels use the very same templates on the device.
 #include "../../go-eth-kzg_amd/csrc/g1.hpp"
+#include "../../go-eth-kzg_amd/csrc/modinv30.hpp"
 #include <cstring>
 using namespace kzg;
 extern "C" {
@@ -18,6 +19,8 @@ void shim_fp_to_plain(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a)
 void shim_fp_from_plain(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp::from_plain(r, x); memcpy(o, r.l, 56); }
 int shim_fp_is_zero16(const uint32_t* a) { fp_t x; Fp::set(x, a); return Fp::is_zero_mod<16>(x); }
 void shim_fp_inv(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp::pow_words(r, x, FpParams::EXP_INV, FpParams::BITS); memcpy(o, r.l, 56); }
+void shim_fp_inv_fast(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); ModInv30<FpParams>::inv_mont(r, x); memcpy(o, r.l, 56); }
+void shim_fr_inv_fast(const uint32_t* a, uint32_t* o) { fr_t x, r; Fr::set(x, a); ModInv30<FrParams>::inv_mont(r, x); memcpy(o, r.l, 36); }
 void shim_fp_words(const uint32_t* w12, uint32_t* o14, uint32_t* back12) { fp_t x; Fp::from_words32(x, w12); memcpy(o14, x.l, 56); Fp::to_words32(back12, x); }
 void shim_fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { fr_t x, y, r; Fr::set(x, a); Fr::set(y, b); FrC::mul(r, x, y); memcpy(o, r.l, 36); }
 void shim_fr_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { fr_t x, y, r; Fr::set(x, a); Fr::set(y, b); FrC::add(r, x, y); memcpy(o, r.l, 36); }

@@ -26,7 +26,7 @@ G1Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744
 def shim():
     so = os.path.join(SHIM_DIR, "libmont29_shim.so")
     src = os.path.join(SHIM_DIR, "mont29_shim.cpp")
-    hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("mont29.hpp", "g1.hpp", "constants29.h")]
+    hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("mont29.hpp", "g1.hpp", "constants29.h", "modinv30.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
     return C.CDLL(so)
@@ -90,6 +90,31 @@ def test_fp_canon_plain_inv(shim):
         o = out()
         shim.shim_fp_inv(limbs(a * RP % P), o)
         assert val(o) % P == pow(a, -1, P) * RP % P
+
+
+def test_divsteps_inversion(shim):
+    """modinv30.hpp (Bernstein-Yang divsteps) against pow(a, -1, M), Fp and Fr, loose inputs included"""
+    rng = random.Random(9)
+    vals = [1, 2, P - 1, P - 2, (P + 1) // 2, 3 * P + 5] + [rng.randrange(1, 1 << 392) for _ in range(200)]
+    for a in vals:
+        o = out()
+        shim.shim_fp_inv_fast(limbs(a), o)
+        x = a * pow(RP, -1, P) % P
+        if x == 0:
+            assert val(o) % P == 0
+        else:
+            assert val(o) % P == pow(x, -1, P) * RP % P, hex(a)
+            assert val(o) < 2 * P
+    o = out()
+    shim.shim_fp_inv_fast(limbs(0), o)
+    assert val(o) % P == 0
+    shim.shim_fp_inv_fast(limbs(P), o)
+    assert val(o) % P == 0
+    for a in [1, 2, R - 1, (R + 1) // 2] + [rng.randrange(1, R) for _ in range(200)]:
+        o = out(9)
+        shim.shim_fr_inv_fast(limbs(a, 9), o)
+        x = a * pow(RF, -1, R) % R
+        assert val(o) % R == pow(x, -1, R) * RF % R
 
 
 def test_fp_words(shim):

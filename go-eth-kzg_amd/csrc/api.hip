@@ -55,32 +55,56 @@ int ensure_plan(mkzg_ctx* c) {
     if (c->plan_ready) return MKZG_OK;
     CommitPlanSizes sz;
     commit_plan_sizes(c->opt_c, c->opt_max_batch, &sz);
-    c->plan.c = c->opt_c;
-    c->plan.max_batch = c->opt_max_batch;
-    HIPCHK(hipMalloc(&c->plan.d_table, sz.table_bytes));
-    HIPCHK(hipMalloc(&c->plan.d_entries, sz.entries_bytes));
-    HIPCHK(hipMalloc(&c->plan.d_task_off, sz.task_off_bytes));
-    HIPCHK(hipMalloc(&c->plan.d_tasks, sz.tasks_bytes));
-    HIPCHK(hipMalloc(&c->plan.d_ntasks, sz.ntasks_bytes));
-    HIPCHK(hipMalloc(&c->plan.d_parts, sz.parts_bytes));
-    HIPCHK(hipMalloc(&c->plan.d_partials, sz.partials_bytes));
+    uint32_t* table = nullptr;
+    HIPCHK(hipMalloc(&table, sz.table_bytes));
+    for (int i = 0; i < mkzg_ctx::NSLOT; i++) {
+        CommitPlan& p = c->slots[i];
+        p.c = c->opt_c;
+        p.max_batch = c->opt_max_batch;
+        p.d_table = table;
+        HIPCHK(hipMalloc(&p.d_entries, sz.entries_bytes));
+        HIPCHK(hipMalloc(&p.d_task_off, sz.task_off_bytes));
+        HIPCHK(hipMalloc(&p.d_tasks, sz.tasks_bytes));
+        HIPCHK(hipMalloc(&p.d_ntasks, sz.ntasks_bytes));
+        HIPCHK(hipMalloc(&p.d_parts, sz.parts_bytes));
+        HIPCHK(hipMalloc(&p.d_partials, sz.partials_bytes));
+        if (!c->slot_done[i]) HIPCHK(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming));
+        if (!c->acc_done[i]) HIPCHK(hipEventCreateWithFlags(&c->acc_done[i], hipEventDisableTiming));
+        c->slot_used[i] = false;
+    }
+    c->plan = c->slots[0];
     // api.go:131: the commit key is the bit-reversed Lagrange SRS
-    build_table_device(c->plan.c, c->d_lagrange_aff, c->plan.d_table, 4096, 12, c->stream);
+    build_table_device(c->plan.c, c->d_lagrange_aff, table, 4096, 12, c->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     c->plan_ready = true;
     return MKZG_OK;
 }
 static void free_plan(mkzg_ctx* c) {
-    if (c->plan.d_table) (void)hipFree(c->plan.d_table);
-    if (c->plan.d_entries) (void)hipFree(c->plan.d_entries);
-    if (c->plan.d_task_off) (void)hipFree(c->plan.d_task_off);
-    if (c->plan.d_tasks) (void)hipFree(c->plan.d_tasks);
-    if (c->plan.d_ntasks) (void)hipFree(c->plan.d_ntasks);
-    if (c->plan.d_parts) (void)hipFree(c->plan.d_parts);
-    if (c->plan.d_partials) (void)hipFree(c->plan.d_partials);
+    if (c->slots[0].d_table) (void)hipFree(c->slots[0].d_table);
+    for (int i = 0; i < mkzg_ctx::NSLOT; i++) {
+        CommitPlan& p = c->slots[i];
+        void* ptrs[] = {p.d_entries, p.d_task_off, p.d_tasks, p.d_ntasks, p.d_parts, p.d_partials};
+        for (void* q : ptrs) if (q) (void)hipFree(q);
+        p = CommitPlan();
+        c->slot_used[i] = false;
+    }
     c->plan = CommitPlan();
     c->plan_ready = false;
+}
+// workspace hand-over between streams: the new user waits (on the device) for the previous one
+int acquire_slot(mkzg_ctx* c, hipStream_t s) {
+    const int slot = (int)(c->slot_counter++ % mkzg_ctx::NSLOT);
+    if (c->slot_used[slot] && hipStreamWaitEvent(s, c->slot_done[slot], 0) != hipSuccess) return -1;
+    c->slots[slot].wait_before_acc = c->last_acc_slot >= 0 ? c->acc_done[c->last_acc_slot] : nullptr;
+    c->slots[slot].record_after_acc = c->acc_done[slot];
+    return slot;
+}
+int release_slot(mkzg_ctx* c, int slot, hipStream_t s) {
+    HIPCHK(hipEventRecord(c->slot_done[slot], s));
+    c->slot_used[slot] = true;
+    c->last_acc_slot = slot;
+    return MKZG_OK;
 }
 
 extern "C" {
@@ -200,8 +224,12 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, s
     size_t done = 0;
     while (done < n) {
         int chunk = (int)std::min<size_t>(n - done, (size_t)c->plan.max_batch);
-        commit_batch_device(c->plan, (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB, MKZG_BYTES_PER_BLOB, 0, chunk, (uint8_t*)d_out48n + done * 48,
+        const int slot = acquire_slot(c, s);
+        if (slot < 0) return MKZG_ERR_HIP;
+        commit_batch_device(c->slots[slot], (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB, MKZG_BYTES_PER_BLOB, 0, chunk, (uint8_t*)d_out48n + done * 48,
                             d_status + done, s, c->profiling ? &c->timer : nullptr);
+        int rr = release_slot(c, slot, s);
+        if (rr) return rr;
         done += chunk;
     }
     HIPCHK(hipGetLastError());

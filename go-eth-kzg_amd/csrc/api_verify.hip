@@ -314,8 +314,11 @@ int mkzg_compute_blob_kzg_proof_batch_device(mkzg_ctx* c, const void* d_blobs, c
         g1_subgroup_check_device(c->d_v_aff, (int)chunk, c->d_q_st + c->q_cap, s);
         KT(KT_SHA256, s, challenge_device(blobs, cms, (int)chunk, c->d_q_z, s));
         KT(KT_QUOTIENT, s, blob_quotient_device(blobs, c->d_q_z, c->d_roots_brp, c->d_inv_roots_brp, (int)chunk, c->d_q_y, c->d_quot, c->d_q_st, s));
-        commit_batch_device(c->plan, (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, (int)chunk, (uint8_t*)d_proofs48 + done * 48, d_status + done, s,
+        const int slot = acquire_slot(c, s);
+        if (slot < 0) return MKZG_ERR_HIP;
+        commit_batch_device(c->slots[slot], (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, (int)chunk, (uint8_t*)d_proofs48 + done * 48, d_status + done, s,
                             c->profiling ? &c->timer : nullptr);
+        if (release_slot(c, slot, s)) return MKZG_ERR_HIP;
         // merge statuses: blob error first, then commitment error (prove.go:49-62)
         HIPCHK(hipGetLastError());
         std::vector<int> stb(chunk), stc(chunk);
@@ -373,7 +376,10 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     int* st_z = c->d_q_st + c->q_cap;
     scalars_to_fr_device(c->d_blobs + MKZG_BYTES_PER_BLOB, 1, c->d_q_z, st_z, s);
     blob_quotient_device(c->d_blobs, c->d_q_z, c->d_roots_brp, c->d_inv_roots_brp, 1, c->d_q_y, c->d_quot, c->d_q_st, s);
-    commit_batch_device(c->plan, (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, 1, c->d_out, c->d_status, s, c->profiling ? &c->timer : nullptr);
+    const int slot = acquire_slot(c, s);
+    if (slot < 0) return MKZG_ERR_HIP;
+    commit_batch_device(c->slots[slot], (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, 1, c->d_out, c->d_status, s, c->profiling ? &c->timer : nullptr);
+    if (release_slot(c, slot, s)) return MKZG_ERR_HIP;
     fr_to_scalars_device(c->d_q_y, 1, c->d_blobs + MKZG_BYTES_PER_BLOB + 64, s);
     HIPCHK(hipGetLastError());
     int stb = 0, stz = 0;

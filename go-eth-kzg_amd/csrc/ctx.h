@@ -36,8 +36,17 @@ struct mkzg_ctx {
     // SRS
     std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes
     uint32_t* d_lagrange_aff = nullptr;    // 4096 affine rows, natural order of the JSON
-    // commit MSM
-    CommitPlan plan;
+    // commit MSM: one shared table, NSLOT independent workspaces so that consecutive calls on different
+    // streams overlap (the latency-bound bucket reduction of one call hides under the accumulation of the
+    // next); slot_done[i] orders the reuse of workspace i across streams without host synchronisation
+    static constexpr int NSLOT = 2;
+    CommitPlan plan;                       // == slots[0] (kept for the single-slot users)
+    CommitPlan slots[NSLOT];
+    hipEvent_t slot_done[NSLOT] = {nullptr, nullptr};
+    bool slot_used[NSLOT] = {false, false};
+    unsigned slot_counter = 0;
+    hipEvent_t acc_done[NSLOT] = {nullptr, nullptr};   // recorded after each call's accumulate kernel
+    int last_acc_slot = -1;
     int opt_c = 13;
     int opt_max_batch = 256;
     bool plan_ready = false;
@@ -115,6 +124,8 @@ struct mkzg_ctx {
 };
 
 int ensure_plan(mkzg_ctx* c);
+int acquire_slot(mkzg_ctx* c, hipStream_t s);          // returns slot index (>= 0) or -1
+int release_slot(mkzg_ctx* c, int slot, hipStream_t s);
 extern "C" int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item);   // defined inside api.hip's extern "C" block
 int ensure_verify_ws(mkzg_ctx* c, size_t n);
 int ensure_quot_ws(mkzg_ctx* c, size_t n);

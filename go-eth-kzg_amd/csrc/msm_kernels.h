@@ -56,6 +56,11 @@ struct CommitPlan {
     uint32_t* d_ntasks = nullptr;    // [batch]
     uint32_t* d_parts = nullptr;     // [batch][max_tasks] XYZZ partial bucket sums, bucket-major
     uint32_t* d_partials = nullptr;  // [batch][nbucket/16][2] XYZZ chunk sums
+    // cross-call pipelining: the accumulate kernel of a call waits for the accumulate kernel of the previous
+    // call (so the VALU-saturating phases run back to back) while the previous call's latency-bound
+    // reduction kernels overlap with it on another stream
+    hipEvent_t wait_before_acc = nullptr;
+    hipEvent_t record_after_acc = nullptr;
 };
 
 void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz);

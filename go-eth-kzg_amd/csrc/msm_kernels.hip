@@ -514,9 +514,11 @@ static void launch_commit(const CommitPlan& pl, const uint8_t* d_scalars, size_t
     if (input_kind == 0) hipLaunchKernelGGL((k_digits_sort<C, 0>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_task_off, tasks, pl.d_ntasks, d_status);
     else hipLaunchKernelGGL((k_digits_sort<C, 1>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_task_off, tasks, pl.d_ntasks, d_status);
     if (kt) kt->end(KT_DIGITS_SORT, s);
+    if (pl.wait_before_acc) (void)hipStreamWaitEvent(s, pl.wait_before_acc, 0);
     if (kt) kt->begin(KT_BUCKET_ACC, s);
     hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3(TG::MAXT / 256, n), dim3(256), 0, s, pl.d_table, pl.d_entries, tasks, pl.d_ntasks, pl.d_parts);
     if (kt) kt->end(KT_BUCKET_ACC, s);
+    if (pl.record_after_acc) (void)hipEventRecord(pl.record_after_acc, s);
     constexpr int NCHUNK = RC::NBUCKET / CHUNK;
     if (kt) kt->begin(KT_REDUCE1, s);
     hipLaunchKernelGGL((k_bucket_reduce1<C>), dim3((NCHUNK + 63) / 64, n), dim3(64), 0, s, pl.d_parts, pl.d_task_off, d_status, pl.d_partials);

@@ -150,7 +150,7 @@ def main():
         avg_ms = dom_ms / max(1, dom_n)
         achieved = ALGO_BYTES_PER_BLOB * B / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom),
                     "avg_kernel_ms": round(avg_ms, 4), "launches": dom_n,
                     "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()}}
         out = {
@@ -170,6 +170,21 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json;
+    FETCH_SIZE/WRITE_SIZE cannot be read from inside the process).  None if no profile covers the kernel."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                k = json.load(fh)["kernels"].get(kernel)
+            if k:
+                return k["traffic_bytes"]
+        except Exception:
+            pass
+    return None
 
 
 def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):

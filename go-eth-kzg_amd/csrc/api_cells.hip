@@ -8,6 +8,12 @@
 #include "ctx.h"
 
 static const size_t V_MISC_WORDS_C = 16 + 4 * VMSM_WINDOWS * 48;
+#define KT(kind, s, call)                                  \
+    do {                                                   \
+        if (c->profiling) c->timer.begin(kind, s);         \
+        call;                                              \
+        if (c->profiling) c->timer.end(kind, s);           \
+    } while (0)
 
 void free_cells(mkzg_ctx* c) {
     void* ptrs[] = {c->d_tw_fwd, c->d_tw_inv, c->d_g1tw_fwd, c->d_g1tw_inv, c->d_coeffs, c->d_cells, c->d_cell_st,
@@ -166,10 +172,10 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* c, const void* d_bl
     while (done < n) {
         size_t chunk = std::min(n - done, c->fk_cap);
         const uint8_t* blobs = (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB;
-        cells_from_blobs_device(blobs, (int)chunk, c->d_tw_fwd, c->d_tw_inv, c->d_coeffs, (uint8_t*)d_cells + done * 262144, d_status + done, s);
-        fk20_scalars_device(c->d_coeffs, (int)chunk, c->d_tw_fwd, d_status + done, c->d_fk_scalars, s);
-        fk20_proofs_device(c->d_fk_scalars, c->d_fk_table, c->d_g1tw_fwd, c->d_g1tw_inv, (int)chunk, d_status + done, c->d_fk_results,
-                           (uint8_t*)d_proofs + done * 128 * 48, s);
+        KT(KT_CELLS_NTT, s, cells_from_blobs_device(blobs, (int)chunk, c->d_tw_fwd, c->d_tw_inv, c->d_coeffs, (uint8_t*)d_cells + done * 262144, d_status + done, s));
+        KT(KT_FK20_SCALARS, s, fk20_scalars_device(c->d_coeffs, (int)chunk, c->d_tw_fwd, d_status + done, c->d_fk_scalars, s));
+        KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, (int)chunk, d_status + done, c->d_fk_results, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_g1tw_fwd, c->d_g1tw_inv, (int)chunk, d_status + done, (uint8_t*)d_proofs + done * 128 * 48, s));
         done += chunk;
     }
     HIPCHK(hipGetLastError());
@@ -256,18 +262,20 @@ int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n,
     uint32_t* aff_q = c->d_v_aff + cap * 32;
     int* st_rows = c->d_v_st;
     int* st_q = c->d_v_st + cap;
-    g1_decompress_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, s);
-    g1_decompress_device(c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s);
-    g1_subgroup_check_device(aff_rows, (int)n_rows, st_rows, s);
-    g1_subgroup_check_device(aff_q, (int)n, st_q, s);
+    KT(KT_DECOMPRESS, s, g1_decompress_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, s));
+    KT(KT_DECOMPRESS, s, g1_decompress_device(c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s));
+    KT(KT_SUBGROUP, s, g1_subgroup_check_device(aff_rows, (int)n_rows, st_rows, s));
+    KT(KT_SUBGROUP, s, g1_subgroup_check_device(aff_q, (int)n, st_q, s));
     // scalars
-    cell_verify_scalars_device(c->d_v_misc, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, c->d_cv_rp, c->d_v_s1,
-                               c->d_v_s3, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st, s);
+    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(c->d_v_misc, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, c->d_cv_rp,
+                                                       c->d_v_s1, c->d_v_s3, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st, s));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
     const uint32_t* scal[4] = {c->d_v_s1, c->d_cv_weights, c->d_cv_interp, c->d_v_s3};
     const uint32_t* pts[4] = {aff_q, aff_rows, c->d_monomial_aff, aff_q};
     const int njob[4] = {(int)n, (int)n_rows, 64, (int)n};
-    if (vmsm_windows_device(scal, pts, njob, 4, c->d_v_misc + 16, s)) return MKZG_ERR_BAD_ARGS;
+    int vrc = 0;
+    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 4, c->d_v_misc + 16, s));
+    if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     int* h_st = (int*)c->h_v;
     std::vector<int> st_cells(n);
@@ -339,12 +347,13 @@ static int recover_front(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, co
     for (size_t i = 0; i < n_cells; i++) memcpy(c->h_stage + i * 2048, cells[i], 2048);
     HIPCHK(hipMemcpyAsync(c->d_blobs, c->h_stage, n_cells * 2048, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_rec_pos, pos, sizeof(pos), hipMemcpyHostToDevice, s));
-    recover_coeffs_device(c->d_blobs, c->d_rec_pos, (const uint32_t*)(c->d_rec_pos + 128), nm, c->d_tw_fwd, c->d_tw_inv, c->d_pow7, c->d_ipow7, c->d_rec_scratch, c->d_coeffs,
-                          c->d_cell_st, s);
-    cells_from_coeffs_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_tw_inv, c->d_cells, c->d_cell_st, s);
+    KT(KT_RECOVER, s, recover_coeffs_device(c->d_blobs, c->d_rec_pos, (const uint32_t*)(c->d_rec_pos + 128), nm, c->d_tw_fwd, c->d_tw_inv, c->d_pow7, c->d_ipow7,
+                                            c->d_rec_scratch, c->d_coeffs, c->d_cell_st, s));
+    KT(KT_CELLS_NTT, s, cells_from_coeffs_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_tw_inv, c->d_cells, c->d_cell_st, s));
     if (with_proofs) {
-        fk20_scalars_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_cell_st, c->d_fk_scalars, s);
-        fk20_proofs_device(c->d_fk_scalars, c->d_fk_table, c->d_g1tw_fwd, c->d_g1tw_inv, 1, c->d_cell_st, c->d_fk_results, c->d_fk_proofs, s);
+        KT(KT_FK20_SCALARS, s, fk20_scalars_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_cell_st, c->d_fk_scalars, s));
+        KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, 1, c->d_cell_st, c->d_fk_results, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_g1tw_fwd, c->d_g1tw_inv, 1, c->d_cell_st, c->d_fk_proofs, s));
     }
     HIPCHK(hipGetLastError());
     return MKZG_OK;

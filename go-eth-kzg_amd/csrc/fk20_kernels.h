@@ -18,4 +18,7 @@ void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fw
 void fk20_proofs_device(const uint32_t* d_scalars, const uint32_t* d_table, const uint32_t* d_g1tw_fwd, const uint32_t* d_g1tw_inv, int n, const int* d_status,
                         uint32_t* d_results, uint8_t* d_proofs48, hipStream_t s);
 
+void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_results, hipStream_t s);
+void fk20_ffts_device(const uint32_t* d_results, const uint32_t* d_g1tw_fwd, const uint32_t* d_g1tw_inv, int n, const int* d_status, uint8_t* d_proofs48, hipStream_t s);
+
 }  // namespace kzg

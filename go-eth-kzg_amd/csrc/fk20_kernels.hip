@@ -309,11 +309,16 @@ void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fw
     const size_t n = (size_t)8192 * FK_NWIN;
     hipLaunchKernelGGL(k_fk20_setup_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_t_aff, d_table, 8192);
 }
+void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_results, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_fk20_msm, dim3(32, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_results);
+}
+void fk20_ffts_device(const uint32_t* d_results, const uint32_t* d_g1tw_fwd, const uint32_t* d_g1tw_inv, int n, const int* d_status, uint8_t* d_proofs48, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_fk20_ffts, dim3(n), dim3(64), 0, s, d_results, d_g1tw_fwd, d_g1tw_inv, d_status, d_proofs48);
+}
 void fk20_proofs_device(const uint32_t* d_scalars, const uint32_t* d_table, const uint32_t* d_g1tw_fwd, const uint32_t* d_g1tw_inv, int n, const int* d_status,
                         uint32_t* d_results, uint8_t* d_proofs48, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(k_fk20_msm, dim3(32, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_results);
-    hipLaunchKernelGGL(k_fk20_ffts, dim3(n), dim3(64), 0, s, d_results, d_g1tw_fwd, d_g1tw_inv, d_status, d_proofs48);
+    fk20_msm_device(d_scalars, d_table, n, d_status, d_results, s);
+    fk20_ffts_device(d_results, d_g1tw_fwd, d_g1tw_inv, n, d_status, d_proofs48, s);
 }
 size_t fk20_table_bytes() { return (size_t)8192 * FK_NWIN * FK_NMULT * 128; }
 

@@ -14,7 +14,8 @@
 //   * each G1 FFT-128 runs in ONE wavefront (64 butterflies = 64 lanes) with the 128 points in
 //     LDS (28 KB, structure-of-arrays); inverse transform by decimation in frequency, forward by
 //     decimation in time, so the truncation/zero-padding between them is "clear the odd slots"
-//     and no permutation pass exists.  Twiddle multiplications are 255-bit double-and-add.
+//     and no permutation pass exists.  Twiddle multiplications use the GLV endomorphism (two 128-bit
+//     halves, precomputed per twiddle) with a shared 4-bit window table: 128 doublings + <= 64 additions.
 // Integer modular arithmetic only -- no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -69,15 +70,38 @@ __device__ __forceinline__ void f_store_xyzz(uint32_t* rec, const G1X& p) {
     for (int i = 0; i < 14; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
-// r = [k]p, k = 8 little-endian words (plain integer < r)
-__device__ __noinline__ void f_mul_words(G1X& r, const G1X& p, const uint32_t* k) {
+// r = [k]p for a twiddle k given by its GLV halves kk = (k1[4 words], k2[4 words]), k = k1 + k2 x^2:
+//   [k]p = [k1]p - [k2]phi(p),  phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ)
+// Straus/Shamir with 4-bit windows over both halves: 128 doublings + <= 64 additions, one table of 15
+// multiples of p (kept in the lane's private memory).
+__device__ __noinline__ void f_mul_glv(G1X& r, const G1X& p, const uint32_t* kk) {
+    G1X tbl[15];
+    tbl[0] = p;
+    for (int i = 1; i < 15; i++) f_add(tbl[i], tbl[i - 1], p);
+    fp_t beta;
+    Fp::set(beta, FP_BETA);
     G1X acc;
     g1x_set_inf(acc);
-    int top = 255;
-    while (top >= 0 && !((k[top >> 5] >> (top & 31)) & 1)) top--;
-    for (int i = top; i >= 0; i--) {
-        f_dbl(acc, acc);
-        if ((k[i >> 5] >> (i & 31)) & 1) f_add(acc, acc, p);
+    int top = 31;
+    while (top >= 0 && (((kk[top >> 3] | kk[4 + (top >> 3)]) >> (4 * (top & 7))) & 15u) == 0) top--;
+    for (int w = top; w >= 0; w--) {
+        if (w != top) {
+            f_dbl(acc, acc);
+            f_dbl(acc, acc);
+            f_dbl(acc, acc);
+            f_dbl(acc, acc);
+        }
+        const uint32_t d1 = (kk[w >> 3] >> (4 * (w & 7))) & 15u;
+        const uint32_t d2 = (kk[4 + (w >> 3)] >> (4 * (w & 7))) & 15u;
+        if (d1) f_add(acc, acc, tbl[d1 - 1]);
+        if (d2) {
+            G1X q = tbl[d2 - 1];
+            if (!g1x_is_inf(q)) {
+                Fp::mul(q.x, q.x, beta);
+                Fp::template neg<2>(q.y, q.y);       // -phi(.)
+            }
+            f_add(acc, acc, q);
+        }
     }
     r = acc;
 }
@@ -103,7 +127,7 @@ __device__ __forceinline__ void lp_put(uint32_t* sh, int e, const G1X& p) {
         sh[(42 + i) * 128 + e] = p.zzz.l[i];
     }
 }
-// decimation in frequency: natural order in, bit-reversed order out.  tw: 64 x 8 words of w^j.
+// decimation in frequency: natural order in, bit-reversed order out.  tw: 64 x 8 words, GLV halves of w^j.
 __device__ __forceinline__ void g1_fft128_dif(uint32_t* sh, const uint32_t* __restrict__ tw, int lane) {
     for (int h = 64; h >= 1; h >>= 1) {
         const int k = lane & (h - 1);
@@ -119,7 +143,7 @@ __device__ __forceinline__ void g1_fft128_dif(uint32_t* sh, const uint32_t* __re
             uint32_t kw[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) kw[q] = tw[e * 8 + q];
-            f_mul_words(d, d, kw);
+            f_mul_glv(d, d, kw);
         }
         lp_put(sh, i0, s);
         lp_put(sh, i1, d);
@@ -139,7 +163,7 @@ __device__ __forceinline__ void g1_fft128_dit(uint32_t* sh, const uint32_t* __re
             uint32_t kw[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) kw[q] = tw[e * 8 + q];
-            f_mul_words(b, b, kw);
+            f_mul_glv(b, b, kw);
         }
         f_add(s, a, b);
         g1x_neg(nb, b);
@@ -169,7 +193,7 @@ __global__ void __launch_bounds__(64) k_fk20_setup_fft(const uint32_t* __restric
         lp_put(sh, j, p);
     }
     __syncthreads();
-    g1_fft128_dif(sh, g1tw_fwd, lane);
+    g1_fft128_dif(sh, &G1TW_GLV_FWD[0][0], lane);
     for (int k = lane; k < 128; k += 64) {
         G1X p;
         lp_get(p, sh, (int)(__brev((uint32_t)k) >> 25));
@@ -279,7 +303,7 @@ __global__ void __launch_bounds__(64) k_fk20_ffts(const uint32_t* __restrict__ r
         lp_put(sh, j, p);
     }
     __syncthreads();
-    g1_fft128_dif(sh, g1tw_inv, lane);
+    g1_fft128_dif(sh, &G1TW_GLV_INV[0][0], lane);
     // slot p now holds h[brev7(p)]; h[j] for j >= 64 lives in the odd slots: drop it (toeplitz.go:124, fk20.go:83-86)
     {
         G1X z;
@@ -287,7 +311,7 @@ __global__ void __launch_bounds__(64) k_fk20_ffts(const uint32_t* __restrict__ r
         lp_put(sh, 2 * lane + 1, z);
     }
     __syncthreads();
-    g1_fft128_dit(sh, g1tw_fwd, lane);
+    g1_fft128_dit(sh, &G1TW_GLV_FWD[0][0], lane);
     for (int i = lane; i < 128; i += 64) {
         G1X p;
         lp_get(p, sh, (int)(__brev((uint32_t)i) >> 25));          // proofs[i] = X[brev(i)]  (fk20.go:90)

@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="blobs per GPU per step (config 2: 256)")
     ap.add_argument("--window", type=int, default=0, help="MSM window bits override (11..13)")
+    ap.add_argument("--direct-bits", type=int, default=0, help="commit_direct_bits option (0 = bucket method, 12..15 = direct table)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate over (1 = strictly serial steps)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents (roofline section is then empty)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +88,8 @@ def main():
     if args.window:
         assert ctx.set_option("msm_window", args.window) == 0
     assert ctx.set_option("max_batch", args.batch) == 0
+    if args.direct_bits:
+        assert ctx.set_option("commit_direct_bits", args.direct_bits) == 0
     B = args.batch
 
     # synthetic inputs of the reference benches, distinct seeds per rank, resident in HBM

@@ -116,6 +116,7 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     (void)hipSetDevice(c->device);
     free_plan(c);
     if (c->d_lagrange_aff) (void)hipFree(c->d_lagrange_aff);
+    if (c->d_direct) (void)hipFree(c->d_direct);
     if (c->d_roots_brp) (void)hipFree(c->d_roots_brp);
     if (c->d_inv_roots_brp) (void)hipFree(c->d_inv_roots_brp);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -205,6 +206,14 @@ int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
         if (c->opt_c != (int)value) { c->opt_c = (int)value; free_plan(c); }
         return MKZG_OK;
     }
+    if (!strcmp(key, "commit_direct_bits")) {
+        if (value != 0 && (value < 12 || value > 15)) return MKZG_ERR_BAD_ARGS;
+        if (c->opt_direct_bits != (int)value) {
+            c->opt_direct_bits = (int)value;
+            if (c->d_direct) { (void)hipFree(c->d_direct); c->d_direct = nullptr; c->direct_bits_built = 0; }
+        }
+        return MKZG_OK;
+    }
     if (!strcmp(key, "max_batch")) {
         if (value < 1 || value > 4096) return MKZG_ERR_BAD_ARGS;
         if (c->opt_max_batch != (int)value) { c->opt_max_batch = (int)value; free_plan(c); }
@@ -218,9 +227,29 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, s
     if (!c || (!d_blobs && n) || (!d_out48n && n) || (!d_status && n)) return MKZG_ERR_BAD_ARGS;
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (c->opt_direct_bits) {
+        if (c->direct_bits_built != c->opt_direct_bits) {
+            const int cb = c->opt_direct_bits, nwin = (255 + cb - 1) / cb;
+            uint32_t* tmp = nullptr;
+            HIPCHK(hipMalloc(&tmp, (size_t)nwin * 4096 * 128));
+            if (c->d_direct) (void)hipFree(c->d_direct);
+            c->d_direct = nullptr;
+            HIPCHK(hipMalloc(&c->d_direct, direct_table_bytes(cb)));
+            build_table_any_device(cb, c->d_lagrange_aff, tmp, 4096, 12, c->stream);
+            build_direct_device(cb, tmp, c->d_direct, c->stream);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));
+            (void)hipFree(tmp);
+            c->direct_bits_built = cb;
+        }
+        commit_direct_device(c->opt_direct_bits, c->d_direct, (const uint8_t*)d_blobs, MKZG_BYTES_PER_BLOB, (int)n, (uint8_t*)d_out48n, d_status, s,
+                             c->profiling ? &c->timer : nullptr);
+        HIPCHK(hipGetLastError());
+        return MKZG_OK;
+    }
     int rc = ensure_plan(c);
     if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
     size_t done = 0;
     while (done < n) {
         int chunk = (int)std::min<size_t>(n - done, (size_t)c->plan.max_batch);

@@ -8,10 +8,10 @@
 
 namespace kzg {
 
-enum KernelKind { KT_DIGITS_SORT = 0, KT_BUCKET_ACC, KT_REDUCE1, KT_REDUCE2, KT_DECOMPRESS, KT_SUBGROUP, KT_SHA256, KT_EVAL, KT_QUOTIENT, KT_RLC, KT_VMSM, KT_CELLS_NTT, KT_FK20_SCALARS, KT_FK20_MSM, KT_FK20_FFTS, KT_CELL_SCALARS, KT_RECOVER, KT_COUNT };
+enum KernelKind { KT_DIGITS_SORT = 0, KT_BUCKET_ACC, KT_REDUCE1, KT_REDUCE2, KT_DECOMPRESS, KT_SUBGROUP, KT_SHA256, KT_EVAL, KT_QUOTIENT, KT_RLC, KT_VMSM, KT_CELLS_NTT, KT_FK20_SCALARS, KT_FK20_MSM, KT_FK20_FFTS, KT_CELL_SCALARS, KT_RECOVER, KT_COMMIT_DIRECT, KT_COUNT };
 static const char* const kKernelNames[KT_COUNT] = {"k_digits_sort", "k_bucket_accumulate", "k_bucket_reduce1", "k_bucket_reduce2", "k_g1_decompress",
                                                    "k_g1_subgroup_check", "k_challenge_sha256", "k_blob_eval", "k_blob_quotient", "k_rlc_scalars", "k_vmsm_window",
-                                                   "k_cells_ntt", "k_fk20_scalars", "k_fk20_msm", "k_fk20_ffts", "k_cell_verify_scalars", "k_recover_*"};
+                                                   "k_cells_ntt", "k_fk20_scalars", "k_fk20_msm", "k_fk20_ffts", "k_cell_verify_scalars", "k_recover_*", "k_commit_direct"};
 
 // hipEvent bracket around each kernel launch, on the stream the kernel is launched on.
 struct KernelTimer {
@@ -69,5 +69,10 @@ void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz);
 void commit_batch_device(const CommitPlan& pl, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt);
 void g1_decompress_device(const uint8_t* d_in48, int n, uint32_t* d_out_aff, int* d_status, hipStream_t s);
 void build_table_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s);
+// direct-table commitment (window bits c in 12..15)
+size_t direct_table_bytes(int c);
+void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s);
+void build_direct_device(int c, const uint32_t* d_table, uint32_t* d_direct, hipStream_t s);
+void commit_direct_device(int c, const uint32_t* d_direct, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt);
 
 }  // namespace kzg

@@ -502,6 +502,133 @@ __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// DIRECT-TABLE commitment (context option "commit_direct_bits" = C, 12..15): trade HBM capacity for
+// arithmetic.  The table holds every signed-digit multiple of every window base,
+//     D[(j*4096 + i)][m-1] = m * 2^(C j) * L_i ,   m = 1 .. 2^(C-1)         (C=13: 43 GB, C=15: 146 GB of the 288 GB)
+// so a commitment is 4096 * ceil(255/C) mixed additions into per-lane accumulators and one tree sum per blob:
+// no buckets, no sort, no bucket reduction, ONE kernel per batch.
+// ------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(64) k_build_direct(const uint32_t* __restrict__ table /* [NWIN][4096] window bases */, uint32_t* __restrict__ direct) {
+    using RC = Recode<C>;
+    const int row = blockIdx.x * 64 + threadIdx.x;            // row = j*4096 + i
+    if (row >= RC::NWIN * 4096) return;
+    G1Aff base;
+    load_affine(base, table + (size_t)row * 32);
+    uint32_t* dst = direct + (size_t)row * RC::NBUCKET * 32;
+    G1X acc;
+    g1x_set_inf(acc);
+    for (int m = 0; m < RC::NBUCKET; m++) {
+        G1Aff a;
+        if (base.inf) {
+            a = base;
+        } else {
+            g1x_madd(acc, base.x, base.y);
+            g1x_to_affine(a, acc);
+            if (!a.inf) g1x_from_affine(acc, a.x, a.y);       // keep Z = 1: cheap next addition, tight values
+        }
+        store_affine(dst + (size_t)m * 32, a);
+    }
+}
+
+constexpr int DT = 512;     // threads per blob
+__device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.x.l[i] = __shfl_xor(a.x.l[i], m);
+        r.y.l[i] = __shfl_xor(a.y.l[i], m);
+        r.zz.l[i] = __shfl_xor(a.zz.l[i], m);
+        r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
+    }
+}
+template <int C>
+__global__ void __launch_bounds__(DT) k_commit_direct(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, const uint32_t* __restrict__ direct,
+                                                       uint8_t* __restrict__ out48, int* __restrict__ status) {
+    using RC = Recode<C>;
+    __shared__ uint32_t xch[(DT / 64) * 56];
+    const int b = blockIdx.x, t = threadIdx.x;
+    uint32_t sc[4096 / DT][8];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4096 / DT; k++) {
+        load_scalar_be(sc[k], scalars + (size_t)b * scalar_stride_bytes + (size_t)(t + DT * k) * 32);
+        bad |= !scalar_is_canonical(sc[k]);
+    }
+    if (__syncthreads_or(bad)) {
+        if (t == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
+        return;
+    }
+    if (t == 0) status[b] = 0;
+    G1X acc;
+    g1x_set_inf(acc);
+#pragma unroll 1
+    for (int k = 0; k < 4096 / DT; k++) {
+        const int i = t + DT * k;
+        int carry = 0;
+        // software pipeline: digit/row of window j+1 is fetched while window j is added
+        G1Aff p;
+        int dcur = 0;
+        p.inf = 1;
+#pragma unroll 1
+        for (int j = 0; j <= RC::NWIN; j++) {
+            G1Aff pn;
+            int dn = 0;
+            pn.inf = 1;
+            if (j < RC::NWIN) {
+                const int bit = C * j, wi = bit >> 5, off = bit & 31;
+                uint32_t v = sc[k][wi] >> off;
+                if (off + C > 32 && wi + 1 < 8) v |= sc[k][wi + 1] << (32 - off);
+                dn = (int)(v & ((1u << C) - 1)) + carry;
+                carry = 0;
+                if (dn > RC::NBUCKET) { dn -= (1 << C); carry = 1; }
+                if (dn != 0) {
+                    const int m = dn < 0 ? -dn : dn;
+                    load_affine(pn, direct + (((size_t)j * 4096 + i) * RC::NBUCKET + (m - 1)) * 32);
+                }
+            }
+            if (!p.inf) {
+                if (dcur < 0) Fp::template neg<0>(p.y, p.y);
+                g1x_madd(acc, p.x, p.y);
+            }
+            p = pn;
+            dcur = dn;
+        }
+    }
+    // sum the DT accumulators: xor-butterfly inside each wavefront, then one wavefront over LDS
+    G1X o;
+    for (int m = 32; m >= 1; m >>= 1) {
+        shfl_xor_xyzz(o, acc, m);
+        g1x_add_ni(acc, acc, o);
+    }
+    const int lane = t & 63, wave = t >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            xch[wave * 56 + i] = acc.x.l[i]; xch[wave * 56 + 14 + i] = acc.y.l[i]; xch[wave * 56 + 28 + i] = acc.zz.l[i]; xch[wave * 56 + 42 + i] = acc.zzz.l[i];
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        G1X tot = acc;
+        for (int w = 1; w < DT / 64; w++) {
+            G1X q;
+#pragma unroll
+            for (int i = 0; i < 14; i++) {
+                q.x.l[i] = xch[w * 56 + i]; q.y.l[i] = xch[w * 56 + 14 + i]; q.zz.l[i] = xch[w * 56 + 28 + i]; q.zzz.l[i] = xch[w * 56 + 42 + i];
+            }
+            g1x_add_ni(tot, tot, q);
+        }
+        G1Aff a;
+        g1x_to_affine(a, tot);
+        uint32_t w12[12];
+        g1_compress_words(w12, a);
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(out48 + (size_t)b * 48);
+#pragma unroll
+        for (int i = 0; i < 12; i++) o32[i] = __builtin_bswap32(w12[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 template <int C>
@@ -534,6 +661,38 @@ void commit_batch_device(const CommitPlan& pl, const uint8_t* d_scalars, size_t 
         case 12: launch_commit<12>(pl, d_scalars, stride, input_kind, n, d_out48, d_status, s, kt); break;
         default: launch_commit<13>(pl, d_scalars, stride, input_kind, n, d_out48, d_status, s, kt); break;
     }
+}
+size_t direct_table_bytes(int c) {
+    const int nwin = (255 + c - 1) / c;
+    return (size_t)nwin * 4096 * ((size_t)1 << (c - 1)) * 128;
+}
+void build_direct_device(int c, const uint32_t* d_table, uint32_t* d_direct, hipStream_t s) {
+    const int nwin = (255 + c - 1) / c;
+    const int rows = nwin * 4096;
+    switch (c) {
+        case 12: hipLaunchKernelGGL((k_build_direct<12>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct); break;
+        case 13: hipLaunchKernelGGL((k_build_direct<13>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct); break;
+        case 14: hipLaunchKernelGGL((k_build_direct<14>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct); break;
+        default: hipLaunchKernelGGL((k_build_direct<15>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct); break;
+    }
+}
+void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s) {
+    switch (c) {
+        case 14: hipLaunchKernelGGL((k_build_table<14>), dim3((n + 63) / 64), dim3(64), 0, s, d_src_aff, d_table, n, bitrev_bits); break;
+        case 15: hipLaunchKernelGGL((k_build_table<15>), dim3((n + 63) / 64), dim3(64), 0, s, d_src_aff, d_table, n, bitrev_bits); break;
+        default: build_table_device(c, d_src_aff, d_table, n, bitrev_bits, s); break;
+    }
+}
+void commit_direct_device(int c, const uint32_t* d_direct, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
+    if (n <= 0) return;
+    if (kt) kt->begin(KT_COMMIT_DIRECT, s);
+    switch (c) {
+        case 12: hipLaunchKernelGGL((k_commit_direct<12>), dim3(n), dim3(DT), 0, s, d_scalars, stride, d_direct, d_out48, d_status); break;
+        case 13: hipLaunchKernelGGL((k_commit_direct<13>), dim3(n), dim3(DT), 0, s, d_scalars, stride, d_direct, d_out48, d_status); break;
+        case 14: hipLaunchKernelGGL((k_commit_direct<14>), dim3(n), dim3(DT), 0, s, d_scalars, stride, d_direct, d_out48, d_status); break;
+        default: hipLaunchKernelGGL((k_commit_direct<15>), dim3(n), dim3(DT), 0, s, d_scalars, stride, d_direct, d_out48, d_status); break;
+    }
+    if (kt) kt->end(KT_COMMIT_DIRECT, s);
 }
 void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz) {
     const int nwin = (255 + c - 1) / c, nb = 1 << (c - 1);

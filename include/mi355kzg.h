@@ -63,7 +63,9 @@ typedef struct mkzg_ctx mkzg_ctx;
  * context per process/rank (DESIGN.md "multi-GPU"). */
 int mkzg_ctx_new(const char* trusted_setup_json, size_t len, const int* device_ids, int n_dev, mkzg_ctx** out);
 void mkzg_ctx_free(mkzg_ctx* ctx);
-/* tuning knobs before first use: key "msm_window" (11..13), "max_batch" (blobs per launch). */
+/* tuning knobs before first use: "msm_window" (11..13), "max_batch" (blobs per launch), "commit_direct_bits"
+ * (0 = bucket method; 12..15 = direct window table for BlobToKZGCommitment: 21 GB .. 146 GB of HBM, fewer group
+ * additions and a single kernel per batch). */
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
 
 /* ---- EIP-4844 ------------------------------------------------------------------------------ */

@@ -99,3 +99,21 @@ def test_windows_agree(product, oracle_ctx):
         rc, out = ctx.BlobToKZGCommitment(blob)
         ctx.close()
         assert rc == 0 and out == exp, c
+
+
+def test_direct_table_mode(product, oracle_ctx):
+    """commit_direct_bits: the direct-table kernel gives the same bytes as the bucket method and the oracle"""
+    import torch
+    torch.cuda.init()
+    blobs = [rand_blob(21), bytes(131072), (R - 1).to_bytes(32, "big") * 4096, rand_blob(22)]
+    ctx = product.Context()
+    assert ctx.set_option("commit_direct_bits", 12) == 0
+    rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
+    assert rc == 0 and st == [0, 0, 0, 0]
+    for b, o in zip(blobs, outs):
+        assert o == oracle_ctx.blob_to_kzg_commitment(b)[1]
+    bad = bytearray(blobs[0])
+    bad[:32] = R.to_bytes(32, "big")
+    rc, outs, st = ctx.BlobToKZGCommitmentBatch([bytes(bad), blobs[3]])
+    assert rc == 3 and st == [3, 0] and outs[1] == oracle_ctx.blob_to_kzg_commitment(blobs[3])[1]
+    ctx.close()

@@ -13,7 +13,7 @@ Multi-GPU: blobs are independent, so each rank commits its own batch (weak scali
 collective); ranks only meet in the barrier/max-reduction that brackets the timed region.
 
 The JSON line also carries
-  roofline     : dominant kernel (k_bucket_accumulate) -- algorithmic bytes per launch
+  roofline     : dominant kernel (k_commit_direct_acc; k_bucket_accumulate with --direct-bits 0) -- algorithmic bytes per launch
                  (131,120 B per blob) / its average duration measured with
                  hipEvents on the launch stream inside the timed region, against 8 TB/s HBM;
   valu         : the honest ceiling of this integer-VALU-bound path: field multiplications per
@@ -62,8 +62,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="blobs per GPU per step (config 2: 256)")
     ap.add_argument("--window", type=int, default=0, help="MSM window bits override (11..13)")
-    ap.add_argument("--direct-bits", type=int, default=0, help="commit_direct_bits option (0 = bucket method, 12..15 = direct table)")
+    ap.add_argument("--direct-bits", type=int, default=15,
+                    help="commit_direct_bits option: 0 = bucket method (0.5 GB table), 12..15 = direct window table (15: 146 GB of the 288 GB HBM)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate over (1 = strictly serial steps)")
+    ap.add_argument("--no-chain", action="store_true", help="chain_accumulate=0: consecutive calls' accumulate kernels are not serialised")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents (roofline section is then empty)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=1024, help="config 3: proofs per VerifyBlobKZGProofBatch call (0 = skip)")
@@ -88,13 +90,21 @@ def main():
     if args.window:
         assert ctx.set_option("msm_window", args.window) == 0
     assert ctx.set_option("max_batch", args.batch) == 0
-    if args.direct_bits:
-        assert ctx.set_option("commit_direct_bits", args.direct_bits) == 0
+    if args.no_chain:
+        assert ctx.set_option("chain_accumulate", 0) == 0
     B = args.batch
 
     # synthetic inputs of the reference benches, distinct seeds per rank, resident in HBM
     host = b"".join(rand_blob(rank * B + s) for s in range(B))
     d_blobs = torch.frombuffer(bytearray(host), dtype=torch.uint8).cuda()
+    d_ref = None
+    if args.direct_bits:
+        # untimed cross-check material: the same batch through the bucket method (the two methods share no kernel)
+        d_ref = torch.zeros(B * 48, dtype=torch.uint8, device="cuda")
+        d_ref_st = torch.zeros(B, dtype=torch.int32, device="cuda")
+        assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), B, d_ref.data_ptr(), d_ref_st.data_ptr(), 0) == 0
+        torch.cuda.synchronize()
+        assert ctx.set_option("commit_direct_bits", args.direct_bits) == 0
     # consecutive steps alternate between two HIP streams (each with its own output buffers): the library keeps
     # two workspaces, so the latency-bound bucket reduction of step i overlaps the accumulation of step i+1
     NS = max(1, args.streams)
@@ -138,6 +148,8 @@ def main():
     assert all(int(t.abs().sum().item()) == 0 for t in d_stats), "some blobs were rejected"
     if NS > 1 and args.steps + args.warmup >= 2:
         assert bool((d_outs[0] == d_outs[1]).all().item()), "streams disagree"
+    if d_ref is not None:
+        assert bool((d_outs[0] == d_ref).all().item()), "direct-table and bucket method disagree"
 
     verify = None
     if args.verify_batch > 0:
@@ -162,7 +174,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery, radix 2^29)",
             "data": "synthetic (GetRandBlob seeds, reference bench_test.go:17-46)",
             "config": {"workload": "configs[1]: BlobToKZGCommitment batch=256 blobs x 4096 scalars per GPU, fixed-base G1 MSM",
-                       "batch_per_gpu": B, "parallelism": f"blob-sharded x{world}, no collective", "streams": NS},
+                       "batch_per_gpu": B, "msm": (f"direct window table c={args.direct_bits}" if args.direct_bits else f"bucket method c={args.window or 13}"), "parallelism": f"blob-sharded x{world}, no collective", "streams": NS},
             "roofline": roofline,
         }
         if verify is not None:

@@ -96,7 +96,7 @@ static void free_plan(mkzg_ctx* c) {
 int acquire_slot(mkzg_ctx* c, hipStream_t s) {
     const int slot = (int)(c->slot_counter++ % mkzg_ctx::NSLOT);
     if (c->slot_used[slot] && hipStreamWaitEvent(s, c->slot_done[slot], 0) != hipSuccess) return -1;
-    c->slots[slot].wait_before_acc = c->last_acc_slot >= 0 ? c->acc_done[c->last_acc_slot] : nullptr;
+    c->slots[slot].wait_before_acc = (c->opt_chain_acc && c->last_acc_slot >= 0) ? c->acc_done[c->last_acc_slot] : nullptr;
     c->slots[slot].record_after_acc = c->acc_done[slot];
     return slot;
 }
@@ -117,6 +117,10 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     free_plan(c);
     if (c->d_lagrange_aff) (void)hipFree(c->d_lagrange_aff);
     if (c->d_direct) (void)hipFree(c->d_direct);
+    for (int i = 0; i < mkzg_ctx::NSLOT; i++) {
+        if (c->dslots[i].d_parts) (void)hipFree(c->dslots[i].d_parts);
+        if (c->dslots[i].d_bad) (void)hipFree(c->dslots[i].d_bad);
+    }
     if (c->d_roots_brp) (void)hipFree(c->d_roots_brp);
     if (c->d_inv_roots_brp) (void)hipFree(c->d_inv_roots_brp);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -214,6 +218,11 @@ int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
         }
         return MKZG_OK;
     }
+    if (!strcmp(key, "chain_accumulate")) {
+        if (value != 0 && value != 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_chain_acc = (int)value;
+        return MKZG_OK;
+    }
     if (!strcmp(key, "max_batch")) {
         if (value < 1 || value > 4096) return MKZG_ERR_BAD_ARGS;
         if (c->opt_max_batch != (int)value) { c->opt_max_batch = (int)value; free_plan(c); }
@@ -243,8 +252,34 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, s
             (void)hipFree(tmp);
             c->direct_bits_built = cb;
         }
-        commit_direct_device(c->opt_direct_bits, c->d_direct, (const uint8_t*)d_blobs, MKZG_BYTES_PER_BLOB, (int)n, (uint8_t*)d_out48n, d_status, s,
-                             c->profiling ? &c->timer : nullptr);
+        if (c->dslot_batch != c->opt_max_batch) {
+            HIPCHK(hipDeviceSynchronize());
+            for (int i = 0; i < mkzg_ctx::NSLOT; i++) {
+                if (c->dslots[i].d_parts) (void)hipFree(c->dslots[i].d_parts);
+                if (c->dslots[i].d_bad) (void)hipFree(c->dslots[i].d_bad);
+                c->dslots[i].d_parts = nullptr; c->dslots[i].d_bad = nullptr;
+                HIPCHK(hipMalloc(&c->dslots[i].d_parts, direct_parts_bytes(c->opt_max_batch)));
+                HIPCHK(hipMalloc(&c->dslots[i].d_bad, (size_t)c->opt_max_batch * 2 * sizeof(int)));
+                if (!c->slot_done[i]) HIPCHK(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming));
+                if (!c->acc_done[i]) HIPCHK(hipEventCreateWithFlags(&c->acc_done[i], hipEventDisableTiming));
+                c->slot_used[i] = false;
+            }
+            c->last_acc_slot = -1;
+            c->dslot_batch = c->opt_max_batch;
+        }
+        size_t done = 0;
+        while (done < n) {
+            const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
+            const int slot = (int)(c->slot_counter++ % mkzg_ctx::NSLOT);
+            if (c->slot_used[slot]) HIPCHK(hipStreamWaitEvent(s, c->slot_done[slot], 0));
+            c->dslots[slot].wait_before_acc = (c->opt_chain_acc && c->last_acc_slot >= 0) ? c->acc_done[c->last_acc_slot] : nullptr;
+            c->dslots[slot].record_after_acc = c->acc_done[slot];
+            commit_direct_device(c->opt_direct_bits, c->d_direct, c->dslots[slot], (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB, MKZG_BYTES_PER_BLOB, chunk,
+                                 (uint8_t*)d_out48n + done * 48, d_status + done, s, c->profiling ? &c->timer : nullptr);
+            int rr = release_slot(c, slot, s);
+            if (rr) return rr;
+            done += chunk;
+        }
         HIPCHK(hipGetLastError());
         return MKZG_OK;
     }

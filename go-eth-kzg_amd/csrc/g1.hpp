@@ -30,6 +30,12 @@ struct G1T {
     };
 
     static KZ_HD bool is_inf(const XYZZ& p) { return F::limbs_all_zero(p.zz); }
+    static KZ_HD void opaque(XYZZ& p) {   // see mont29.hpp KZ_OPAQUE32
+        F::opaque(p.x);
+        F::opaque(p.y);
+        F::opaque(p.zz);
+        F::opaque(p.zzz);
+    }
     static KZ_HD void set_inf(XYZZ& p) {
         F::set_one(p.x);
         F::set_one(p.y);
@@ -61,16 +67,17 @@ struct G1T {
         F::dbl(t, S);
         F::template sub<2>(X3, X3, t);        // M^2 - 2S + 4p        (< 5.01p)
         F::template sub<3>(t, S, X3);         // S - X3 + 8p
-        F::mul(t, M, t);
-        F::mul(S, W, y);
-        F::template sub<1>(r.y, t, S);        // < 3.01p
+        F::template neg<1>(S, y);             // 2p - y
+        F::mul2(r.y, M, t, W, S);             // M (S - X3) - W y      (< 1.01p)
         r.x = X3;
         r.zz = V;
         r.zzz = W;
     }
     // r = 2*p (dbl-2008-s-1, a = 0)
-    static KZ_HD void dbl(XYZZ& r, const XYZZ& p) {
+    static KZ_HD void dbl(XYZZ& r, const XYZZ& p_) {
+        XYZZ p = p_;
         if (is_inf(p)) { r = p; return; }
+        opaque(p);
         fe U, V, W, S, M, t, X3, Y3;
         F::dbl(U, p.y);
         F::sqr(V, U);
@@ -83,9 +90,8 @@ struct G1T {
         F::dbl(t, S);
         F::template sub<2>(X3, X3, t);
         F::template sub<3>(t, S, X3);
-        F::mul(t, M, t);
-        F::mul(S, W, p.y);
-        F::template sub<1>(Y3, t, S);
+        F::template neg<2>(S, p.y);           // 4p - Y
+        F::mul2(Y3, M, t, W, S);              // M (S - X3) - W Y      (< 1.01p)
         F::mul(r.zz, V, p.zz);
         F::mul(r.zzz, W, p.zzz);
         r.x = X3;
@@ -93,8 +99,14 @@ struct G1T {
     }
 
     // acc += (x2, y2) with (x2, y2) affine and not the identity (madd-2008-s)
-    static KZ_HD void madd(XYZZ& acc, const fe& x2, const fe& y2) {
+    static KZ_HD void madd(XYZZ& acc, const fe& x2_, const fe& y2_) {
+        // the F::opaque calls sit at the head of each basic block that multiplies values defined in an earlier
+        // block (instruction selection only sees 32-bit-ness inside one block; see mont29.hpp KZ_OPAQUE32)
+        fe x2 = x2_, y2 = y2_;
         if (is_inf(acc)) { from_affine(acc, x2, y2); return; }
+        opaque(acc);
+        F::opaque(x2);
+        F::opaque(y2);
         fe U2, S2, Pd, Rd, PP, PPP, Q, t, X3;
         F::mul(U2, x2, acc.zz);
         F::mul(S2, y2, acc.zzz);
@@ -105,26 +117,31 @@ struct G1T {
             else set_inf(acc);
             return;
         }
+        opaque(acc);
+        F::opaque(Pd);
+        F::opaque(Rd);
         F::sqr(PP, Pd);
         F::mul(PPP, Pd, PP);
         F::mul(Q, acc.x, PP);
+        F::mul(acc.zz, acc.zz, PP);           // PP, Pd and X1 are dead from here on (keeps the live set small for R^2)
+        F::mul(acc.zzz, acc.zzz, PPP);
         F::sqr(X3, Rd);
         F::template sub<1>(X3, X3, PPP);      // R^2 - PPP + 2p        (< 3.01p)
         F::dbl(t, Q);
         F::template sub<2>(X3, X3, t);        // ... - 2Q + 4p         (< 7.01p)
         F::template sub<3>(t, Q, X3);         // Q - X3 + 8p
-        F::mul(t, Rd, t);
-        F::mul(S2, acc.y, PPP);
-        F::template sub<1>(acc.y, t, S2);     // < 3.01p
+        F::template neg<2>(S2, acc.y);        // 4p - Y1
+        F::mul2(acc.y, Rd, t, S2, PPP);       // R (Q - X3) - Y1 PPP   (< 1.01p), one reduction for both products
         acc.x = X3;
-        F::mul(acc.zz, acc.zz, PP);
-        F::mul(acc.zzz, acc.zzz, PPP);
     }
 
     // r = a + b, both XYZZ (add-2008-s)
-    static KZ_HD void add(XYZZ& r, const XYZZ& a, const XYZZ& b) {
+    static KZ_HD void add(XYZZ& r, const XYZZ& a_, const XYZZ& b_) {
+        XYZZ a = a_, b = b_;
         if (is_inf(a)) { r = b; return; }
         if (is_inf(b)) { r = a; return; }
+        opaque(a);
+        opaque(b);
         fe U1, U2, S1, S2, Pd, Rd, PP, PPP, Q, t, X3, Y3;
         F::mul(U1, a.x, b.zz);
         F::mul(U2, b.x, a.zz);
@@ -137,6 +154,12 @@ struct G1T {
             else set_inf(r);
             return;
         }
+        opaque(a);
+        opaque(b);
+        F::opaque(Pd);
+        F::opaque(Rd);
+        F::opaque(U1);
+        F::opaque(S1);
         F::sqr(PP, Pd);
         F::mul(PPP, Pd, PP);
         F::mul(Q, U1, PP);
@@ -145,9 +168,8 @@ struct G1T {
         F::dbl(t, Q);
         F::template sub<2>(X3, X3, t);
         F::template sub<3>(t, Q, X3);
-        F::mul(t, Rd, t);
-        F::mul(S1, S1, PPP);
-        F::template sub<1>(Y3, t, S1);
+        F::template neg<1>(S1, S1);           // 2p - S1
+        F::mul2(Y3, Rd, t, S1, PPP);          // R (Q - X3) - S1 PPP   (< 1.01p)
         F::mul(t, a.zz, b.zz);
         F::mul(r.zz, t, PP);
         F::mul(t, a.zzz, b.zzz);

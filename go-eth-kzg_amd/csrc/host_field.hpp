@@ -52,6 +52,13 @@ struct HostFp {
         memcpy(r.l, t, 48);
     }
     static inline void sqr(El& r, const El& a) { mul(r, a, a); }
+    static inline void opaque(El&) {}
+    static inline void mul2(El& r, const El& a, const El& b, const El& c, const El& d) {   // a*b + c*d
+        El t1, t2;
+        mul(t1, a, b);
+        mul(t2, c, d);
+        add(r, t1, t2);
+    }
     static inline uint64_t add_raw(uint64_t* o, const uint64_t* a, const uint64_t* b) {
         uint64_t c = 0;
         for (int i = 0; i < 6; i++) { u128 s = (u128)a[i] + b[i] + c; o[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }

@@ -8,10 +8,10 @@
 
 namespace kzg {
 
-enum KernelKind { KT_DIGITS_SORT = 0, KT_BUCKET_ACC, KT_REDUCE1, KT_REDUCE2, KT_DECOMPRESS, KT_SUBGROUP, KT_SHA256, KT_EVAL, KT_QUOTIENT, KT_RLC, KT_VMSM, KT_CELLS_NTT, KT_FK20_SCALARS, KT_FK20_MSM, KT_FK20_FFTS, KT_CELL_SCALARS, KT_RECOVER, KT_COMMIT_DIRECT, KT_COUNT };
+enum KernelKind { KT_DIGITS_SORT = 0, KT_BUCKET_ACC, KT_REDUCE1, KT_REDUCE2, KT_DECOMPRESS, KT_SUBGROUP, KT_SHA256, KT_EVAL, KT_QUOTIENT, KT_RLC, KT_VMSM, KT_CELLS_NTT, KT_FK20_SCALARS, KT_FK20_MSM, KT_FK20_FFTS, KT_CELL_SCALARS, KT_RECOVER, KT_COMMIT_DIRECT, KT_COMMIT_DIRECT_FIN, KT_COUNT };
 static const char* const kKernelNames[KT_COUNT] = {"k_digits_sort", "k_bucket_accumulate", "k_bucket_reduce1", "k_bucket_reduce2", "k_g1_decompress",
                                                    "k_g1_subgroup_check", "k_challenge_sha256", "k_blob_eval", "k_blob_quotient", "k_rlc_scalars", "k_vmsm_window",
-                                                   "k_cells_ntt", "k_fk20_scalars", "k_fk20_msm", "k_fk20_ffts", "k_cell_verify_scalars", "k_recover_*", "k_commit_direct"};
+                                                   "k_cells_ntt", "k_fk20_scalars", "k_fk20_msm", "k_fk20_ffts", "k_cell_verify_scalars", "k_recover_*", "k_commit_direct_acc", "k_commit_direct_fin"};
 
 // hipEvent bracket around each kernel launch, on the stream the kernel is launched on.
 struct KernelTimer {
@@ -73,6 +73,15 @@ void build_table_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int
 size_t direct_table_bytes(int c);
 void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s);
 void build_direct_device(int c, const uint32_t* d_table, uint32_t* d_direct, hipStream_t s);
-void commit_direct_device(int c, const uint32_t* d_direct, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt);
+// per-call workspace of the direct mode: 512 lane accumulators per blob + 2 rejection flags per blob
+struct DirectSlot {
+    uint32_t* d_parts = nullptr;
+    int* d_bad = nullptr;
+    hipEvent_t wait_before_acc = nullptr;      // same cross-call chaining as CommitPlan
+    hipEvent_t record_after_acc = nullptr;
+};
+size_t direct_parts_bytes(int max_batch);
+void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status,
+                          hipStream_t s, KernelTimer* kt);
 
 }  // namespace kzg

@@ -531,7 +531,8 @@ __global__ void __launch_bounds__(64) k_build_direct(const uint32_t* __restrict_
     }
 }
 
-constexpr int DT = 512;     // threads per blob
+constexpr int DTA = 256;      // threads per accumulate workgroup: half a blob, 8 points per lane
+constexpr int DPARTS = 512;   // lane accumulators per blob (64-word XYZZ records)
 __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
 #pragma unroll
     for (int i = 0; i < 14; i++) {
@@ -541,85 +542,105 @@ __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
         r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
     }
 }
+// Accumulate: grid (2, n blobs).  Each lane walks its 8 scalars window by window (the 256-bit scalar is a
+// shift register: static register indices only), prefetching the table row of window j+1 while the row of
+// window j is added.  When C divides 255 the signed recoding has no spare top window; scalars with bit 254
+// set are replaced by r - s (top digit then <= 2^(C-1)) and every digit sign is flipped.
 template <int C>
-__global__ void __launch_bounds__(DT) k_commit_direct(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, const uint32_t* __restrict__ direct,
-                                                       uint8_t* __restrict__ out48, int* __restrict__ status) {
+__global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, const uint32_t* __restrict__ direct,
+                                                            uint32_t* __restrict__ parts, int* __restrict__ bad_flags) {
     using RC = Recode<C>;
-    __shared__ uint32_t xch[(DT / 64) * 56];
-    const int b = blockIdx.x, t = threadIdx.x;
-    uint32_t sc[4096 / DT][8];
+    constexpr bool TIGHT = (C * RC::NWIN < 256);
+    const int half = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
     bool bad = false;
-#pragma unroll
-    for (int k = 0; k < 4096 / DT; k++) {
-        load_scalar_be(sc[k], scalars + (size_t)b * scalar_stride_bytes + (size_t)(t + DT * k) * 32);
-        bad |= !scalar_is_canonical(sc[k]);
-    }
-    if (__syncthreads_or(bad)) {
-        if (t == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
-        return;
-    }
-    if (t == 0) status[b] = 0;
     G1X acc;
     g1x_set_inf(acc);
 #pragma unroll 1
-    for (int k = 0; k < 4096 / DT; k++) {
-        const int i = t + DT * k;
+    for (int k = 0; k < 2048 / DTA; k++) {
+        const int i = half * 2048 + k * DTA + t;
+        uint32_t w[8];
+        load_scalar_be(w, scalars + (size_t)b * scalar_stride_bytes + (size_t)i * 32);
+        bad |= !scalar_is_canonical(w);
+        bool flip = false;
+        if (TIGHT && ((w[7] >> 30) & 1)) {
+            flip = true;
+            uint64_t br = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint64_t d = (uint64_t)FrParams::MOD32[q] - w[q] - br;
+                w[q] = (uint32_t)d;
+                br = (d >> 32) & 1;
+            }
+        }
+        // software pipeline through L2: the row of window j+1 is touched (one dword -> the 128-byte line is pulled from
+        // HBM into L2) while window j is added, and fetched in full at the top of its own iteration.  Holding the whole
+        // next row in registers instead costs 28 VGPRs across the addition and spills.
         int carry = 0;
-        // software pipeline: digit/row of window j+1 is fetched while window j is added
-        G1Aff p;
-        int dcur = 0;
-        p.inf = 1;
+        const uint32_t* row = nullptr;     // table row of the current window (nullptr: digit 0)
+        bool rneg = false;
 #pragma unroll 1
         for (int j = 0; j <= RC::NWIN; j++) {
-            G1Aff pn;
-            int dn = 0;
-            pn.inf = 1;
+            const uint32_t* nrow = nullptr;
+            bool nneg = false;
+            uint32_t touch = 0;
             if (j < RC::NWIN) {
-                const int bit = C * j, wi = bit >> 5, off = bit & 31;
-                uint32_t v = sc[k][wi] >> off;
-                if (off + C > 32 && wi + 1 < 8) v |= sc[k][wi + 1] << (32 - off);
-                dn = (int)(v & ((1u << C) - 1)) + carry;
+                int dn = (int)(w[0] & ((1u << C) - 1)) + carry;
+#pragma unroll
+                for (int q = 0; q < 7; q++) w[q] = (w[q] >> C) | (w[q + 1] << (32 - C));
+                w[7] >>= C;
                 carry = 0;
                 if (dn > RC::NBUCKET) { dn -= (1 << C); carry = 1; }
                 if (dn != 0) {
                     const int m = dn < 0 ? -dn : dn;
-                    load_affine(pn, direct + (((size_t)j * 4096 + i) * RC::NBUCKET + (m - 1)) * 32);
+                    nneg = (dn < 0) != flip;
+                    nrow = direct + (((size_t)j * 4096 + i) * RC::NBUCKET + (m - 1)) * 32;
+                    touch = *reinterpret_cast<const volatile uint32_t*>(nrow);
                 }
             }
-            if (!p.inf) {
-                if (dcur < 0) Fp::template neg<0>(p.y, p.y);
-                g1x_madd(acc, p.x, p.y);
+            if (row) {
+                G1Aff p;
+                load_affine(p, row);
+#pragma unroll
+                for (int q = 0; q < 14; q++) asm volatile("" : "+v"(p.x.l[q]), "+v"(p.y.l[q]));   // whole row in flight before the infinity test
+                if (!p.inf) {
+                    if (rneg) Fp::template neg<0>(p.y, p.y);
+                    g1x_madd(acc, p.x, p.y);
+                }
             }
-            p = pn;
-            dcur = dn;
+            asm volatile("" ::"v"(touch));      // keeps the touch load alive; it has long landed by now
+            row = nrow;
+            rneg = nneg;
         }
     }
-    // sum the DT accumulators: xor-butterfly inside each wavefront, then one wavefront over LDS
-    G1X o;
+    store_xyzz(parts + ((size_t)b * DPARTS + half * DTA + t) * 64, acc);
+    const int anybad = __syncthreads_or(bad);
+    if (t == 0) bad_flags[b * 2 + half] = anybad;
+}
+// Finish: one wavefront per blob sums the 512 lane accumulators (8 per lane, then an xor butterfly), converts to
+// affine and writes the compressed commitment.  Tiny and latency-bound: it runs beside the next accumulate kernel.
+__global__ void __launch_bounds__(64) k_commit_direct_fin(const uint32_t* __restrict__ parts, const int* __restrict__ bad_flags, uint8_t* __restrict__ out48,
+                                                          int* __restrict__ status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (bad_flags[b * 2] | bad_flags[b * 2 + 1]) {
+        if (lane == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
+        return;
+    }
+    G1X acc, o;
+    load_xyzz(acc, parts + ((size_t)b * DPARTS + lane) * 64);
+#pragma unroll 1
+    for (int q = 1; q < DPARTS / 64; q++) {
+        load_xyzz(o, parts + ((size_t)b * DPARTS + q * 64 + lane) * 64);
+        g1x_add_ni(acc, acc, o);
+    }
+#pragma unroll 1
     for (int m = 32; m >= 1; m >>= 1) {
         shfl_xor_xyzz(o, acc, m);
         g1x_add_ni(acc, acc, o);
     }
-    const int lane = t & 63, wave = t >> 6;
     if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 14; i++) {
-            xch[wave * 56 + i] = acc.x.l[i]; xch[wave * 56 + 14 + i] = acc.y.l[i]; xch[wave * 56 + 28 + i] = acc.zz.l[i]; xch[wave * 56 + 42 + i] = acc.zzz.l[i];
-        }
-    }
-    __syncthreads();
-    if (t == 0) {
-        G1X tot = acc;
-        for (int w = 1; w < DT / 64; w++) {
-            G1X q;
-#pragma unroll
-            for (int i = 0; i < 14; i++) {
-                q.x.l[i] = xch[w * 56 + i]; q.y.l[i] = xch[w * 56 + 14 + i]; q.zz.l[i] = xch[w * 56 + 28 + i]; q.zzz.l[i] = xch[w * 56 + 42 + i];
-            }
-            g1x_add_ni(tot, tot, q);
-        }
+        status[b] = 0;
         G1Aff a;
-        g1x_to_affine(a, tot);
+        g1x_to_affine(a, acc);
         uint32_t w12[12];
         g1_compress_words(w12, a);
         uint32_t* o32 = reinterpret_cast<uint32_t*>(out48 + (size_t)b * 48);
@@ -683,16 +704,24 @@ void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table,
         default: build_table_device(c, d_src_aff, d_table, n, bitrev_bits, s); break;
     }
 }
-void commit_direct_device(int c, const uint32_t* d_direct, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
+size_t direct_parts_bytes(int max_batch) { return (size_t)max_batch * DPARTS * 64 * sizeof(uint32_t); }
+void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status,
+                          hipStream_t s, KernelTimer* kt) {
     if (n <= 0) return;
+    if (ws.wait_before_acc) (void)hipStreamWaitEvent(s, ws.wait_before_acc, 0);
     if (kt) kt->begin(KT_COMMIT_DIRECT, s);
+    const dim3 grid(2, n);
     switch (c) {
-        case 12: hipLaunchKernelGGL((k_commit_direct<12>), dim3(n), dim3(DT), 0, s, d_scalars, stride, d_direct, d_out48, d_status); break;
-        case 13: hipLaunchKernelGGL((k_commit_direct<13>), dim3(n), dim3(DT), 0, s, d_scalars, stride, d_direct, d_out48, d_status); break;
-        case 14: hipLaunchKernelGGL((k_commit_direct<14>), dim3(n), dim3(DT), 0, s, d_scalars, stride, d_direct, d_out48, d_status); break;
-        default: hipLaunchKernelGGL((k_commit_direct<15>), dim3(n), dim3(DT), 0, s, d_scalars, stride, d_direct, d_out48, d_status); break;
+        case 12: hipLaunchKernelGGL((k_commit_direct_acc<12>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
+        case 13: hipLaunchKernelGGL((k_commit_direct_acc<13>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
+        case 14: hipLaunchKernelGGL((k_commit_direct_acc<14>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
+        default: hipLaunchKernelGGL((k_commit_direct_acc<15>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
     }
     if (kt) kt->end(KT_COMMIT_DIRECT, s);
+    if (ws.record_after_acc) (void)hipEventRecord(ws.record_after_acc, s);
+    if (kt) kt->begin(KT_COMMIT_DIRECT_FIN, s);
+    hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status);
+    if (kt) kt->end(KT_COMMIT_DIRECT_FIN, s);
 }
 void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz) {
     const int nwin = (255 + c - 1) / c, nb = 1 << (c - 1);

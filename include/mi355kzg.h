@@ -65,7 +65,8 @@ int mkzg_ctx_new(const char* trusted_setup_json, size_t len, const int* device_i
 void mkzg_ctx_free(mkzg_ctx* ctx);
 /* tuning knobs before first use: "msm_window" (11..13), "max_batch" (blobs per launch), "commit_direct_bits"
  * (0 = bucket method; 12..15 = direct window table for BlobToKZGCommitment: 21 GB .. 146 GB of HBM, fewer group
- * additions and a single kernel per batch). */
+ * additions, two kernels per batch), "chain_accumulate" (1 = consecutive calls' accumulate kernels run back to back
+ * even when issued on different streams; 0 = no cross-call ordering). */
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
 
 /* ---- EIP-4844 ------------------------------------------------------------------------------ */

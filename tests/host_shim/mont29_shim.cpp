@@ -8,6 +8,11 @@
 using namespace kzg;
 extern "C" {
 void shim_fp_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { fp_t x, y, r; Fp::set(x, a); Fp::set(y, b); Fp::mul(r, x, y); memcpy(o, r.l, 56); }
+void shim_fp_sqr(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp::sqr(r, x); memcpy(o, r.l, 56); }
+void shim_fp_mul2(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* o) {
+    fp_t x, y, z, w, r; Fp::set(x, a); Fp::set(y, b); Fp::set(z, c); Fp::set(w, d); Fp::mul2(r, x, y, z, w); memcpy(o, r.l, 56);
+}
+void shim_fr_sqr(const uint32_t* a, uint32_t* o) { fr_t x, r; Fr::set(x, a); Fr::sqr(r, x); memcpy(o, r.l, 36); }
 void shim_fp_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { fp_t x, y, r; Fp::set(x, a); Fp::set(y, b); Fp::add(r, x, y); memcpy(o, r.l, 56); }
 void shim_fp_sub(int klog, const uint32_t* a, const uint32_t* b, uint32_t* o) {
     fp_t x, y, r; Fp::set(x, a); Fp::set(y, b);

@@ -101,19 +101,24 @@ def test_windows_agree(product, oracle_ctx):
         assert rc == 0 and out == exp, c
 
 
-def test_direct_table_mode(product, oracle_ctx):
-    """commit_direct_bits: the direct-table kernel gives the same bytes as the bucket method and the oracle"""
+@pytest.mark.parametrize("bits", [12, 14, 15])
+def test_direct_table_mode(product, oracle_ctx, bits):
+    """commit_direct_bits: the direct-table kernels give the same bytes as the oracle.  15 divides 255, so that
+    width has no spare top window and takes the r - s branch for scalars with bit 254 set"""
     import torch
     torch.cuda.init()
-    blobs = [rand_blob(21), bytes(131072), (R - 1).to_bytes(32, "big") * 4096, rand_blob(22)]
+    top = b"".join(((1 << 254) + 977 * i).to_bytes(32, "big") for i in range(4096))         # every scalar has bit 254 set
+    edge = b"".join(v.to_bytes(32, "big") for v in ([R - 1, 1 << 254, (1 << 254) - 1, 1, 0, (1 << 240) - 1, R - (1 << 254)] * 586)[:4096])
+    blobs = [rand_blob(21), bytes(131072), (R - 1).to_bytes(32, "big") * 4096, rand_blob(22), top, edge]
     ctx = product.Context()
-    assert ctx.set_option("commit_direct_bits", 12) == 0
+    assert ctx.set_option("max_batch", 4) == 0          # 6 blobs -> two chunks through both workspaces
+    assert ctx.set_option("commit_direct_bits", bits) == 0
     rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
-    assert rc == 0 and st == [0, 0, 0, 0]
+    assert rc == 0 and st == [0] * len(blobs)
     for b, o in zip(blobs, outs):
         assert o == oracle_ctx.blob_to_kzg_commitment(b)[1]
     bad = bytearray(blobs[0])
-    bad[:32] = R.to_bytes(32, "big")
+    bad[-32:] = R.to_bytes(32, "big")
     rc, outs, st = ctx.BlobToKZGCommitmentBatch([bytes(bad), blobs[3]])
     assert rc == 3 and st == [3, 0] and outs[1] == oracle_ctx.blob_to_kzg_commitment(blobs[3])[1]
     ctx.close()

@@ -69,6 +69,26 @@ def test_fp_mul_add_sub(shim):
             assert val(o) == a - bb + (1 << klog) * P and normalized(o)
 
 
+def test_fp_sqr_mul2(shim):
+    """dedicated squaring and the fused two-product multiply (one Montgomery reduction), loose inputs, worst-case limbs"""
+    rng = random.Random(11)
+    allones = (1 << 392) - 1                                       # every limb 2^29 - 1: the column-sum worst case
+    cases = [(allones, allones, allones, allones)]
+    cases += [tuple(rng.randrange(0, 1 << rng.choice([381, 385, 390, 392])) for _ in range(4)) for _ in range(300)]
+    for a, b, c, d in cases:
+        o = out()
+        shim.shim_fp_sqr(limbs(a), o)
+        v = val(o)
+        assert normalized(o) and (v * RP - a * a) % P == 0 and v < a * a // RP + P + 1
+        shim.shim_fp_mul2(limbs(a), limbs(b), limbs(c), limbs(d), o)
+        v = val(o)
+        assert normalized(o) and (v * RP - a * b - c * d) % P == 0 and v < (a * b + c * d) // RP + P + 1
+    for a in [0, 1, R - 1] + [rng.randrange(0, R) for _ in range(100)]:
+        o = out(9)
+        shim.shim_fr_sqr(limbs(a, 9), o)
+        assert val(o) % R == a * a * pow(RF, -1, R) % R
+
+
 def test_fp_canon_plain_inv(shim):
     rng = random.Random(2)
     for it in range(100):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # tools/sweep_direct.sh -- bench.py over commit_direct_bits / stream counts (GPU box)
-for cfg in "14 1" "15 2" "15 1" "0 2"; do
-  set -- $cfg
+for cfg in ${SWEEP:-15:2 15:1 14:2 13:2}; do
+  set -- ${cfg/:/ }
   t0=$(date +%s.%N)
-  python bench.py --steps 6 --warmup 2 --no-cpu-baseline --verify-batch 0 --direct-bits $1 --streams $2 2>/dev/null | tail -1 > /tmp/sweep_line.json
+  python bench.py --steps 6 --warmup 2 --no-cpu-baseline --verify-batch 0 --direct-bits $1 --streams $2 $EXTRA 2>/tmp/sweep_err.txt | tail -1 > /tmp/sweep_line.json
   t1=$(date +%s.%N)
   python - "$1" "$2" "$t0" "$t1" <<'PY'
 import json, sys

@@ -15,7 +15,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmi355kzg.so")
+LIB_PATH = os.environ.get("MI355KZG_LIB") or os.path.join(HERE, "libmi355kzg.so")      # override: A/B builds while tuning
 DEFAULT_SETUP = os.path.join(HERE, "trusted_setup.json")
 
 BYTES_PER_BLOB = 131072

@@ -551,7 +551,10 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
                                                             uint32_t* __restrict__ parts, int* __restrict__ bad_flags) {
     using RC = Recode<C>;
     constexpr bool TIGHT = (C * RC::NWIN < 256);
-    const int half = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[(DTA / 64) * 8 * 256];     // 32 KB: one table row per lane
+    const int half = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    __shared__ uint32_t scal[8 * DTA];              // this lane's scalar, word-major: the window position is wave-uniform
+    uint32_t* wb = rowbuf + (t >> 6) * (8 * 256);
     bool bad = false;
     G1X acc;
     g1x_set_inf(acc);
@@ -572,44 +575,58 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
                 br = (d >> 32) & 1;
             }
         }
-        // software pipeline through L2: the row of window j+1 is touched (one dword -> the 128-byte line is pulled from
-        // HBM into L2) while window j is added, and fetched in full at the top of its own iteration.  Holding the whole
-        // next row in registers instead costs 28 VGPRs across the addition and spills.
+        // software pipeline through LDS: the table row of window j+1 travels HBM -> LDS with global_load_lds_dwordx4 (no
+        // VGPR destination) while window j is added; a row is read back from LDS only when its addition starts, so the
+        // 28 coordinate registers are live for the first two multiplications only (holding the next row in VGPRs across
+        // the addition spills).  Per wavefront: 8 chunks x 64 lanes x 16 B, lane-contiguous as the DMA writes them.
+#pragma unroll
+        for (int q = 0; q < 8; q++) scal[q * DTA + t] = w[q];
         int carry = 0;
-        const uint32_t* row = nullptr;     // table row of the current window (nullptr: digit 0)
-        bool rneg = false;
+        bool cur = false, cneg = false;
 #pragma unroll 1
         for (int j = 0; j <= RC::NWIN; j++) {
-            const uint32_t* nrow = nullptr;
-            bool nneg = false;
-            uint32_t touch = 0;
-            if (j < RC::NWIN) {
-                int dn = (int)(w[0] & ((1u << C) - 1)) + carry;
+            G1Aff p;
+            p.inf = 1;
+            if (cur) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t rw[32];
 #pragma unroll
-                for (int q = 0; q < 7; q++) w[q] = (w[q] >> C) | (w[q + 1] << (32 - C));
-                w[7] >>= C;
+                for (int q = 0; q < 8; q++) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(wb + q * 256 + lane * 4);
+                    rw[4 * q] = v.x; rw[4 * q + 1] = v.y; rw[4 * q + 2] = v.z; rw[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 14; q++) { p.x.l[q] = rw[q]; p.y.l[q] = rw[14 + q]; }
+                p.inf = rw[28];
+#pragma unroll
+                for (int q = 0; q < 14; q++) asm volatile("" : "+v"(p.x.l[q]), "+v"(p.y.l[q]));   // LDS reads retired before the next DMA
+                asm volatile("" : "+v"(p.inf));
+            }
+            bool nxt = false, nneg = false;
+            if (j < RC::NWIN) {
+                const int bit = C * j, wi = bit >> 5, off = bit & 31;
+                const uint32_t lo = scal[wi * DTA + t], hi = scal[(wi < 7 ? wi + 1 : 7) * DTA + t];
+                const uint32_t v = (uint32_t)((((uint64_t)(wi < 7 ? hi : 0u) << 32) | lo) >> off);
+                int dn = (int)(v & ((1u << C) - 1)) + carry;
                 carry = 0;
                 if (dn > RC::NBUCKET) { dn -= (1 << C); carry = 1; }
                 if (dn != 0) {
                     const int m = dn < 0 ? -dn : dn;
                     nneg = (dn < 0) != flip;
-                    nrow = direct + (((size_t)j * 4096 + i) * RC::NBUCKET + (m - 1)) * 32;
-                    touch = *reinterpret_cast<const volatile uint32_t*>(nrow);
-                }
-            }
-            if (row) {
-                G1Aff p;
-                load_affine(p, row);
+                    nxt = true;
+                    const uint32_t* row = direct + (((size_t)j * 4096 + i) * RC::NBUCKET + (m - 1)) * 32;
 #pragma unroll
-                for (int q = 0; q < 14; q++) asm volatile("" : "+v"(p.x.l[q]), "+v"(p.y.l[q]));   // whole row in flight before the infinity test
-                if (!p.inf) {
-                    if (rneg) Fp::template neg<0>(p.y, p.y);
-                    g1x_madd(acc, p.x, p.y);
+                    for (int q = 0; q < 8; q++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + 4 * q),
+                                                         (__attribute__((address_space(3))) void*)(wb + q * 256), 16, 0, 0);
                 }
             }
-            asm volatile("" ::"v"(touch));      // keeps the touch load alive; it has long landed by now
-            row = nrow;
-            rneg = nneg;
+            if (!p.inf) {
+                if (cneg) Fp::template neg<0>(p.y, p.y);
+                g1x_madd(acc, p.x, p.y);
+            }
+            cur = nxt;
+            cneg = nneg;
         }
     }
     store_xyzz(parts + ((size_t)b * DPARTS + half * DTA + t) * 64, acc);

@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 # one small counter group per pass: FETCH_SIZE + WRITE_SIZE in one pass exceed the hardware's counters (error 38, and
 # rocprofv3 then hangs), hence also the per-pass timeout
 PASSES=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES")
+if [ -n "${PMC_PASSES:-}" ]; then IFS=";" read -r -a PASSES <<< "$PMC_PASSES"; fi
 i=0
 for p in "${PASSES[@]}"; do
   timeout -k 5 ${PASS_TIMEOUT:-240} rocprofv3 --pmc $p -d $OUT/pass$i --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --verify-batch 0 --streams 1 "$@" > $OUT/pass$i.log 2>&1 || { echo "pass $i ($p) failed"; grep -m2 -i "error\|exceeds" $OUT/pass$i.log; }

@@ -151,6 +151,19 @@ def main():
     if d_ref is not None:
         assert bool((d_outs[0] == d_ref).all().item()), "direct-table and bucket method disagree"
 
+    # untimed: the kernels' isolated durations (one stream, nothing overlapping) and this GPU's VALU calibration
+    isolated, calib = None, None
+    if rank == 0 and not args.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        for _ in range(3):
+            rc = ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), B, d_outs[0].data_ptr(), d_stats[0].data_ptr(), streams[0].cuda_stream)
+            assert rc == 0
+            torch.cuda.synchronize()
+        isolated = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        calib = ctx.valu_calibrate()
+
     verify = None
     if args.verify_batch > 0:
         verify = bench_verify(ctx, torch, dist, world, rank, args, d_blobs, B)
@@ -164,10 +177,23 @@ def main():
         dom, (dom_ms, dom_n) = max(prof.items(), key=lambda kv: kv[1][0])
         avg_ms = dom_ms / max(1, dom_n)
         achieved = ALGO_BYTES_PER_BLOB * B / (avg_ms * 1e-3) / 1e9
+        pmc = pmc_profile(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(dom),
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic_bytes"),
                     "avg_kernel_ms": round(avg_ms, 4), "launches": dom_n,
-                    "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items()}}
+                    "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]}}
+        if NS > 1:
+            roofline["note"] = f"{NS} streams: a launch's duration includes the time it shares the GPU with the other stream's kernels"
+        # what actually bounds this path: integer VALU issue.  Wave-instructions of the dominant kernel (rocprofv3 SQ_INSTS_VALU,
+        # profiles/*_traffic.json) over its isolated duration, against this GPU's calibrated v_mad_u64_u32 issue rate.
+        valu = None
+        if isolated is not None and calib and pmc.get("valu_wave_insts"):
+            iso_ms = isolated.get(dom, (0, 0))
+            if iso_ms[1]:
+                rate = pmc["valu_wave_insts"] * (B / 256.0) / (iso_ms[0] / iso_ms[1] * 1e-3)
+                valu = {"kernel": dom, "isolated_kernel_ms": round(iso_ms[0] / iso_ms[1], 4), "wave_insts_per_launch": pmc["valu_wave_insts"] * (B / 256.0),
+                        "achieved": round(rate / 1e9, 2), "peak_calibrated": round(calib / 1e9, 2), "unit": "G wave-instr/s",
+                        "frac": round(rate / calib, 4)}
         out = {
             "metric": "blobs/sec BlobToKZGCommitment (batch=256 per GPU)", "value": round(value, 2), "unit": "blobs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -175,7 +201,7 @@ def main():
             "data": "synthetic (GetRandBlob seeds, reference bench_test.go:17-46)",
             "config": {"workload": "configs[1]: BlobToKZGCommitment batch=256 blobs x 4096 scalars per GPU, fixed-base G1 MSM",
                        "batch_per_gpu": B, "msm": (f"direct window table c={args.direct_bits}" if args.direct_bits else f"bucket method c={args.window or 13}"), "parallelism": f"blob-sharded x{world}, no collective", "streams": NS},
-            "roofline": roofline,
+            "roofline": roofline, "valu": valu,
         }
         if verify is not None:
             out["verify_blob_kzg_proof_batch"] = verify
@@ -187,19 +213,19 @@ def main():
     ctx.close()
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_traffic.json;
-    FETCH_SIZE/WRITE_SIZE cannot be read from inside the process).  None if no profile covers the kernel."""
+def pmc_profile(kernel):
+    """Per-launch PMC figures of `kernel` from the committed rocprofv3 passes (profiles/*_traffic.json: HBM-side bytes,
+    VALU wave-instructions; the counters cannot be read from inside the process).  {} if no profile covers the kernel."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         try:
             with open(f) as fh:
                 k = json.load(fh)["kernels"].get(kernel)
             if k:
-                return k["traffic_bytes"]
+                return k
         except Exception:
             pass
-    return None
+    return {}
 
 
 def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):

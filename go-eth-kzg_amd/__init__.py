@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_commit_lagrange", "mkzg_profile_enable", "mkzg_profile_read", "mkzg_version",
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
-    "mkzg_last_host_finish_us", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
+    "mkzg_last_host_finish_us", "mkzg_valu_calibrate", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
     "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch",
     "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
     "mkzg_verify_blob_kzg_proof_batch_partial_device", "mkzg_verify_blob_kzg_proof_batch_finish",
@@ -88,6 +88,7 @@ def lib():
         L.mkzg_version.restype = C.c_char_p
         L.mkzg_last_host_finish_us.argtypes = [vp]
         L.mkzg_last_host_finish_us.restype = C.c_double
+        L.mkzg_valu_calibrate.argtypes = [vp, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -274,6 +275,12 @@ class Context:
         return self._L.mkzg_last_host_finish_us(self._h)
 
     # ---- profiling --------------------------------------------------------------------------
+    def valu_calibrate(self):
+        """sustained v_mad_u64_u32 wave-instructions per second of this GPU (diagnostic)"""
+        v = C.c_double(0.0)
+        rc = self._L.mkzg_valu_calibrate(self._h, C.byref(v))
+        return v.value if rc == 0 else None
+
     def profile_enable(self, on=True):
         return self._L.mkzg_profile_enable(self._h, int(on))
 

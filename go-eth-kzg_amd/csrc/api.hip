@@ -110,6 +110,13 @@ int release_slot(mkzg_ctx* c, int slot, hipStream_t s) {
 extern "C" {
 
 const char* mkzg_version(void) { return "mi355kzg 0.1 (gfx950)"; }
+int mkzg_valu_calibrate(mkzg_ctx* c, double* wave_instr_per_s) {
+    if (!c || !wave_instr_per_s) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    *wave_instr_per_s = valu_calibrate_device(c->stream);
+    return *wave_instr_per_s > 0.0 ? MKZG_OK : MKZG_ERR_HIP;
+}
 
 void mkzg_ctx_free(mkzg_ctx* c) {
     if (!c) return;
@@ -259,7 +266,7 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, s
                 if (c->dslots[i].d_bad) (void)hipFree(c->dslots[i].d_bad);
                 c->dslots[i].d_parts = nullptr; c->dslots[i].d_bad = nullptr;
                 HIPCHK(hipMalloc(&c->dslots[i].d_parts, direct_parts_bytes(c->opt_max_batch)));
-                HIPCHK(hipMalloc(&c->dslots[i].d_bad, (size_t)c->opt_max_batch * 2 * sizeof(int)));
+                HIPCHK(hipMalloc(&c->dslots[i].d_bad, (size_t)c->opt_max_batch * 64 * sizeof(int)));
                 if (!c->slot_done[i]) HIPCHK(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming));
                 if (!c->acc_done[i]) HIPCHK(hipEventCreateWithFlags(&c->acc_done[i], hipEventDisableTiming));
                 c->slot_used[i] = false;

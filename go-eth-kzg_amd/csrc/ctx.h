@@ -48,7 +48,7 @@ struct mkzg_ctx {
     hipEvent_t acc_done[NSLOT] = {nullptr, nullptr};   // recorded after each call's accumulate kernel
     int last_acc_slot = -1;
     int opt_c = 13;
-    int opt_chain_acc = 1;                 // 1: the accumulate kernel of a call waits for the previous call's accumulate kernel
+    int opt_chain_acc = 0;                 // 1: the accumulate kernel of a call waits for the previous call's accumulate kernel
     int opt_direct_bits = 0;               // 0: bucket method; 12..15: direct-table commitment (HBM-hungry, see msm_kernels.hip)
     uint32_t* d_direct = nullptr;
     int direct_bits_built = 0;

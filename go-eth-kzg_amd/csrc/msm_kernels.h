@@ -73,7 +73,7 @@ void build_table_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int
 size_t direct_table_bytes(int c);
 void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s);
 void build_direct_device(int c, const uint32_t* d_table, uint32_t* d_direct, hipStream_t s);
-// per-call workspace of the direct mode: 512 lane accumulators per blob + 2 rejection flags per blob
+// per-call workspace of the direct mode: 512 lane accumulators per blob + one rejection flag per accumulate workgroup
 struct DirectSlot {
     uint32_t* d_parts = nullptr;
     int* d_bad = nullptr;
@@ -81,6 +81,7 @@ struct DirectSlot {
     hipEvent_t record_after_acc = nullptr;
 };
 size_t direct_parts_bytes(int max_batch);
+double valu_calibrate_device(hipStream_t s);   // sustained v_mad_u64_u32 wave-instructions per second on this GPU
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status,
                           hipStream_t s, KernelTimer* kt);
 

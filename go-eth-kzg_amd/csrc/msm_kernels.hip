@@ -531,7 +531,11 @@ __global__ void __launch_bounds__(64) k_build_direct(const uint32_t* __restrict_
     }
 }
 
-constexpr int DTA = 256;      // threads per accumulate workgroup: half a blob, 8 points per lane
+#ifndef MKZG_DTA
+#define MKZG_DTA 64
+#endif
+constexpr int DTA = MKZG_DTA; // threads per accumulate workgroup, 8 points per lane (64: single-wave workgroups, any free wave slot takes one)
+constexpr int DBLK = 4096 / (8 * DTA);   // accumulate workgroups per blob
 constexpr int DPARTS = 512;   // lane accumulators per blob (64-word XYZZ records)
 __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
 #pragma unroll
@@ -542,7 +546,7 @@ __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
         r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
     }
 }
-// Accumulate: grid (2, n blobs).  Each lane walks its 8 scalars window by window (the 256-bit scalar is a
+// Accumulate: grid (DBLK, n blobs).  Each lane walks its 8 scalars window by window (the 256-bit scalar is a
 // shift register: static register indices only), prefetching the table row of window j+1 while the row of
 // window j is added.  When C divides 255 the signed recoding has no spare top window; scalars with bit 254
 // set are replaced by r - s (top digit then <= 2^(C-1)) and every digit sign is flipped.
@@ -559,8 +563,8 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
     G1X acc;
     g1x_set_inf(acc);
 #pragma unroll 1
-    for (int k = 0; k < 2048 / DTA; k++) {
-        const int i = half * 2048 + k * DTA + t;
+    for (int k = 0; k < 8; k++) {
+        const int i = (half * 8 + k) * DTA + t;
         uint32_t w[8];
         load_scalar_be(w, scalars + (size_t)b * scalar_stride_bytes + (size_t)i * 32);
         bad |= !scalar_is_canonical(w);
@@ -631,14 +635,16 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
     }
     store_xyzz(parts + ((size_t)b * DPARTS + half * DTA + t) * 64, acc);
     const int anybad = __syncthreads_or(bad);
-    if (t == 0) bad_flags[b * 2 + half] = anybad;
+    if (t == 0) bad_flags[b * DBLK + half] = anybad;
 }
 // Finish: one wavefront per blob sums the 512 lane accumulators (8 per lane, then an xor butterfly), converts to
 // affine and writes the compressed commitment.  Tiny and latency-bound: it runs beside the next accumulate kernel.
 __global__ void __launch_bounds__(64) k_commit_direct_fin(const uint32_t* __restrict__ parts, const int* __restrict__ bad_flags, uint8_t* __restrict__ out48,
                                                           int* __restrict__ status) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    if (bad_flags[b * 2] | bad_flags[b * 2 + 1]) {
+    int anybad = 0;
+    for (int q = 0; q < DBLK; q++) anybad |= bad_flags[b * DBLK + q];
+    if (anybad) {
         if (lane == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
         return;
     }
@@ -664,6 +670,48 @@ __global__ void __launch_bounds__(64) k_commit_direct_fin(const uint32_t* __rest
 #pragma unroll
         for (int i = 0; i < 12; i++) o32[i] = __builtin_bswap32(w12[i]);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// VALU calibration: what this particular GPU sustains on v_mad_u64_u32 (the instruction ~70% of every kernel
+// here consists of), two wavefronts per SIMD, eight independent accumulators per lane.  Boxes of one pool differ
+// by up to 1.5x on this number (power management), so efficiency is quoted against it, not against a data sheet.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_valu_calibrate(uint32_t* out, int iters, uint32_t seed) {
+    uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;
+    uint64_t c0 = a0, c1 = a1, c2 = a2, c3 = a3, c4 = a0 + 9, c5 = a1 + 9, c6 = a2 + 9, c7 = a3 + 9;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %10, %1\n v_mad_u64_u32 %2, vcc, %9, %10, %2\n v_mad_u64_u32 %3, vcc, %8, %11, %3\n"
+                         "v_mad_u64_u32 %4, vcc, %9, %11, %4\n v_mad_u64_u32 %5, vcc, %10, %11, %5\n v_mad_u64_u32 %6, vcc, %8, %8, %6\n v_mad_u64_u32 %7, vcc, %9, %9, %7\n"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7);
+}
+// returns wave-instructions per second (0 on failure)
+double valu_calibrate_device(hipStream_t s) {
+    int cus = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0.0;
+    const int blocks = cus * 2, iters = 20000;         // 4 wavefronts per workgroup -> 2 per SIMD
+    uint32_t* d = nullptr;
+    if (hipMalloc(&d, (size_t)blocks * 256 * sizeof(uint32_t)) != hipSuccess) return 0.0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_valu_calibrate, dim3(blocks), dim3(256), 0, s, d, 100, 1u);
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(k_valu_calibrate, dim3(blocks), dim3(256), 0, s, d, iters, 1u);
+    (void)hipEventRecord(e1, s);
+    float ms = 0.f;
+    double rate = 0.0;
+    if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
+        rate = (double)blocks * 4 * iters * 64 / (ms * 1e-3);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    return rate;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -727,7 +775,7 @@ void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws,
     if (n <= 0) return;
     if (ws.wait_before_acc) (void)hipStreamWaitEvent(s, ws.wait_before_acc, 0);
     if (kt) kt->begin(KT_COMMIT_DIRECT, s);
-    const dim3 grid(2, n);
+    const dim3 grid(DBLK, n);
     switch (c) {
         case 12: hipLaunchKernelGGL((k_commit_direct_acc<12>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
         case 13: hipLaunchKernelGGL((k_commit_direct_acc<13>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;

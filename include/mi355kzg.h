@@ -142,6 +142,9 @@ int mkzg_profile_read(mkzg_ctx* ctx, mkzg_kernel_time* out, int cap, int reset);
 
 /* host-side share (Horner + [e]G + pairing) of the last verification call, in microseconds */
 double mkzg_last_host_finish_us(mkzg_ctx* ctx);
+/* diagnostic: sustained v_mad_u64_u32 issue rate of this GPU (wave-instructions per second, two wavefronts per SIMD);
+ * bench.py quotes the kernels' VALU efficiency against it (boxes of one pool differ by up to 1.5x) */
+int mkzg_valu_calibrate(mkzg_ctx* ctx, double* wave_instr_per_s);
 
 const char* mkzg_version(void);
 

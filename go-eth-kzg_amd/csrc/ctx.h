@@ -123,7 +123,8 @@ struct mkzg_ctx {
     uint32_t* d_fk_table = nullptr;        // direct window table (4.3 GB)
     size_t fk_cap = 0;
     uint32_t* d_fk_scalars = nullptr;      // fk_cap x 128 x 64 x 8 words
-    uint32_t* d_fk_results = nullptr;      // fk_cap x 128 XYZZ rows
+    uint32_t* d_fk_results = nullptr;      // 2 x fk_cap x 128 XYZZ rows (MSM results + ping-pong buffer of the G1 DFT levels)
+    uint32_t* d_fk_plan = nullptr;         // FK_PLAN_WORDS lane descriptors of the G1 DFT levels
     uint8_t* d_fk_proofs = nullptr;        // fk_cap x 128 x 48 B
     // host finish timing (last call), microseconds
     double last_host_finish_us = 0, last_verify_total_us = 0;

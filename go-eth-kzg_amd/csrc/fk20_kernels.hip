@@ -289,40 +289,75 @@ __global__ void __launch_bounds__(64) k_fk20_msm(const uint32_t* __restrict__ sc
 }
 
 // ------------------------------------------------------------------------------------------
-// k_fk20_ffts: one wavefront per blob: IFFT_128 (1/128 already folded into the scalars), keep
-// h[0..63], FFT_128, bit-reverse, compress.
+// The two G1 transforms of a blob, IFFT_128 -> keep h[0..63] -> FFT_128 (fk20.go:76-90, toeplitz.go:95-125).
+//
+// A twiddle multiplication of a G1 point is a 128-doubling chain (~2.3 ms for a lone wavefront), so a radix-2
+// transform with one wavefront per blob is 12 such chains back to back per blob: latency-bound, 3/4 of the SIMDs idle
+// at batch 64.  Here each transform is TWO table-driven levels of a 16 x 8 Cooley-Tukey split with the twiddle
+// merged into the small DFT's coefficients,
+//     level 1:  Y[j1 + r1 i2]  = sum_{i1<r1}  w^{ r2 i1 j1}        x[r2 i1 + i2]
+//     level 2:  X[j1 + r1 j2]  = sum_{i2<r2}  w^{ i2 (j1 + r1 j2)} Y[j1 + r1 i2]
+// (r1, r2) = (8, 16) for the IFFT, whose level 2 only produces j < 64, and (16, 8) for the FFT, whose level 1 skips the
+// eight i1 that address the identity padding: 1024 lanes per blob in every one of the four levels,
+// one LANE per term (each lane: one GLV scalar multiplication by a fixed power of w), the terms of an output in adjacent
+// lanes and summed with a shuffle tree.  5x the group operations of radix 2, but 4 chains deep instead of 12 and
+// 16 wavefronts per blob and level instead of one (batch 64 = one wavefront per SIMD).
+// Plan entry (one per lane): out << 16 | src << 8 | exponent (0..127, w^64 = -1).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_fk20_ffts(const uint32_t* __restrict__ results, const uint32_t* __restrict__ g1tw_fwd, const uint32_t* __restrict__ g1tw_inv,
-                                                  const int* __restrict__ status, uint8_t* __restrict__ proofs48) {
-    __shared__ uint32_t sh[56 * 128];
-    const int b = blockIdx.x, lane = threadIdx.x;
+void fk20_build_plan(uint32_t* plan /* FK_PLAN_WORDS */) {
+    uint32_t* p = plan;
+    // IFFT as 8 x 16:  level 1: 128 outputs x 8 terms, Y[j1 + 8 i2] = sum_{i1<8} w^{-16 i1 j1} x[16 i1 + i2]
+    for (int i2 = 0; i2 < 16; i2++) for (int j1 = 0; j1 < 8; j1++) for (int i1 = 0; i1 < 8; i1++)
+        *p++ = (uint32_t)(j1 + 8 * i2) << 16 | (uint32_t)(16 * i1 + i2) << 8 | (uint32_t)((128 * 8 - 16 * i1 * j1) & 127);
+    // IFFT level 2: outputs j = j1 + 8 j2 < 64 only, 16 terms, exponent -(i2 j)
+    for (int j = 0; j < 64; j++) for (int i2 = 0; i2 < 16; i2++)
+        *p++ = (uint32_t)j << 16 | (uint32_t)((j & 7) + 8 * i2) << 8 | (uint32_t)((128 * 8 - i2 * j) & 127);
+    // FFT level 1: inputs x[8 i1 + i2] with i1 < 8 (upper half is the identity), exponent 8 i1 j1
+    for (int i2 = 0; i2 < 8; i2++) for (int j1 = 0; j1 < 16; j1++) for (int i1 = 0; i1 < 8; i1++)
+        *p++ = (uint32_t)(j1 + 16 * i2) << 16 | (uint32_t)(8 * i1 + i2) << 8 | (uint32_t)((8 * i1 * j1) & 127);
+    // FFT level 2: 128 outputs x 8 terms, exponent i2 j
+    for (int j = 0; j < 128; j++) for (int i2 = 0; i2 < 8; i2++)
+        *p++ = (uint32_t)j << 16 | (uint32_t)((j & 15) + 16 * i2) << 8 | (uint32_t)((i2 * j) & 127);
+}
+static_assert(FK_PLAN_WORDS == 128 * 8 + 64 * 16 + 128 * 8 + 128 * 8, "plan size");
+
+template <int R>
+__global__ void __launch_bounds__(64) k_g1_dft_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ plan,
+                                                     const int* __restrict__ status) {
+    const int b = blockIdx.y;
     if (status[b] != 0) return;
-    for (int j = lane; j < 128; j += 64) {
-        G1X p;
-        f_load_xyzz(p, results + ((size_t)b * 128 + j) * 64);
-        lp_put(sh, j, p);
-    }
-    __syncthreads();
-    g1_fft128_dif(sh, &G1TW_GLV_INV[0][0], lane);
-    // slot p now holds h[brev7(p)]; h[j] for j >= 64 lives in the odd slots: drop it (toeplitz.go:124, fk20.go:83-86)
-    {
-        G1X z;
-        g1x_set_inf(z);
-        lp_put(sh, 2 * lane + 1, z);
-    }
-    __syncthreads();
-    g1_fft128_dit(sh, &G1TW_GLV_FWD[0][0], lane);
-    for (int i = lane; i < 128; i += 64) {
-        G1X p;
-        lp_get(p, sh, (int)(__brev((uint32_t)i) >> 25));          // proofs[i] = X[brev(i)]  (fk20.go:90)
-        G1Aff a;
-        f_to_affine(a, p);
-        uint32_t w[12];
-        g1_compress_words(w, a);
-        uint32_t* o32 = reinterpret_cast<uint32_t*>(proofs48 + ((size_t)b * 128 + i) * 48);
+    const uint32_t e = plan[blockIdx.x * 64 + threadIdx.x];
+    const int o = (int)(e >> 16), src = (int)((e >> 8) & 0xff), ex = (int)(e & 0xff);
+    G1X p;
+    f_load_xyzz(p, in + ((size_t)b * 128 + src) * 64);
+    if (ex & 63) {
+        uint32_t kw[8];
 #pragma unroll
-        for (int q = 0; q < 12; q++) o32[q] = __builtin_bswap32(w[q]);
+        for (int q = 0; q < 8; q++) kw[q] = G1TW_GLV_FWD[ex & 63][q];
+        f_mul_glv(p, p, kw);
     }
+    if (ex & 64) g1x_neg(p, p);
+    G1X q;
+#pragma unroll 1
+    for (int m = R / 2; m >= 1; m >>= 1) {
+        f_shfl_xor_xyzz(q, p, m);
+        f_add(p, p, q);
+    }
+    if ((threadIdx.x & (R - 1)) == 0) f_store_xyzz(out + ((size_t)b * 128 + o) * 64, p);
+}
+// proofs[i] = X[brev7(i)] (fk20.go:90), affine, compressed
+__global__ void __launch_bounds__(64) k_fk20_finish(const uint32_t* __restrict__ x, const int* __restrict__ status, uint8_t* __restrict__ proofs48) {
+    const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
+    if (status[b] != 0) return;
+    G1X p;
+    f_load_xyzz(p, x + ((size_t)b * 128 + (int)(__brev((uint32_t)i) >> 25)) * 64);
+    G1Aff a;
+    f_to_affine(a, p);
+    uint32_t w[12];
+    g1_compress_words(w, a);
+    uint32_t* o32 = reinterpret_cast<uint32_t*>(proofs48 + ((size_t)b * 128 + i) * 48);
+#pragma unroll
+    for (int q = 0; q < 12; q++) o32[q] = __builtin_bswap32(w[q]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -336,14 +371,19 @@ void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fw
 void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_results, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_fk20_msm, dim3(32, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_results);
 }
-void fk20_ffts_device(const uint32_t* d_results, const uint32_t* d_g1tw_fwd, const uint32_t* d_g1tw_inv, int n, const int* d_status, uint8_t* d_proofs48, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_fk20_ffts, dim3(n), dim3(64), 0, s, d_results, d_g1tw_fwd, d_g1tw_inv, d_status, d_proofs48);
+void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, const uint32_t* d_plan, int n, const int* d_status, uint8_t* d_proofs48, hipStream_t s) {
+    if (n <= 0) return;
+    const uint32_t* pl = d_plan;
+    hipLaunchKernelGGL((k_g1_dft_level<8>), dim3(128 * 8 / 64, n), dim3(64), 0, s, d_results, d_tmp, pl, d_status);
+    pl += 128 * 8;
+    hipLaunchKernelGGL((k_g1_dft_level<16>), dim3(64 * 16 / 64, n), dim3(64), 0, s, d_tmp, d_results, pl, d_status);    // h[0..63] -> d_results[0..63]
+    pl += 64 * 16;
+    hipLaunchKernelGGL((k_g1_dft_level<8>), dim3(128 * 8 / 64, n), dim3(64), 0, s, d_results, d_tmp, pl, d_status);
+    pl += 128 * 8;
+    hipLaunchKernelGGL((k_g1_dft_level<8>), dim3(128 * 8 / 64, n), dim3(64), 0, s, d_tmp, d_results, pl, d_status);
+    hipLaunchKernelGGL(k_fk20_finish, dim3(2, n), dim3(64), 0, s, d_results, d_status, d_proofs48);
 }
-void fk20_proofs_device(const uint32_t* d_scalars, const uint32_t* d_table, const uint32_t* d_g1tw_fwd, const uint32_t* d_g1tw_inv, int n, const int* d_status,
-                        uint32_t* d_results, uint8_t* d_proofs48, hipStream_t s) {
-    fk20_msm_device(d_scalars, d_table, n, d_status, d_results, s);
-    fk20_ffts_device(d_results, d_g1tw_fwd, d_g1tw_inv, n, d_status, d_proofs48, s);
-}
+
 size_t fk20_table_bytes() { return (size_t)8192 * FK_NWIN * FK_NMULT * 128; }
 
 }  // namespace kzg

@@ -17,14 +17,14 @@ static const size_t V_MISC_WORDS_C = 16 + 4 * VMSM_WINDOWS * 48;
 
 void free_cells(mkzg_ctx* c) {
     void* ptrs[] = {c->d_tw_fwd, c->d_tw_inv, c->d_g1tw_fwd, c->d_g1tw_inv, c->d_coeffs, c->d_cells, c->d_cell_st,
-                    c->d_monomial_aff, c->d_fk_t_aff, c->d_fk_table, c->d_fk_scalars, c->d_fk_results, c->d_fk_proofs, c->d_fk_plan,
+                    c->d_monomial_aff, c->d_fk_t_aff, c->d_fk_table, c->d_fk_scalars, c->d_fk_results, c->d_fk_proofs, c->d_fk_plan, c->d_fk_parts,
                     c->d_cv_cells, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_rp, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st,
                     c->d_pow7, c->d_ipow7, c->d_rec_scratch, c->d_rec_pos};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->d_tw_fwd = c->d_tw_inv = c->d_g1tw_fwd = c->d_g1tw_inv = c->d_coeffs = nullptr;
     c->d_cells = nullptr;
     c->d_cell_st = nullptr;
-    c->d_monomial_aff = c->d_fk_t_aff = c->d_fk_table = c->d_fk_scalars = c->d_fk_results = c->d_fk_plan = nullptr;
+    c->d_monomial_aff = c->d_fk_t_aff = c->d_fk_table = c->d_fk_scalars = c->d_fk_results = c->d_fk_plan = c->d_fk_parts = nullptr;
     c->d_fk_proofs = nullptr;
     c->d_cv_cells = nullptr; c->d_cv_cell_idx = nullptr; c->d_cv_row_idx = nullptr; c->d_cv_rp = nullptr; c->d_cv_weights = nullptr;
     c->d_cv_partials = nullptr; c->d_cv_interp = nullptr; c->d_cv_st = nullptr; c->cv_cap = 0;
@@ -94,10 +94,12 @@ int ensure_fk20(mkzg_ctx* c, size_t n) {
     if (n > c->fk_cap) {
         if (c->d_fk_scalars) (void)hipFree(c->d_fk_scalars);
         if (c->d_fk_results) (void)hipFree(c->d_fk_results);
+        if (c->d_fk_parts) (void)hipFree(c->d_fk_parts);
         if (c->d_fk_proofs) (void)hipFree(c->d_fk_proofs);
         c->fk_cap = 0;
         HIPCHK(hipMalloc(&c->d_fk_scalars, n * 128 * 64 * 32));
         HIPCHK(hipMalloc(&c->d_fk_results, 2 * n * 128 * 256));
+        HIPCHK(hipMalloc(&c->d_fk_parts, n * 128 * 16 * 256));
         HIPCHK(hipMalloc(&c->d_fk_proofs, n * 128 * 48));
         c->fk_cap = n;
     }
@@ -180,7 +182,7 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* c, const void* d_bl
         const uint8_t* blobs = (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB;
         KT(KT_CELLS_NTT, s, cells_from_blobs_device(blobs, (int)chunk, c->d_tw_fwd, c->d_tw_inv, c->d_coeffs, (uint8_t*)d_cells + done * 262144, d_status + done, s));
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(c->d_coeffs, (int)chunk, c->d_tw_fwd, d_status + done, c->d_fk_scalars, s));
-        KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, (int)chunk, d_status + done, c->d_fk_results, s));
+        KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, (int)chunk, d_status + done, c->d_fk_parts, c->d_fk_results, s));
         KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_fk_results + c->fk_cap * 128 * 64, c->d_fk_plan, (int)chunk, d_status + done, (uint8_t*)d_proofs + done * 128 * 48, s));
         done += chunk;
     }
@@ -358,7 +360,7 @@ static int recover_front(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, co
     KT(KT_CELLS_NTT, s, cells_from_coeffs_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_tw_inv, c->d_cells, c->d_cell_st, s));
     if (with_proofs) {
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_cell_st, c->d_fk_scalars, s));
-        KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, 1, c->d_cell_st, c->d_fk_results, s));
+        KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, 1, c->d_cell_st, c->d_fk_parts, c->d_fk_results, s));
         KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_fk_results + c->fk_cap * 128 * 64, c->d_fk_plan, 1, c->d_cell_st, c->d_fk_proofs, s));
     }
     HIPCHK(hipGetLastError());

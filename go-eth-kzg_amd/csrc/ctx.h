@@ -124,6 +124,7 @@ struct mkzg_ctx {
     size_t fk_cap = 0;
     uint32_t* d_fk_scalars = nullptr;      // fk_cap x 128 x 64 x 8 words
     uint32_t* d_fk_results = nullptr;      // 2 x fk_cap x 128 XYZZ rows (MSM results + ping-pong buffer of the G1 DFT levels)
+    uint32_t* d_fk_parts = nullptr;        // fk_cap x 128 x 16 XYZZ rows: per-lane partial sums of the FK20 MSMs
     uint32_t* d_fk_plan = nullptr;         // FK_PLAN_WORDS lane descriptors of the G1 DFT levels
     uint8_t* d_fk_proofs = nullptr;        // fk_cap x 128 x 48 B
     // host finish timing (last call), microseconds

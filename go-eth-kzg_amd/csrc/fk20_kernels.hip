@@ -75,32 +75,41 @@ __device__ __forceinline__ void f_store_xyzz(uint32_t* rec, const G1X& p) {
 // Straus/Shamir with 4-bit windows over both halves: 128 doublings + <= 64 additions, one table of 15
 // multiples of p (kept in the lane's private memory).
 __device__ __noinline__ void f_mul_glv(G1X& r, const G1X& p, const uint32_t* kk) {
+    // group operations are inlined here (one copy each, inside rolled loops) so that the accumulator stays in registers;
+    // only the 15-entry table is addressed dynamically and lives in the lane's scratch memory
     G1X tbl[15];
     tbl[0] = p;
-    for (int i = 1; i < 15; i++) f_add(tbl[i], tbl[i - 1], p);
+    {
+        G1X run = p;
+#pragma unroll 1
+        for (int i = 1; i < 15; i++) {
+            g1x_add(run, run, p);
+            tbl[i] = run;
+        }
+    }
     fp_t beta;
     Fp::set(beta, FP_BETA);
     G1X acc;
     g1x_set_inf(acc);
     int top = 31;
     while (top >= 0 && (((kk[top >> 3] | kk[4 + (top >> 3)]) >> (4 * (top & 7))) & 15u) == 0) top--;
+#pragma unroll 1
     for (int w = top; w >= 0; w--) {
         if (w != top) {
-            f_dbl(acc, acc);
-            f_dbl(acc, acc);
-            f_dbl(acc, acc);
-            f_dbl(acc, acc);
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) g1x_dbl(acc, acc);
         }
-        const uint32_t d1 = (kk[w >> 3] >> (4 * (w & 7))) & 15u;
-        const uint32_t d2 = (kk[4 + (w >> 3)] >> (4 * (w & 7))) & 15u;
-        if (d1) f_add(acc, acc, tbl[d1 - 1]);
-        if (d2) {
-            G1X q = tbl[d2 - 1];
-            if (!g1x_is_inf(q)) {
-                Fp::mul(q.x, q.x, beta);
-                Fp::template neg<2>(q.y, q.y);       // -phi(.)
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            const uint32_t d = (kk[4 * half + (w >> 3)] >> (4 * (w & 7))) & 15u;
+            if (d) {
+                G1X q = tbl[d - 1];
+                if (half) {                                  // -phi(.): (beta X, -Y); harmless on the identity (ZZ stays 0)
+                    Fp::mul(q.x, q.x, beta);
+                    Fp::template neg<2>(q.y, q.y);
+                }
+                g1x_add(acc, acc, q);
             }
-            f_add(acc, acc, q);
         }
     }
     r = acc;
@@ -242,8 +251,17 @@ __device__ __forceinline__ void f_shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
         r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
     }
 }
-__global__ void __launch_bounds__(64) k_fk20_msm(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ table, const int* __restrict__ status,
-                                                 uint32_t* __restrict__ results) {
+// 17-bit Booth field (two byte-windows and the bit below them) of lane `sub` for one scalar
+__device__ __forceinline__ uint32_t fk_field(const uint32_t* __restrict__ s, int sub) {
+    if (sub == 0) return (s[0] << 1) & 0x1ffffu;
+    const int bit = 16 * sub - 1, wi = bit >> 5, off = bit & 31;      // off is 15 or 31
+    const uint64_t v = ((uint64_t)(wi + 1 < 8 ? s[wi + 1] : 0u) << 32) | s[wi];
+    return (uint32_t)(v >> off) & 0x1ffffu;
+}
+__global__ void __launch_bounds__(64, 2) k_fk20_msm(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ table, const int* __restrict__ status,
+                                                    uint32_t* __restrict__ parts) {
+    // table rows travel HBM -> LDS with global_load_lds_dwordx4 while the previous row is added (see k_commit_direct_acc)
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[8 * 256];
     const int b = blockIdx.y;
     if (status[b] != 0) return;
     const int lane = threadIdx.x, sub = lane & 15;
@@ -251,41 +269,68 @@ __global__ void __launch_bounds__(64) k_fk20_msm(const uint32_t* __restrict__ sc
     const uint32_t* sc = scalars + ((size_t)b * 128 + k) * 64 * 8;
     G1X acc;
     g1x_set_inf(acc);
-    for (int i = 0; i < 64; i++) {
-        const uint32_t* s = sc + i * 8;
+    uint32_t fld = fk_field(sc, sub), fld_next = 0;
+    bool cur = false, cneg = false;
+#pragma unroll 1
+    for (int t = 0; t <= 128; t++) {
+        G1Aff p;
+        p.inf = 1;
+        if (cur) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint32_t rw[32];
 #pragma unroll
-        for (int ww = 0; ww < 2; ww++) {
-            const int w = 2 * sub + ww;
-            const int bit = FK_C * w - 1;
-            uint32_t v;
-            if (bit < 0) {
-                v = (s[0] << 1) & 0x1ffu;
-            } else {
-                const int wi = bit >> 5, off = bit & 31;
-                v = s[wi] >> off;
-                if (off + FK_C + 1 > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - off);
-                v &= 0x1ffu;
+            for (int q = 0; q < 8; q++) {
+                const uint4 v = *reinterpret_cast<const uint4*>(rowbuf + q * 256 + lane * 4);
+                rw[4 * q] = v.x; rw[4 * q + 1] = v.y; rw[4 * q + 2] = v.z; rw[4 * q + 3] = v.w;
             }
+#pragma unroll
+            for (int q = 0; q < 14; q++) { p.x.l[q] = rw[q]; p.y.l[q] = rw[14 + q]; }
+            p.inf = rw[28];
+#pragma unroll
+            for (int q = 0; q < 14; q++) asm volatile("" : "+v"(p.x.l[q]), "+v"(p.y.l[q]));
+            asm volatile("" : "+v"(p.inf));
+        }
+        bool nxt = false, nneg = false;
+        if (t < 128) {
+            const int i = t >> 1, ww = t & 1;
+            if (ww == 0 && i + 1 < 64) fld_next = fk_field(sc + (i + 1) * 8, sub);       // lands long before it is needed
+            const uint32_t v = (fld >> (8 * ww)) & 0x1ffu;
             int d = (int)((v + 1) >> 1);
             if (v >> FK_C) d -= (1 << FK_C);
+            if (ww == 1) fld = fld_next;
             if (d != 0) {
                 const int m = d < 0 ? -d : d;
-                G1Aff p;
-                f_load_affine(p, table + (((size_t)(k * 64 + i) * FK_NWIN + w) * FK_NMULT + (m - 1)) * 32);
-                if (!p.inf) {
-                    if (d < 0) Fp::template neg<0>(p.y, p.y);
-                    f_madd(acc, p.x, p.y);
-                }
+                nneg = d < 0;
+                nxt = true;
+                const uint32_t* row = table + (((size_t)(k * 64 + i) * FK_NWIN + (2 * sub + ww)) * FK_NMULT + (m - 1)) * 32;
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + 4 * q),
+                                                     (__attribute__((address_space(3))) void*)(rowbuf + q * 256), 16, 0, 0);
             }
         }
+        if (!p.inf) {
+            if (cneg) Fp::template neg<0>(p.y, p.y);
+            g1x_madd(acc, p.x, p.y);
+        }
+        cur = nxt;
+        cneg = nneg;
     }
-    // combine the 16 partial sums
-    G1X o;
+    // the 16 partial sums of an MSM are combined by k_fk20_msm_reduce: any group addition here (inlined or called) makes the
+    // compiler keep `acc` in scratch memory, whose loads then queue behind the row DMA on vmcnt
+    f_store_xyzz(parts + (((size_t)b * 128 + k) * 16 + sub) * 64, acc);
+}
+__global__ void __launch_bounds__(64) k_fk20_msm_reduce(const uint32_t* __restrict__ parts, const int* __restrict__ status, uint32_t* __restrict__ results) {
+    const int b = blockIdx.y;
+    if (status[b] != 0) return;
+    const int lane = threadIdx.x, k = blockIdx.x * 4 + (lane >> 4);
+    G1X acc, o;
+    f_load_xyzz(acc, parts + (((size_t)b * 128 + k) * 16 + (lane & 15)) * 64);
     for (int m = 8; m >= 1; m >>= 1) {
         f_shfl_xor_xyzz(o, acc, m);
         f_add(acc, acc, o);
     }
-    if (sub == 0) f_store_xyzz(results + ((size_t)b * 128 + k) * 64, acc);
+    if ((lane & 15) == 0) f_store_xyzz(results + ((size_t)b * 128 + k) * 64, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -368,8 +413,10 @@ void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fw
     const size_t n = (size_t)8192 * FK_NWIN;
     hipLaunchKernelGGL(k_fk20_setup_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_t_aff, d_table, 8192);
 }
-void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_results, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_fk20_msm, dim3(32, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_results);
+void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_fk20_msm, dim3(32, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_parts);
+    hipLaunchKernelGGL(k_fk20_msm_reduce, dim3(32, n), dim3(64), 0, s, d_parts, d_status, d_results);
 }
 void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, const uint32_t* d_plan, int n, const int* d_status, uint8_t* d_proofs48, hipStream_t s) {
     if (n <= 0) return;

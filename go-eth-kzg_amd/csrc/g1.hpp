@@ -73,10 +73,9 @@ struct G1T {
         r.zz = V;
         r.zzz = W;
     }
-    // r = 2*p (dbl-2008-s-1, a = 0)
+    // r = 2*p (dbl-2008-s-1, a = 0).  No special case for the identity: ZZ = 0 gives ZZ3 = V*0 = 0 (all-zero limbs) again.
     static KZ_HD void dbl(XYZZ& r, const XYZZ& p_) {
         XYZZ p = p_;
-        if (is_inf(p)) { r = p; return; }
         opaque(p);
         fe U, V, W, S, M, t, X3, Y3;
         F::dbl(U, p.y);
@@ -144,47 +143,58 @@ struct G1T {
         acc.x = X3;
     }
 
-    // r = a + b, both XYZZ (add-2008-s)
+    // r = a + b, both XYZZ (add-2008-s).  Identity operands are resolved with per-limb selects at the end, not with early
+    // returns that copy whole structs: LLVM merges such copies into one memcpy from a phi of pointers, which pins every
+    // XYZZ involved to scratch memory (seen as 220 B of scratch per lane in any kernel that inlines this).
     static KZ_HD void add(XYZZ& r, const XYZZ& a_, const XYZZ& b_) {
         XYZZ a = a_, b = b_;
-        if (is_inf(a)) { r = b; return; }
-        if (is_inf(b)) { r = a; return; }
         opaque(a);
         opaque(b);
+        const bool a_inf = is_inf(a), b_inf = is_inf(b);
         fe U1, U2, S1, S2, Pd, Rd, PP, PPP, Q, t, X3, Y3;
+        XYZZ res;
         F::mul(U1, a.x, b.zz);
         F::mul(U2, b.x, a.zz);
         F::mul(S1, a.y, b.zzz);
         F::mul(S2, b.y, a.zzz);
         F::template sub<1>(Pd, U2, U1);
         F::template sub<1>(Rd, S2, S1);
-        if (F::template is_zero_mod<16>(Pd)) {
-            if (F::template is_zero_mod<16>(Rd)) dbl(r, a);
-            else set_inf(r);
-            return;
+        if (!a_inf && !b_inf && F::template is_zero_mod<16>(Pd)) {
+            if (F::template is_zero_mod<16>(Rd)) dbl(res, a);
+            else set_inf(res);
+        } else {
+            opaque(a);
+            opaque(b);
+            F::opaque(Pd);
+            F::opaque(Rd);
+            F::opaque(U1);
+            F::opaque(S1);
+            F::sqr(PP, Pd);
+            F::mul(PPP, Pd, PP);
+            F::mul(Q, U1, PP);
+            F::sqr(X3, Rd);
+            F::template sub<1>(X3, X3, PPP);
+            F::dbl(t, Q);
+            F::template sub<2>(X3, X3, t);
+            F::template sub<3>(t, Q, X3);
+            F::template neg<1>(S1, S1);           // 2p - S1
+            F::mul2(Y3, Rd, t, S1, PPP);          // R (Q - X3) - S1 PPP   (< 1.01p)
+            F::mul(t, a.zz, b.zz);
+            F::mul(res.zz, t, PP);
+            F::mul(t, a.zzz, b.zzz);
+            F::mul(res.zzz, t, PPP);
+            res.x = X3;
+            res.y = Y3;
         }
-        opaque(a);
-        opaque(b);
-        F::opaque(Pd);
-        F::opaque(Rd);
-        F::opaque(U1);
-        F::opaque(S1);
-        F::sqr(PP, Pd);
-        F::mul(PPP, Pd, PP);
-        F::mul(Q, U1, PP);
-        F::sqr(X3, Rd);
-        F::template sub<1>(X3, X3, PPP);
-        F::dbl(t, Q);
-        F::template sub<2>(X3, X3, t);
-        F::template sub<3>(t, Q, X3);
-        F::template neg<1>(S1, S1);           // 2p - S1
-        F::mul2(Y3, Rd, t, S1, PPP);          // R (Q - X3) - S1 PPP   (< 1.01p)
-        F::mul(t, a.zz, b.zz);
-        F::mul(r.zz, t, PP);
-        F::mul(t, a.zzz, b.zzz);
-        F::mul(r.zzz, t, PPP);
-        r.x = X3;
-        r.y = Y3;
+        select(res, b_inf, a, res);
+        select(res, a_inf, b, res);
+        r = res;
+    }
+    static KZ_HD void select(XYZZ& r, bool c, const XYZZ& a, const XYZZ& b) {   // r = c ? a : b, limb by limb
+        F::select(r.x, c, a.x, b.x);
+        F::select(r.y, c, a.y, b.y);
+        F::select(r.zz, c, a.zz, b.zz);
+        F::select(r.zzz, c, a.zzz, b.zzz);
     }
     static KZ_HD void neg(XYZZ& r, const XYZZ& a) {
         r = a;

@@ -53,6 +53,7 @@ struct HostFp {
     }
     static inline void sqr(El& r, const El& a) { mul(r, a, a); }
     static inline void opaque(El&) {}
+    static inline void select(El& r, bool c, const El& a, const El& b) { r = c ? a : b; }
     static inline void mul2(El& r, const El& a, const El& b, const El& c, const El& d) {   // a*b + c*d
         El t1, t2;
         mul(t1, a, b);

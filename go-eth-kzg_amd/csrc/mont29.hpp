@@ -63,6 +63,10 @@ struct Mont29 {
 #pragma unroll
         for (int i = 0; i < N; i++) KZ_OPAQUE32(r.l[i]);
     }
+    static KZ_HD void select(El& r, bool c, const El& a, const El& b) {
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    }
     static KZ_HD void set_zero(El& r) {
 #pragma unroll
         for (int i = 0; i < N; i++) r.l[i] = 0;

@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) k_bucket_accumulate(const uint32_t* __res
 // ------------------------------------------------------------------------------------------
 constexpr int CHUNK = 16;
 template <int C>
-__global__ void __launch_bounds__(64) k_bucket_reduce1(const uint32_t* __restrict__ parts, const uint32_t* __restrict__ task_off, const int* __restrict__ status,
+__global__ void __launch_bounds__(64, 2) k_bucket_reduce1(const uint32_t* __restrict__ parts, const uint32_t* __restrict__ task_off, const int* __restrict__ status,
                                                        uint32_t* __restrict__ partials) {
     using RC = Recode<C>;
     using TG = TaskGeom<C>;
@@ -357,7 +357,7 @@ __device__ __forceinline__ void shfl_down_xyzz(G1X& r, const G1X& a, int d) {
 // Lane j owns chunks t = M j .. M j + M - 1 (M = chunks per blob / 64).
 // ------------------------------------------------------------------------------------------
 template <int C>
-__global__ void __launch_bounds__(64) k_bucket_reduce2(const uint32_t* __restrict__ partials, const int* __restrict__ status, uint8_t* __restrict__ out48) {
+__global__ void __launch_bounds__(64, 2) k_bucket_reduce2(const uint32_t* __restrict__ partials, const int* __restrict__ status, uint8_t* __restrict__ out48) {
     using RC = Recode<C>;
     constexpr int NCHUNK = RC::NBUCKET / CHUNK;
     constexpr int M = NCHUNK / 64;
@@ -639,7 +639,7 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
 }
 // Finish: one wavefront per blob sums the 512 lane accumulators (8 per lane, then an xor butterfly), converts to
 // affine and writes the compressed commitment.  Tiny and latency-bound: it runs beside the next accumulate kernel.
-__global__ void __launch_bounds__(64) k_commit_direct_fin(const uint32_t* __restrict__ parts, const int* __restrict__ bad_flags, uint8_t* __restrict__ out48,
+__global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __restrict__ parts, const int* __restrict__ bad_flags, uint8_t* __restrict__ out48,
                                                           int* __restrict__ status) {
     const int b = blockIdx.x, lane = threadIdx.x;
     int anybad = 0;
@@ -653,12 +653,12 @@ __global__ void __launch_bounds__(64) k_commit_direct_fin(const uint32_t* __rest
 #pragma unroll 1
     for (int q = 1; q < DPARTS / 64; q++) {
         load_xyzz(o, parts + ((size_t)b * DPARTS + q * 64 + lane) * 64);
-        g1x_add_ni(acc, acc, o);
+        g1x_add(acc, acc, o);
     }
 #pragma unroll 1
     for (int m = 32; m >= 1; m >>= 1) {
         shfl_xor_xyzz(o, acc, m);
-        g1x_add_ni(acc, acc, o);
+        g1x_add(acc, acc, o);
     }
     if (lane == 0) {
         status[b] = 0;

@@ -116,41 +116,86 @@ __device__ __forceinline__ void load16_be(uint32_t* w, const uint8_t* p) {   // 
 }
 
 // z_b = SHA256("FSBLOBVERIFY_V1_" || u128be(4096) || blob_b || commitment_b) mod r   (Montgomery rows)
-__global__ void __launch_bounds__(64) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= n) return;
-    const uint8_t* blob = blobs + (size_t)b * 131072;
-    const uint8_t* cm = commitments48 + (size_t)b * 48;
-    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    uint32_t w[16];
-    // block 0: domain separator, degree, blob[0..32)
-    w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;   // "FSBLOBVERIFY_V1_"
-    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = 4096;
-    load16_be(w + 8, blob);
-    load16_be(w + 12, blob + 16);
-    sha256_compress(h, w);
-    // blocks 1..2047: blob[64k-32 .. 64k+32)
-    for (int k = 1; k < 2048; k++) {
+//
+// A transcript is a serial chain of 2050 compressions, so the only parallel axis is the blob: one LANE per blob.  What
+// can still be taken off that chain is everything that does not depend on the hash state: loading, byte swapping and the
+// message schedule (a third of the instructions).  Each workgroup is therefore two wavefronts on two SIMDs: wave 0
+// PRODUCES W[i] + K[i] of message block k for its 64 blobs into an LDS double buffer while wave 1 CONSUMES block k-1
+// (64 rounds, nothing else); one barrier per message block.  1412 -> ~970 instructions per block on the critical wave.
+__device__ __forceinline__ void sha_load_block(uint32_t w[16], int k, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ cm) {
+    if (k >= 1 && k < 2048) {                       // blob[64k-32 .. 64k+32)
         const uint8_t* p = blob + 64 * k - 32;
         load16_be(w, p);
         load16_be(w + 4, p + 16);
         load16_be(w + 8, p + 32);
         load16_be(w + 12, p + 48);
-        sha256_compress(h, w);
-    }
-    // block 2048: blob[131040..131072) || commitment[0..32)
-    load16_be(w, blob + 131040);
-    load16_be(w + 4, blob + 131056);
-    load16_be(w + 8, cm);
-    load16_be(w + 12, cm + 16);
-    sha256_compress(h, w);
-    // block 2049: commitment[32..48) || 0x80 || zeros || bit length (131152 * 8)
-    load16_be(w, cm + 32);
-    w[4] = 0x80000000u;
+    } else if (k == 0) {                            // domain separator, degree, blob[0..32)
+        w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;   // "FSBLOBVERIFY_V1_"
+        w[4] = 0; w[5] = 0; w[6] = 0; w[7] = 4096;
+        load16_be(w + 8, blob);
+        load16_be(w + 12, blob + 16);
+    } else if (k == 2048) {                         // blob[131040..131072) || commitment[0..32)
+        load16_be(w, blob + 131040);
+        load16_be(w + 4, blob + 131056);
+        load16_be(w + 8, cm);
+        load16_be(w + 12, cm + 16);
+    } else {                                        // commitment[32..48) || 0x80 || zeros || bit length (131152 * 8)
+        load16_be(w, cm + 32);
+        w[4] = 0x80000000u;
 #pragma unroll
-    for (int i = 5; i < 15; i++) w[i] = 0;
-    w[15] = 131152u * 8u;
-    sha256_compress(h, w);
+        for (int i = 5; i < 15; i++) w[i] = 0;
+        w[15] = 131152u * 8u;
+    }
+}
+constexpr int SHA_NBLOCKS = 2050;
+__global__ void __launch_bounds__(128) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
+    __shared__ uint32_t wk[2][64][64];              // [buffer][round][lane]: W + K, conflict-free both ways
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * 64 + lane;
+    const int b = b0 < n ? b0 : n - 1;              // surplus lanes shadow the last blob (they must keep the barriers)
+    const uint8_t* blob = blobs + (size_t)b * 131072;
+    const uint8_t* cm = commitments48 + (size_t)b * 48;
+    if (role == 0) {
+#pragma unroll 1
+        for (int k = 0; k <= SHA_NBLOCKS; k++) {
+            if (k < SHA_NBLOCKS) {
+                uint32_t w[16];
+                sha_load_block(w, k, blob, cm);
+                uint32_t (*dst)[64] = wk[k & 1];
+#pragma unroll
+                for (int i = 0; i < 64; i++) {
+                    if (i >= 16) {
+                        const uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                        const uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
+                        const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
+                        w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+                    }
+                    dst[i][lane] = w[i & 15] + SHA_K[i];
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+#pragma unroll 1
+    for (int k = 0; k <= SHA_NBLOCKS; k++) {
+        if (k >= 1) {
+            const uint32_t (*src)[64] = wk[(k - 1) & 1];
+            uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+            for (int i = 0; i < 64; i++) {
+                const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
+                const uint32_t t1 = hh + S1 + sha_ch(e, f, g) + src[i][lane];
+                const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
+                const uint32_t t2 = S0 + sha_maj(a, bb, c);
+                hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+            }
+            h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+        }
+        __syncthreads();
+    }
+    if (b0 >= n) return;
     // digest (big-endian h[0..7]) as little-endian words, reduced mod r (2^256 < 3r: at most two subtractions)
     uint32_t v[8];
 #pragma unroll
@@ -649,7 +694,7 @@ __global__ void __launch_bounds__(64) k_fr_to_scalars(const uint32_t* __restrict
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(64), 0, s, d_blobs, d_commitments, n, d_z);
+    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(128), 0, s, d_blobs, d_commitments, n, d_z);
 }
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EV_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);

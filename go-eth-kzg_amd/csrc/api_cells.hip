@@ -250,33 +250,42 @@ int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n,
     if (!rc) rc = ensure_staging(c, 1, n * 2048);
     if (rc) return rc;
     const size_t cap = c->v_cap;
-    // uploads
-    std::vector<uint8_t> zero_cell;
-    for (size_t i = 0; i < n; i++) {
-        const uint8_t* src = cells[i];
-        if (!src) { if (zero_cell.empty()) zero_cell.assign(2048, 0); src = zero_cell.data(); }
-        memcpy(c->h_stage + i * 2048, src, 2048);
-    }
-    HIPCHK(hipMemcpyAsync(c->d_cv_cells, c->h_stage, n * 2048, hipMemcpyHostToDevice, s));
+    uint32_t* h_misc = (uint32_t*)(c->h_v + 3 * cap * sizeof(int));
+    // uploads, part 1: the points (small) -- their validation starts on the side stream before the 2 KiB cells are staged
     HIPCHK(hipMemcpyAsync(c->d_v_raw, rows.data(), n_rows * 48, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(c->d_v_raw + cap * 48, proofs48n, n * 48, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->d_cv_cell_idx, cell_indices, n * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->d_cv_row_idx, row_idx.data(), n * 4, hipMemcpyHostToDevice, s));
-    uint32_t* h_misc = (uint32_t*)(c->h_v + 3 * cap * sizeof(int));
-    if (getrandom(h_misc, 32, 0) != 32) return MKZG_ERR_HIP;
-    HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
     // points
     uint32_t* aff_rows = c->d_v_aff;
     uint32_t* aff_q = c->d_v_aff + cap * 32;
     int* st_rows = c->d_v_st;
     int* st_q = c->d_v_st + cap;
-    KT(KT_DECOMPRESS, s, g1_decompress_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, s));
-    KT(KT_DECOMPRESS, s, g1_decompress_device(c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s));
-    KT(KT_SUBGROUP, s, g1_subgroup_check_device(aff_rows, (int)n_rows, st_rows, s));
-    KT(KT_SUBGROUP, s, g1_subgroup_check_device(aff_q, (int)n, st_q, s));
+    // point decoding + subgroup checks on the side stream, beside the interpolation scalars (independent until the MSMs)
+    hipStream_t s2 = c->side;
+    HIPCHK(hipEventRecord(c->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    KT(KT_DECOMPRESS, s2, g1_decompress_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, s2));
+    KT(KT_DECOMPRESS, s2, g1_decompress_device(c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s2));
+    KT(KT_SUBGROUP, s2, g1_subgroup_check_device(aff_rows, (int)n_rows, st_rows, s2));
+    KT(KT_SUBGROUP, s2, g1_subgroup_check_device(aff_q, (int)n, st_q, s2));
+    HIPCHK(hipEventRecord(c->ev_join, s2));
+    // uploads, part 2 (host memcpy of n x 2 KiB into the pinned staging area runs while the GPU validates the points)
+    {
+        std::vector<uint8_t> zero_cell;
+        for (size_t i = 0; i < n; i++) {
+            const uint8_t* src = cells[i];
+            if (!src) { if (zero_cell.empty()) zero_cell.assign(2048, 0); src = zero_cell.data(); }
+            memcpy(c->h_stage + i * 2048, src, 2048);
+        }
+        HIPCHK(hipMemcpyAsync(c->d_cv_cells, c->h_stage, n * 2048, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->d_cv_cell_idx, cell_indices, n * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->d_cv_row_idx, row_idx.data(), n * 4, hipMemcpyHostToDevice, s));
+        if (getrandom(h_misc, 32, 0) != 32) return MKZG_ERR_HIP;
+        HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
+    }
     // scalars
     KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(c->d_v_misc, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, c->d_cv_rp,
                                                        c->d_v_s1, c->d_v_s3, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st, s));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
     const uint32_t* scal[4] = {c->d_v_s1, c->d_cv_weights, c->d_cv_interp, c->d_v_s3};
     const uint32_t* pts[4] = {aff_q, aff_rows, c->d_monomial_aff, aff_q};

@@ -8,6 +8,7 @@
 // (reference internal/kzg/kzg_verify.go:160-199).
 #include <sys/random.h>
 #include <chrono>
+#include <thread>
 #include "ctx.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -152,9 +153,9 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     }
     // 6. Horner over the window sums (the 255 serial doublings stay on the host)
     auto t_h0 = std::chrono::steady_clock::now();
-    G1HX win[VMSM_WINDOWS];
     const uint32_t* wsum = h_misc + 16;
     auto horner = [&](int m, G1HX& out) {
+        G1HX win[VMSM_WINDOWS];
         for (int w = 0; w < VMSM_WINDOWS; w++) {
             const uint32_t* p = wsum + ((size_t)m * VMSM_WINDOWS + w) * 48;
             bool zero = true;
@@ -163,9 +164,13 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
         }
         g1h_horner(out, win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
     };
-    horner(0, out->A);
-    horner(1, out->Cc);
-    horner(2, out->D);
+    {   // three independent 255-doubling chains: one per host thread
+        std::thread ta([&] { horner(0, out->A); });
+        std::thread tc([&] { horner(1, out->Cc); });
+        horner(2, out->D);
+        ta.join();
+        tc.join();
+    }
     memcpy(out->e, h_misc + 8, 32);
     c->last_host_finish_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
     return MKZG_OK;
@@ -176,8 +181,11 @@ static int verify_finish(mkzg_ctx* c, const VerifyFold& f) {
     G1HX eG, gen, Fsum, negA;
     uint64_t e64[4];
     for (int i = 0; i < 4; i++) e64[i] = (uint64_t)f.e[2 * i] | ((uint64_t)f.e[2 * i + 1] << 32);
-    g1h_generator(gen);
-    g1h_mul(eG, gen, e64);
+    if (!c->gen_fixed.ready) {
+        g1h_generator(gen);
+        g1h_fixed_build(c->gen_fixed, gen);
+    }
+    g1h_fixed_mul(eG, c->gen_fixed, e64);
     G1H::neg(eG, eG);
     G1H::add(Fsum, f.Cc, eG);
     G1H::add(Fsum, Fsum, f.D);

@@ -392,20 +392,39 @@ __global__ void __launch_bounds__(256) k_cell_rpowers(const uint32_t* __restrict
     c_fr_mul(v, rp, hp);
     fr_store_plain8(s4 + (size_t)k * 8, v);
 }
-// weights[row] = sum_{k : row_idx[k] == row} r^k   (kzg_verify.go:36-40)
-__global__ void __launch_bounds__(64) k_cell_weights(const uint32_t* __restrict__ rp_rows, const uint32_t* __restrict__ row_idx, int n, int n_rows, uint32_t* __restrict__ weights8) {
-    const int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= n_rows) return;
+// weights[row] = sum of r^k over the cells k that belong to commitment `row` (kzg_verify.go:35-41).  One 256-thread
+// workgroup per row: strided scan of the row indices, LDS tree over the Fr partial sums.
+__global__ void __launch_bounds__(256) k_cell_weights(const uint32_t* __restrict__ rp_rows, const uint32_t* __restrict__ row_idx, int n, int n_rows, uint32_t* __restrict__ weights8) {
+    __shared__ uint32_t sh[9 * 256];
+    const int row = blockIdx.x, t = threadIdx.x;
     fr_t acc;
     Fr::set_zero(acc);
-    for (int k = 0; k < n; k++) {
+    for (int k = t; k < n; k += 256) {
         if ((int)row_idx[k] == row) {
             fr_t v;
             c_load_fr12(v, rp_rows + (size_t)k * 12);
             FrC::add(acc, acc, v);
         }
     }
-    fr_store_plain8(weights8 + (size_t)row * 8, acc);
+#pragma unroll
+    for (int q = 0; q < 9; q++) sh[q * 256 + t] = acc.l[q];
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if (t < st) {
+            fr_t a, b2;
+#pragma unroll
+            for (int q = 0; q < 9; q++) { a.l[q] = sh[q * 256 + t]; b2.l[q] = sh[q * 256 + t + st]; }
+            FrC::add(a, a, b2);
+#pragma unroll
+            for (int q = 0; q < 9; q++) sh[q * 256 + t] = a.l[q];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) acc.l[q] = sh[q * 256];
+        fr_store_plain8(weights8 + (size_t)row * 8, acc);
+    }
 }
 // per cell: canonical check, coset IFFT-64 on the bit-reversed evaluations, times r^k, summed per
 // workgroup into partials[block][64]   (kzg_verify.go:50-66, coset_fft.go:55-70)
@@ -514,7 +533,7 @@ void cell_verify_scalars_device(const uint32_t* d_r8, const uint64_t* d_cell_idx
                                 uint32_t* d_partials, uint32_t* d_interp8, int* d_cell_status, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_cell_rpowers, dim3((n + 255) / 256), dim3(256), 0, s, d_r8, d_cell_idx, n, d_tw_fwd, d_rp_rows, d_s1, d_s4);
-    hipLaunchKernelGGL(k_cell_weights, dim3((n_rows + 63) / 64), dim3(64), 0, s, d_rp_rows, d_row_idx, n, n_rows, d_weights8);
+    hipLaunchKernelGGL(k_cell_weights, dim3(n_rows), dim3(256), 0, s, d_rp_rows, d_row_idx, n, n_rows, d_weights8);
     const int nb = n < CELL_INTERP_BLOCKS ? n : CELL_INTERP_BLOCKS;
     hipLaunchKernelGGL(k_cell_interp, dim3(nb), dim3(64), 0, s, d_cells, d_cell_idx, d_rp_rows, n, d_tw_inv, d_partials, d_cell_status);
     hipLaunchKernelGGL(k_cell_interp_reduce, dim3(1), dim3(64), 0, s, d_partials, nb, d_interp8);

@@ -70,6 +70,7 @@ struct mkzg_ctx {
     // ---- EIP-4844 proofs / verification
     uint32_t* d_roots_brp = nullptr;       // 4096 Fr rows (12 words), bit-reversed domain (api.go:132)
     uint32_t* d_inv_roots_brp = nullptr;
+    G1HFixedBase gen_fixed;                // host byte-window table of the G1 generator ([e]G of the batch verifiers)
     G2Prepared g2_gen, g2_alpha;           // prepared [1]G2, [alpha]G2 (kzg.OpeningKey, internal/kzg/srs.go:10-20)
     G2Prepared g2_neg_gen, g2_alpha64;     // prepared -[1]G2, [alpha^64]G2 (kzgmulti.OpeningKey, internal/kzg_multi/kzg_verify.go:89-92)
     // verify workspace, sized for v_cap proofs

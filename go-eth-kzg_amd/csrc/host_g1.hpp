@@ -3,6 +3,7 @@
 // handful of group operations per *batch* that reference internal/kzg/kzg_verify.go:160-188
 // performs after its MSMs.  Shares the group law with the device through g1.hpp.
 #pragma once
+#include <vector>
 #include "g1.hpp"
 #include "host_pairing.hpp"
 
@@ -44,6 +45,34 @@ inline void g1h_to_affine(G1AffH& r, const G1HX& p) {
     r.inf = a.inf != 0;
 }
 // sum_w 2^(c w) S_w  (Horner from the top window)
+// fixed-base multiplication for the generator: 32 byte-windows x 255 multiples (XYZZ, built once per context):
+// [k]G is 32 additions instead of 256 doublings + ~128 additions
+struct G1HFixedBase {
+    std::vector<G1HX> t;
+    bool ready = false;
+};
+inline void g1h_fixed_build(G1HFixedBase& fb, const G1HX& g) {
+    fb.t.resize(32 * 255);
+    G1HX base = g;
+    for (int w = 0; w < 32; w++) {
+        G1HX run = base;
+        for (int d = 1; d <= 255; d++) {
+            fb.t[(size_t)w * 255 + d - 1] = run;
+            G1H::add(run, run, base);
+        }
+        base = run;                                  // 256 * base
+    }
+    fb.ready = true;
+}
+inline void g1h_fixed_mul(G1HX& r, const G1HFixedBase& fb, const uint64_t k[4]) {
+    G1HX acc;
+    G1H::set_inf(acc);
+    for (int w = 0; w < 32; w++) {
+        const unsigned d = (unsigned)(k[w >> 3] >> (8 * (w & 7))) & 0xffu;
+        if (d) G1H::add(acc, acc, fb.t[(size_t)w * 255 + d - 1]);
+    }
+    r = acc;
+}
 inline void g1h_horner(G1HX& r, const G1HX* sums, int nwin, int c) {
     G1HX acc;
     G1H::set_inf(acc);

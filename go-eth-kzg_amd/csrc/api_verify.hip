@@ -88,10 +88,8 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     hipStream_t s2 = c->side;
     HIPCHK(hipEventRecord(c->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    KT(KT_DECOMPRESS, s2, g1_decompress_device(d_commitments, (int)n, aff_c, st_c, s2));
-    KT(KT_DECOMPRESS, s2, g1_decompress_device(d_proofs, (int)n, aff_q, st_q, s2));
-    KT(KT_SUBGROUP, s2, g1_subgroup_check_device(aff_c, (int)n, st_c, s2));
-    KT(KT_SUBGROUP, s2, g1_subgroup_check_device(aff_q, (int)n, st_q, s2));
+    KT(KT_DECOMPRESS, s2, g1_decompress2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2));
+    KT(KT_SUBGROUP, s2, g1_subgroup_check2_device(aff_c, (int)n, st_c, aff_q, (int)n, st_q, s2));
     HIPCHK(hipEventRecord(c->ev_join, s2));
     // 2. challenge and claimed value per blob, or caller-supplied z / y
     if (d_blobs) {

@@ -68,6 +68,8 @@ void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz);
 // scalars: input_kind 0 = 32-byte big-endian scalars, 4096 per item, items `stride` bytes apart
 void commit_batch_device(const CommitPlan& pl, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt);
 void g1_decompress_device(const uint8_t* d_in48, int n, uint32_t* d_out_aff, int* d_status, hipStream_t s);
+void g1_decompress2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_out_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_out_aff_b, int* d_st_b,
+                           hipStream_t s);   // two arrays, one launch
 void build_table_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s);
 // direct-table commitment (window bits c in 12..15)
 size_t direct_table_bytes(int c);

@@ -417,9 +417,15 @@ __global__ void __launch_bounds__(64, 2) k_bucket_reduce2(const uint32_t* __rest
 // serialization.go:108-115): flag bits, x < p, on curve; the r-torsion check is a separate
 // kernel (k_subgroup_check) because trusted-setup points are decoded without it
 // (reference trusted_setup.go:104-117).
-__global__ void __launch_bounds__(64) k_g1_decompress(const uint8_t* __restrict__ in48, int n, uint32_t* __restrict__ out_aff, int* __restrict__ st) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
+// two arrays in one launch: the square root is a ~380-squaring chain per lane (latency-bound), see k_g1_subgroup_check
+__global__ void __launch_bounds__(64) k_g1_decompress(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ out_aff_a, int* __restrict__ st_a,
+                                                      const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ out_aff_b, int* __restrict__ st_b) {
+    int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_a + n_b) return;
+    const uint8_t* in48 = in48_a;
+    uint32_t* out_aff = out_aff_a;
+    int* st = st_a;
+    if (i >= n_a) { i -= n_a; in48 = in48_b; out_aff = out_aff_b; st = st_b; }
     const uint32_t* p = reinterpret_cast<const uint32_t*>(in48 + (size_t)i * 48);
     uint32_t w[12];
 #pragma unroll
@@ -803,8 +809,14 @@ void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz) {
     sz->parts_bytes = (size_t)max_batch * maxt * 256;
     sz->partials_bytes = (size_t)max_batch * (nb / CHUNK) * 512;
 }
+void g1_decompress2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_out_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_out_aff_b, int* d_st_b,
+                           hipStream_t s) {
+    const int n = n_a + n_b;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in48_a, n_a, d_out_aff_a, d_st_a, d_in48_b, n_b, d_out_aff_b, d_st_b);
+}
 void g1_decompress_device(const uint8_t* d_in48, int n, uint32_t* d_out_aff, int* d_status, hipStream_t s) {
-    hipLaunchKernelGGL(k_g1_decompress, dim3((n + 63) / 64), dim3(64), 0, s, d_in48, n, d_out_aff, d_status);
+    g1_decompress2_device(d_in48, n, d_out_aff, d_status, nullptr, 0, nullptr, nullptr, s);
 }
 void build_table_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s) {
     switch (c) {

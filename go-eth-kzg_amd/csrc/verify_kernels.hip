@@ -401,9 +401,15 @@ __global__ void __launch_bounds__(EV_T) k_blob_eval(const uint8_t* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // G1 subgroup membership: phi(P) == -[x^2]P, one lane per affine row; st[i] |= NOT_IN_SUBGROUP
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __restrict__ aff, int n, int* __restrict__ st) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
+// two point arrays in one launch (commitments and proofs): the test is one 126-doubling chain per lane, i.e. latency-bound,
+// so two launches back to back cost twice the time of one
+__global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __restrict__ aff_a, int n_a, int* __restrict__ st_a,
+                                                          const uint32_t* __restrict__ aff_b, int n_b, int* __restrict__ st_b) {
+    int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_a + n_b) return;
+    const uint32_t* aff = aff_a;
+    int* st = st_a;
+    if (i >= n_a) { i -= n_a; aff = aff_b; st = st_b; }
     if (st[i] != 0) return;
     G1Aff p;
     load_affine_v(p, aff + (size_t)i * 32);
@@ -703,8 +709,10 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
                           int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<1>), dim3(n), dim3(EV_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, d_quot, d_status);
 }
-void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_g1_subgroup_check, dim3((n + 63) / 64), dim3(64), 0, s, d_aff, n, d_status);
+void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s) { g1_subgroup_check2_device(d_aff, n, d_status, nullptr, 0, nullptr, s); }
+void g1_subgroup_check2_device(const uint32_t* d_aff_a, int n_a, int* d_st_a, const uint32_t* d_aff_b, int n_b, int* d_st_b, hipStream_t s) {
+    const int n = n_a + n_b;
+    if (n > 0) hipLaunchKernelGGL(k_g1_subgroup_check, dim3((n + 63) / 64), dim3(64), 0, s, d_aff_a, n_a, d_st_a, d_aff_b, n_b, d_st_b);
 }
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         hipStream_t s) {

@@ -122,3 +122,23 @@ def test_direct_table_mode(product, oracle_ctx, bits):
     rc, outs, st = ctx.BlobToKZGCommitmentBatch([bytes(bad), blobs[3]])
     assert rc == 3 and st == [3, 0] and outs[1] == oracle_ctx.blob_to_kzg_commitment(blobs[3])[1]
     ctx.close()
+
+
+def test_options_and_calibration(product, oracle_ctx):
+    """chain_accumulate only reorders kernels (same bytes); mkzg_valu_calibrate returns a plausible issue rate"""
+    import torch
+    torch.cuda.init()
+    blobs = [rand_blob(31), rand_blob(32), rand_blob(33)]
+    exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
+    for chain in (0, 1):
+        ctx = product.Context()
+        assert ctx.set_option("max_batch", 2) == 0
+        assert ctx.set_option("chain_accumulate", chain) == 0
+        assert ctx.set_option("chain_accumulate", 2) == 17           # MKZG_ERR_BAD_ARGS
+        rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
+        assert rc == 0 and outs == exp
+        ctx.close()
+    ctx = product.Context()
+    rate = ctx.valu_calibrate()
+    ctx.close()
+    assert rate is not None and 1e11 < rate < 2e12                   # 100 G .. 2 T wave-instructions / s

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
     "mkzg_last_host_finish_us", "mkzg_valu_calibrate", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
-    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch",
+    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch", "mkzg_verify_cell_kzg_proof_batch_partial", "mkzg_verify_cell_kzg_proof_batch_finish",
     "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
     "mkzg_verify_blob_kzg_proof_batch_partial_device", "mkzg_verify_blob_kzg_proof_batch_finish",
 ]
@@ -79,6 +79,9 @@ def lib():
         L.mkzg_compute_cells_and_kzg_proofs.argtypes = [vp, C.c_char_p, i32, C.c_char_p, C.c_char_p]
         L.mkzg_compute_cells_and_kzg_proofs_batch_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
         L.mkzg_verify_cell_kzg_proof_batch.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, C.c_char_p, sz]
+        L.mkzg_verify_cell_kzg_proof_batch_partial.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, C.c_char_p, sz, C.c_uint64,
+                                                               C.c_char_p, C.c_char_p]
+        L.mkzg_verify_cell_kzg_proof_batch_finish.argtypes = [vp, C.c_char_p, sz]
         L.mkzg_recover_cells_and_kzg_proofs.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p, C.c_char_p]
         L.mkzg_recover_cells.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p]
         L.mkzg_verify_blob_kzg_proof_batch_partial_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
@@ -234,6 +237,19 @@ class Context:
         arr = (C.c_char_p * max(1, len(cells)))(*keep)
         return self._L.mkzg_verify_cell_kzg_proof_batch(self._h, b"".join(commitments), len(commitments), idx, len(cell_indices), arr, len(cells),
                                                         b"".join(proofs), len(proofs))
+
+    def verify_cell_batch_partial(self, commitments, cell_indices, cells, proofs, offset, r32):
+        """this rank's share of a sharded VerifyCellKZGProofBatch -> (rc, 512-byte record); see include/mi355kzg.h"""
+        idx = (C.c_uint64 * max(1, len(cell_indices)))(*cell_indices)
+        keep = [None if x is None else bytes(x) for x in cells]
+        arr = (C.c_char_p * max(1, len(cells)))(*keep)
+        rec = C.create_string_buffer(512)
+        rc = self._L.mkzg_verify_cell_kzg_proof_batch_partial(self._h, b"".join(commitments), len(commitments), idx, len(cell_indices), arr, len(cells),
+                                                              b"".join(proofs), len(proofs), offset, bytes(r32), rec)
+        return rc, rec.raw
+
+    def verify_cell_batch_finish(self, records):
+        return self._L.mkzg_verify_cell_kzg_proof_batch_finish(self._h, b"".join(records), len(records))
 
     def RecoverCellsAndComputeKZGProofs(self, cell_ids, cells, num_goroutines=0):
         """reference api_eip7594.go:144 -> (rc, [128 cells], [128 proofs])"""

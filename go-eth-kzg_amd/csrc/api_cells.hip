@@ -4,6 +4,7 @@
 // All field work happens in cells_kernels.hip / fk20_kernels.hip; the host only stages bytes.
 #include <sys/random.h>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include "ctx.h"
 
@@ -215,8 +216,16 @@ int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* c, const uint8_t* blob, int num_
 // Context.VerifyCellKZGProofBatch (reference api_eip7594.go:163-214 + internal/kzg_multi/kzg_verify.go:16-105).
 // commitments: n_c x 48 B (one per cell, duplicates allowed); cell_indices: n_i; cells: n_cells host pointers;
 // proofs: n_p x 48 B.  At most 8192 cells per call.
-int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
-                                     size_t n_cells, const uint8_t* proofs48n, size_t n_p) {
+// The fold (everything up to the four group sums) and the finish (one pairing check) are separate so that multi-GPU jobs can
+// shard the cells: a rank folds its cells with the batch-wide r and the GLOBAL exponents r^(exp_offset + k), ranks exchange
+// one 512-byte record, and the sums add up.  sums: [0] sum r^k pi_k, [1] sum w_row C_row, [2] [I(tau)]G1,
+// [3] sum r^k h_k^64 pi_k   (kzg_verify.go:32,41,68,80)
+struct CellFold {
+    G1HX sums[4];
+};
+static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
+                            size_t n_cells, const uint8_t* proofs48n, size_t n_p, uint32_t exp_offset, const uint8_t* r32 /* big-endian, or null: draw it */, CellFold* out) {
+    for (int m = 0; m < 4; m++) G1H::set_inf(out->sums[m]);
     if (!c) return MKZG_ERR_BAD_ARGS;
     // deduplicateKZGCommitments (api_eip7594.go:238-265)
     std::unordered_map<std::string, uint32_t> seen;
@@ -277,11 +286,15 @@ int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n,
         HIPCHK(hipMemcpyAsync(c->d_cv_cells, c->h_stage, n * 2048, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->d_cv_cell_idx, cell_indices, n * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->d_cv_row_idx, row_idx.data(), n * 4, hipMemcpyHostToDevice, s));
-        if (getrandom(h_misc, 32, 0) != 32) return MKZG_ERR_HIP;
+        if (r32) {
+            for (int i = 0; i < 8; i++) h_misc[i] = ((uint32_t)r32[28 - 4 * i] << 24) | ((uint32_t)r32[29 - 4 * i] << 16) | ((uint32_t)r32[30 - 4 * i] << 8) | r32[31 - 4 * i];
+        } else if (getrandom(h_misc, 32, 0) != 32) {
+            return MKZG_ERR_HIP;
+        }
         HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
     }
     // scalars
-    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(c->d_v_misc, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, c->d_cv_rp,
+    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(c->d_v_misc, exp_offset, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, c->d_cv_rp,
                                                        c->d_v_s1, c->d_v_s3, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st, s));
     HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
@@ -305,27 +318,89 @@ int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n,
         if (i == first_nil) return MKZG_ERR_NIL_INPUT;
         if (st_cells[i]) return st_cells[i];
     }
-    // host finish (kzg_verify.go:85-104)
-    G1HX win[VMSM_WINDOWS], sums[4];
+    // Horner over the window sums: four independent 255-doubling chains, one host thread each
     const uint32_t* wsum = h_misc + 16;
-    for (int m = 0; m < 4; m++) {
+    auto horner = [&](int m) {
+        G1HX win[VMSM_WINDOWS];
         for (int w = 0; w < VMSM_WINDOWS; w++) {
             const uint32_t* p = wsum + ((size_t)m * VMSM_WINDOWS + w) * 48;
             bool zero = true;
             for (int q = 24; q < 36; q++) zero = zero && p[q] == 0;
             if (zero) G1H::set_inf(win[w]); else g1h_from_plain_words(win[w], p);
         }
-        g1h_horner(sums[m], win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
+        g1h_horner(out->sums[m], win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
+    };
+    {
+        std::thread t0([&] { horner(0); }), t1([&] { horner(1); }), t2([&] { horner(2); });
+        horner(3);
+        t0.join();
+        t1.join();
+        t2.join();
     }
+    return MKZG_OK;
+}
+// kzg_verify.go:85-104: e(sum r^k pi_k, [tau^64]G2) == e(sum w C - [I(tau)] + sum r^k h^64 pi_k, G2)
+static int cell_verify_finish(mkzg_ctx* c, const CellFold& f) {
     G1HX rl, t;
-    G1H::neg(t, sums[2]);
-    G1H::add(rl, sums[1], t);
-    G1H::add(rl, rl, sums[3]);
+    G1H::neg(t, f.sums[2]);
+    G1H::add(rl, f.sums[1], t);
+    G1H::add(rl, rl, f.sums[3]);
     G1AffH ps[2];
-    g1h_to_affine(ps[0], sums[0]);
+    g1h_to_affine(ps[0], f.sums[0]);
     g1h_to_affine(ps[1], rl);
     const G2Prepared* qs[2] = {&c->g2_alpha64, &c->g2_neg_gen};
     return pairing_check_prepared(ps, qs, 2) ? MKZG_OK : MKZG_VERIFY_FAILED;
+}
+int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
+                                     size_t n_cells, const uint8_t* proofs48n, size_t n_p) {
+    if (!c) return MKZG_ERR_BAD_ARGS;
+    if (n_c == n_i && n_c == n_cells && n_c == n_p && n_c == 0) return MKZG_OK;          // api_eip7594.go:173-175
+    CellFold f;
+    int rc = cell_verify_fold(c, commitments48n, n_c, cell_indices, n_i, cells, n_cells, proofs48n, n_p, 0, nullptr, &f);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    return cell_verify_finish(c, f);
+}
+// Sharded form (see CellFold): record = status@0 (int32), compressed sums[0..3] at 16, 64, 112, 160.
+int mkzg_verify_cell_kzg_proof_batch_partial(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
+                                             size_t n_cells, const uint8_t* proofs48n, size_t n_p, uint64_t offset, const uint8_t r32[32], uint8_t record512[512]) {
+    if (!c || !r32 || !record512) return MKZG_ERR_BAD_ARGS;
+    memset(record512, 0, 512);
+    CellFold f;
+    int rc = cell_verify_fold(c, commitments48n, n_c, cell_indices, n_i, cells, n_cells, proofs48n, n_p, (uint32_t)offset, r32, &f);
+    int32_t st = rc;
+    memcpy(record512, &st, 4);
+    if (rc == MKZG_OK) {
+        for (int m = 0; m < 4; m++) {
+            G1AffH a;
+            g1h_to_affine(a, f.sums[m]);
+            g1h_compress(record512 + 16 + 48 * m, a);
+        }
+    }
+    return rc;
+}
+int mkzg_verify_cell_kzg_proof_batch_finish(mkzg_ctx* c, const uint8_t* records512, size_t n_records) {
+    if (!c || (n_records && !records512)) return MKZG_ERR_BAD_ARGS;
+    if (c->g2_alpha64.lines.empty()) return MKZG_ERR_BAD_TRUSTED_SETUP;
+    for (size_t k = 0; k < n_records; k++) {                       // first failing rank (lowest indices) decides the error
+        int32_t st;
+        memcpy(&st, records512 + 512 * k, 4);
+        if (st) return st;
+    }
+    CellFold f;
+    for (int m = 0; m < 4; m++) G1H::set_inf(f.sums[m]);
+    for (size_t k = 0; k < n_records; k++) {
+        for (int m = 0; m < 4; m++) {
+            G1AffH a;
+            G1HX t;
+            if (!g1h_decompress(a, records512 + 512 * k + 16 + 48 * m)) return MKZG_ERR_BAD_ARGS;
+            if (a.inf) continue;
+            G1H::from_affine(t, a.x, a.y);
+            G1H::add(f.sums[m], f.sums[m], t);
+        }
+    }
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    return cell_verify_finish(c, f);
 }
 
 // shared front end of RecoverCells / RecoverCellsAndComputeKZGProofs: reference api_eip7594.go:93-142

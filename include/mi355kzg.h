@@ -125,6 +125,15 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* ctx, const void* d_
  * proof per entry; the four counts mirror the four Go slices.  At most 8192 cells per call. */
 int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* commitments48n, size_t n_commitments, const uint64_t* cell_indices, size_t n_indices,
                                      const uint8_t* const* cells, size_t n_cells, const uint8_t* proofs48n, size_t n_proofs);
+/* Sharded form for multi-GPU jobs (the algebra of reference internal/kzg_multi/kzg_verify.go:16-105 split at its
+ * four group sums): a rank folds ITS cells -- global positions offset .. offset + n - 1 of the batch -- with the batch-wide
+ * scalar r32 (32 bytes, big-endian, reduced mod r; the same on every rank) into a 512-byte record: int32 status at 0, then
+ * compressed sum r^k proof_k at 16, sum w_row C_row at 64, [I(tau)]G1 at 112, sum r^k h_k^64 proof_k at 160.  Records of all
+ * ranks (all-gathered, 512 B each) go to _finish on any rank: sums are added, one pairing check decides. */
+int mkzg_verify_cell_kzg_proof_batch_partial(mkzg_ctx* ctx, const uint8_t* commitments48n, size_t n_commitments, const uint64_t* cell_indices, size_t n_indices,
+                                             const uint8_t* const* cells, size_t n_cells, const uint8_t* proofs48n, size_t n_proofs, uint64_t offset,
+                                             const uint8_t r32[32], uint8_t record512[512]);
+int mkzg_verify_cell_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* records512, size_t n_records);
 
 /* Context.RecoverCellsAndComputeKZGProofs (reference api_eip7594.go:144-161): cell_ids strictly ascending, < 128,
  * at least 64 of them; cells are host pointers in the same order. */

@@ -60,6 +60,8 @@ def lib():
         L.kzgo_verify_cell_kzg_proof_batch.argtypes = [vp, u8p, sz, vp, sz, u8p, sz, u8p, sz]
         L.kzgo_verify_blob_batch_partial.argtypes = [vp, u8p, u8p, u8p, sz, C.c_uint64, u8p, u8p]
         L.kzgo_verify_blob_batch_finish.argtypes = [vp, u8p, sz]
+        L.kzgo_verify_cell_batch_partial.argtypes = [vp, u8p, sz, vp, u8p, u8p, C.c_uint64, u8p, u8p]
+        L.kzgo_verify_cell_batch_finish.argtypes = [vp, u8p, sz]
         L.kzgo_fr_fft.argtypes = [u8p, sz, i32]
         L.kzgo_fr_coset_fft.argtypes = [u8p, sz, u8p, i32]
         L.kzgo_g1_msm.argtypes = [u8p, u8p, sz, u8p]
@@ -166,6 +168,17 @@ class OracleContext:
 
     def verify_blob_batch_finish(self, records):
         return self._L.kzgo_verify_blob_batch_finish(self._h, b"".join(records), len(records))
+
+    def verify_cell_batch_partial(self, commitments, cell_indices, cells, proofs, offset, r32):
+        n = len(commitments)
+        assert n == len(cell_indices) == len(cells) == len(proofs)
+        idx = (C.c_uint64 * max(1, n))(*cell_indices)
+        rec = _buf(512)
+        rc = self._L.kzgo_verify_cell_batch_partial(self._h, b"".join(commitments), n, idx, b"".join(cells), b"".join(proofs), offset, bytes(r32), rec)
+        return rc, rec.raw
+
+    def verify_cell_batch_finish(self, records):
+        return self._L.kzgo_verify_cell_batch_finish(self._h, b"".join(records), len(records))
 
     # ---- EIP-7594 (reference api_eip7594.go, api_eip.go)
     def compute_cells(self, blob):

@@ -697,6 +697,71 @@ KZGO_EXPORT int kzgo_verify_cell_kzg_proof_batch(const kzgo_ctx *c, const uint8_
     return rc;
 }
 
+/* Sharded form of VerifyMultiPointKZGProofBatch for multi-GPU jobs: the same algebra (internal/kzg_multi/kzg_verify.go:16-105)
+ * split at its four group sums.  A rank folds the cells with global positions offset..offset+n-1 using the batch-wide r;
+ * record layout as include/mi355kzg.h (mkzg_verify_cell_kzg_proof_batch_partial). */
+KZGO_EXPORT int kzgo_verify_cell_batch_partial(const kzgo_ctx *c, const uint8_t *commitments48, size_t n, const uint64_t *cell_indices, const uint8_t *cells,
+                                               const uint8_t *proofs48, uint64_t offset, const uint8_t r32[32], uint8_t record[512]) {
+    memset(record, 0, 512);
+    size_t n_rows = 0;
+    uint64_t *row_idx = malloc((n + 1) * sizeof(uint64_t)); size_t *row_first = malloc((n + 1) * sizeof(size_t));
+    for (size_t i = 0; i < n; i++) {
+        size_t j;
+        for (j = 0; j < n_rows; j++) if (!memcmp(commitments48 + 48 * row_first[j], commitments48 + 48 * i, 48)) break;
+        if (j == n_rows) row_first[n_rows++] = i;
+        row_idx[i] = j;
+    }
+    int rc = KZG_OK;
+    for (size_t i = 0; i < n; i++) if (cell_indices[i] >= N_CELLS) { rc = KZG_ERR_INVALID_CELL_ID; break; }
+    g1a_t *rows = malloc((n_rows + 1) * sizeof(g1a_t)), *prs = malloc((n + 1) * sizeof(g1a_t));
+    fr_t *ev = malloc((n + 1) * CELL_SZ * sizeof(fr_t));
+    for (size_t i = 0; i < n_rows && !rc; i++) rc = deserialize_g1(&rows[i], commitments48 + 48 * row_first[i]);
+    for (size_t i = 0; i < n && !rc; i++) rc = deserialize_g1(&prs[i], proofs48 + 48 * i);
+    for (size_t i = 0; i < n && !rc; i++) rc = deserialize_cell(&ev[i * CELL_SZ], cells + i * CELL_BYTES);
+    int32_t st = rc;
+    memcpy(record, &st, 4);
+    if (!rc) {
+        fr_t r, *rp = malloc((n + 1) * sizeof(fr_t)), *wts = calloc(n_rows + 1, sizeof(fr_t)), *wrp = malloc((n + 1) * sizeof(fr_t)), interp[CELL_SZ];
+        fr_from_be32_reduce(&r, r32);
+        if (n) fr_pow_u64(&rp[0], &r, offset);
+        for (size_t i = 1; i < n; i++) fr_mul(&rp[i], &rp[i - 1], &r);
+        g1j_t sums[4];
+        msm_g1(&sums[0], rp, prs, n);
+        for (size_t k = 0; k < n; k++) fr_add(&wts[row_idx[k]], &wts[row_idx[k]], &rp[k]);
+        msm_g1(&sums[1], wts, rows, n_rows);
+        for (int i = 0; i < CELL_SZ; i++) fr_zero(&interp[i]);
+        for (size_t k = 0; k < n; k++) {
+            fr_t *e = &ev[k * CELL_SZ];
+            bitrev_fr(e, CELL_SZ);
+            coset_ifft(&c->dom64, &c->coset_shift_inv[cell_indices[k]], e);
+            for (int i = 0; i < CELL_SZ; i++) { fr_t t; fr_mul(&t, &e[i], &rp[k]); fr_add(&interp[i], &interp[i], &t); }
+        }
+        msm_g1(&sums[2], interp, c->g1_monomial, CELL_SZ);
+        for (size_t k = 0; k < n; k++) fr_mul(&wrp[k], &c->coset_shift_pow[cell_indices[k]], &rp[k]);
+        msm_g1(&sums[3], wrp, prs, n);
+        for (int m = 0; m < 4; m++) serialize_g1j(record + 16 + 48 * m, &sums[m]);
+        free(rp); free(wts); free(wrp);
+    }
+    free(row_idx); free(row_first); free(rows); free(prs); free(ev);
+    return rc;
+}
+KZGO_EXPORT int kzgo_verify_cell_batch_finish(const kzgo_ctx *c, const uint8_t *records, size_t n_records) {
+    for (size_t k = 0; k < n_records; k++) { int32_t st; memcpy(&st, records + 512 * k, 4); if (st) return st; }
+    g1j_t sums[4], rl;
+    for (int m = 0; m < 4; m++) g1j_set_inf(&sums[m]);
+    for (size_t k = 0; k < n_records; k++)
+        for (int m = 0; m < 4; m++) {
+            g1a_t p;
+            if (g1a_decompress(&p, records + 512 * k + 16 + 48 * m, 0)) return KZG_ERR_BAD_ARGS;
+            g1j_add_affine(&sums[m], &sums[m], &p);
+        }
+    g1j_sub(&rl, &sums[1], &sums[2]); g1j_add(&rl, &rl, &sums[3]);
+    g1a_t ps[2]; g2a_t qs[2];
+    g1j_to_affine(&ps[0], &sums[0]); g1j_to_affine(&ps[1], &rl);
+    qs[0] = c->g2[CELL_SZ]; g2a_neg(&qs[1], &c->g2[0]);
+    return pairing_check(ps, qs, 2) ? KZG_OK : KZG_VERIFY_FAILED;
+}
+
 /* ------------------------------------------------------------------ unit-level probes (tests only) */
 /* n scalars (32 B big-endian each), in place; inverse!=0 -> IfftFr. n power of two <= 2^20 */
 KZGO_EXPORT int kzgo_fr_fft(uint8_t *vals32, size_t n, int inverse) {

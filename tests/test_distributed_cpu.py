@@ -59,6 +59,38 @@ def _worker(rank, world, port, q):
         out["noncanonical"] = D.verify_blob_kzg_proof_batch_sharded(OracleEngine(), (nc[lo:hi], cms[lo:hi], prs[lo:hi]), n_total, dist)
         out["bounds"] = (lo, hi)
         out["single"] = octx.verify_blob_kzg_proof_batch(blobs, cms, prs)
+
+        # --- sharded VerifyCellKZGProofBatch: 2 blobs x 6 cells, cut 6 / 6 across the two ranks (rows repeat inside a shard)
+        fctx = oracle.OracleContext(with_fk20=True)
+        tuples = []
+        for bi in (0, 1):
+            rc, cells, proofs = fctx.compute_cells_and_kzg_proofs(blobs[bi])
+            assert rc == 0
+            for ci in (0, 5, 64, 127, 33, 2):
+                tuples.append((cms[bi], ci, cells[ci * 2048:(ci + 1) * 2048], proofs[ci * 48:(ci + 1) * 48]))
+
+        class OracleCellEngine:
+            def cell_partial(self, shard, offset, r32):
+                return fctx.verify_cell_batch_partial(*shard, offset, r32)
+
+            def cell_finish(self, records):
+                return fctx.verify_cell_batch_finish(records)
+
+        def run(tups):
+            nt = len(tups)
+            l2, h2 = D.shard_bounds(nt, world, rank)
+            sh = tups[l2:h2]
+            return D.verify_cell_kzg_proof_batch_sharded(OracleCellEngine(), ([t[0] for t in sh], [t[1] for t in sh], [t[2] for t in sh], [t[3] for t in sh]), nt, dist)
+
+        out["cells_valid"] = run(tuples)
+        badp = list(tuples)
+        badp[7] = (badp[7][0], badp[7][1], badp[7][2], badp[8][3])                 # proof of another cell
+        out["cells_corrupt"] = run(badp)
+        badc = list(tuples)
+        badc[10] = (badc[10][0], badc[10][1], b"\xff" * 2048, badc[10][3])          # non-canonical cell on rank 1
+        out["cells_noncanonical"] = run(badc)
+        out["cells_single"] = fctx.verify_cell_kzg_proof_batch([t[0] for t in tuples], [t[1] for t in tuples], [t[2] for t in tuples], [t[3] for t in tuples])
+        fctx.close()
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, out))
@@ -85,6 +117,9 @@ def test_sharded_verify_gloo_world2():
         assert res[r]["valid"] == 0 and res[r]["single"] == 0
         assert res[r]["corrupt"] == 1
         assert res[r]["noncanonical"] == 3
+        assert res[r]["cells_valid"] == 0 and res[r]["cells_single"] == 0
+        assert res[r]["cells_corrupt"] == 1
+        assert res[r]["cells_noncanonical"] == 3
 
 
 def test_shard_bounds_cover():

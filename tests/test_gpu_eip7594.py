@@ -136,3 +136,44 @@ def test_recover_patterns_vs_oracle(gpu_ctx, oracle_ctx):
     assert gpu_ctx.RecoverCells(ids[::-1], [cells[i] for i in ids[::-1]])[0] == 8          # ErrCellIDsNotOrdered
     assert gpu_ctx.RecoverCells(ids, [cells[i] for i in ids[:-1]])[0] == 7                 # ErrNumCellIDsNotEqualNumCells
     assert gpu_ctx.RecoverCells(ids[:-1] + [128], [cells[i] for i in ids])[0] == 9         # ErrFoundInvalidCellID
+
+
+def test_sharded_cell_verifier_records(gpu_ctx, oracle_ctx):
+    """mkzg_verify_cell_kzg_proof_batch_partial / _finish (multi-GPU form): with the same r and offsets the product's 512-byte
+    records equal the oracle's byte for byte, and the combined verdicts agree (valid, corrupted proof, bad cell)"""
+    tuples = []
+    for seed in (61, 62):
+        blob = rand_blob(seed)
+        rc, cm = gpu_ctx.BlobToKZGCommitment(blob)
+        rc2, cells, proofs = gpu_ctx.ComputeCellsAndKZGProofs(blob)
+        assert rc == 0 and rc2 == 0
+        for ci in (0, 5, 64, 127, 33, 2, 99):
+            tuples.append((cm, ci, cells[ci], proofs[ci]))
+    r32 = bytes(range(7, 39))
+    cut = 9                                                   # ranks hold 9 and 5 cells; a commitment row spans the cut
+
+    def records(eng, tups):
+        recs = []
+        for lo, hi in ((0, cut), (cut, len(tups))):
+            sh = tups[lo:hi]
+            rc, rec = eng.verify_cell_batch_partial([t[0] for t in sh], [t[1] for t in sh], [t[2] for t in sh], [t[3] for t in sh], lo, r32)
+            recs.append((rc, rec))
+        return recs
+
+    g, o = records(gpu_ctx, tuples), records(oracle_ctx, tuples)
+    assert [x[0] for x in g] == [0, 0] and g == o
+    assert gpu_ctx.verify_cell_batch_finish([x[1] for x in g]) == 0
+    assert oracle_ctx.verify_cell_batch_finish([x[1] for x in g]) == 0
+    assert gpu_ctx.verify_cell_batch_finish([g[1][1]]) == 0            # a shard alone is a valid (r^offset-scaled) batch as well
+    bad = list(tuples)
+    bad[11] = (bad[11][0], bad[11][1], bad[11][2], bad[12][3])
+    gb = records(gpu_ctx, bad)
+    assert gb == records(oracle_ctx, bad)
+    assert gpu_ctx.verify_cell_batch_finish([x[1] for x in gb]) == 1
+    nc = list(tuples)
+    nc[3] = (nc[3][0], nc[3][1], b"\xff" * 2048, nc[3][3])
+    gn = records(gpu_ctx, nc)
+    assert gn[0][0] == 3 and gpu_ctx.verify_cell_batch_finish([x[1] for x in gn]) == 3
+    # an empty shard contributes the identity
+    rc, rec = gpu_ctx.verify_cell_batch_partial([], [], [], [], 14, r32)
+    assert rc == 0 and gpu_ctx.verify_cell_batch_finish([g[0][1], g[1][1], rec]) == 0

@@ -14,7 +14,8 @@ constexpr int FK_NMULT = 128;    // multiples 1..128 (signed Booth digits)
 size_t fk20_table_bytes();
 // monomial SRS (4096 affine rows) -> T (8192 affine rows, [k][i]) -> direct table (fk20_table_bytes())
 void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fwd, uint32_t* d_t_aff, uint32_t* d_table, hipStream_t s);
-constexpr int FK_PLAN_WORDS = 128 * 8 + 64 * 16 + 128 * 8 + 128 * 8;   // lanes of the four DFT levels (see fk20_kernels.hip)
+constexpr int FK_PLAN_WORDS = 128 * 8 + 64 * 16 + 128 * 8 + 128 * 8 + 128 * 64 + 128 * 64;
+constexpr int FK_DIRECT_MAX_BATCH = 8;   // up to this many blobs per call the G1 transforms run as single-level DFTs (latency over work)   // lanes of the four DFT levels (see fk20_kernels.hip)
 void fk20_build_plan(uint32_t* plan /* FK_PLAN_WORDS, host */);
 
 // scalars [n][128][64][8 words] -> parts [n][128][16] XYZZ rows (scratch) -> results [n][128] XYZZ rows

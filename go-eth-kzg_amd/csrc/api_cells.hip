@@ -302,7 +302,7 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     const uint32_t* pts[4] = {aff_q, aff_rows, c->d_monomial_aff, aff_q};
     const int njob[4] = {(int)n, (int)n_rows, 64, (int)n};
     int vrc = 0;
-    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 4, c->d_v_misc + 16, s));
+    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 4, c->d_v_misc + V_MISC_WORDS_C, c->d_v_misc + 16, s));
     if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     int* h_st = (int*)c->h_v;

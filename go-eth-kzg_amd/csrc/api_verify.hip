@@ -44,7 +44,7 @@ int ensure_verify_ws(mkzg_ctx* c, size_t n) {
     HIPCHK(hipMalloc(&c->d_v_y, cap * 48));
     HIPCHK(hipMalloc(&c->d_v_s1, cap * 32));
     HIPCHK(hipMalloc(&c->d_v_s3, cap * 32));
-    HIPCHK(hipMalloc(&c->d_v_misc, V_MISC_WORDS * 4));
+    HIPCHK(hipMalloc(&c->d_v_misc, (V_MISC_WORDS + VMSM_PART_WORDS) * 4));      // window sums for the host + slice sums (device only)
     c->h_v_bytes = 3 * cap * sizeof(int) + V_MISC_WORDS * 4 + 64;
     HIPCHK(hipHostMalloc(&c->h_v, c->h_v_bytes, hipHostMallocDefault));
     c->v_cap = cap;
@@ -127,7 +127,7 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
     int vrc = 0;
     const int njob[3] = {(int)n, (int)n, (int)n};
-    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, c->d_v_misc + 16, s));
+    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, c->d_v_misc + V_MISC_WORDS, c->d_v_misc + 16, s));
     if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     // 5. one round trip: statuses, e, window sums

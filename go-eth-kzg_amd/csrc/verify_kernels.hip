@@ -19,6 +19,7 @@
 //                        does the 255 serial doublings of the Horner combination.
 // Integer modular arithmetic only -- no MFMA.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include "g1.hpp"
 #include "verify_kernels.h"
@@ -523,17 +524,22 @@ struct VmsmJob {
     const uint32_t* points;    // n affine rows (32 words)
     int n;
 };
-struct VmsmJobs { VmsmJob j[4]; };
+struct VmsmJobs { VmsmJob j[4]; int k[4]; };    // k: point-range slices per (job, window), 1..VMSM_KMAX
 
-__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
+// grid (window, job, slice): a (job, window) pair with many points is cut into up to VMSM_KMAX slices of the point range, each
+// with its own 128 buckets -- the bucket walk is a serial chain of mixed additions per lane, so 8192 points in one workgroup
+// are 64 additions deep where eight slices are 8 deep; k_vmsm_combine adds the slices' window sums.
+__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __restrict__ parts /* [msm][VNWIN][VMSM_KMAX][64] XYZZ */) {
     __shared__ uint32_t ent[VMAXN];
     __shared__ uint32_t hist[VNB + 1];
     __shared__ uint32_t cursor[VNB];
     __shared__ uint32_t xchg[2 * 56];
-    const int w = blockIdx.x, m = blockIdx.y, t = threadIdx.x;
-    const uint32_t* sc = jobs.j[m].scalars;
-    const uint32_t* pts = jobs.j[m].points;
-    const int n = jobs.j[m].n;
+    const int w = blockIdx.x, m = blockIdx.y, t = threadIdx.x, z = blockIdx.z;
+    if (z >= jobs.k[m]) return;
+    const int n_all = jobs.j[m].n, lo = (int)((long long)n_all * z / jobs.k[m]), hi = (int)((long long)n_all * (z + 1) / jobs.k[m]);
+    const uint32_t* sc = jobs.j[m].scalars + (size_t)lo * 8;
+    const uint32_t* pts = jobs.j[m].points + (size_t)lo * 32;
+    const int n = hi - lo;
     hist[t] = 0;
     if (t == 0) hist[VNB] = 0;
     __syncthreads();
@@ -619,27 +625,39 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
         g1x_add_nv(tot, tot, S1);
         for (int q = 0; q < 6; q++) g1x_dbl_nv(S1, S1);
         g1x_add_nv(tot, tot, S1);
-        // export canonical plain coordinates
-        uint32_t* dst = out + ((size_t)m * VNWIN + w) * 48;
-        fp_t c;
-        uint32_t ww[12];
-        const fp_t* src[4] = {&tot.x, &tot.y, &tot.zz, &tot.zzz};
-        for (int k = 0; k < 4; k++) {
-            if (g1x_is_inf(tot)) {
-                for (int q = 0; q < 12; q++) dst[12 * k + q] = 0;
-            } else {
-                Fp::to_plain(c, *src[k]);
-                Fp::to_words32(ww, c);
-                for (int q = 0; q < 12; q++) dst[12 * k + q] = ww[q];
-            }
+        uint32_t* dst = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + z) * 64;
+#pragma unroll
+        for (int i = 0; i < 14; i++) { dst[i] = tot.x.l[i]; dst[14 + i] = tot.y.l[i]; dst[28 + i] = tot.zz.l[i]; dst[42 + i] = tot.zzz.l[i]; }
+    }
+}
+// window sum = sum of its slices; exported as canonical plain coordinates (all-zero = identity) for the host's Horner step
+__global__ void __launch_bounds__(64) k_vmsm_combine(VmsmJobs jobs, int n_msm, const uint32_t* __restrict__ parts, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_msm * VNWIN) return;
+    const int m = g / VNWIN;
+    const uint32_t* src = parts + (size_t)g * VMSM_KMAX * 64;
+    G1X tot, q;
+    g1x_set_inf(tot);
+    for (int z = 0; z < jobs.k[m]; z++) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) { q.x.l[i] = src[z * 64 + i]; q.y.l[i] = src[z * 64 + 14 + i]; q.zz.l[i] = src[z * 64 + 28 + i]; q.zzz.l[i] = src[z * 64 + 42 + i]; }
+        g1x_add_nv(tot, tot, q);
+    }
+    uint32_t* dst = out + (size_t)g * 48;
+    fp_t c;
+    uint32_t ww[12];
+    const fp_t* srcf[4] = {&tot.x, &tot.y, &tot.zz, &tot.zzz};
+    for (int k = 0; k < 4; k++) {
+        if (g1x_is_inf(tot)) {
+            for (int qq = 0; qq < 12; qq++) dst[12 * k + qq] = 0;
+        } else {
+            Fp::to_plain(c, *srcf[k]);
+            Fp::to_words32(ww, c);
+            for (int qq = 0; qq < 12; qq++) dst[12 * k + qq] = ww[qq];
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// set-up: bit-reversed 4096-domain roots and their inverses (Montgomery rows of 12 words)
-// (reference internal/domain/domain.go:51-98 + ReverseRoots, api.go:132)
-// ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_build_roots(uint32_t* __restrict__ roots_brp, uint32_t* __restrict__ inv_roots_brp, int log_n) {
     const int n = 1 << log_n;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -718,17 +736,21 @@ void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_
                         hipStream_t s) {
     hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, exp_offset, d_s1, d_s3, d_e);
 }
-int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_out, hipStream_t s) {
+int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_parts, uint32_t* d_out, hipStream_t s) {
     if (n_msm < 1 || n_msm > 4) return -1;
     VmsmJobs jobs;
+    int kmax = 1;
     for (int m = 0; m < 4; m++) {
         const int q = m < n_msm ? m : 0;
         if (n_per_job[q] < 0 || n_per_job[q] > VMAXN) return -1;
         jobs.j[m].scalars = d_scalars[q];
         jobs.j[m].points = d_points[q];
         jobs.j[m].n = n_per_job[q];
+        jobs.k[m] = std::min(VMSM_KMAX, std::max(1, n_per_job[q] / 1024));
+        if (m < n_msm) kmax = std::max(kmax, jobs.k[m]);
     }
-    hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm), dim3(VNB), 0, s, jobs, d_out);
+    hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts);
+    hipLaunchKernelGGL(k_vmsm_combine, dim3((n_msm * VNWIN + 63) / 64), dim3(64), 0, s, jobs, n_msm, d_parts, d_out);
     return 0;
 }
 void build_roots_device(uint32_t* d_roots_brp, uint32_t* d_inv_roots_brp, int log_n, hipStream_t s) {

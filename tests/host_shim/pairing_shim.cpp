@@ -17,6 +17,47 @@ int shim_pairing_check(const uint8_t* p48, const uint8_t* q96, int n) {
     }
     return pairing_check_prepared(ps.data(), qp.data(), n) ? 1 : 0;
 }
+// cyclotomic_sqr against the general squaring on an element of the cyclotomic subgroup (f^((p^6-1)(p^2+1)) of a Miller-loop
+// value) and on its powers; returns the number of mismatches.  Also checks that it is NOT a squaring outside the subgroup
+// (so the test would notice if the check were vacuous).
+int shim_cyclotomic_sqr_check(const uint8_t* p48, const uint8_t* q96) {
+    G1AffH P;
+    G2Aff Q;
+    if (!g1h_decompress(P, p48) || !g2_decompress(Q, q96)) return -1;
+    G2Prepared pr;
+    g2_prepare(pr, Q);
+    Fp12 f;
+    fp12::one(f);
+    size_t idx = 0;
+    for (int i = 62; i >= 0; i--) {
+        fp12::sqr(f, f);
+        mul_by_line(f, P.y, P.x, pr.lines[idx++]);
+        if ((BLS_X_ABS >> i) & 1) mul_by_line(f, P.y, P.x, pr.lines[idx++]);
+    }
+    Fp12 raw = f, t, g;
+    fp12::conj(t, f);
+    fp12::inv(g, f);
+    fp12::mul(f, t, g);
+    frobenius(t, f);
+    frobenius(t, t);
+    fp12::mul(f, t, f);                       // cyclotomic now
+    int bad = 0;
+    for (int k = 0; k < 20; k++) {
+        Fp12 a, b;
+        fp12::sqr(a, f);
+        cyclotomic_sqr(b, f);
+        if (!(fp6::eq(a.c0, b.c0) && fp6::eq(a.c1, b.c1))) bad++;
+        fp12::mul(f, a, raw.c0.c0.c0.l[0] & 1 ? f : a);      // move to another element of the subgroup
+        fp12::conj(t, f);
+        fp12::mul(t, t, f);                   // x * conj(x) = 1 inside the subgroup
+        if (!fp12::is_one(t)) bad += 100;
+    }
+    Fp12 a, b;
+    fp12::sqr(a, raw);
+    cyclotomic_sqr(b, raw);
+    if (fp6::eq(a.c0, b.c0) && fp6::eq(a.c1, b.c1)) bad += 1000;   // must differ outside the subgroup
+    return bad;
+}
 // [k]P for compressed P, k = 32-byte little-endian words; returns affine x,y as 2x48 big-endian + inf flag
 int shim_g1_mul(const uint8_t* p48, const uint64_t* k, uint8_t* out_xy96) {
     G1AffH a;

@@ -72,6 +72,13 @@ def test_bilinearity(shim, setup):
     print("2-pairing check incl. line preparation: %.1f ms" % (dt * 1e3))
 
 
+def test_cyclotomic_squaring(shim, setup):
+    """Granger-Scott squaring == general Fp12 squaring on 20 elements of the cyclotomic subgroup, and differs outside it"""
+    g1, g2 = setup
+    assert shim.shim_cyclotomic_sqr_check(g1[3], g2[2]) == 0
+    assert shim.shim_cyclotomic_sqr_check(g1[1], g2[0]) == 0
+
+
 def test_g1_mul_matches_oracle(shim, setup):
     import oracle
     g1, _ = setup

@@ -120,9 +120,10 @@ __device__ __forceinline__ void load16_be(uint32_t* w, const uint8_t* p) {   // 
 //
 // A transcript is a serial chain of 2050 compressions, so the only parallel axis is the blob: one LANE per blob.  What
 // can still be taken off that chain is everything that does not depend on the hash state: loading, byte swapping and the
-// message schedule (a third of the instructions).  Each workgroup is therefore two wavefronts on two SIMDs: wave 0
-// PRODUCES W[i] + K[i] of message block k for its 64 blobs into an LDS double buffer while wave 1 CONSUMES block k-1
-// (64 rounds, nothing else); one barrier per message block.  1412 -> ~970 instructions per block on the critical wave.
+// message schedule (more than half of the instructions).  Each workgroup is therefore three wavefronts on three SIMDs:
+// waves 0 and 1 PRODUCE W[i] + K[i] of the even / odd message blocks of their 64 blobs into a four-deep LDS ring while
+// wave 2 CONSUMES the two blocks of the previous step (64 rounds each, nothing else); one barrier per two message blocks.
+// 1412 -> ~640 instructions per block on the critical wave.
 __device__ __forceinline__ void sha_load_block(uint32_t w[16], int k, const uint8_t* __restrict__ blob, const uint8_t* __restrict__ cm) {
     if (k >= 1 && k < 2048) {                       // blob[64k-32 .. 64k+32)
         const uint8_t* p = blob + 64 * k - 32;
@@ -149,20 +150,28 @@ __device__ __forceinline__ void sha_load_block(uint32_t w[16], int k, const uint
     }
 }
 constexpr int SHA_NBLOCKS = 2050;
-__global__ void __launch_bounds__(128) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
-    __shared__ uint32_t wk[2][64][64];              // [buffer][round][lane]: W + K, conflict-free both ways
+__global__ void __launch_bounds__(192) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
+    __shared__ uint4 wk[4][16][64];                 // [message block mod 4][round / 4][lane]: four W + K per 16-byte LDS access
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     const int b0 = blockIdx.x * 64 + lane;
     const int b = b0 < n ? b0 : n - 1;              // surplus lanes shadow the last blob (they must keep the barriers)
     const uint8_t* blob = blobs + (size_t)b * 131072;
     const uint8_t* cm = commitments48 + (size_t)b * 48;
-    if (role == 0) {
+    if (role < 2) {
+        // producers: wave 0 expands the even message blocks, wave 1 the odd ones (the schedule is ~1.5x the instructions of
+        // the rounds, so one producer per consumer would be the bottleneck)
+        uint32_t wn[16];                                  // this wave's next message block, in flight while the current one is expanded
+        sha_load_block(wn, role, blob, cm);
 #pragma unroll 1
-        for (int k = 0; k <= SHA_NBLOCKS; k++) {
+        for (int j = 0; j <= SHA_NBLOCKS / 2; j++) {
+            const int k = 2 * j + role;
             if (k < SHA_NBLOCKS) {
                 uint32_t w[16];
-                sha_load_block(w, k, blob, cm);
-                uint32_t (*dst)[64] = wk[k & 1];
+#pragma unroll
+                for (int i = 0; i < 16; i++) w[i] = wn[i];
+                if (k + 2 < SHA_NBLOCKS) sha_load_block(wn, k + 2, blob, cm);
+                uint4 (*dst)[64] = wk[k & 3];
+                uint32_t q4[4];
 #pragma unroll
                 for (int i = 0; i < 64; i++) {
                     if (i >= 16) {
@@ -171,28 +180,36 @@ __global__ void __launch_bounds__(128) k_challenge_sha256(const uint8_t* __restr
                         const uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
                         w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
                     }
-                    dst[i][lane] = w[i & 15] + SHA_K[i];
+                    q4[i & 3] = w[i & 15] + SHA_K[i];
+                    if ((i & 3) == 3) dst[i >> 2][lane] = make_uint4(q4[0], q4[1], q4[2], q4[3]);
                 }
             }
             __syncthreads();
         }
         return;
     }
+    // consumer: during step j it runs the rounds of blocks 2j-2 and 2j-1 (written in step j-1) while the producers fill 2j, 2j+1
     uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
 #pragma unroll 1
-    for (int k = 0; k <= SHA_NBLOCKS; k++) {
-        if (k >= 1) {
-            const uint32_t (*src)[64] = wk[(k - 1) & 1];
-            uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int j = 0; j <= SHA_NBLOCKS / 2; j++) {
+        if (j >= 1) {
+#pragma unroll 1
+            for (int k = 2 * j - 2; k < 2 * j; k++) {
+                const uint4 (*src)[64] = wk[k & 3];
+                uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+                uint4 wq = src[0][lane];
 #pragma unroll
-            for (int i = 0; i < 64; i++) {
-                const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
-                const uint32_t t1 = hh + S1 + sha_ch(e, f, g) + src[i][lane];
-                const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
-                const uint32_t t2 = S0 + sha_maj(a, bb, c);
-                hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+                for (int i = 0; i < 64; i++) {
+                    if ((i & 3) == 0 && i) wq = src[i >> 2][lane];
+                    const uint32_t wki = (i & 3) == 0 ? wq.x : (i & 3) == 1 ? wq.y : (i & 3) == 2 ? wq.z : wq.w;
+                    const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
+                    const uint32_t t1 = hh + S1 + sha_ch(e, f, g) + wki;
+                    const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
+                    const uint32_t t2 = S0 + sha_maj(a, bb, c);
+                    hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+                }
+                h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
             }
-            h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
         }
         __syncthreads();
     }
@@ -718,7 +735,7 @@ __global__ void __launch_bounds__(64) k_fr_to_scalars(const uint32_t* __restrict
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(128), 0, s, d_blobs, d_commitments, n, d_z);
+    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(192), 0, s, d_blobs, d_commitments, n, d_z);
 }
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EV_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);

@@ -232,6 +232,8 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     std::vector<uint32_t> row_idx(n_c);
     std::vector<uint8_t> rows;
     for (size_t i = 0; i < n_c; i++) {
+        // cells usually arrive blob-major: a commitment equal to its predecessor needs no hashing
+        if (i > 0 && !memcmp(commitments48n + 48 * i, commitments48n + 48 * (i - 1), 48)) { row_idx[i] = row_idx[i - 1]; continue; }
         std::string key((const char*)commitments48n + 48 * i, 48);
         auto it = seen.find(key);
         if (it == seen.end()) {

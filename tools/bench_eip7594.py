@@ -73,7 +73,18 @@ def main():
         assert ctx.VerifyCellKZGProofBatch(c_list, i_list, cell_list, p_list) == 0
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile_read(reset=True)
+    # the same call at the C ABI, arguments marshalled once (what a cgo caller pays: no Python list handling in the loop)
+    import ctypes as C
+    L = kzg.lib()
+    idx = (C.c_uint64 * n)(*i_list)
+    arr = (C.c_char_p * n)(*cell_list)
+    cj, pj = b"".join(c_list), b"".join(p_list)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, pj, n) == 0
+    dt_c = (time.perf_counter() - t0) / steps
     out["verify_cell_kzg_proof_batch"] = {"cells": n, "ms_per_call_incl_host_copy_of_16MiB": round(dt * 1e3, 3), "cells_per_s": round(n / dt, 1),
+                                          "ms_per_call_c_abi": round(dt_c * 1e3, 3), "cells_per_s_c_abi": round(n / dt_c, 1),
                                           "kernels_ms": {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}}
     # config 5b
     ids = list(range(0, 128, 2))

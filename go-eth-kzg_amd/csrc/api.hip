@@ -249,10 +249,20 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, s
         if (c->direct_bits_built != c->opt_direct_bits) {
             const int cb = c->opt_direct_bits, nwin = (255 + cb - 1) / cb;
             uint32_t* tmp = nullptr;
-            HIPCHK(hipMalloc(&tmp, (size_t)nwin * 4096 * 128));
             if (c->d_direct) (void)hipFree(c->d_direct);
             c->d_direct = nullptr;
-            HIPCHK(hipMalloc(&c->d_direct, direct_table_bytes(cb)));
+            c->direct_bits_built = 0;
+            if (hipMalloc(&c->d_direct, direct_table_bytes(cb)) != hipSuccess) {       // e.g. 146 GB not available on this device
+                (void)hipGetLastError();
+                c->d_direct = nullptr;
+                return MKZG_ERR_HIP;
+            }
+            if (hipMalloc(&tmp, (size_t)nwin * 4096 * 128) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipFree(c->d_direct);
+                c->d_direct = nullptr;
+                return MKZG_ERR_HIP;
+            }
             build_table_any_device(cb, c->d_lagrange_aff, tmp, 4096, 12, c->stream);
             build_direct_device(cb, tmp, c->d_direct, c->stream);
             HIPCHK(hipGetLastError());

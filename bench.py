@@ -225,7 +225,7 @@ def main():
         }
         if verify is not None:
             out["verify_blob_kzg_proof_batch"] = verify
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -239,12 +239,10 @@ int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
     return MKZG_ERR_BAD_ARGS;
 }
 
-// device-resident batch: the product's hot path
-int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, size_t n, void* d_out48n, int* d_status, void* stream) {
-    if (!c || (!d_blobs && n) || (!d_out48n && n) || (!d_status && n)) return MKZG_ERR_BAD_ARGS;
-    std::lock_guard<std::recursive_mutex> g(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = (hipStream_t)stream;
+// Commitments of n polynomials in Lagrange form against the bit-reversed Lagrange SRS, with the method the context is
+// configured for (direct window table or buckets).  input_kind 0: 32-byte big-endian scalars (blobs, canonicity checked);
+// 1: 12-word Montgomery Fr rows (quotient polynomials of the proof path).  Caller holds c->mu and has set the device.
+int commit_scalars_device(mkzg_ctx* c, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s) {
     if (c->opt_direct_bits) {
         if (c->direct_bits_built != c->opt_direct_bits) {
             const int cb = c->opt_direct_bits, nwin = (255 + cb - 1) / cb;
@@ -292,8 +290,8 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, s
             if (c->slot_used[slot]) HIPCHK(hipStreamWaitEvent(s, c->slot_done[slot], 0));
             c->dslots[slot].wait_before_acc = (c->opt_chain_acc && c->last_acc_slot >= 0) ? c->acc_done[c->last_acc_slot] : nullptr;
             c->dslots[slot].record_after_acc = c->acc_done[slot];
-            commit_direct_device(c->opt_direct_bits, c->d_direct, c->dslots[slot], (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB, MKZG_BYTES_PER_BLOB, chunk,
-                                 (uint8_t*)d_out48n + done * 48, d_status + done, s, c->profiling ? &c->timer : nullptr);
+            commit_direct_device(c->opt_direct_bits, c->d_direct, c->dslots[slot], d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, d_out48n + done * 48,
+                                 d_status + done, s, c->profiling ? &c->timer : nullptr);
             int rr = release_slot(c, slot, s);
             if (rr) return rr;
             done += chunk;
@@ -308,14 +306,21 @@ int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, s
         int chunk = (int)std::min<size_t>(n - done, (size_t)c->plan.max_batch);
         const int slot = acquire_slot(c, s);
         if (slot < 0) return MKZG_ERR_HIP;
-        commit_batch_device(c->slots[slot], (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB, MKZG_BYTES_PER_BLOB, 0, chunk, (uint8_t*)d_out48n + done * 48,
-                            d_status + done, s, c->profiling ? &c->timer : nullptr);
+        commit_batch_device(c->slots[slot], d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, d_out48n + done * 48, d_status + done, s,
+                            c->profiling ? &c->timer : nullptr);
         int rr = release_slot(c, slot, s);
         if (rr) return rr;
         done += chunk;
     }
     HIPCHK(hipGetLastError());
     return MKZG_OK;
+}
+// device-resident batch: the product's hot path
+int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, size_t n, void* d_out48n, int* d_status, void* stream) {
+    if (!c || (!d_blobs && n) || (!d_out48n && n) || (!d_status && n)) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    return commit_scalars_device(c, (const uint8_t*)d_blobs, MKZG_BYTES_PER_BLOB, 0, n, (uint8_t*)d_out48n, d_status, (hipStream_t)stream);
 }
 
 int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item) {

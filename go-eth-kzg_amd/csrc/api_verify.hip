@@ -28,7 +28,7 @@ void free_verify_ws(mkzg_ctx* c) {
     if (c->h_v) (void)hipHostFree(c->h_v);
     c->d_v_raw = nullptr; c->d_v_aff = nullptr; c->d_v_st = nullptr; c->d_v_z = nullptr; c->d_v_y = nullptr; c->d_v_s1 = nullptr; c->d_v_s3 = nullptr;
     c->d_v_misc = nullptr; c->d_quot = nullptr; c->d_q_z = nullptr; c->d_q_y = nullptr; c->d_q_st = nullptr; c->h_v = nullptr;
-    c->v_cap = 0; c->q_cap = 0; c->h_v_bytes = 0;
+    c->v_cap = 0; c->q_cap = 0; c->quot_cap = 0; c->h_v_bytes = 0;
 }
 int ensure_verify_ws(mkzg_ctx* c, size_t n) {
     if (n <= c->v_cap) return MKZG_OK;
@@ -50,12 +50,21 @@ int ensure_verify_ws(mkzg_ctx* c, size_t n) {
     c->v_cap = cap;
     return MKZG_OK;
 }
-int ensure_quot_ws(mkzg_ctx* c, size_t n) {
+// n: scalars / statuses per call (z, y, status arrays); n_quot: polynomials whose 4096 quotient rows are held at once
+int ensure_quot_ws(mkzg_ctx* c, size_t n, size_t n_quot) {
+    if (n_quot > c->quot_cap) {
+        if (c->d_quot) (void)hipFree(c->d_quot);
+        c->d_quot = nullptr;
+        c->quot_cap = 0;
+        HIPCHK(hipMalloc(&c->d_quot, n_quot * 4096 * 48));
+        c->quot_cap = n_quot;
+    }
     if (n <= c->q_cap) return MKZG_OK;
-    void* ptrs[] = {c->d_quot, c->d_q_z, c->d_q_y, c->d_q_st};
+    void* ptrs[] = {c->d_q_z, c->d_q_y, c->d_q_st};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    c->d_q_z = c->d_q_y = nullptr;
+    c->d_q_st = nullptr;
     c->q_cap = 0;
-    HIPCHK(hipMalloc(&c->d_quot, n * 4096 * 48));
     HIPCHK(hipMalloc(&c->d_q_z, n * 48));
     HIPCHK(hipMalloc(&c->d_q_y, n * 48));
     HIPCHK(hipMalloc(&c->d_q_st, 2 * n * sizeof(int)));
@@ -303,39 +312,47 @@ int mkzg_compute_blob_kzg_proof_batch_device(mkzg_ctx* c, const void* d_blobs, c
     if (n == 0) return MKZG_OK;
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
-    int rc = ensure_plan(c);
-    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    // Slices of up to 4096 proofs.  Per slice the latency-bound stages run ONCE over the whole slice -- Fiat-Shamir challenges
+    // (a 2050-compression chain per blob whatever the count) on the caller's stream, commitment decoding + subgroup checks on the
+    // side stream -- and only the quotient + MSM stage is cut into max_batch pieces (its workspace is 196 KB per blob).
     size_t done = 0;
     while (done < n) {
-        size_t chunk = std::min<size_t>(n - done, (size_t)c->plan.max_batch);
-        rc = ensure_quot_ws(c, (size_t)c->plan.max_batch);
+        const size_t slice = std::min<size_t>(n - done, 4096);
+        int rc = ensure_quot_ws(c, std::max<size_t>((size_t)c->opt_max_batch, slice), (size_t)c->opt_max_batch);
         if (rc) return rc;
-        rc = ensure_verify_ws(c, chunk);
+        rc = ensure_verify_ws(c, slice);
         if (rc) return rc;
         const uint8_t* blobs = (const uint8_t*)d_blobs + done * MKZG_BYTES_PER_BLOB;
         const uint8_t* cms = (const uint8_t*)d_commitments48 + done * 48;
+        int* st_blob = c->d_q_st;
+        int* st_cm = c->d_q_st + c->q_cap;
         // commitment must be a valid subgroup point (prove.go:56-62)
-        g1_decompress_device(cms, (int)chunk, c->d_v_aff, c->d_q_st + c->q_cap, s);
-        g1_subgroup_check_device(c->d_v_aff, (int)chunk, c->d_q_st + c->q_cap, s);
-        KT(KT_SHA256, s, challenge_device(blobs, cms, (int)chunk, c->d_q_z, s));
-        KT(KT_QUOTIENT, s, blob_quotient_device(blobs, c->d_q_z, c->d_roots_brp, c->d_inv_roots_brp, (int)chunk, c->d_q_y, c->d_quot, c->d_q_st, s));
-        const int slot = acquire_slot(c, s);
-        if (slot < 0) return MKZG_ERR_HIP;
-        commit_batch_device(c->slots[slot], (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, (int)chunk, (uint8_t*)d_proofs48 + done * 48, d_status + done, s,
-                            c->profiling ? &c->timer : nullptr);
-        if (release_slot(c, slot, s)) return MKZG_ERR_HIP;
+        HIPCHK(hipEventRecord(c->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        g1_decompress_device(cms, (int)slice, c->d_v_aff, st_cm, c->side);
+        g1_subgroup_check_device(c->d_v_aff, (int)slice, st_cm, c->side);
+        HIPCHK(hipEventRecord(c->ev_join, c->side));
+        KT(KT_SHA256, s, challenge_device(blobs, cms, (int)slice, c->d_q_z, s));
+        for (size_t off = 0; off < slice; off += (size_t)c->opt_max_batch) {
+            const size_t chunk = std::min<size_t>(slice - off, (size_t)c->opt_max_batch);
+            KT(KT_QUOTIENT, s, blob_quotient_device(blobs + off * MKZG_BYTES_PER_BLOB, c->d_q_z + off * 12, c->d_roots_brp, c->d_inv_roots_brp, (int)chunk, c->d_q_y + off * 12,
+                                                    c->d_quot, st_blob + off, s));
+            rc = commit_scalars_device(c, (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, chunk, (uint8_t*)d_proofs48 + (done + off) * 48, d_status + done + off, s);
+            if (rc) return rc;
+        }
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
         // merge statuses: blob error first, then commitment error (prove.go:49-62)
         HIPCHK(hipGetLastError());
-        std::vector<int> stb(chunk), stc(chunk);
-        HIPCHK(hipMemcpyAsync(stb.data(), c->d_q_st, chunk * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(stc.data(), c->d_q_st + c->q_cap, chunk * sizeof(int), hipMemcpyDeviceToHost, s));
+        std::vector<int> stb(slice), stc(slice);
+        HIPCHK(hipMemcpyAsync(stb.data(), st_blob, slice * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(stc.data(), st_cm, slice * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         bool any = false;
-        for (size_t i = 0; i < chunk; i++) { stb[i] = stb[i] ? stb[i] : stc[i]; any = any || stb[i]; }
-        if (any) HIPCHK(hipMemcpyAsync(d_status + done, stb.data(), chunk * sizeof(int), hipMemcpyHostToDevice, s));
+        for (size_t i = 0; i < slice; i++) { stb[i] = stb[i] ? stb[i] : stc[i]; any = any || stb[i]; }
+        if (any) HIPCHK(hipMemcpyAsync(d_status + done, stb.data(), slice * sizeof(int), hipMemcpyHostToDevice, s));
         if (any) HIPCHK(hipStreamSynchronize(s));
-        done += chunk;
+        done += slice;
     }
     return MKZG_OK;
 }
@@ -369,11 +386,9 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     if (!blob) return MKZG_ERR_NIL_INPUT;
     std::lock_guard<std::recursive_mutex> g(c->mu);
     HIPCHK(hipSetDevice(c->device));
-    int rc = ensure_plan(c);
+    int rc = ensure_staging(c, 1, MKZG_BYTES_PER_BLOB + 128);
     if (rc) return rc;
-    rc = ensure_staging(c, 1, MKZG_BYTES_PER_BLOB + 128);
-    if (rc) return rc;
-    rc = ensure_quot_ws(c, (size_t)c->plan.max_batch);
+    rc = ensure_quot_ws(c, (size_t)c->opt_max_batch, (size_t)c->opt_max_batch);
     if (rc) return rc;
     hipStream_t s = c->stream;
     memcpy(c->h_stage, blob, MKZG_BYTES_PER_BLOB);
@@ -382,10 +397,8 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     int* st_z = c->d_q_st + c->q_cap;
     scalars_to_fr_device(c->d_blobs + MKZG_BYTES_PER_BLOB, 1, c->d_q_z, st_z, s);
     blob_quotient_device(c->d_blobs, c->d_q_z, c->d_roots_brp, c->d_inv_roots_brp, 1, c->d_q_y, c->d_quot, c->d_q_st, s);
-    const int slot = acquire_slot(c, s);
-    if (slot < 0) return MKZG_ERR_HIP;
-    commit_batch_device(c->slots[slot], (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, 1, c->d_out, c->d_status, s, c->profiling ? &c->timer : nullptr);
-    if (release_slot(c, slot, s)) return MKZG_ERR_HIP;
+    rc = commit_scalars_device(c, (const uint8_t*)c->d_quot, (size_t)4096 * 48, 1, 1, c->d_out, c->d_status, s);
+    if (rc) return rc;
     fr_to_scalars_device(c->d_q_y, 1, c->d_blobs + MKZG_BYTES_PER_BLOB + 64, s);
     HIPCHK(hipGetLastError());
     int stb = 0, stz = 0;

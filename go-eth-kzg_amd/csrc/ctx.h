@@ -86,7 +86,7 @@ struct mkzg_ctx {
     uint8_t* h_v = nullptr;                // pinned: statuses + misc
     size_t h_v_bytes = 0;
     // quotient workspace (proof computation), q_cap blobs
-    size_t q_cap = 0;
+    size_t q_cap = 0, quot_cap = 0;        // capacities of the scalar/status arrays and of the quotient rows
     uint32_t* d_quot = nullptr;            // q_cap x 4096 Fr rows
     uint32_t* d_q_z = nullptr;
     uint32_t* d_q_y = nullptr;
@@ -135,9 +135,10 @@ struct mkzg_ctx {
 int ensure_plan(mkzg_ctx* c);
 int acquire_slot(mkzg_ctx* c, hipStream_t s);          // returns slot index (>= 0) or -1
 int release_slot(mkzg_ctx* c, int slot, hipStream_t s);
+extern "C" int commit_scalars_device(mkzg_ctx* c, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s);
 extern "C" int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item);   // defined inside api.hip's extern "C" block
 int ensure_verify_ws(mkzg_ctx* c, size_t n);
-int ensure_quot_ws(mkzg_ctx* c, size_t n);
+int ensure_quot_ws(mkzg_ctx* c, size_t n, size_t n_quot);
 void free_verify_ws(mkzg_ctx* c);
 int ensure_cells(mkzg_ctx* c, size_t n);
 void free_cells(mkzg_ctx* c);

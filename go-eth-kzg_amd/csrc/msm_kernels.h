@@ -84,7 +84,7 @@ struct DirectSlot {
 };
 size_t direct_parts_bytes(int max_batch);
 double valu_calibrate_device(hipStream_t s);   // sustained v_mad_u64_u32 wave-instructions per second on this GPU
-void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status,
-                          hipStream_t s, KernelTimer* kt);
+void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48,
+                          int* d_status, hipStream_t s, KernelTimer* kt);
 
 }  // namespace kzg

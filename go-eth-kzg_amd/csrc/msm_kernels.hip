@@ -556,7 +556,7 @@ __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
 // shift register: static register indices only), prefetching the table row of window j+1 while the row of
 // window j is added.  When C divides 255 the signed recoding has no spare top window; scalars with bit 254
 // set are replaced by r - s (top digit then <= 2^(C-1)) and every digit sign is flipped.
-template <int C>
+template <int C, int INPUT_KIND>     // INPUT_KIND 0: 32-byte big-endian scalars (blobs); 1: 12-word Montgomery Fr rows (quotient polynomials)
 __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, const uint32_t* __restrict__ direct,
                                                             uint32_t* __restrict__ parts, int* __restrict__ bad_flags) {
     using RC = Recode<C>;
@@ -572,8 +572,17 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
     for (int k = 0; k < 8; k++) {
         const int i = (half * 8 + k) * DTA + t;
         uint32_t w[8];
-        load_scalar_be(w, scalars + (size_t)b * scalar_stride_bytes + (size_t)i * 32);
-        bad |= !scalar_is_canonical(w);
+        if (INPUT_KIND == 0) {
+            load_scalar_be(w, scalars + (size_t)b * scalar_stride_bytes + (size_t)i * 32);
+            bad |= !scalar_is_canonical(w);
+        } else {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(scalars + (size_t)b * scalar_stride_bytes) + (size_t)i * 12;
+            fr_t m, pl;
+#pragma unroll
+            for (int q = 0; q < 9; q++) m.l[q] = src[q];
+            Fr::to_plain(pl, m);
+            Fr::to_words32(w, pl);
+        }
         bool flip = false;
         if (TIGHT && ((w[7] >> 30) & 1)) {
             flip = true;
@@ -776,18 +785,23 @@ void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table,
     }
 }
 size_t direct_parts_bytes(int max_batch) { return (size_t)max_batch * DPARTS * 64 * sizeof(uint32_t); }
-void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int n, uint8_t* d_out48, int* d_status,
+template <int KIND>
+static void launch_direct_acc(int c, dim3 grid, hipStream_t s, const uint8_t* d_scalars, size_t stride, const uint32_t* d_direct, const DirectSlot& ws) {
+    switch (c) {
+        case 12: hipLaunchKernelGGL((k_commit_direct_acc<12, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
+        case 13: hipLaunchKernelGGL((k_commit_direct_acc<13, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
+        case 14: hipLaunchKernelGGL((k_commit_direct_acc<14, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
+        default: hipLaunchKernelGGL((k_commit_direct_acc<15, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
+    }
+}
+void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status,
                           hipStream_t s, KernelTimer* kt) {
     if (n <= 0) return;
     if (ws.wait_before_acc) (void)hipStreamWaitEvent(s, ws.wait_before_acc, 0);
     if (kt) kt->begin(KT_COMMIT_DIRECT, s);
     const dim3 grid(DBLK, n);
-    switch (c) {
-        case 12: hipLaunchKernelGGL((k_commit_direct_acc<12>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
-        case 13: hipLaunchKernelGGL((k_commit_direct_acc<13>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
-        case 14: hipLaunchKernelGGL((k_commit_direct_acc<14>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
-        default: hipLaunchKernelGGL((k_commit_direct_acc<15>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
-    }
+    if (input_kind == 0) launch_direct_acc<0>(c, grid, s, d_scalars, stride, d_direct, ws);
+    else launch_direct_acc<1>(c, grid, s, d_scalars, stride, d_direct, ws);
     if (kt) kt->end(KT_COMMIT_DIRECT, s);
     if (ws.record_after_acc) (void)hipEventRecord(ws.record_after_acc, s);
     if (kt) kt->begin(KT_COMMIT_DIRECT_FIN, s);

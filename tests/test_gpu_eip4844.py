@@ -189,3 +189,40 @@ def test_sharded_verify_records_match_oracle(gpu_ctx, oracle_ctx, product):
     spec.loader.exec_module(D)
     eng = D.ProductEngine(gpu_ctx)
     assert D.verify_blob_kzg_proof_batch_sharded(eng, (d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, st), n) == 0
+
+
+def test_proofs_with_direct_table(product, oracle_ctx):
+    """with commit_direct_bits set, the proof MSMs (quotient polynomials as Montgomery Fr rows) go through the direct window
+    table as well: ComputeKZGProof / ComputeBlobKZGProof / the device batch path (several max_batch pieces) equal the oracle"""
+    import torch
+    torch.cuda.init()
+    from test_gpu_commit import rand_blob
+    ctx = product.Context()
+    assert ctx.set_option("max_batch", 2) == 0
+    assert ctx.set_option("commit_direct_bits", 12) == 0
+    blobs = [rand_blob(70 + i) for i in range(5)] + [bytes(131072)]
+    cms = []
+    for b in blobs:
+        rc, cm = ctx.BlobToKZGCommitment(b)
+        assert rc == 0 and cm == oracle_ctx.blob_to_kzg_commitment(b)[1]
+        cms.append(cm)
+    for b, cm in zip(blobs[:2] + blobs[5:], cms[:2] + cms[5:]):
+        rc, pr = ctx.ComputeBlobKZGProof(b, cm)
+        assert rc == 0 and pr == oracle_ctx.compute_blob_kzg_proof(b, cm)[1]
+    z = (12345).to_bytes(32, "big")
+    rc, pr, y = ctx.ComputeKZGProof(blobs[1], z)
+    assert (rc, pr, y) == (0,) + tuple(oracle_ctx.compute_kzg_proof(blobs[1], z)[1:])
+    n = len(blobs)
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cm = torch.frombuffer(bytearray(b"".join(cms)), dtype=torch.uint8).cuda()
+    d_pr = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), n, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert d_st.cpu().tolist() == [0] * n
+    pr = bytes(d_pr.cpu().tolist())
+    for i in range(n):
+        assert pr[48 * i:48 * i + 48] == oracle_ctx.compute_blob_kzg_proof(blobs[i], cms[i])[1]
+    assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), n, st) == 0
+    ctx.close()

@@ -58,8 +58,8 @@ def rand_blob(seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="blobs per GPU per step (config 2: 256)")
     ap.add_argument("--window", type=int, default=0, help="MSM window bits override (11..13)")
     ap.add_argument("--direct-bits", type=int, default=15,

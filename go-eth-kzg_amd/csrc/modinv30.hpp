@@ -29,14 +29,14 @@ struct ModInv30 {
             if (delta > 0 && (g & 1u)) {
                 delta = 1 - delta;
                 uint32_t nf = g, ng = (g - f) >> 1;
-                int32_t nu = q << 1, nv = r << 1, nq = q - u, nr = r - v;
+                int32_t nu = q * 2, nv = r * 2, nq = q - u, nr = r - v;      // (* 2, not << 1: the entries are signed)
                 f = nf; g = ng; u = nu; v = nv; q = nq; r = nr;
             } else {
                 delta = 1 + delta;
                 if (g & 1u) { g += f; q += u; r += v; }
                 g >>= 1;
-                u <<= 1;
-                v <<= 1;
+                u *= 2;
+                v *= 2;
             }
         }
         t[0] = u; t[1] = v; t[2] = q; t[3] = r;

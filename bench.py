@@ -78,12 +78,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test aids for a 1-GPU box (never set by the driver): run the N > 1 code path with all ranks on GPU 0 over gloo
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     kzg = load_product()
     ctx = kzg.Context(device=local_rank)
@@ -292,7 +299,7 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
         D = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(D)
         eng = D.ProductEngine(ctx)
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         for _ in range(args.verify_steps):
             rc = D.verify_blob_kzg_proof_batch_sharded(eng, (d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st), N * world, dist, dev)
             assert rc == 0

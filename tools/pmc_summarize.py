@@ -13,12 +13,21 @@ src, prefix = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: [0.0, 0])          # (kernel, counter) -> [sum, launches]
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     per_dispatch = defaultdict(float)
+    grid = {}
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row["Kernel_Name"].split("(")[0]
             k = k.replace("void ", "").split("<")[0].replace("kzg::", "")
             per_dispatch[(row["Dispatch_Id"], k, row["Counter_Name"])] += float(row["Counter_Value"])
-    for (_, k, c), v in per_dispatch.items():
+            grid[(row["Dispatch_Id"], k)] = int(row["Grid_Size"])
+    # per kernel, keep the launches with the LARGEST grid only: bench.py also launches some kernels on a single blob
+    # (table-build probe, cross-check), which would dilute the per-launch means of the batch-256 launches
+    gmax = defaultdict(int)
+    for (d, k), g in grid.items():
+        gmax[k] = max(gmax[k], g)
+    for (d, k, c), v in per_dispatch.items():
+        if grid[(d, k)] != gmax[k]:
+            continue
         acc[(k, c)][0] += v
         acc[(k, c)][1] += 1
 rows = sorted(acc.items())

@@ -44,3 +44,24 @@ def test_no_cpu_fallback(product):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         product.Context()
+
+
+def test_c_caller_compiles_links_and_fails_cleanly(product):
+    """include/mi355kzg.h is plain C99 and libmi355kzg.so links into a C program (what cgo does); without a GPU the
+    program's mkzg_ctx_new returns MKZG_ERR_HIP instead of aborting or falling back"""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c_abi", "use_all.c")
+    exe = os.path.join(ROOT, "tests", "c_abi", "use_all")
+    libdir = os.path.join(ROOT, "go-eth-kzg_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L", libdir, "-lmi355kzg", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "trusted_setup.json")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert "MKZG_ERR_HIP" in r.stdout
+    # every declared symbol is referenced by the C program
+    with open(src) as fh:
+        txt = fh.read()
+    for n in declared_symbols():
+        assert "(any_fn)" + n in txt, n

@@ -142,3 +142,15 @@ def test_options_and_calibration(product, oracle_ctx):
     rate = ctx.valu_calibrate()
     ctx.close()
     assert rate is not None and 1e11 < rate < 2e12                   # 100 G .. 2 T wave-instructions / s
+
+
+def test_c_program_through_the_abi():
+    """tests/c_abi/use_all.c (plain C99 against include/mi355kzg.h, as cgo would bind it) commits the zero blob on the GPU"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src, exe, libdir = os.path.join(root, "tests", "c_abi", "use_all.c"), os.path.join(root, "tests", "c_abi", "use_all"), os.path.join(root, "go-eth-kzg_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), src, "-o", exe, "-L", libdir, "-lmi355kzg",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, os.path.join(root, "tests", "golden", "trusted_setup.json")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "commitment of the zero blob: rc=0 ok" in r.stdout, r.stdout + r.stderr

@@ -72,17 +72,33 @@ __device__ __forceinline__ void f_store_xyzz(uint32_t* rec, const G1X& p) {
 
 // r = [k]p for a twiddle k given by its GLV halves kk = (k1[4 words], k2[4 words]), k = k1 + k2 x^2:
 //   [k]p = [k1]p - [k2]phi(p),  phi(X, Y, ZZ, ZZZ) = (beta X, Y, ZZ, ZZZ)
-// Straus/Shamir with 4-bit windows over both halves: 128 doublings + <= 64 additions, one table of 15
-// multiples of p (kept in the lane's private memory).
+// Straus/Shamir with signed 5-bit windows over both halves, one table of 16 multiples of p (kept in the lane's private memory).
+// Signed 5-bit Booth digit w of a 128-bit half-scalar k (4 words): value in [-16, 16], sum_w d_w 32^w = k, w = 0..25
+__device__ __forceinline__ int glv_digit5(const uint32_t* k, int w) {
+    const int bit = 5 * w - 1;
+    uint32_t v;
+    if (bit < 0) {
+        v = (k[0] << 1) & 0x3fu;
+    } else {
+        const int wi = bit >> 5, off = bit & 31;
+        v = wi < 4 ? k[wi] >> off : 0u;
+        if (off + 6 > 32 && wi + 1 < 4) v |= k[wi + 1] << (32 - off);
+        v &= 0x3fu;
+    }
+    int d = (int)((v + 1) >> 1);
+    if (v >> 5) d -= 32;
+    return d;
+}
 __device__ __noinline__ void f_mul_glv(G1X& r, const G1X& p, const uint32_t* kk) {
     // group operations are inlined here (one copy each, inside rolled loops) so that the accumulator stays in registers;
-    // only the 15-entry table is addressed dynamically and lives in the lane's scratch memory
-    G1X tbl[15];
+    // only the 16-entry table (1..16 times p) is addressed dynamically and lives in the lane's scratch memory.
+    // 26 signed 5-bit windows over both half-scalars: 125 doublings + <= 52 additions + 15 for the table.
+    G1X tbl[16];
     tbl[0] = p;
     {
         G1X run = p;
 #pragma unroll 1
-        for (int i = 1; i < 15; i++) {
+        for (int i = 1; i < 16; i++) {
             g1x_add(run, run, p);
             tbl[i] = run;
         }
@@ -91,23 +107,22 @@ __device__ __noinline__ void f_mul_glv(G1X& r, const G1X& p, const uint32_t* kk)
     Fp::set(beta, FP_BETA);
     G1X acc;
     g1x_set_inf(acc);
-    int top = 31;
-    while (top >= 0 && (((kk[top >> 3] | kk[4 + (top >> 3)]) >> (4 * (top & 7))) & 15u) == 0) top--;
+    int top = 25;
+    while (top >= 0 && glv_digit5(kk, top) == 0 && glv_digit5(kk + 4, top) == 0) top--;
 #pragma unroll 1
     for (int w = top; w >= 0; w--) {
         if (w != top) {
 #pragma unroll 1
-            for (int q = 0; q < 4; q++) g1x_dbl(acc, acc);
+            for (int q = 0; q < 5; q++) g1x_dbl(acc, acc);
         }
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
-            const uint32_t d = (kk[4 * half + (w >> 3)] >> (4 * (w & 7))) & 15u;
+            const int d = glv_digit5(kk + 4 * half, w);
             if (d) {
-                G1X q = tbl[d - 1];
-                if (half) {                                  // -phi(.): (beta X, -Y); harmless on the identity (ZZ stays 0)
-                    Fp::mul(q.x, q.x, beta);
-                    Fp::template neg<2>(q.y, q.y);
-                }
+                G1X q = tbl[(d < 0 ? -d : d) - 1];
+                // second half: -phi(.) = (beta X, -Y); a negative digit flips the sign once more
+                if (half) Fp::mul(q.x, q.x, beta);
+                if ((d < 0) != (half != 0)) Fp::template neg<2>(q.y, q.y);
                 g1x_add(acc, acc, q);
             }
         }

@@ -433,16 +433,19 @@ __global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __rest
     load_affine_v(p, aff + (size_t)i * 32);
     if (p.inf) return;
     // T = [|x|]P, Q = [|x|]T   (|x| = 0xd201000000010000, top bit at 63)
-    G1X T, Q;
-    g1x_from_affine(T, p.x, p.y);
-    for (int bit = 62; bit >= 0; bit--) {
-        g1x_dbl_nv(T, T);
-        if ((BLS_X_ABS >> bit) & 1) g1x_madd_nv(T, p.x, p.y);
-    }
-    Q = T;
-    for (int bit = 62; bit >= 0; bit--) {
-        g1x_dbl_nv(Q, Q);
-        if ((BLS_X_ABS >> bit) & 1) g1x_add_nv(Q, Q, T);
+    // both chains in ONE rolled loop (pass 0: T = [|x|]P, pass 1: Q = [|x|]T) with the doubling inlined, so that the running
+    // point stays in registers through the 126 doublings; the five additions per pass go through the called routine
+    G1X Q, base;
+    g1x_from_affine(base, p.x, p.y);
+    Q = base;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+        for (int bit = 62; bit >= 0; bit--) {
+            g1x_dbl(Q, Q);
+            if ((BLS_X_ABS >> bit) & 1) g1x_add_nv(Q, Q, base);
+        }
+        if (pass == 0) base = Q;
     }
     // phi(P) = (beta x, y) must equal -Q = (X, -Y, ZZ, ZZZ):   beta x ZZ == X  and  y ZZZ == -Y
     bool ok;

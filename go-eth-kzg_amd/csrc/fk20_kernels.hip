@@ -11,11 +11,10 @@
 //     for the 32 byte-windows w and m = 1..128 (signed Booth digits) -- 4.3 GB, sized for a
 //     288 GB part -- so an MSM-64 is 64 x 32 mixed additions with no bucket reduction at all and
 //     no sort; 16 lanes share one MSM and combine with a 4-level wavefront tree.
-//   * each G1 FFT-128 runs in ONE wavefront (64 butterflies = 64 lanes) with the 128 points in
-//     LDS (28 KB, structure-of-arrays); inverse transform by decimation in frequency, forward by
-//     decimation in time, so the truncation/zero-padding between them is "clear the odd slots"
-//     and no permutation pass exists.  Twiddle multiplications use the GLV endomorphism (two 128-bit
-//     halves, precomputed per twiddle) with a shared 4-bit window table: 128 doublings + <= 64 additions.
+//   * the per-blob G1 transforms are four table-driven DFT levels with one lane per twiddle multiplication
+//     (k_g1_dft_level, below); the one-wavefront radix-2 FFT (g1_fft128_dif, points in LDS) is kept for the
+//     one-off set-up of the table.  Twiddle multiplications use the GLV endomorphism (two 128-bit halves,
+//     precomputed per twiddle) with signed 5-bit windows: 125 doublings + <= 52 additions.
 // Integer modular arithmetic only -- no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -174,30 +173,6 @@ __device__ __forceinline__ void g1_fft128_dif(uint32_t* sh, const uint32_t* __re
         __syncthreads();
     }
 }
-// decimation in time: bit-reversed order in, natural order out
-__device__ __forceinline__ void g1_fft128_dit(uint32_t* sh, const uint32_t* __restrict__ tw, int lane) {
-    for (int h = 1; h <= 64; h <<= 1) {
-        const int k = lane & (h - 1);
-        const int i0 = ((lane - k) << 1) + k, i1 = i0 + h;
-        G1X a, b, s, d, nb;
-        lp_get(a, sh, i0);
-        lp_get(b, sh, i1);
-        const int e = k * (64 / h);
-        if (e != 0) {
-            uint32_t kw[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) kw[q] = tw[e * 8 + q];
-            f_mul_glv(b, b, kw);
-        }
-        f_add(s, a, b);
-        g1x_neg(nb, b);
-        f_add(d, a, nb);
-        lp_put(sh, i0, s);
-        lp_put(sh, i1, d);
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // set-up, step 1: T[k][i] = FFT_128(vec_i)[k], vec_i = (reversed monomial SRS without its first 64
 // points, stride 64 from offset i, padded with the identity)        reference fk20.go:28-35,

@@ -93,24 +93,6 @@ __device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | 
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 __device__ __forceinline__ uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xca); }    // e ? f : g
 __device__ __forceinline__ uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8); }
-__device__ __forceinline__ void sha256_compress(uint32_t h[8], uint32_t w[16]) {
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-        if (i >= 16) {
-            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            uint32_t s0 = xor3(rotr(w15, 7), rotr(w15, 18), w15 >> 3);
-            uint32_t s1 = xor3(rotr(w2, 17), rotr(w2, 19), w2 >> 10);
-            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
-        }
-        uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
-        uint32_t t1 = hh + S1 + sha_ch(e, f, g) + SHA_K[i] + w[i & 15];
-        uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
-        uint32_t t2 = S0 + sha_maj(a, b, c);
-        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-}
 __device__ __forceinline__ void load16_be(uint32_t* w, const uint8_t* p) {   // 16 bytes -> 4 big-endian words
     uint4 v = *reinterpret_cast<const uint4*>(p);
     w[0] = __builtin_bswap32(v.x); w[1] = __builtin_bswap32(v.y); w[2] = __builtin_bswap32(v.z); w[3] = __builtin_bswap32(v.w);

@@ -226,3 +226,41 @@ def test_proofs_with_direct_table(product, oracle_ctx):
         assert pr[48 * i:48 * i + 48] == oracle_ctx.compute_blob_kzg_proof(blobs[i], cms[i])[1]
     assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), n, st) == 0
     ctx.close()
+
+
+def test_shared_context_from_threads(gpu_ctx, oracle_ctx):
+    """the reference's Context is shared by goroutines (verify.go:159-165); here: four host threads hammer one context with
+    different calls (ctypes drops the GIL, so they really contend for the library's mutex and workspaces)"""
+    import threading
+    from test_gpu_commit import rand_blob
+    blobs = [rand_blob(300 + i) for i in range(4)]
+    exp_cm = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
+    exp_pr = [oracle_ctx.compute_blob_kzg_proof(b, c)[1] for b, c in zip(blobs, exp_cm)]
+    errors = []
+
+    def worker(k):
+        try:
+            for it in range(6):
+                i = (k + it) % 4
+                which = (k + it) % 3
+                if which == 0:
+                    rc, cm = gpu_ctx.BlobToKZGCommitment(blobs[i])
+                    assert rc == 0 and cm == exp_cm[i]
+                elif which == 1:
+                    rc, pr = gpu_ctx.ComputeBlobKZGProof(blobs[i], exp_cm[i])
+                    assert rc == 0 and pr == exp_pr[i]
+                else:
+                    assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, exp_cm, exp_pr) == 0
+                    bad = list(exp_pr)
+                    bad[i] = exp_pr[(i + 1) % 4]
+                    assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, exp_cm, bad) == 1
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not errors, errors[0]

@@ -514,26 +514,88 @@ __global__ void __launch_bounds__(64) k_build_table(const uint32_t* __restrict__
 // so a commitment is 4096 * ceil(255/C) mixed additions into per-lane accumulators and one tree sum per blob:
 // no buckets, no sort, no bucket reduction, ONE kernel per batch.
 // ------------------------------------------------------------------------------------------
+// Table construction in C - 1 launches instead of one 2^(C-1)-step chain per row:
+//   k_build_direct_pow2 : D[row][2^k - 1] = 2^k B_row                      (k = 0 .. C-1, one lane per row)
+//   k_build_direct_level: D[row][2^k + t - 1] = D[row][t - 1] + 2^k B_row  (t = 1 .. 2^k - 1), level k = 1 .. C-2
+// A level's additions are independent AFFINE additions with a common addend; each lane takes eight of them and shares one field
+// inversion among them (Montgomery's trick: 1 + 2 multiplications per element), so an entry costs ~6 multiplications + 1/8
+// inversion instead of a mixed addition + a full inversion.  t B = +-2^k B is impossible for 0 < t < 2^k < r, so the only
+// exceptional case is an identity base (all its multiples are the identity).
 template <int C>
-__global__ void __launch_bounds__(64) k_build_direct(const uint32_t* __restrict__ table /* [NWIN][4096] window bases */, uint32_t* __restrict__ direct) {
+__global__ void __launch_bounds__(64) k_build_direct_pow2(const uint32_t* __restrict__ table /* [NWIN][4096] window bases */, uint32_t* __restrict__ direct) {
     using RC = Recode<C>;
     const int row = blockIdx.x * 64 + threadIdx.x;            // row = j*4096 + i
     if (row >= RC::NWIN * 4096) return;
-    G1Aff base;
-    load_affine(base, table + (size_t)row * 32);
+    G1Aff a;
+    load_affine(a, table + (size_t)row * 32);
     uint32_t* dst = direct + (size_t)row * RC::NBUCKET * 32;
     G1X acc;
-    g1x_set_inf(acc);
-    for (int m = 0; m < RC::NBUCKET; m++) {
-        G1Aff a;
-        if (base.inf) {
-            a = base;
-        } else {
-            g1x_madd(acc, base.x, base.y);
+    if (!a.inf) g1x_from_affine(acc, a.x, a.y);
+    for (int k = 0; k < C; k++) {
+        if (k > 0 && !a.inf) {
+            g1x_dbl_ni(acc, acc);
             g1x_to_affine(a, acc);
-            if (!a.inf) g1x_from_affine(acc, a.x, a.y);       // keep Z = 1: cheap next addition, tight values
+            g1x_from_affine(acc, a.x, a.y);                   // keep Z = 1: tight values
         }
-        store_affine(dst + (size_t)m * 32, a);
+        store_affine(dst + ((size_t)(1u << k) - 1) * 32, a);
+    }
+}
+template <int C>
+__global__ void __launch_bounds__(64, 2) k_build_direct_level(uint32_t* __restrict__ direct, int k) {
+    using RC = Recode<C>;
+    constexpr int G = 8;
+    const int n_t = (1 << k) - 1, per_row = (n_t + G - 1) / G;
+    const size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= (size_t)RC::NWIN * 4096 * per_row) return;
+    const size_t row = gid / per_row;
+    const int t0 = 1 + (int)(gid % per_row) * G;
+    const int cnt = n_t - (t0 - 1) < G ? n_t - (t0 - 1) : G;
+    uint32_t* base = direct + row * RC::NBUCKET * 32;
+    G1Aff P;
+    load_affine(P, base + ((size_t)(1u << k) - 1) * 32);
+    uint32_t* dst = base + ((size_t)(1u << k) + t0 - 1) * 32;
+    if (P.inf) {
+        for (int g = 0; g < cnt; g++) store_affine(dst + (size_t)g * 32, P);
+        return;
+    }
+    const uint32_t* src = base + ((size_t)t0 - 1) * 32;
+    fp_t pre[G], acc, d;
+    Fp::set_one(acc);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (g < cnt) {
+            fp_t xg;
+#pragma unroll
+            for (int q = 0; q < 14; q++) xg.l[q] = src[(size_t)g * 32 + q];
+            Fp::template sub<0>(d, P.x, xg);                  // xP - x_g + p, non-zero mod p
+            pre[g] = acc;
+            Fp::mul(acc, acc, d);
+        }
+    }
+    fp_t inv;
+    Fp::inv(inv, acc);
+#pragma unroll
+    for (int g = G - 1; g >= 0; g--) {
+        if (g < cnt) {
+            G1Aff e, o;
+            load_affine(e, src + (size_t)g * 32);
+            fp_t dinv, lam, t, x3, y3;
+            Fp::template sub<0>(d, P.x, e.x);
+            Fp::mul(dinv, inv, pre[g]);                       // 1 / (xP - x_g)
+            Fp::mul(inv, inv, d);
+            Fp::template sub<0>(t, P.y, e.y);
+            Fp::mul(lam, t, dinv);                            // (yP - y_g) / (xP - x_g)
+            Fp::sqr(x3, lam);
+            Fp::add(t, P.x, e.x);
+            Fp::template sub<1>(x3, x3, t);                   // lam^2 - xP - x_g + 2p      (< 3.01p)
+            Fp::template sub<2>(t, e.x, x3);                  // x_g - x3 + 4p
+            Fp::mul(y3, lam, t);
+            Fp::template sub<0>(y3, y3, e.y);                 // lam (x_g - x3) - y_g + p
+            Fp::canon(o.x, x3);
+            Fp::canon(o.y, y3);
+            o.inf = 0;
+            store_affine(dst + (size_t)g * 32, o);
+        }
     }
 }
 
@@ -767,14 +829,22 @@ size_t direct_table_bytes(int c) {
     const int nwin = (255 + c - 1) / c;
     return (size_t)nwin * 4096 * ((size_t)1 << (c - 1)) * 128;
 }
+template <int C>
+static void build_direct_t(const uint32_t* d_table, uint32_t* d_direct, hipStream_t s) {
+    using RC = Recode<C>;
+    const int rows = RC::NWIN * 4096;
+    hipLaunchKernelGGL((k_build_direct_pow2<C>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct);
+    for (int k = 1; k <= C - 2; k++) {
+        const size_t lanes = (size_t)rows * ((((size_t)1 << k) - 1 + 7) / 8);
+        hipLaunchKernelGGL((k_build_direct_level<C>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, d_direct, k);
+    }
+}
 void build_direct_device(int c, const uint32_t* d_table, uint32_t* d_direct, hipStream_t s) {
-    const int nwin = (255 + c - 1) / c;
-    const int rows = nwin * 4096;
     switch (c) {
-        case 12: hipLaunchKernelGGL((k_build_direct<12>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct); break;
-        case 13: hipLaunchKernelGGL((k_build_direct<13>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct); break;
-        case 14: hipLaunchKernelGGL((k_build_direct<14>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct); break;
-        default: hipLaunchKernelGGL((k_build_direct<15>), dim3((rows + 63) / 64), dim3(64), 0, s, d_table, d_direct); break;
+        case 12: build_direct_t<12>(d_table, d_direct, s); break;
+        case 13: build_direct_t<13>(d_table, d_direct, s); break;
+        case 14: build_direct_t<14>(d_table, d_direct, s); break;
+        default: build_direct_t<15>(d_table, d_direct, s); break;
     }
 }
 void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s) {

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
     "mkzg_last_host_finish_us", "mkzg_valu_calibrate", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
-    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch", "mkzg_verify_cell_kzg_proof_batch_partial", "mkzg_verify_cell_kzg_proof_batch_finish",
+    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch", "mkzg_verify_cell_kzg_proof_batch_partial", "mkzg_verify_cell_kzg_proof_batch_finish", "mkzg_recover_cells_and_kzg_proofs_batch",
     "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
     "mkzg_verify_blob_kzg_proof_batch_partial_device", "mkzg_verify_blob_kzg_proof_batch_finish",
 ]
@@ -82,6 +82,8 @@ def lib():
         L.mkzg_verify_cell_kzg_proof_batch_partial.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, C.c_char_p, sz, C.c_uint64,
                                                                C.c_char_p, C.c_char_p]
         L.mkzg_verify_cell_kzg_proof_batch_finish.argtypes = [vp, C.c_char_p, sz]
+        L.mkzg_recover_cells_and_kzg_proofs_batch.argtypes = [vp, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(sz),
+                                                              C.c_char_p, C.c_char_p, C.POINTER(i32)]
         L.mkzg_recover_cells_and_kzg_proofs.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p, C.c_char_p]
         L.mkzg_recover_cells.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p]
         L.mkzg_verify_blob_kzg_proof_batch_partial_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
@@ -147,7 +149,8 @@ class Context:
         out = C.create_string_buffer(48 * max(1, n))
         st = (C.c_int * max(1, n))()
         rc = self._L.mkzg_blob_to_kzg_commitment_batch(self._h, arr, n, out, st)
-        return rc, [out.raw[48 * i:48 * i + 48] for i in range(n)], list(st)[:n]
+        raw = out.raw
+        return rc, [raw[48 * i:48 * i + 48] for i in range(n)], list(st)[:n]
 
     def blob_to_kzg_commitment_batch_device(self, d_blobs_ptr, n, d_out_ptr, d_status_ptr, stream=0):
         """raw device pointers (ints) + hipStream_t handle; asynchronous"""
@@ -211,7 +214,8 @@ class Context:
         rc = self._L.mkzg_compute_cells(self._h, None if blob is None else bytes(blob), num_goroutines, out)
         if rc:
             return rc, None
-        return 0, [out.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)]
+        raw = out.raw                              # .raw copies the buffer: once, not per cell
+        return 0, [raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)]
 
     def ComputeCellsAndKZGProofs(self, blob, num_goroutines=0):
         """reference api_eip7594.go:28 -> (rc, [128 cells], [128 proofs])"""
@@ -222,8 +226,8 @@ class Context:
         rc = self._L.mkzg_compute_cells_and_kzg_proofs(self._h, None if blob is None else bytes(blob), num_goroutines, cells, proofs)
         if rc:
             return rc, None, None
-        return (0, [cells.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)],
-                [proofs.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
+        cr, pr = cells.raw, proofs.raw
+        return (0, [cr[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)], [pr[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
 
     def compute_cells_and_kzg_proofs_batch_device(self, d_blobs_ptr, n, d_cells_ptr, d_proofs_ptr, d_status_ptr, stream=0):
         return self._L.mkzg_compute_cells_and_kzg_proofs_batch_device(self._h, d_blobs_ptr, n, d_cells_ptr, d_proofs_ptr, d_status_ptr, stream)
@@ -263,7 +267,32 @@ class Context:
         rc = self._L.mkzg_recover_cells_and_kzg_proofs(self._h, ids, len(cell_ids), arr, len(cells), num_goroutines, oc, op)
         if rc:
             return rc, None, None
-        return (0, [oc.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)], [op.raw[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
+        ocr, opr = oc.raw, op.raw
+        return (0, [ocr[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)], [opr[i * 48:(i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)])
+
+    def RecoverCellsAndComputeKZGProofsBatch(self, jobs):
+        """jobs: list of (cell_ids, cells) -> (rc, [(status, [128 cells], [128 proofs]) per job])"""
+        n = len(jobs)
+        id_arrs = [(C.c_uint64 * max(1, len(ids)))(*ids) for ids, _ in jobs]
+        cell_arrs = [(C.c_char_p * max(1, len(cells)))(*[bytes(x) for x in cells]) for _, cells in jobs]
+        pid = (C.POINTER(C.c_uint64) * max(1, n))(*[C.cast(a, C.POINTER(C.c_uint64)) for a in id_arrs])
+        pcl = (C.POINTER(C.c_char_p) * max(1, n))(*[C.cast(a, C.POINTER(C.c_char_p)) for a in cell_arrs])
+        nid = (C.c_size_t * max(1, n))(*[len(ids) for ids, _ in jobs])
+        ncl = (C.c_size_t * max(1, n))(*[len(cells) for _, cells in jobs])
+        oc = C.create_string_buffer(max(1, n) * CELLS_PER_EXT_BLOB * BYTES_PER_CELL)
+        op = C.create_string_buffer(max(1, n) * CELLS_PER_EXT_BLOB * 48)
+        st = (C.c_int32 * max(1, n))()
+        rc = self._L.mkzg_recover_cells_and_kzg_proofs_batch(self._h, n, pid, nid, pcl, ncl, oc, op, st)
+        res = []
+        ocr, opr = oc.raw, op.raw              # .raw copies the whole buffer: take it once
+        for b in range(n):
+            if st[b]:
+                res.append((st[b], None, None))
+                continue
+            co, po = b * CELLS_PER_EXT_BLOB * BYTES_PER_CELL, b * CELLS_PER_EXT_BLOB * 48
+            res.append((0, [ocr[co + i * BYTES_PER_CELL:co + (i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)],
+                        [opr[po + i * 48:po + (i + 1) * 48] for i in range(CELLS_PER_EXT_BLOB)]))
+        return rc, res
 
     def RecoverCells(self, cell_ids, cells, num_goroutines=0):
         """reference api_eip.go:8 -> (rc, [128 cells])"""
@@ -276,7 +305,8 @@ class Context:
         rc = self._L.mkzg_recover_cells(self._h, ids, len(cell_ids), arr, len(cells), num_goroutines, oc)
         if rc:
             return rc, None
-        return 0, [oc.raw[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)]
+        ocr = oc.raw
+        return 0, [ocr[i * BYTES_PER_CELL:(i + 1) * BYTES_PER_CELL] for i in range(CELLS_PER_EXT_BLOB)]
 
     # ---- sharded batch verification (see distributed.py)
     def verify_blob_batch_partial_device(self, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n_local, offset, r32, stream=0):

@@ -29,7 +29,7 @@ void free_cells(mkzg_ctx* c) {
     c->d_fk_proofs = nullptr;
     c->d_cv_cells = nullptr; c->d_cv_cell_idx = nullptr; c->d_cv_row_idx = nullptr; c->d_cv_rp = nullptr; c->d_cv_weights = nullptr;
     c->d_cv_partials = nullptr; c->d_cv_interp = nullptr; c->d_cv_st = nullptr; c->cv_cap = 0;
-    c->d_pow7 = c->d_ipow7 = c->d_rec_scratch = nullptr; c->d_rec_pos = nullptr; c->rec_ready = false;
+    c->d_pow7 = c->d_ipow7 = c->d_rec_scratch = nullptr; c->d_rec_pos = nullptr; c->rec_ready = false; c->rec_cap = 0;
     c->cells_ready = false;
     c->cell_cap = 0;
     c->fk_ready = false;
@@ -405,49 +405,83 @@ int mkzg_verify_cell_kzg_proof_batch_finish(mkzg_ctx* c, const uint8_t* records5
     return cell_verify_finish(c, f);
 }
 
-// shared front end of RecoverCells / RecoverCellsAndComputeKZGProofs: reference api_eip7594.go:93-142
-static int recover_front(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, bool with_proofs) {
+// shared front end of RecoverCells / RecoverCellsAndComputeKZGProofs (reference api_eip7594.go:93-142) for n_blobs independent
+// recoveries: per-blob validation in the reference's order, then ONE set of launches over the blobs that passed (blockIdx.y = blob),
+// so that a batch runs the NTT stages and FK20 at batch efficiency (a single recovery is a chain of latency-bound launches).
+// status[b] receives the reference's error for blob b; device outputs: c->d_cells (n x 128 x 2048 B), c->d_fk_proofs (n x 128 x 48 B).
+static int recover_validate(const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells) {
     if (n_ids != n_cells) return MKZG_ERR_NUM_CELL_IDS;                                  // :94-96
+    if ((n_ids && !cell_ids) || (n_cells && !cells)) return MKZG_ERR_BAD_ARGS;
     for (size_t i = 1; i < n_ids; i++) if (cell_ids[i] <= cell_ids[i - 1]) return MKZG_ERR_CELL_IDS_NOT_ORDERED;   // :99-101
     for (size_t i = 0; i < n_ids; i++) if (cell_ids[i] >= MKZG_CELLS_PER_EXT_BLOB) return MKZG_ERR_FOUND_INVALID_CELL_ID;   // :104-108
     if (n_ids < 64) return MKZG_ERR_NOT_ENOUGH_CELLS;                                    // :111-113
     for (size_t i = 0; i < n_cells; i++) if (!cells[i]) return MKZG_ERR_NIL_INPUT;       // serialization.go:197-199
+    return MKZG_OK;
+}
+static int recover_front(mkzg_ctx* c, size_t n_blobs, const uint64_t* const* cell_ids, const size_t* n_ids, const uint8_t* const* const* cells, const size_t* n_cells,
+                         bool with_proofs, int* status) {
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    int rc = with_proofs ? ensure_fk20(c, 1) : ensure_cells(c, 1);
-    if (!rc) rc = ensure_staging(c, 1, n_cells * 2048);
+    size_t total_cells = 0;
+    for (size_t b = 0; b < n_blobs; b++) {
+        status[b] = recover_validate(cell_ids[b], n_ids[b], cells[b], n_cells[b]);
+        if (!status[b]) total_cells += n_cells[b];
+    }
+    int rc = with_proofs ? ensure_fk20(c, n_blobs) : ensure_cells(c, n_blobs);
+    if (!rc) rc = ensure_staging(c, 1, std::max<size_t>(total_cells, 1) * 2048);
     if (rc) return rc;
     if (!c->rec_ready) {
         HIPCHK(hipMalloc(&c->d_pow7, 8192 * 48));
         HIPCHK(hipMalloc(&c->d_ipow7, 4096 * 48));
-        HIPCHK(hipMalloc(&c->d_rec_scratch, recover_scratch_words() * 4));
-        HIPCHK(hipMalloc(&c->d_rec_pos, (128 + 64) * sizeof(int)));
         recover_tables_device(c->d_pow7, c->d_ipow7, s);
         c->rec_ready = true;
     }
-    int pos[128 + 64];
-    for (int i = 0; i < 128; i++) pos[i] = -1;
-    for (size_t i = 0; i < n_ids; i++) pos[cell_ids[i]] = (int)i;
-    int nm = 0;
-    for (uint32_t cid = 0; cid < 128; cid++) {
-        if (pos[cid] < 0) {
-            uint32_t r = 0;
-            for (int b = 0; b < 7; b++) if (cid & (1u << b)) r |= 1u << (6 - b);             // BitReverseInt(cellID, 128)  (:117-122)
-            pos[128 + nm++] = (int)r;
-        }
+    if (n_blobs > c->rec_cap) {
+        if (c->d_rec_scratch) (void)hipFree(c->d_rec_scratch);
+        if (c->d_rec_pos) (void)hipFree(c->d_rec_pos);
+        c->d_rec_scratch = nullptr; c->d_rec_pos = nullptr; c->rec_cap = 0;
+        HIPCHK(hipMalloc(&c->d_rec_scratch, n_blobs * recover_scratch_words() * 4));
+        HIPCHK(hipMalloc(&c->d_rec_pos, n_blobs * (192 + 1) * sizeof(int)));
+        c->rec_cap = n_blobs;
     }
-    for (size_t i = 0; i < n_cells; i++) memcpy(c->h_stage + i * 2048, cells[i], 2048);
-    HIPCHK(hipMemcpyAsync(c->d_blobs, c->h_stage, n_cells * 2048, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(c->d_rec_pos, pos, sizeof(pos), hipMemcpyHostToDevice, s));
-    KT(KT_RECOVER, s, recover_coeffs_device(c->d_blobs, c->d_rec_pos, (const uint32_t*)(c->d_rec_pos + 128), nm, c->d_tw_fwd, c->d_tw_inv, c->d_pow7, c->d_ipow7,
+    // positions: per blob 128 cell positions (global index into the staged cells, -1 = missing) + up to 64 missing ids; counts after them
+    std::vector<int> pos(n_blobs * 193, -1);
+    int* nmiss = pos.data() + n_blobs * 192;
+    size_t at = 0;
+    for (size_t b = 0; b < n_blobs; b++) {
+        int* pb = pos.data() + b * 192;
+        nmiss[b] = 0;
+        if (status[b]) {                      // rejected blob: give the kernels a well-formed dummy (all cells "missing" is not valid, so
+            for (int i = 0; i < 128; i++) pb[i] = -1;      // mark everything absent and no missing ids: the stages then run on zeros, output ignored)
+            continue;
+        }
+        for (size_t i = 0; i < n_ids[b]; i++) pb[cell_ids[b][i]] = (int)(at + i);
+        for (uint32_t cid = 0; cid < 128; cid++) {
+            if (pb[cid] < 0) {
+                uint32_t r = 0;
+                for (int q = 0; q < 7; q++) if (cid & (1u << q)) r |= 1u << (6 - q);       // BitReverseInt(cellID, 128)  (:117-122)
+                pb[128 + nmiss[b]++] = (int)r;
+            }
+        }
+        for (size_t i = 0; i < n_cells[b]; i++) memcpy(c->h_stage + (at + i) * 2048, cells[b][i], 2048);
+        at += n_cells[b];
+    }
+    if (total_cells) HIPCHK(hipMemcpyAsync(c->d_blobs, c->h_stage, total_cells * 2048, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_rec_pos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    KT(KT_RECOVER, s, recover_coeffs_device(c->d_blobs, c->d_rec_pos, c->d_rec_pos + n_blobs * 192, (int)n_blobs, c->d_tw_fwd, c->d_tw_inv, c->d_pow7, c->d_ipow7,
                                             c->d_rec_scratch, c->d_coeffs, c->d_cell_st, s));
-    KT(KT_CELLS_NTT, s, cells_from_coeffs_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_tw_inv, c->d_cells, c->d_cell_st, s));
+    KT(KT_CELLS_NTT, s, cells_from_coeffs_device(c->d_coeffs, (int)n_blobs, c->d_tw_fwd, c->d_tw_inv, c->d_cells, c->d_cell_st, s));
     if (with_proofs) {
-        KT(KT_FK20_SCALARS, s, fk20_scalars_device(c->d_coeffs, 1, c->d_tw_fwd, c->d_cell_st, c->d_fk_scalars, s));
-        KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, 1, c->d_cell_st, c->d_fk_parts, c->d_fk_results, s));
-        KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_fk_results + c->fk_cap * 128 * 64, c->d_fk_plan, 1, c->d_cell_st, c->d_fk_proofs, s));
+        KT(KT_FK20_SCALARS, s, fk20_scalars_device(c->d_coeffs, (int)n_blobs, c->d_tw_fwd, c->d_cell_st, c->d_fk_scalars, s));
+        KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, (int)n_blobs, c->d_cell_st, c->d_fk_parts, c->d_fk_results, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_fk_results + c->fk_cap * 128 * 64, c->d_fk_plan, (int)n_blobs, c->d_cell_st, c->d_fk_proofs, s));
     }
     HIPCHK(hipGetLastError());
+    // device-side statuses (non-canonical field elements in the cells) join the host-side ones
+    std::vector<int> dst(n_blobs);
+    HIPCHK(hipMemcpyAsync(dst.data(), c->d_cell_st, n_blobs * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t b = 0; b < n_blobs; b++) if (!status[b]) status[b] = dst[b];
     return MKZG_OK;
 }
 
@@ -456,28 +490,51 @@ int mkzg_recover_cells_and_kzg_proofs(mkzg_ctx* c, const uint64_t* cell_ids, siz
                                       uint8_t* proofs_out) {
     (void)num_threads;
     if (!c || !cells_out || !proofs_out || (n_ids && !cell_ids) || (n_cells && !cells)) return MKZG_ERR_BAD_ARGS;
+    int st = recover_validate(cell_ids, n_ids, cells, n_cells);
+    if (st) return st;
     std::lock_guard<std::recursive_mutex> g(c->mu);
-    int rc = recover_front(c, cell_ids, n_ids, cells, n_cells, true);
+    int rc = recover_front(c, 1, &cell_ids, &n_ids, &cells, &n_cells, true, &st);
     if (rc) return rc;
-    int st = 0;
-    HIPCHK(hipMemcpyAsync(&st, c->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (st) return st;
     HIPCHK(hipMemcpyAsync(cells_out, c->d_cells, 262144, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(proofs_out, c->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return st;
+    return MKZG_OK;
+}
+// n_blobs independent recoveries in one call (no reference analogue; throughput form of the above, used by sharded recovery jobs).
+// cell_ids[b] / cells[b]: the n_ids[b] = n_cells[b] supplied cells of blob b.  cells_out: n_blobs x 128 x 2048 B, proofs_out: n_blobs x 128 x 48 B,
+// status[b]: the reference's error for blob b (outputs of a failed blob are left untouched).  Returns the first non-zero status.
+int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* c, size_t n_blobs, const uint64_t* const* cell_ids, const size_t* n_ids, const uint8_t* const* const* cells,
+                                            const size_t* n_cells, uint8_t* cells_out, uint8_t* proofs_out, int* status) {
+    if (!c || (n_blobs && (!cell_ids || !n_ids || !cells || !n_cells || !cells_out || !proofs_out || !status))) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    int first = MKZG_OK;
+    for (size_t done = 0; done < n_blobs; done += 64) {                 // pieces of 64 blobs bound the workspaces
+        const size_t m = std::min<size_t>(64, n_blobs - done);
+        int rc = recover_front(c, m, cell_ids + done, n_ids + done, cells + done, n_cells + done, true, status + done);
+        if (rc) return rc;
+        for (size_t b = 0; b < m; b++) {
+            if (status[done + b]) { if (!first) first = status[done + b]; continue; }
+            HIPCHK(hipMemcpyAsync(cells_out + (done + b) * 262144, c->d_cells + b * 262144, 262144, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(proofs_out + (done + b) * 128 * 48, c->d_fk_proofs + b * 128 * 48, 128 * 48, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return first;
 }
 // Context.RecoverCells (reference api_eip.go:8-15)
 int mkzg_recover_cells(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads, uint8_t* cells_out) {
     (void)num_threads;
     if (!c || !cells_out || (n_ids && !cell_ids) || (n_cells && !cells)) return MKZG_ERR_BAD_ARGS;
+    int st = recover_validate(cell_ids, n_ids, cells, n_cells);
+    if (st) return st;
     std::lock_guard<std::recursive_mutex> g(c->mu);
-    int rc = recover_front(c, cell_ids, n_ids, cells, n_cells, false);
+    int rc = recover_front(c, 1, &cell_ids, &n_ids, &cells, &n_cells, false, &st);
     if (rc) return rc;
-    int st = 0;
-    HIPCHK(hipMemcpyAsync(&st, c->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (st) return st;
     HIPCHK(hipMemcpyAsync(cells_out, c->d_cells, 262144, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return st;
+    return MKZG_OK;
 }
 
 }  // extern "C"

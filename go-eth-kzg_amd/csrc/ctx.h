@@ -113,10 +113,11 @@ struct mkzg_ctx {
     int* d_cv_st = nullptr;                // cv_cap
     // recovery
     bool rec_ready = false;
+    size_t rec_cap = 0;                    // blobs the recovery scratch / position arrays hold
     uint32_t* d_pow7 = nullptr;
     uint32_t* d_ipow7 = nullptr;
     uint32_t* d_rec_scratch = nullptr;
-    int* d_rec_pos = nullptr;              // 128 ints + 64 missing ids
+    int* d_rec_pos = nullptr;              // per blob 128 positions + 64 missing ids, then one count per blob
     // FK20
     bool fk_ready = false;
     uint32_t* d_monomial_aff = nullptr;    // 4096 affine rows

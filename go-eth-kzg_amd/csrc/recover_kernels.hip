@@ -21,6 +21,8 @@
 
 namespace kzg {
 
+constexpr size_t RECOVER_SCRATCH_WORDS = (size_t)(256 + 2 * 8192) * 12;   // per blob: zeval | inv_zc | buf0 | buf1 (Fr rows of 12 words)
+
 constexpr int RNT = 1024, RN = 4096;
 
 __device__ __forceinline__ void r_load_fr12(fr_t& r, const uint32_t* p) {
@@ -125,10 +127,16 @@ __global__ void __launch_bounds__(256) k_recover_tables(uint32_t* __restrict__ p
 // vanishing polynomial of the missing blocks and its two 128-periodic evaluation tables
 //   zeval[j]  = S(w_128^j)              (= FFT_8192(Z)[j'] for j' = j mod 128)
 //   inv_zc[j] = 1 / S(7^64 w_128^j)     (= 1 / FFT_coset(Z)[j'])
-__global__ void __launch_bounds__(128) k_recover_vanishing(const uint32_t* __restrict__ missing, int n_missing, const uint32_t* __restrict__ tw_fwd,
-                                                           const uint32_t* __restrict__ pow7, uint32_t* __restrict__ zeval, uint32_t* __restrict__ inv_zc) {
+// All stage kernels take the blob in blockIdx.y: per blob 192 ints of positions (cell_pos[128] | missing[64]), one count of missing
+// cells, RECOVER_SCRATCH_WORDS of scratch, 4096 coefficient rows and one status word.
+__global__ void __launch_bounds__(128) k_recover_vanishing(const int* __restrict__ pos_all, const int* __restrict__ n_missing_all, const uint32_t* __restrict__ tw_fwd,
+                                                           const uint32_t* __restrict__ pow7, uint32_t* __restrict__ scratch_all) {
     __shared__ uint32_t sz[2][65 * 9];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, blob = blockIdx.y;
+    const uint32_t* missing = reinterpret_cast<const uint32_t*>(pos_all + (size_t)blob * 192 + 128);
+    const int n_missing = n_missing_all[blob];
+    uint32_t* zeval = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS;
+    uint32_t* inv_zc = zeval + 128 * 12;
     auto get = [&](int buf, int j, fr_t& v) {
 #pragma unroll
         for (int q = 0; q < 9; q++) v.l[q] = sz[buf][j * 9 + q];
@@ -186,10 +194,15 @@ __global__ void __launch_bounds__(128) k_recover_vanishing(const uint32_t* __res
 
 // stage A: dz_br = DIF-IFFT_8192( E . Zeval ) without the 1/8192, E[j] = ext[brev13(j)] from the cells
 //   cell_pos[c] = index of cell c among the supplied cells, or -1 (missing)
-__global__ void __launch_bounds__(RNT) k_recover_stage_a(const uint8_t* __restrict__ cells, const int* __restrict__ cell_pos, const uint32_t* __restrict__ zeval,
-                                                         const uint32_t* __restrict__ tw_inv, uint32_t* __restrict__ dz_br, int* __restrict__ status) {
+//   (positions are indices into the whole staged cell array of the call, so ragged batches need no per-blob base)
+__global__ void __launch_bounds__(RNT) k_recover_stage_a(const uint8_t* __restrict__ cells, const int* __restrict__ pos_all, uint32_t* __restrict__ scratch_all,
+                                                         const uint32_t* __restrict__ tw_inv, int* __restrict__ status_all) {
     extern __shared__ uint32_t sh[];
-    const int half = blockIdx.x, t = threadIdx.x;
+    const int half = blockIdx.x, t = threadIdx.x, blob = blockIdx.y;
+    const int* cell_pos = pos_all + (size_t)blob * 192;
+    const uint32_t* zeval = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS;
+    uint32_t* dz_br = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS + 256 * 12;
+    int* status = status_all + blob;
     bool bad = false;
     auto load_e = [&](uint32_t j, fr_t& out) {       // E[j] * Zeval[j mod 128]
         const uint32_t src = brev13(j);              // index into the cell-ordered extended blob
@@ -240,10 +253,13 @@ __global__ void __launch_bounds__(RNT) k_recover_stage_a(const uint8_t* __restri
 }
 
 // stage B1: halves of the DIT forward NTT_8192 of (dz[i] 7^i / 8192): Y_h natural
-__global__ void __launch_bounds__(RNT) k_recover_stage_b1(const uint32_t* __restrict__ dz_br, const uint32_t* __restrict__ pow7, const uint32_t* __restrict__ tw_fwd,
-                                                          const int* __restrict__ status, uint32_t* __restrict__ y_halves) {
+__global__ void __launch_bounds__(RNT) k_recover_stage_b1(uint32_t* __restrict__ scratch_all, const uint32_t* __restrict__ pow7, const uint32_t* __restrict__ tw_fwd,
+                                                          const int* __restrict__ status_all) {
     extern __shared__ uint32_t sh[];
-    const int half = blockIdx.x, t = threadIdx.x;
+    const int half = blockIdx.x, t = threadIdx.x, blob = blockIdx.y;
+    const uint32_t* dz_br = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS + 256 * 12;
+    uint32_t* y_halves = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS + (256 + 8192) * 12;
+    const int* status = status_all + blob;
     if (status[0] != 0) return;
     fr_t inv8192;
     {
@@ -280,9 +296,12 @@ __global__ void __launch_bounds__(RNT) k_recover_stage_b1(const uint32_t* __rest
 }
 
 // stage C: last DIT stage + division by the coset evaluations of Z:  q natural
-__global__ void __launch_bounds__(256) k_recover_stage_c(const uint32_t* __restrict__ y_halves, const uint32_t* __restrict__ tw_fwd, const uint32_t* __restrict__ inv_zc,
-                                                         const int* __restrict__ status, uint32_t* __restrict__ q) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) k_recover_stage_c(uint32_t* __restrict__ scratch_all, const uint32_t* __restrict__ tw_fwd, const int* __restrict__ status_all) {
+    const int m = blockIdx.x * 256 + threadIdx.x, blob = blockIdx.y;
+    const uint32_t* inv_zc = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS + 128 * 12;
+    const uint32_t* y_halves = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS + (256 + 8192) * 12;
+    uint32_t* q = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS + 256 * 12;
+    const int* status = status_all + blob;
     if (m >= RN || status[0] != 0) return;
     fr_t y0, y1, w, tt, a, b, iz;
     r_load_fr12(y0, y_halves + (size_t)m * 12);
@@ -299,10 +318,13 @@ __global__ void __launch_bounds__(256) k_recover_stage_c(const uint32_t* __restr
 }
 
 // stage D: coefficients[i] = IFFT_8192(q)[i] * 7^-i / 8192 for i < 4096 (DIF, natural -> bit-reversed)
-__global__ void __launch_bounds__(RNT) k_recover_stage_d(const uint32_t* __restrict__ q, const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ ipow7,
-                                                         const int* __restrict__ status, uint32_t* __restrict__ coeffs) {
+__global__ void __launch_bounds__(RNT) k_recover_stage_d(const uint32_t* __restrict__ scratch_all, const uint32_t* __restrict__ tw_inv, const uint32_t* __restrict__ ipow7,
+                                                         const int* __restrict__ status_all, uint32_t* __restrict__ coeffs_all) {
     extern __shared__ uint32_t sh[];
-    const int half = blockIdx.x, t = threadIdx.x;
+    const int half = blockIdx.x, t = threadIdx.x, blob = blockIdx.y;
+    const uint32_t* q = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS + 256 * 12;
+    uint32_t* coeffs = coeffs_all + (size_t)blob * 4096 * 12;
+    const int* status = status_all + blob;
     if (status[0] != 0) return;
 #pragma unroll
     for (int k = 0; k < RN / RNT; k++) {
@@ -357,21 +379,19 @@ static void set_attrs() {
     g_rattr = true;
 }
 void recover_tables_device(uint32_t* d_pow7, uint32_t* d_ipow7, hipStream_t s) { hipLaunchKernelGGL(k_recover_tables, dim3(32), dim3(256), 0, s, d_pow7, d_ipow7); }
-void recover_coeffs_device(const uint8_t* d_cells, const int* d_cell_pos, const uint32_t* d_missing, int n_missing, const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv,
+void recover_coeffs_device(const uint8_t* d_cells, const int* d_pos, const int* d_n_missing, int n_blobs, const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv,
                            const uint32_t* d_pow7, const uint32_t* d_ipow7, uint32_t* d_scratch, uint32_t* d_coeffs, int* d_status, hipStream_t s) {
+    if (n_blobs <= 0) return;
     set_attrs();
-    uint32_t* zeval = d_scratch;                       // 128 rows
-    uint32_t* inv_zc = d_scratch + 128 * 12;           // 128 rows
-    uint32_t* buf0 = d_scratch + 256 * 12;             // 8192 rows
-    uint32_t* buf1 = buf0 + 8192 * 12;                 // 8192 rows
+    // scratch per blob: zeval 128 rows | inv_zc 128 rows | buf0 8192 rows | buf1 8192 rows
     const size_t lds = 9 * 4096 * 4;
-    (void)hipMemsetAsync(d_status, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_recover_vanishing, dim3(1), dim3(128), 0, s, d_missing, n_missing, d_tw_fwd, d_pow7, zeval, inv_zc);
-    hipLaunchKernelGGL(k_recover_stage_a, dim3(2), dim3(RNT), lds, s, d_cells, d_cell_pos, zeval, d_tw_inv, buf0, d_status);
-    hipLaunchKernelGGL(k_recover_stage_b1, dim3(2), dim3(RNT), lds, s, buf0, d_pow7, d_tw_fwd, d_status, buf1);
-    hipLaunchKernelGGL(k_recover_stage_c, dim3(16), dim3(256), 0, s, buf1, d_tw_fwd, inv_zc, d_status, buf0);
-    hipLaunchKernelGGL(k_recover_stage_d, dim3(2), dim3(RNT), lds, s, buf0, d_tw_inv, d_ipow7, d_status, d_coeffs);
+    (void)hipMemsetAsync(d_status, 0, (size_t)n_blobs * sizeof(int), s);
+    hipLaunchKernelGGL(k_recover_vanishing, dim3(1, n_blobs), dim3(128), 0, s, d_pos, d_n_missing, d_tw_fwd, d_pow7, d_scratch);
+    hipLaunchKernelGGL(k_recover_stage_a, dim3(2, n_blobs), dim3(RNT), lds, s, d_cells, d_pos, d_scratch, d_tw_inv, d_status);
+    hipLaunchKernelGGL(k_recover_stage_b1, dim3(2, n_blobs), dim3(RNT), lds, s, d_scratch, d_pow7, d_tw_fwd, d_status);
+    hipLaunchKernelGGL(k_recover_stage_c, dim3(16, n_blobs), dim3(256), 0, s, d_scratch, d_tw_fwd, d_status);
+    hipLaunchKernelGGL(k_recover_stage_d, dim3(2, n_blobs), dim3(RNT), lds, s, d_scratch, d_tw_inv, d_ipow7, d_status, d_coeffs);
 }
-size_t recover_scratch_words() { return (size_t)(256 + 2 * 8192) * 12; }
+size_t recover_scratch_words() { return RECOVER_SCRATCH_WORDS; }
 
 }  // namespace kzg

@@ -139,6 +139,12 @@ int mkzg_verify_cell_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* record
  * at least 64 of them; cells are host pointers in the same order. */
 int mkzg_recover_cells_and_kzg_proofs(mkzg_ctx* ctx, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads,
                                       uint8_t* cells_out, uint8_t* proofs_out);
+/* n_blobs independent recoveries in one call (no reference analogue: the throughput form for sharded recovery jobs).
+ * cell_ids[b] / cells[b]: the n_ids[b] == n_cells[b] supplied cells of blob b, each list validated like the single-blob call;
+ * cells_out: n_blobs x 128 x 2048 B, proofs_out: n_blobs x 128 x 48 B; status[b]: the reference's error for blob b (its outputs are
+ * then left untouched).  Returns the first non-zero status. */
+int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* ctx, size_t n_blobs, const uint64_t* const* cell_ids, const size_t* n_ids, const uint8_t* const* const* cells,
+                                            const size_t* n_cells, uint8_t* cells_out, uint8_t* proofs_out, int* status);
 /* Context.RecoverCells (reference api_eip.go:8-15). */
 int mkzg_recover_cells(mkzg_ctx* ctx, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads, uint8_t* cells_out);
 

@@ -177,3 +177,35 @@ def test_sharded_cell_verifier_records(gpu_ctx, oracle_ctx):
     # an empty shard contributes the identity
     rc, rec = gpu_ctx.verify_cell_batch_partial([], [], [], [], 14, r32)
     assert rc == 0 and gpu_ctx.verify_cell_batch_finish([g[0][1], g[1][1], rec]) == 0
+
+
+def test_recover_batch(gpu_ctx, oracle_ctx):
+    """mkzg_recover_cells_and_kzg_proofs_batch: ragged jobs (different erasure patterns per blob, one invalid job in the middle) give the
+    same bytes as the single-blob call and the oracle"""
+    jobs, expect = [], []
+    patterns = [list(range(0, 128, 2)), list(range(64, 128)), list(range(0, 100)), [i for i in range(128) if i % 5 != 0][:90], list(range(128))]
+    for k, ids in enumerate(patterns):
+        blob = rand_blob(80 + k)
+        rc, cells, proofs = gpu_ctx.ComputeCellsAndKZGProofs(blob)
+        assert rc == 0
+        jobs.append((ids, [cells[i] for i in ids]))
+        expect.append((cells, proofs))
+    bad_job = (list(range(63)), [expect[0][0][i] for i in range(63)])            # too few cells
+    jobs.insert(2, bad_job)
+    expect.insert(2, None)
+    rc, res = gpu_ctx.RecoverCellsAndComputeKZGProofsBatch(jobs)
+    assert rc == 10                                                               # MKZG_ERR_NOT_ENOUGH_CELLS: first failing job
+    for (st, oc, op), exp, job in zip(res, expect, jobs):
+        if exp is None:
+            assert st == 10 and oc is None
+            continue
+        assert st == 0 and oc == exp[0] and op == exp[1]
+        rc1, oc1, op1 = gpu_ctx.RecoverCellsAndComputeKZGProofs(job[0], job[1])
+        assert rc1 == 0 and oc1 == oc and op1 == op
+    rco, oco, opo = oracle_ctx.recover_cells_and_kzg_proofs(jobs[1][0], jobs[1][1])
+    assert rco == 0 and b"".join(res[1][1]) == oco and b"".join(res[1][2]) == opo
+    # a non-canonical field element inside one job only fails that job
+    poisoned = list(jobs[0][1])
+    poisoned[3] = b"\xff" * 2048
+    rc, res2 = gpu_ctx.RecoverCellsAndComputeKZGProofsBatch([(jobs[0][0], poisoned), jobs[1]])
+    assert rc == 3 and res2[0][0] == 3 and res2[1][0] == 0 and res2[1][1] == res[1][1]

@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
     "mkzg_verify_kzg_proof", "mkzg_verify_blob_kzg_proof", "mkzg_verify_blob_kzg_proof_batch", "mkzg_verify_blob_kzg_proof_batch_device",
     "mkzg_last_host_finish_us", "mkzg_valu_calibrate", "mkzg_compute_cells", "mkzg_compute_cells_batch_device",
-    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch", "mkzg_verify_cell_kzg_proof_batch_partial", "mkzg_verify_cell_kzg_proof_batch_finish", "mkzg_recover_cells_and_kzg_proofs_batch",
+    "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch", "mkzg_verify_cell_kzg_proof_batch_partial", "mkzg_verify_cell_kzg_proof_batch_finish", "mkzg_recover_cells_and_kzg_proofs_batch", "mkzg_msm_g1",
     "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
     "mkzg_verify_blob_kzg_proof_batch_partial_device", "mkzg_verify_blob_kzg_proof_batch_finish",
 ]
@@ -82,6 +82,7 @@ def lib():
         L.mkzg_verify_cell_kzg_proof_batch_partial.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, C.c_char_p, sz, C.c_uint64,
                                                                C.c_char_p, C.c_char_p]
         L.mkzg_verify_cell_kzg_proof_batch_finish.argtypes = [vp, C.c_char_p, sz]
+        L.mkzg_msm_g1.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), sz, C.POINTER(C.c_uint64)]
         L.mkzg_recover_cells_and_kzg_proofs_batch.argtypes = [vp, sz, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(sz), C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(sz),
                                                               C.c_char_p, C.c_char_p, C.POINTER(i32)]
         L.mkzg_recover_cells_and_kzg_proofs.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p, C.c_char_p]
@@ -321,6 +322,18 @@ class Context:
         return self._L.mkzg_last_host_finish_us(self._h)
 
     # ---- profiling --------------------------------------------------------------------------
+    def msm_g1(self, scalars_mont, points_mont):
+        """multiexp.MultiExpG1 seam: scalars as ints in gnark's Montgomery form (s * 2^256 mod r), points as (X, Y) ints in
+        Montgomery form (x * 2^384 mod p), (0, 0) = identity -> (rc, (X, Y))"""
+        n = len(scalars_mont)
+        sc = (C.c_uint64 * max(1, 4 * n))(*[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for v in scalars_mont for k in range(4)])
+        pt = (C.c_uint64 * max(1, 12 * n))(*[(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for xy in points_mont for v in xy for k in range(6)])
+        out = (C.c_uint64 * 12)()
+        rc = self._L.mkzg_msm_g1(self._h, sc, pt, n, out)
+        x = sum(int(out[k]) << (64 * k) for k in range(6))
+        y = sum(int(out[6 + k]) << (64 * k) for k in range(6))
+        return rc, (x, y)
+
     def valu_calibrate(self):
         """sustained v_mad_u64_u32 wave-instructions per second of this GPU (diagnostic)"""
         v = C.c_double(0.0)

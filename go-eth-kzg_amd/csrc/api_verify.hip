@@ -413,6 +413,53 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     return MKZG_OK;
 }
 
+// The finer seam of the reference, multiexp.MultiExpG1 (internal/multiexp/multiexp.go:20-26): sum s_i P_i with gnark-crypto's in-memory
+// layouts on both sides -- scalars n x 4 u64 (fr.Element, Montgomery R = 2^256), points n x 12 u64 (G1Affine: X, Y as fp.Element, Montgomery
+// R = 2^384, identity (0,0)), result one G1Affine.  Like the reference it does not validate the points.  Any n (pieces of 8192).
+int mkzg_msm_g1(mkzg_ctx* c, const uint64_t* scalars_mont4, const uint64_t* points_mont12, size_t n, uint64_t out_mont12[12]) {
+    if (!c || !out_mont12 || (n && (!scalars_mont4 || !points_mont12))) return MKZG_ERR_BAD_ARGS;
+    std::lock_guard<std::recursive_mutex> g(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    G1HX total;
+    G1H::set_inf(total);
+    for (size_t done = 0; done < n; done += VMSM_MAX_N) {
+        const size_t m = std::min<size_t>(VMSM_MAX_N, n - done);
+        int rc = ensure_verify_ws(c, m);
+        if (rc) return rc;
+        // d_v_raw holds 2 x cap x 48 B = cap x 96 B: exactly the points; d_v_s3 takes the raw scalars, d_v_s1 the converted ones
+        HIPCHK(hipMemcpyAsync(c->d_v_raw, points_mont12 + done * 12, m * 96, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->d_v_s3, scalars_mont4 + done * 4, m * 32, hipMemcpyHostToDevice, s));
+        gnark_to_vmsm_device(c->d_v_s3, (const uint32_t*)c->d_v_raw, (int)m, c->d_v_s1, c->d_v_aff, s);
+        const uint32_t* scal[1] = {c->d_v_s1};
+        const uint32_t* pts[1] = {c->d_v_aff};
+        const int nj[1] = {(int)m};
+        if (vmsm_windows_device(scal, pts, nj, 1, c->d_v_misc + V_MISC_WORDS, c->d_v_misc + 16, s)) return MKZG_ERR_BAD_ARGS;
+        HIPCHK(hipGetLastError());
+        uint32_t* h_misc = (uint32_t*)(c->h_v + 3 * c->v_cap * sizeof(int));
+        HIPCHK(hipMemcpyAsync(h_misc, c->d_v_misc, (16 + VMSM_WINDOWS * 48) * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        G1HX win[VMSM_WINDOWS], part;
+        for (int w = 0; w < VMSM_WINDOWS; w++) {
+            const uint32_t* p = h_misc + 16 + (size_t)w * 48;
+            bool zero = true;
+            for (int q = 24; q < 36; q++) zero = zero && p[q] == 0;
+            if (zero) G1H::set_inf(win[w]); else g1h_from_plain_words(win[w], p);
+        }
+        g1h_horner(part, win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
+        G1H::add(total, total, part);
+    }
+    G1AffH a;
+    g1h_to_affine(a, total);
+    if (a.inf) {
+        memset(out_mont12, 0, 96);
+    } else {
+        memcpy(out_mont12, a.x.l, 48);             // HostFp is 6 x u64 Montgomery with R = 2^384: gnark's fp.Element as is
+        memcpy(out_mont12 + 6, a.y.l, 48);
+    }
+    return MKZG_OK;
+}
+
 // ---- sharded batch verification (multi-GPU): each rank folds its shard with the GLOBAL exponents
 // r^(offset + i) and publishes one 512-byte record; any rank adds the records and runs the pairing.
 // Record: [0..4) status (LE int) | [16..64) A | [64..112) Cc | [112..160) D (compressed G1) | [160..192) e (32 B big-endian) | zero padding

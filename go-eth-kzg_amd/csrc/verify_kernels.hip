@@ -755,6 +755,57 @@ int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const*
     hipLaunchKernelGGL(k_vmsm_combine, dim3((n_msm * VNWIN + 63) / 64), dim3(64), 0, s, jobs, n_msm, d_parts, d_out);
     return 0;
 }
+// ------------------------------------------------------------------------------------------
+// gnark-crypto in-memory layouts (the finer seam multiexp.MultiExpG1, reference internal/multiexp/multiexp.go:20-26):
+//   fr.Element = 4 x u64 little-endian limbs, Montgomery with R = 2^256;  G1Affine = X, Y as fp.Element = 6 x u64 limbs,
+//   Montgomery with R = 2^384, identity = (0, 0).
+// -> 8-word plain scalars and radix-2^29 affine rows, the inputs of k_vmsm_window.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_gnark_to_vmsm(const uint32_t* __restrict__ scalars_mont /* n x 8 words */, const uint32_t* __restrict__ points_mont /* n x 24 words */, int n,
+                                                      uint32_t* __restrict__ out_scalars8, uint32_t* __restrict__ out_aff) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    {   // s = a * 2^-256 mod r: one Montgomery multiplication (radix 2^261) by the plain constant 2^5
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) w[q] = scalars_mont[(size_t)i * 8 + q];
+        fr_t a, k, t;
+        Fr::from_words32(a, w);
+        Fr::set_zero(k);
+        k.l[0] = 32;
+        Fr::mul(t, a, k);
+        Fr::reduce_once(t, t);
+        Fr::to_words32(w, t);
+#pragma unroll
+        for (int q = 0; q < 8; q++) out_scalars8[(size_t)i * 8 + q] = w[q];
+    }
+    {   // x 2^384 -> x 2^406: one multiplication by the constant FP_R406_OVER_R384_M
+        uint32_t wx[12], wy[12];
+        uint32_t any = 0;
+#pragma unroll
+        for (int q = 0; q < 12; q++) { wx[q] = points_mont[(size_t)i * 24 + q]; wy[q] = points_mont[(size_t)i * 24 + 12 + q]; any |= wx[q] | wy[q]; }
+        G1Aff a;
+        fp_t c, t;
+        Fp::set(c, FP_R406_OVER_R384_M);
+        Fp::from_words32(t, wx);
+        Fp::mul(t, t, c);
+        Fp::canon(a.x, t);
+        Fp::from_words32(t, wy);
+        Fp::mul(t, t, c);
+        Fp::canon(a.y, t);
+        a.inf = any == 0 ? 1u : 0u;
+        uint32_t row[32];
+#pragma unroll
+        for (int q = 0; q < 14; q++) { row[q] = a.x.l[q]; row[14 + q] = a.y.l[q]; }
+        row[28] = a.inf; row[29] = 0; row[30] = 0; row[31] = 0;
+        uint4* dst = reinterpret_cast<uint4*>(out_aff + (size_t)i * 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = make_uint4(row[4 * q], row[4 * q + 1], row[4 * q + 2], row[4 * q + 3]);
+    }
+}
+void gnark_to_vmsm_device(const uint32_t* d_scalars_mont, const uint32_t* d_points_mont, int n, uint32_t* d_scalars8, uint32_t* d_aff, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(k_gnark_to_vmsm, dim3((n + 63) / 64), dim3(64), 0, s, d_scalars_mont, d_points_mont, n, d_scalars8, d_aff);
+}
 void build_roots_device(uint32_t* d_roots_brp, uint32_t* d_inv_roots_brp, int log_n, hipStream_t s) {
     int n = 1 << log_n;
     hipLaunchKernelGGL(k_build_roots, dim3((n + 255) / 256), dim3(256), 0, s, d_roots_brp, d_inv_roots_brp, log_n);

@@ -111,6 +111,11 @@ int mkzg_verify_blob_kzg_proof_batch_partial_device(mkzg_ctx* ctx, const void* d
                                                     uint64_t offset, const uint8_t r32[32], uint8_t record512[512], void* stream);
 int mkzg_verify_blob_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* records512, size_t n_records);
 
+/* The finer seam: multiexp.MultiExpG1 (reference internal/multiexp/multiexp.go:20-26) with gnark-crypto's in-memory layouts.
+ * scalars: n x 4 u64 (fr.Element, little-endian limbs, Montgomery R = 2^256); points: n x 12 u64 (G1Affine = X, Y as fp.Element,
+ * Montgomery R = 2^384; the identity is (0, 0)); out: one G1Affine in the same layout.  No point validation (as the reference). */
+int mkzg_msm_g1(mkzg_ctx* ctx, const uint64_t* scalars_mont4, const uint64_t* points_mont12, size_t n, uint64_t out_mont12[12]);
+
 /* ---- EIP-7594 ------------------------------------------------------------------------------ */
 /* Context.ComputeCells (reference api_eip7594.go:12-26): 128 cells of 2048 bytes, contiguous. */
 int mkzg_compute_cells(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint8_t* cells_out /* 128 x 2048 */);

@@ -154,3 +154,51 @@ def test_c_program_through_the_abi():
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([exe, os.path.join(root, "tests", "golden", "trusted_setup.json")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "commitment of the zero blob: rc=0 ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_msm_g1_gnark_layouts(gpu_ctx):
+    """mkzg_msm_g1, the multiexp.MultiExpG1 seam with gnark-crypto's Montgomery layouts, on the reference's own KAT
+    (internal/multiexp/multiexp_test.go:13-33: scalars 1234567^i, points (i+1) G, 256 of them) plus identity points, zero scalars and a
+    10000-point run that crosses the 8192-point piece size; expected values from Python big-integer curve arithmetic and the oracle"""
+    import oracle
+    from test_mont29_host import P, G1X, G1Y, ec_add, ec_mul, compress
+    RP, RF = 1 << 384, 1 << 256
+    G = (G1X, G1Y)
+    n = 256
+    pts, cur = [], None
+    for i in range(n):
+        cur = ec_add(cur, G)
+        pts.append(cur)
+    scal = [pow(1234567, i, R) for i in range(n)]
+
+    def mont_pt(pt):
+        return (0, 0) if pt is None else (pt[0] * RP % P, pt[1] * RP % P)
+
+    def run(ss, pp):
+        rc, (x, y) = gpu_ctx.msm_g1([s * RF % R for s in ss], [mont_pt(p) for p in pp])
+        assert rc == 0
+        if x == 0 and y == 0:
+            return None
+        inv = pow(RP, -1, P)
+        return (x * inv % P, y * inv % P)
+
+    def expect(ss, pp):
+        keep = [(s, p) for s, p in zip(ss, pp) if p is not None]
+        rc, out = oracle.g1_msm(b"".join(s.to_bytes(32, "big") for s, _ in keep), b"".join(compress(p) for _, p in keep))
+        assert rc == 0
+        return out
+
+    got = run(scal, pts)
+    assert compress(got) == expect(scal, pts)
+    # identity points and zero scalars contribute nothing; all-zero input gives the identity
+    scal2 = list(scal); pts2 = list(pts)
+    pts2[5] = None; pts2[200] = None; scal2[7] = 0; scal2[0] = R - 1
+    assert compress(run(scal2, pts2)) == expect(scal2, pts2)
+    assert run([0] * 8, pts[:8]) is None and run([], []) is None
+    # more than one 8192-point piece: 10000 points (multiples of the first 256, cheap to build) with small distinct scalars
+    big_pts = [pts[i % 256] for i in range(10000)]
+    big_sc = [(i * 2654435761 + 12345) % R for i in range(10000)]
+    folded = [0] * 256
+    for i, sv in enumerate(big_sc):
+        folded[i % 256] = (folded[i % 256] + sv) % R
+    assert compress(run(big_sc, big_pts)) == expect(folded, pts)

@@ -322,16 +322,7 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     }
     // Horner over the window sums: four independent 255-doubling chains, one host thread each
     const uint32_t* wsum = h_misc + 16;
-    auto horner = [&](int m) {
-        G1HX win[VMSM_WINDOWS];
-        for (int w = 0; w < VMSM_WINDOWS; w++) {
-            const uint32_t* p = wsum + ((size_t)m * VMSM_WINDOWS + w) * 48;
-            bool zero = true;
-            for (int q = 24; q < 36; q++) zero = zero && p[q] == 0;
-            if (zero) G1H::set_inf(win[w]); else g1h_from_plain_words(win[w], p);
-        }
-        g1h_horner(out->sums[m], win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
-    };
+    auto horner = [&](int m) { g1h_horner_words(out->sums[m], wsum + (size_t)m * VMSM_WINDOWS * 48, VMSM_WINDOWS, VMSM_WINDOW_BITS); };
     {
         std::thread t0([&] { horner(0); }), t1([&] { horner(1); }), t2([&] { horner(2); });
         horner(3);

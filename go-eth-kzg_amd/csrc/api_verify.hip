@@ -161,16 +161,7 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     // 6. Horner over the window sums (the 255 serial doublings stay on the host)
     auto t_h0 = std::chrono::steady_clock::now();
     const uint32_t* wsum = h_misc + 16;
-    auto horner = [&](int m, G1HX& out) {
-        G1HX win[VMSM_WINDOWS];
-        for (int w = 0; w < VMSM_WINDOWS; w++) {
-            const uint32_t* p = wsum + ((size_t)m * VMSM_WINDOWS + w) * 48;
-            bool zero = true;
-            for (int q = 24; q < 36; q++) zero = zero && p[q] == 0;   // ZZ == 0 marks the identity
-            if (zero) G1H::set_inf(win[w]); else g1h_from_plain_words(win[w], p);
-        }
-        g1h_horner(out, win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
-    };
+    auto horner = [&](int m, G1HX& out) { g1h_horner_words(out, wsum + (size_t)m * VMSM_WINDOWS * 48, VMSM_WINDOWS, VMSM_WINDOW_BITS); };
     {   // three independent 255-doubling chains: one per host thread
         std::thread ta([&] { horner(0, out->A); });
         std::thread tc([&] { horner(1, out->Cc); });
@@ -439,14 +430,8 @@ int mkzg_msm_g1(mkzg_ctx* c, const uint64_t* scalars_mont4, const uint64_t* poin
         uint32_t* h_misc = (uint32_t*)(c->h_v + 3 * c->v_cap * sizeof(int));
         HIPCHK(hipMemcpyAsync(h_misc, c->d_v_misc, (16 + VMSM_WINDOWS * 48) * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        G1HX win[VMSM_WINDOWS], part;
-        for (int w = 0; w < VMSM_WINDOWS; w++) {
-            const uint32_t* p = h_misc + 16 + (size_t)w * 48;
-            bool zero = true;
-            for (int q = 24; q < 36; q++) zero = zero && p[q] == 0;
-            if (zero) G1H::set_inf(win[w]); else g1h_from_plain_words(win[w], p);
-        }
-        g1h_horner(part, win, VMSM_WINDOWS, VMSM_WINDOW_BITS);
+        G1HX part;
+        g1h_horner_words(part, h_misc + 16, VMSM_WINDOWS, VMSM_WINDOW_BITS);
         G1H::add(total, total, part);
     }
     G1AffH a;

@@ -45,6 +45,18 @@ inline void g1h_to_affine(G1AffH& r, const G1HX& p) {
     r.inf = a.inf != 0;
 }
 // sum_w 2^(c w) S_w  (Horner from the top window)
+inline void g1h_horner(G1HX& r, const G1HX* sums, int nwin, int c);
+// sum_w 2^(c w) W_w over the device's window sums (nwin x 48 words: X, Y, ZZ, ZZZ as canonical plain integers; ZZ == 0 marks the identity)
+inline void g1h_horner_words(G1HX& r, const uint32_t* wsum, int nwin, int c) {
+    std::vector<G1HX> win((size_t)nwin);
+    for (int w = 0; w < nwin; w++) {
+        const uint32_t* p = wsum + (size_t)w * 48;
+        bool zero = true;
+        for (int q = 24; q < 36; q++) zero = zero && p[q] == 0;
+        if (zero) G1H::set_inf(win[(size_t)w]); else g1h_from_plain_words(win[(size_t)w], p);
+    }
+    g1h_horner(r, win.data(), nwin, c);
+}
 // fixed-base multiplication for the generator: 32 byte-windows x 255 multiples (XYZZ, built once per context):
 // [k]G is 32 additions instead of 256 doublings + ~128 additions
 struct G1HFixedBase {

@@ -574,8 +574,8 @@ __global__ void __launch_bounds__(64, 2) k_build_direct_level(uint32_t* __restri
     }
     fp_t inv;
     Fp::inv(inv, acc);
-#pragma unroll
-    for (int g = G - 1; g >= 0; g--) {
+#pragma unroll 1
+    for (int g = G - 1; g >= 0; g--) {       // rolled: one copy of the addition; pre[] then lives in the lane's scratch memory
         if (g < cnt) {
             G1Aff e, o;
             load_affine(e, src + (size_t)g * 32);

@@ -224,7 +224,7 @@ def main():
         out = {
             "metric": "blobs/sec BlobToKZGCommitment (batch=256 per GPU)", "value": round(value, 2), "unit": "blobs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery, radix 2^29)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Montgomery field elements as 14 x 29-bit limbs in u32, 64-bit column accumulators (v_mad_u64_u32)",
             "data": "synthetic (GetRandBlob seeds, reference bench_test.go:17-46)",
             "config": {"workload": "configs[1]: BlobToKZGCommitment batch=256 blobs x 4096 scalars per GPU, fixed-base G1 MSM",
                        "batch_per_gpu": B, "msm": (f"direct window table c={args.direct_bits}" if args.direct_bits else f"bucket method c={args.window or 13}"), "parallelism": f"blob-sharded x{world}, no collective", "streams": NS},

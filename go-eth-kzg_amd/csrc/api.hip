@@ -141,6 +141,7 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->fk_ws_done) (void)hipEventDestroy(c->fk_ws_done);
     delete c;
 }
 

@@ -16,6 +16,19 @@ static const size_t V_MISC_WORDS_C = 16 + 4 * VMSM_WINDOWS * 48;
         if (c->profiling) c->timer.end(kind, s);           \
     } while (0)
 
+// The cells / FK20 / recovery workspaces are shared by every call; entry points that return before the GPU is done record
+// fk_ws_done, and every user of the workspaces first makes its stream wait for it (no host synchronisation).
+static int fk_ws_acquire(mkzg_ctx* c, hipStream_t s) {
+    if (!c->fk_ws_done) HIPCHK(hipEventCreateWithFlags(&c->fk_ws_done, hipEventDisableTiming));
+    if (c->fk_ws_used) HIPCHK(hipStreamWaitEvent(s, c->fk_ws_done, 0));
+    return MKZG_OK;
+}
+static int fk_ws_release(mkzg_ctx* c, hipStream_t s) {
+    HIPCHK(hipEventRecord(c->fk_ws_done, s));
+    c->fk_ws_used = true;
+    return MKZG_OK;
+}
+
 void free_cells(mkzg_ctx* c) {
     void* ptrs[] = {c->d_tw_fwd, c->d_tw_inv, c->d_g1tw_fwd, c->d_g1tw_inv, c->d_coeffs, c->d_cells, c->d_cell_st,
                     c->d_monomial_aff, c->d_fk_t_aff, c->d_fk_table, c->d_fk_scalars, c->d_fk_results, c->d_fk_proofs, c->d_fk_plan, c->d_fk_parts,
@@ -177,6 +190,8 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* c, const void* d_bl
     const size_t chunk_max = 64;
     int rc = ensure_fk20(c, std::min(n, chunk_max));
     if (rc) return rc;
+    rc = fk_ws_acquire(c, s);
+    if (rc) return rc;
     size_t done = 0;
     while (done < n) {
         size_t chunk = std::min(n - done, c->fk_cap);
@@ -188,7 +203,7 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* c, const void* d_bl
         done += chunk;
     }
     HIPCHK(hipGetLastError());
-    return MKZG_OK;
+    return fk_ws_release(c, s);
 }
 
 int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* c, const uint8_t* blob, int num_threads, uint8_t* cells_out, uint8_t* proofs_out) {
@@ -420,6 +435,8 @@ static int recover_front(mkzg_ctx* c, size_t n_blobs, const uint64_t* const* cel
     }
     int rc = with_proofs ? ensure_fk20(c, n_blobs) : ensure_cells(c, n_blobs);
     if (!rc) rc = ensure_staging(c, 1, std::max<size_t>(total_cells, 1) * 2048);
+    if (rc) return rc;
+    rc = fk_ws_acquire(c, s);
     if (rc) return rc;
     if (!c->rec_ready) {
         HIPCHK(hipMalloc(&c->d_pow7, 8192 * 48));

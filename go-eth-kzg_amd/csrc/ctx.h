@@ -120,6 +120,8 @@ struct mkzg_ctx {
     int* d_rec_pos = nullptr;              // per blob 128 positions + 64 missing ids, then one count per blob
     // FK20
     bool fk_ready = false;
+    hipEvent_t fk_ws_done = nullptr;       // orders reuse of the cells / FK20 / recovery workspaces across streams (asynchronous entry points)
+    bool fk_ws_used = false;
     uint32_t* d_monomial_aff = nullptr;    // 4096 affine rows
     uint32_t* d_fk_t_aff = nullptr;        // 8192 affine rows T[k][i]
     uint32_t* d_fk_table = nullptr;        // direct window table (4.3 GB)

@@ -209,3 +209,29 @@ def test_recover_batch(gpu_ctx, oracle_ctx):
     poisoned[3] = b"\xff" * 2048
     rc, res2 = gpu_ctx.RecoverCellsAndComputeKZGProofsBatch([(jobs[0][0], poisoned), jobs[1]])
     assert rc == 3 and res2[0][0] == 3 and res2[1][0] == 0 and res2[1][1] == res[1][1]
+
+
+def test_cells_and_proofs_async_on_two_streams(gpu_ctx, oracle_ctx):
+    """mkzg_compute_cells_and_kzg_proofs_batch_device returns before the GPU is done and shares its workspaces between calls: two calls
+    issued back to back on different streams must not clobber each other (the library orders them with an event)"""
+    import torch
+    blobs_a = [rand_blob(90 + i) for i in range(3)]
+    blobs_b = [rand_blob(95 + i) for i in range(3)]
+    da = torch.frombuffer(bytearray(b"".join(blobs_a)), dtype=torch.uint8).cuda()
+    db = torch.frombuffer(bytearray(b"".join(blobs_b)), dtype=torch.uint8).cuda()
+    outs = []
+    streams = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)]
+    torch.cuda.synchronize()
+    for d, s in ((da, streams[0]), (db, streams[1])):
+        cells = torch.zeros(3 * 262144, dtype=torch.uint8, device="cuda")
+        proofs = torch.zeros(3 * 128 * 48, dtype=torch.uint8, device="cuda")
+        st = torch.zeros(3, dtype=torch.int32, device="cuda")
+        assert gpu_ctx.compute_cells_and_kzg_proofs_batch_device(d.data_ptr(), 3, cells.data_ptr(), proofs.data_ptr(), st.data_ptr(), s.cuda_stream) == 0
+        outs.append((cells, proofs, st))
+    torch.cuda.synchronize()
+    for (cells, proofs, st), blobs in zip(outs, (blobs_a, blobs_b)):
+        assert st.cpu().tolist() == [0, 0, 0]
+        cb, pb = bytes(cells.cpu().tolist()), bytes(proofs.cpu().tolist())
+        for i, b in enumerate(blobs):
+            rc, oc, op = oracle_ctx.compute_cells_and_kzg_proofs(b)
+            assert rc == 0 and cb[i * 262144:(i + 1) * 262144] == oc and pb[i * 6144:(i + 1) * 6144] == op

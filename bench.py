@@ -333,7 +333,8 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
             "compute_blob_kzg_proof_batch_proofs_per_s": round(proofs_per_s, 1),
             "ms_per_call": round(ms, 3), "host_finish_ms": round(host_us / args.verify_steps / 1e3, 3), "kernels_ms_per_call": kern,
             "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(algo / (dom[1] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(algo / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None}}
+                         "frac": round(algo / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": (pmc_profile(dom[0]).get("traffic_bytes") if N == 1024 else None)}}
 
 
 def cpu_baseline():

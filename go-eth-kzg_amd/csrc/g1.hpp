@@ -61,11 +61,9 @@ struct G1T {
         F::mul(W, U, V);
         F::mul(S, x, V);
         F::sqr(t, x);
-        F::dbl(M, t);
-        F::add(M, M, t);
+        F::triple(M, t);
         F::sqr(X3, M);
-        F::dbl(t, S);
-        F::template sub<2>(X3, X3, t);        // M^2 - 2S + 4p        (< 5.01p)
+        F::template sub_2c<2>(X3, X3, S);     // M^2 - 2S + 4p        (< 5.01p)
         F::template sub<3>(t, S, X3);         // S - X3 + 8p
         F::template neg<1>(S, y);             // 2p - y
         F::mul2(r.y, M, t, W, S);             // M (S - X3) - W y      (< 1.01p)
@@ -83,11 +81,9 @@ struct G1T {
         F::mul(W, U, V);
         F::mul(S, p.x, V);
         F::sqr(t, p.x);
-        F::dbl(M, t);
-        F::add(M, M, t);
+        F::triple(M, t);
         F::sqr(X3, M);
-        F::dbl(t, S);
-        F::template sub<2>(X3, X3, t);
+        F::template sub_2c<2>(X3, X3, S);
         F::template sub<3>(t, S, X3);
         F::template neg<2>(S, p.y);           // 4p - Y
         F::mul2(Y3, M, t, W, S);              // M (S - X3) - W Y      (< 1.01p)
@@ -133,9 +129,7 @@ struct G1T {
         KZ_SCHED_FENCE();
         F::sqr(X3, Rd);
         KZ_SCHED_FENCE();
-        F::template sub<1>(X3, X3, PPP);      // R^2 - PPP + 2p        (< 3.01p)
-        F::dbl(t, Q);
-        F::template sub<2>(X3, X3, t);        // ... - 2Q + 4p         (< 7.01p)
+        F::template sub_b_2c<2>(X3, X3, PPP, Q);   // R^2 - PPP - 2Q + 4p   (PPP + 2Q < 3.03p; result < 5.01p)
         F::template sub<3>(t, Q, X3);         // Q - X3 + 8p
         F::template neg<2>(S2, acc.y);        // 4p - Y1
         KZ_SCHED_FENCE();
@@ -173,9 +167,7 @@ struct G1T {
             F::mul(PPP, Pd, PP);
             F::mul(Q, U1, PP);
             F::sqr(X3, Rd);
-            F::template sub<1>(X3, X3, PPP);
-            F::dbl(t, Q);
-            F::template sub<2>(X3, X3, t);
+            F::template sub_b_2c<2>(X3, X3, PPP, Q);
             F::template sub<3>(t, Q, X3);
             F::template neg<1>(S1, S1);           // 2p - S1
             F::mul2(Y3, Rd, t, S1, PPP);          // R (Q - X3) - S1 PPP   (< 1.01p)

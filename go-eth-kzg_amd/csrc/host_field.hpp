@@ -53,6 +53,24 @@ struct HostFp {
     }
     static inline void sqr(El& r, const El& a) { mul(r, a, a); }
     static inline void opaque(El&) {}
+    template <int KLOG>
+    static inline void sub_2c(El& r, const El& a, const El& c2) {
+        El t;
+        sub<KLOG>(t, a, c2);
+        sub<KLOG>(r, t, c2);
+    }
+    static inline void triple(El& r, const El& a) {
+        El t;
+        add(t, a, a);
+        add(r, t, a);
+    }
+    template <int KLOG>
+    static inline void sub_b_2c(El& r, const El& a, const El& b, const El& c2) {
+        El t;
+        sub<KLOG>(t, a, b);
+        sub<KLOG>(t, t, c2);
+        sub<KLOG>(r, t, c2);
+    }
     static inline void select(El& r, bool c, const El& a, const El& b) { r = c ? a : b; }
     static inline void mul2(El& r, const El& a, const El& b, const El& c, const El& d) {   // a*b + c*d
         El t1, t2;

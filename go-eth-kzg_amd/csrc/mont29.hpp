@@ -201,6 +201,49 @@ struct Mont29 {
             }
         }
     }
+    // r = a - b - 2c + K*M with K = 2^KLOG; requires b + 2c <= K*M.  One carry sweep instead of three (X3 = R^2 - PPP - 2Q).
+    template <int KLOG>
+    static KZ_HD void sub_b_2c(El& r, const El& a, const El& b, const El& c2) {
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            int32_t v = (int32_t)(a.l[i] - b.l[i] - 2 * c2.l[i] + P::KMOD[KLOG][i]) + c;
+            if (i < N - 1) {
+                r.l[i] = (uint32_t)v & MASK29;
+                c = v >> W29;
+            } else {
+                r.l[i] = (uint32_t)v;
+            }
+        }
+    }
+    // r = a - 2c + K*M (requires 2c <= K*M) and r = 3a: fused forms for the doubling formulas, one carry sweep each
+    template <int KLOG>
+    static KZ_HD void sub_2c(El& r, const El& a, const El& c2) {
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            int32_t v = (int32_t)(a.l[i] - 2 * c2.l[i] + P::KMOD[KLOG][i]) + c;
+            if (i < N - 1) {
+                r.l[i] = (uint32_t)v & MASK29;
+                c = v >> W29;
+            } else {
+                r.l[i] = (uint32_t)v;
+            }
+        }
+    }
+    static KZ_HD void triple(El& r, const El& a) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            uint32_t v = 3 * a.l[i] + c;
+            if (i < N - 1) {
+                r.l[i] = v & MASK29;
+                c = v >> W29;
+            } else {
+                r.l[i] = v;
+            }
+        }
+    }
     // r = K*M - a
     template <int KLOG>
     static KZ_HD void neg(El& r, const El& a) {

@@ -12,6 +12,9 @@ void shim_fp_sqr(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp:
 void shim_fp_mul2(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* o) {
     fp_t x, y, z, w, r; Fp::set(x, a); Fp::set(y, b); Fp::set(z, c); Fp::set(w, d); Fp::mul2(r, x, y, z, w); memcpy(o, r.l, 56);
 }
+void shim_fp_sub_b_2c(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* o) { fp_t x, y, z, r; Fp::set(x, a); Fp::set(y, b); Fp::set(z, c); Fp::sub_b_2c<2>(r, x, y, z); memcpy(o, r.l, 56); }
+void shim_fp_sub_2c(const uint32_t* a, const uint32_t* c, uint32_t* o) { fp_t x, z, r; Fp::set(x, a); Fp::set(z, c); Fp::sub_2c<2>(r, x, z); memcpy(o, r.l, 56); }
+void shim_fp_triple(const uint32_t* a, uint32_t* o) { fp_t x, r; Fp::set(x, a); Fp::triple(r, x); memcpy(o, r.l, 56); }
 void shim_fr_sqr(const uint32_t* a, uint32_t* o) { fr_t x, r; Fr::set(x, a); Fr::sqr(r, x); memcpy(o, r.l, 36); }
 void shim_fp_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { fp_t x, y, r; Fp::set(x, a); Fp::set(y, b); Fp::add(r, x, y); memcpy(o, r.l, 56); }
 void shim_fp_sub(int klog, const uint32_t* a, const uint32_t* b, uint32_t* o) {

@@ -89,6 +89,22 @@ def test_fp_sqr_mul2(shim):
         assert val(o) % R == a * a * pow(RF, -1, R) % R
 
 
+def test_fp_fused_linear_forms(shim):
+    """a - b - 2c + 4p, a - 2c + 4p and 3a: exact integer results, normalized limbs"""
+    rng = random.Random(12)
+    for it in range(300):
+        a = rng.randrange(0, 1 << rng.choice([381, 383, 385]))
+        b = rng.randrange(0, P + P // 100)
+        c = rng.randrange(0, P + P // 100)
+        o = out()
+        shim.shim_fp_sub_b_2c(limbs(a), limbs(b), limbs(c), o)
+        assert val(o) == a - b - 2 * c + 4 * P and normalized(o)
+        shim.shim_fp_sub_2c(limbs(a), limbs(c), o)
+        assert val(o) == a - 2 * c + 4 * P and normalized(o)
+        shim.shim_fp_triple(limbs(a), o)
+        assert val(o) == 3 * a and normalized(o)
+
+
 def test_fp_canon_plain_inv(shim):
     rng = random.Random(2)
     for it in range(100):

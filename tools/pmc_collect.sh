@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 # one small counter group per pass: FETCH_SIZE + WRITE_SIZE in one pass exceed the hardware's counters (error 38, and
 # rocprofv3 then hangs), hence also the per-pass timeout
-PASSES=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES")
+PASSES=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAVES" "VALUBusy" "VALUUtilization")
 if [ -n "${PMC_PASSES:-}" ]; then IFS=";" read -r -a PASSES <<< "$PMC_PASSES"; fi
 i=0
 for p in "${PASSES[@]}"; do

@@ -590,20 +590,22 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
         load_affine_v(p, pts + (size_t)(v & 0x7fffffffu) * 32);
         if (p.inf) continue;
         if (v >> 31) Fp::template neg<0>(p.y, p.y);
-        g1x_madd_nv(acc, p.x, p.y);
+        g1x_madd(acc, p.x, p.y);
     }
-    // per wave (64 buckets): S = sum B_l ; Q = sum l B_l  via suffix scan + tree
+    // per wave (64 buckets): S = sum B_l ; Q = sum l B_l  via suffix scan + tree.  The additions are inlined (one copy, rolled loop over
+    // the 12 rounds): the points stay in registers between rounds instead of travelling through the called routine's stack
     const int lane = t & 63, wave = t >> 6;
-    G1X Pf = acc, o;
-    for (int d = 1; d < 64; d <<= 1) {
+    G1X Pf = acc, o, S;
+#pragma unroll 1
+    for (int round = 0; round < 12; round++) {
+        const int d = round < 6 ? (1 << round) : (32 >> (round - 6));
+        if (round == 6) {
+            S = Pf;                // lane 0: sum of the wave's buckets
+            if (lane == 0) g1x_set_inf(Pf);
+        }
         shfl_down_xyzz_v(o, Pf, d);
-        if (lane + d < 64) g1x_add_nv(Pf, Pf, o);
-    }
-    G1X S = Pf;                    // lane 0: sum of the wave's buckets
-    if (lane == 0) g1x_set_inf(Pf);
-    for (int d = 32; d >= 1; d >>= 1) {
-        shfl_down_xyzz_v(o, Pf, d);
-        if (lane < d) g1x_add_nv(Pf, Pf, o);
+        const bool take = round < 6 ? (lane + d < 64) : (lane < d);
+        if (take) g1x_add(Pf, Pf, o);
     }
     // lane 0 of each wave now holds S_w (in S) and Q_w (in Pf)
     if (wave == 1 && lane == 0) {

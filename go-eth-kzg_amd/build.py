@@ -47,5 +47,14 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def _main():
+    try:
+        print(build(force="--force" in sys.argv, verbose=True))
+    except Exception as e:                      # the LAST line of the output must say so (people pipe this through tail)
+        print(str(e)[-3000:])
+        print("BUILD FAILED")
+        sys.exit(1)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    _main()

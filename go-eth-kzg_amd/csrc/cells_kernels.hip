@@ -485,16 +485,29 @@ __global__ void __launch_bounds__(64) k_cell_interp(const uint8_t* __restrict__ 
     }
     c_store_fr12(partials + ((size_t)blockIdx.x * 64 + lane) * 12, acc);
 }
-__global__ void __launch_bounds__(64) k_cell_interp_reduce(const uint32_t* __restrict__ partials, int n_blocks, uint32_t* __restrict__ interp8) {
-    const int lane = threadIdx.x;
+// interp[i] = sum over the workgroups' partial sums; 16 wavefronts each add a strided share of the partials, then an LDS tree
+__global__ void __launch_bounds__(1024) k_cell_interp_reduce(const uint32_t* __restrict__ partials, int n_blocks, uint32_t* __restrict__ interp8) {
+    __shared__ uint32_t sh[16 * 64 * 9];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     fr_t acc;
     Fr::set_zero(acc);
-    for (int b = 0; b < n_blocks; b++) {
+    for (int b = grp; b < n_blocks; b += 16) {
         fr_t v;
         c_load_fr12(v, partials + ((size_t)b * 64 + lane) * 12);
         FrC::add(acc, acc, v);
     }
-    fr_store_plain8(interp8 + (size_t)lane * 8, acc);
+#pragma unroll
+    for (int q = 0; q < 9; q++) sh[(grp * 9 + q) * 64 + lane] = acc.l[q];
+    __syncthreads();
+    if (grp == 0) {
+        for (int g = 1; g < 16; g++) {
+            fr_t v;
+#pragma unroll
+            for (int q = 0; q < 9; q++) v.l[q] = sh[(g * 9 + q) * 64 + lane];
+            FrC::add(acc, acc, v);
+        }
+        fr_store_plain8(interp8 + (size_t)lane * 8, acc);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -536,7 +549,7 @@ void cell_verify_scalars_device(const uint32_t* d_r8, uint32_t exp_offset, const
     hipLaunchKernelGGL(k_cell_weights, dim3(n_rows), dim3(256), 0, s, d_rp_rows, d_row_idx, n, n_rows, d_weights8);
     const int nb = n < CELL_INTERP_BLOCKS ? n : CELL_INTERP_BLOCKS;
     hipLaunchKernelGGL(k_cell_interp, dim3(nb), dim3(64), 0, s, d_cells, d_cell_idx, d_rp_rows, n, d_tw_inv, d_partials, d_cell_status);
-    hipLaunchKernelGGL(k_cell_interp_reduce, dim3(1), dim3(64), 0, s, d_partials, nb, d_interp8);
+    hipLaunchKernelGGL(k_cell_interp_reduce, dim3(1), dim3(1024), 0, s, d_partials, nb, d_interp8);
 }
 
 }  // namespace kzg

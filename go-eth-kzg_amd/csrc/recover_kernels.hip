@@ -261,18 +261,9 @@ __global__ void __launch_bounds__(RNT) k_recover_stage_b1(uint32_t* __restrict__
     uint32_t* y_halves = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS + (256 + 8192) * 12;
     const int* status = status_all + blob;
     if (status[0] != 0) return;
-    fr_t inv8192;
-    {
-        // 1/8192 = (1/4096)/2 : multiply by (r+1)/2 is awkward; use 1/4096 * 1/2 via inverse of 2 = (r+1)/2 -> compute by pow once per thread (cheap relative to the NTT)
-        fr_t two, half_;
-        Fr::set_one(two);
-        FrC::add(two, two, two);
-        Fr::pow_words(half_, two, FrParams::EXP_INV, FrParams::BITS);
-        Fr::reduce_once(half_, half_);
-        fr_t i4096;
-        Fr::set(i4096, FR_INV_4096);
-        r_mul(inv8192, i4096, half_);
-    }
+    fr_t inv8192;                       // 1/8192 in Montgomery form is R / 2^13 = 2^248: a single set limb (2^16 at weight 2^232)
+    Fr::set_zero(inv8192);
+    inv8192.l[8] = 0x10000u;
 #pragma unroll
     for (int k = 0; k < RN / RNT; k++) {
         const int pl = t + RNT * k;
@@ -344,16 +335,9 @@ __global__ void __launch_bounds__(RNT) k_recover_stage_d(const uint32_t* __restr
     }
     __syncthreads();
     ntt4096_dif(sh, tw_inv, t);
-    fr_t inv8192;
-    {
-        fr_t two, half_, i4096;
-        Fr::set_one(two);
-        FrC::add(two, two, two);
-        Fr::pow_words(half_, two, FrParams::EXP_INV, FrParams::BITS);
-        Fr::reduce_once(half_, half_);
-        Fr::set(i4096, FR_INV_4096);
-        r_mul(inv8192, i4096, half_);
-    }
+    fr_t inv8192;                       // 1/8192 in Montgomery form is R / 2^13 = 2^248: a single set limb (2^16 at weight 2^232)
+    Fr::set_zero(inv8192);
+    inv8192.l[8] = 0x10000u;
 #pragma unroll
     for (int k = 0; k < RN / RNT; k++) {
         const int pl = t + RNT * k;

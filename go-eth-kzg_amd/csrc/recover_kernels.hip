@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(128) k_recover_vanishing(const int* __restrict
     }
     r_store_fr12(zeval + (size_t)t * 12, a0);
     fr_t inv;
-    Fr::pow_words(inv, a1, FrParams::EXP_INV, FrParams::BITS);
+    Fr::inv(inv, a1);                       // divsteps (modinv30.hpp): ~10x cheaper than the Fermat exponentiation
     Fr::reduce_once(inv, inv);
     r_store_fr12(inv_zc + (size_t)t * 12, inv);
 }

@@ -294,11 +294,19 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     HIPCHK(hipEventRecord(c->ev_join, s2));
     // uploads, part 2 (host memcpy of n x 2 KiB into the pinned staging area runs while the GPU validates the points)
     {
-        std::vector<uint8_t> zero_cell;
-        for (size_t i = 0; i < n; i++) {
-            const uint8_t* src = cells[i];
-            if (!src) { if (zero_cell.empty()) zero_cell.assign(2048, 0); src = zero_cell.data(); }
-            memcpy(c->h_stage + i * 2048, src, 2048);
+        const std::vector<uint8_t> zero_cell(2048, 0);           // stands in for nil entries (reported after the device work)
+        auto gather = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) memcpy(c->h_stage + i * 2048, cells[i] ? cells[i] : zero_cell.data(), 2048);
+        };
+        if (n >= 1024) {                                          // 16 MiB for 8192 cells: four host threads
+            const size_t q = (n + 3) / 4;
+            std::thread t1(gather, q, std::min(n, 2 * q)), t2(gather, std::min(n, 2 * q), std::min(n, 3 * q)), t3(gather, std::min(n, 3 * q), n);
+            gather(0, q);
+            t1.join();
+            t2.join();
+            t3.join();
+        } else {
+            gather(0, n);
         }
         HIPCHK(hipMemcpyAsync(c->d_cv_cells, c->h_stage, n * 2048, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->d_cv_cell_idx, cell_indices, n * 8, hipMemcpyHostToDevice, s));

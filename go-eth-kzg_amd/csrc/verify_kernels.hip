@@ -750,7 +750,7 @@ int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const*
         jobs.j[m].scalars = d_scalars[q];
         jobs.j[m].points = d_points[q];
         jobs.j[m].n = n_per_job[q];
-        jobs.k[m] = std::min(VMSM_KMAX, std::max(1, n_per_job[q] / 1024));
+        jobs.k[m] = std::min(VMSM_KMAX, std::max(1, n_per_job[q] / 2048));   // 2048 points per slice: 8192-point jobs fill the GPU in one round of workgroups
         if (m < n_msm) kmax = std::max(kmax, jobs.k[m]);
     }
     hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts);

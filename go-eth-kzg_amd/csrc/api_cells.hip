@@ -365,7 +365,7 @@ static int cell_verify_finish(mkzg_ctx* c, const CellFold& f) {
     g1h_to_affine(ps[0], f.sums[0]);
     g1h_to_affine(ps[1], rl);
     const G2Prepared* qs[2] = {&c->g2_alpha64, &c->g2_neg_gen};
-    return pairing_check_prepared(ps, qs, 2) ? MKZG_OK : MKZG_VERIFY_FAILED;
+    return pairing_check_prepared_2mt(ps, qs) ? MKZG_OK : MKZG_VERIFY_FAILED;
 }
 int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
                                      size_t n_cells, const uint8_t* proofs48n, size_t n_p) {

@@ -15,6 +15,11 @@ int shim_pairing_check(const uint8_t* p48, const uint8_t* q96, int n) {
         g2_prepare(prep[i], q);
         qp[i] = &prep[i];
     }
+    if (n == 2) {                    // the two-thread variant must agree with the shared-squaring loop
+        const bool a = pairing_check_prepared(ps.data(), qp.data(), 2), b = pairing_check_prepared_2mt(ps.data(), qp.data());
+        if (a != b) return -3;
+        return a ? 1 : 0;
+    }
     return pairing_check_prepared(ps.data(), qp.data(), n) ? 1 : 0;
 }
 // cyclotomic_sqr against the general squaring on an element of the cyclotomic subgroup (f^((p^6-1)(p^2+1)) of a Miller-loop

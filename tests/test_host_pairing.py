@@ -22,7 +22,7 @@ def shim():
     src = os.path.join(SHIM_DIR, "pairing_shim.cpp")
     hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("host_pairing.hpp", "host_field.hpp", "host_g1.hpp", "g1.hpp", "mont29.hpp", "constants29.h")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
     return C.CDLL(so)
 
 

@@ -32,7 +32,7 @@ __device__ __forceinline__ void c_store_fr12(uint32_t* p, const fr_t& r) {
     q[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
     q[2] = make_uint4(r.l[8], 0, 0, 0);
 }
-__device__ __noinline__ void c_fr_mul(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
+__device__ __forceinline__ void c_fr_mul(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
 
 // LDS element access, structure-of-arrays: word q of element e at sh[q * N + e]
 template <int N>

@@ -36,7 +36,7 @@ __device__ __forceinline__ void r_store_fr12(uint32_t* p, const fr_t& r) {
     q[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
     q[2] = make_uint4(r.l[8], 0, 0, 0);
 }
-__device__ __noinline__ void r_mul(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
+__device__ __forceinline__ void r_mul(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
 __device__ __forceinline__ void r_get(fr_t& r, const uint32_t* sh, int e) {
 #pragma unroll
     for (int q = 0; q < 9; q++) r.l[q] = sh[q * RN + e];

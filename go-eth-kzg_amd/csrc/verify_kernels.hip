@@ -71,7 +71,7 @@ __device__ __forceinline__ void fr_from_words(fr_t& r, const uint32_t w[8]) {
     Fr::from_plain(t, pl);
     Fr::reduce_once(r, t);
 }
-__device__ __noinline__ void fr_mul_n(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
+__device__ __forceinline__ void fr_mul_n(fr_t& r, const fr_t& a, const fr_t& b) { FrC::mul(r, a, b); }
 __device__ __noinline__ void fr_inv_n(fr_t& r, const fr_t& a) {
     fr_t t;
     Fr::inv(t, a);             // divsteps (modinv30.hpp)
@@ -219,27 +219,29 @@ __global__ void __launch_bounds__(192) k_challenge_sha256(const uint8_t* __restr
 // ------------------------------------------------------------------------------------------
 // barycentric evaluation / quotient: one 256-thread workgroup per blob, 16 scalars per lane
 // ------------------------------------------------------------------------------------------
-constexpr int EV_T = 256, EV_PER = 16;
+constexpr int EV_T = 256;          // k_rlc_scalars workgroup
+constexpr int EVB_T = 128, EVB_PER = 32;   // k_blob_eval: one wave per blob, 64 scalars per lane -> one inversion per 64 elements
 
 // block-wide sum of one Fr per thread (result valid in thread 0)
-__device__ __forceinline__ void block_sum_fr(fr_t& v, uint32_t* sh /* EV_T*9 words */) {
+template <int BT>
+__device__ __forceinline__ void block_sum_fr(fr_t& v, uint32_t* sh /* BT*9 words */) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int q = 0; q < 9; q++) sh[q * EV_T + t] = v.l[q];
+    for (int q = 0; q < 9; q++) sh[q * BT + t] = v.l[q];
     __syncthreads();
-    for (int s = EV_T / 2; s >= 1; s >>= 1) {
+    for (int s = BT / 2; s >= 1; s >>= 1) {
         if (t < s) {
             fr_t a, b2;
 #pragma unroll
-            for (int q = 0; q < 9; q++) { a.l[q] = sh[q * EV_T + t]; b2.l[q] = sh[q * EV_T + t + s]; }
+            for (int q = 0; q < 9; q++) { a.l[q] = sh[q * BT + t]; b2.l[q] = sh[q * BT + t + s]; }
             FrC::add(a, a, b2);
 #pragma unroll
-            for (int q = 0; q < 9; q++) sh[q * EV_T + t] = a.l[q];
+            for (int q = 0; q < 9; q++) sh[q * BT + t] = a.l[q];
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int q = 0; q < 9; q++) v.l[q] = sh[q * EV_T];
+    for (int q = 0; q < 9; q++) v.l[q] = sh[q * BT];
     __syncthreads();
 }
 
@@ -247,10 +249,10 @@ __device__ __forceinline__ void block_sum_fr(fr_t& v, uint32_t* sh /* EV_T*9 wor
 // MODE 1: q_b = (f_b - y_b)/(X - z_b) in evaluation form   -> quot_out (4096 rows of 12 words), also y_out
 // z comes from z_in (rows of 12 words); if y_given != nullptr MODE 1 trusts it (not used).
 template <int MODE>
-__global__ void __launch_bounds__(EV_T) k_blob_eval(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ z_in, const uint32_t* __restrict__ roots_brp,
+__global__ void __launch_bounds__(EVB_T) k_blob_eval(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ z_in, const uint32_t* __restrict__ roots_brp,
                                                     const uint32_t* __restrict__ inv_roots_brp, uint32_t* __restrict__ y_out, uint32_t* __restrict__ quot_out,
                                                     int* __restrict__ status) {
-    __shared__ uint32_t sh[EV_T * 9];
+    __shared__ uint32_t sh[EVB_T * 9];
     __shared__ int sh_found;
     __shared__ int sh_bad;
     const int b = blockIdx.x, t = threadIdx.x;
@@ -261,14 +263,14 @@ __global__ void __launch_bounds__(EV_T) k_blob_eval(const uint8_t* __restrict__ 
     load_fr12(z, z_in + (size_t)b * 12);
 
     // pass 1: canonical check, d_i = z - w_i, per-lane prefix products (zeros skipped)
-    fr_t pre[EV_PER];
+    fr_t pre[EVB_PER];
     fr_t acc;
     Fr::set_one(acc);
     bool bad = false;
     int found = -1;
-#pragma unroll
-    for (int k = 0; k < EV_PER; k++) {
-        const int i = t + EV_T * k;
+#pragma unroll 4
+    for (int k = 0; k < EVB_PER; k++) {
+        const int i = t + EVB_T * k;
         uint32_t w[8];
         load_be32_words(w, blob + (size_t)i * 32);
         bad |= Fr::words32_geq_mod(w);
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(EV_T) k_blob_eval(const uint8_t* __restrict__ 
         load_fr12(wi, roots_brp + (size_t)i * 12);
         FrC::sub(d, z, wi);
         if (Fr::limbs_all_zero(d)) found = i;
-        else fr_mul_n(acc, acc, d);
+        else FrC::mul(acc, acc, d);
         pre[k] = acc;
     }
     if (bad) sh_bad = 1;
@@ -308,47 +310,47 @@ __global__ void __launch_bounds__(EV_T) k_blob_eval(const uint8_t* __restrict__ 
         // sum_i f_i w_i / (z - w_i)
         fr_t part;
         Fr::set_zero(part);
-#pragma unroll
-        for (int k = EV_PER - 1; k >= 0; k--) {
-            const int i = t + EV_T * k;
+#pragma unroll 4
+        for (int k = EVB_PER - 1; k >= 0; k--) {
+            const int i = t + EVB_T * k;
             fr_t wi, d, di, f, term;
             load_fr12(wi, roots_brp + (size_t)i * 12);
             FrC::sub(d, z, wi);
-            if (k > 0) fr_mul_n(di, inv, pre[k - 1]); else di = inv;
-            fr_mul_n(inv, inv, d);
+            if (k > 0) FrC::mul(di, inv, pre[k - 1]); else di = inv;
+            FrC::mul(inv, inv, d);
             uint32_t w[8];
             load_be32_words(w, blob + (size_t)i * 32);
             fr_from_words(f, w);
-            fr_mul_n(term, f, wi);
-            fr_mul_n(term, term, di);
+            FrC::mul(term, f, wi);
+            FrC::mul(term, term, di);
             FrC::add(part, part, term);
             if (MODE == 1) pre[k] = di;   // keep 1/(z - w_i) for the quotient
         }
-        block_sum_fr(part, sh);
+        block_sum_fr<EVB_T>(part, sh);
         // y = (z^4096 - 1)/4096 * sum
         fr_t y;
         {
             fr_t zp = z, one, c;
 #pragma unroll 1
-            for (int s = 0; s < 12; s++) fr_mul_n(zp, zp, zp);
+            for (int s = 0; s < 12; s++) FrC::mul(zp, zp, zp);
             Fr::set_one(one);
             FrC::sub(zp, zp, one);
             Fr::set(c, FR_INV_4096);
-            fr_mul_n(zp, zp, c);
-            fr_mul_n(y, zp, part);
+            FrC::mul(zp, zp, c);
+            FrC::mul(y, zp, part);
         }
         if (t == 0) store_fr12(y_out + (size_t)b * 12, y);
         if (MODE == 1) {
             // q_i = (f_i - y) / (w_i - z) = (y - f_i) * 1/(z - w_i)          (kzg_prove.go:81-112)
-#pragma unroll
-            for (int k = 0; k < EV_PER; k++) {
-                const int i = t + EV_T * k;
+#pragma unroll 4
+            for (int k = 0; k < EVB_PER; k++) {
+                const int i = t + EVB_T * k;
                 uint32_t w[8];
                 load_be32_words(w, blob + (size_t)i * 32);
                 fr_t f, q;
                 fr_from_words(f, w);
                 FrC::sub(f, y, f);
-                fr_mul_n(q, f, pre[k]);
+                FrC::mul(q, f, pre[k]);
                 store_fr12(quot_out + ((size_t)b * 4096 + i) * 12, q);
             }
         }
@@ -367,32 +369,32 @@ __global__ void __launch_bounds__(EV_T) k_blob_eval(const uint8_t* __restrict__ 
         if (t == 0) store_fr12(y_out + (size_t)b * 12, y);
         fr_t part;
         Fr::set_zero(part);
-#pragma unroll
-        for (int k = EV_PER - 1; k >= 0; k--) {
-            const int i = t + EV_T * k;
+#pragma unroll 4
+        for (int k = EVB_PER - 1; k >= 0; k--) {
+            const int i = t + EVB_T * k;
             fr_t wi, d, di, f, q, term;
             load_fr12(wi, roots_brp + (size_t)i * 12);
             FrC::sub(d, z, wi);
             const bool self = (i == fidx);
             if (!self) {
                 // pre[] skipped the zero, so the chain is consistent: previous prefix is pre[k-1]
-                if (k > 0) fr_mul_n(di, inv, pre[k - 1]); else di = inv;
-                fr_mul_n(inv, inv, d);
+                if (k > 0) FrC::mul(di, inv, pre[k - 1]); else di = inv;
+                FrC::mul(inv, inv, d);
                 uint32_t w[8];
                 load_be32_words(w, blob + (size_t)i * 32);
                 fr_from_words(f, w);
                 FrC::sub(f, y, f);               // y - f_i
-                fr_mul_n(q, f, di);              // (y - f_i)/(z - w_i) = (f_i - y)/(w_i - z)
+                FrC::mul(q, f, di);              // (y - f_i)/(z - w_i) = (f_i - y)/(w_i - z)
                 store_fr12(quot_out + ((size_t)b * 4096 + i) * 12, q);
-                fr_mul_n(term, q, wi);
+                FrC::mul(term, q, wi);
                 FrC::sub(part, part, term);      // accumulate -q_j w_j
             }
         }
-        block_sum_fr(part, sh);
+        block_sum_fr<EVB_T>(part, sh);
         if (t == 0) {
             fr_t iw, qm;
             load_fr12(iw, inv_roots_brp + (size_t)fidx * 12);
-            fr_mul_n(qm, part, iw);
+            FrC::mul(qm, part, iw);
             store_fr12(quot_out + ((size_t)b * 4096 + fidx) * 12, qm);
         }
     }
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(EV_T) k_rlc_scalars(const uint32_t* __restrict
 #pragma unroll
         for (int q = 0; q < 8; q++) s3[(size_t)i * 8 + q] = w[q];
     }
-    block_sum_fr(part, sh);
+    block_sum_fr<EV_T>(part, sh);
     if (t == 0) {
         fr_t pl;
         uint32_t w[8];
@@ -725,11 +727,11 @@ void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int 
     if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(192), 0, s, d_blobs, d_commitments, n, d_z);
 }
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EV_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);
+    if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);
 }
 void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
                           int* d_status, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL((k_blob_eval<1>), dim3(n), dim3(EV_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, d_quot, d_status);
+    if (n > 0) hipLaunchKernelGGL((k_blob_eval<1>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, d_quot, d_status);
 }
 void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s) { g1_subgroup_check2_device(d_aff, n, d_status, nullptr, 0, nullptr, s); }
 void g1_subgroup_check2_device(const uint32_t* d_aff_a, int n_a, int* d_st_a, const uint32_t* d_aff_b, int n_b, int* d_st_b, hipStream_t s) {

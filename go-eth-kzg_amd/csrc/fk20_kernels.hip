@@ -89,44 +89,51 @@ __device__ __forceinline__ int glv_digit5(const uint32_t* k, int w) {
     return d;
 }
 __device__ __noinline__ void f_mul_glv(G1X& r, const G1X& p, const uint32_t* kk) {
-    // group operations are inlined here (one copy each, inside rolled loops) so that the accumulator stays in registers;
-    // only the 16-entry table (1..16 times p) is addressed dynamically and lives in the lane's scratch memory.
+    // The accumulator is Jacobian (g1.hpp jdbl: 5 squarings + 2 multiplications per doubling, against 3 + 6 in XYZZ -- the 125
+    // doublings are two thirds of this routine); the 16 table entries carry Z^2 and Z^3 so that an addition costs what the XYZZ
+    // one does.  Group operations are inlined (one copy each, inside rolled loops) so that the accumulator stays in registers;
+    // only the table (1..16 times p) is addressed dynamically and lives in the lane's scratch memory.
     // 26 signed 5-bit windows over both half-scalars: 125 doublings + <= 52 additions + 15 for the table.
-    G1X tbl[16];
-    tbl[0] = p;
+    G1JC tbl[16];
     {
-        G1X run = p;
+        G1J run;
+        G1JC pc;
+        G1D::jac_from_xyzz(run, p);
+        G1D::jac_cache(pc, run);
+        tbl[0] = pc;
 #pragma unroll 1
         for (int i = 1; i < 16; i++) {
-            g1x_add(run, run, p);
-            tbl[i] = run;
+            G1JC e;
+            G1D::jadd(run, run, pc);
+            G1D::jac_cache(e, run);
+            tbl[i] = e;
         }
     }
     fp_t beta;
     Fp::set(beta, FP_BETA);
-    G1X acc;
-    g1x_set_inf(acc);
+    G1J acc;
+    G1D::set_inf(acc);
     int top = 25;
     while (top >= 0 && glv_digit5(kk, top) == 0 && glv_digit5(kk + 4, top) == 0) top--;
 #pragma unroll 1
     for (int w = top; w >= 0; w--) {
         if (w != top) {
 #pragma unroll 1
-            for (int q = 0; q < 5; q++) g1x_dbl(acc, acc);
+            for (int q = 0; q < 5; q++) G1D::jdbl(acc, acc);
         }
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             const int d = glv_digit5(kk + 4 * half, w);
             if (d) {
-                G1X q = tbl[(d < 0 ? -d : d) - 1];
+                G1JC q = tbl[(d < 0 ? -d : d) - 1];
                 // second half: -phi(.) = (beta X, -Y); a negative digit flips the sign once more
                 if (half) Fp::mul(q.x, q.x, beta);
-                if ((d < 0) != (half != 0)) Fp::template neg<2>(q.y, q.y);
-                g1x_add(acc, acc, q);
+                if ((d < 0) != (half != 0)) Fp::template neg<3>(q.y, q.y);   // 8p - Y (Y < 5.01p)
+                G1D::jadd(acc, acc, q);
             }
         }
     }
-    r = acc;
+    G1D::jac_to_xyzz(r, acc);
 }
 
 // ------------------------------------------------------------------------------------------

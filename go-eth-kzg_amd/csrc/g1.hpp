@@ -213,6 +213,141 @@ struct G1T {
         F::canon(r.y, t);
         r.inf = 0;
     }
+
+    // ------------------------------------------------------------------------------------------
+    // Jacobian accumulator (x = X/Z^2, y = Y/Z^3) for the doubling-dominated chains -- the GLV twiddle multiplications of
+    // the FK20 transforms and the subgroup test: a = 0 doubling "dbl-2009-l" is 5 squarings + 2 multiplications against
+    // 3 + 6 (one of them a fused pair) for the XYZZ doubling; the addition takes an operand with cached Z^2, Z^3 and costs
+    // the same as the XYZZ one.  Same role as gnark-crypto's G1Jac under the reference's subgroup checks (reached from
+    // internal/kzg/kzg_verify.go through G1Affine.IsInSubGroup) -- formulas from the EFD, not from that code.
+    // Loose bounds when F = Fp:  X < 17.01p, Y < 5.01p, Z < 1.01p.
+    // ------------------------------------------------------------------------------------------
+    struct Jac {   // Z == all-zero limbs marks the identity
+        fe x, y, z;
+    };
+    struct JacC {  // addition operand: Jacobian with zz = Z^2, zzz = Z^3 cached
+        fe x, y, z, zz, zzz;
+    };
+    static KZ_HD bool is_inf(const Jac& p) { return F::limbs_all_zero(p.z); }
+    static KZ_HD void opaque(Jac& p) {
+        F::opaque(p.x);
+        F::opaque(p.y);
+        F::opaque(p.z);
+    }
+    static KZ_HD void set_inf(Jac& p) {
+        F::set_one(p.x);
+        F::set_one(p.y);
+        F::set_zero(p.z);
+    }
+    static KZ_HD void select(Jac& r, bool c, const Jac& a, const Jac& b) {
+        F::select(r.x, c, a.x, b.x);
+        F::select(r.y, c, a.y, b.y);
+        F::select(r.z, c, a.z, b.z);
+    }
+    // XYZZ -> Jacobian with Z = ZZ:  (X ZZ, Y ZZZ, ZZ)   [x = X/ZZ = X ZZ/ZZ^2,  y = Y/ZZZ = Y ZZZ/ZZ^3 since ZZZ^2 = ZZ^3]
+    static KZ_HD void jac_from_xyzz(Jac& r, const XYZZ& p) {
+        F::mul(r.x, p.x, p.zz);
+        F::mul(r.y, p.y, p.zzz);
+        r.z = p.zz;
+    }
+    // Jacobian -> XYZZ (X, Y, Z^2, Z^3); X and Y pass through a multiplication by one so that the XYZZ bounds hold again
+    static KZ_HD void jac_to_xyzz(XYZZ& r, const Jac& p) {
+        fe one;
+        F::set_one(one);
+        F::sqr(r.zz, p.z);
+        F::mul(r.zzz, r.zz, p.z);
+        F::mul(r.x, p.x, one);
+        F::mul(r.y, p.y, one);
+    }
+    static KZ_HD void jac_cache(JacC& r, const Jac& p) {
+        r.x = p.x;
+        r.y = p.y;
+        r.z = p.z;
+        F::sqr(r.zz, p.z);
+        F::mul(r.zzz, r.zz, p.z);
+    }
+    static KZ_HD void jac_cache_affine(JacC& r, const fe& x, const fe& y) {
+        r.x = x;
+        r.y = y;
+        F::set_one(r.z);
+        F::set_one(r.zz);
+        F::set_one(r.zzz);
+    }
+    // r = 2p (dbl-2009-l with B doubled up front, so that 4XY^2 = (X + 2Y^2)^2 - X^2 - 4Y^4 needs no further scaling).
+    // The identity needs no branch: Z = 0 gives Z3 = 2Y * 0 = 0 (all-zero limbs).
+    static KZ_HD void jdbl(Jac& r, const Jac& p_) {
+        Jac p = p_;
+        opaque(p);
+        fe A, B2, C4, t, D, E, X3, Y3, U;
+        F::sqr(A, p.x);
+        F::sqr(B2, p.y);
+        F::dbl(B2, B2);                           // 2 Y^2            (< 2.01p)
+        F::sqr(C4, B2);                           // 4 Y^4
+        F::add(t, p.x, B2);                       //                   (< 19.1p)
+        F::sqr(t, t);
+        F::template sub_b_c<2>(D, t, A, C4);      // D = 4 X Y^2 + 4p  (< 5.01p)
+        F::triple(E, A);                          // 3 X^2
+        F::sqr(X3, E);
+        F::template sub_2c<4>(X3, X3, D);         // E^2 - 2D + 16p    (< 17.01p)
+        F::template sub<5>(t, D, X3);             // D - X3 + 32p      (< 37.1p)
+        F::mul(Y3, E, t);
+        F::template sub_2c<2>(Y3, Y3, C4);        // E (D - X3) - 8 Y^4 + 4p   (< 5.01p)
+        F::dbl(U, p.y);
+        F::mul(r.z, U, p.z);
+        r.x = X3;
+        r.y = Y3;
+    }
+    // r = a + b (add-2007-bl with b's Z^2, Z^3 cached); every exceptional case exact, resolved with selects as in add() above
+    static KZ_HD void jadd(Jac& r, const Jac& a_, const JacC& b_) {
+        Jac a = a_;
+        JacC b = b_;
+        opaque(a);
+        F::opaque(b.x);
+        F::opaque(b.y);
+        F::opaque(b.z);
+        F::opaque(b.zz);
+        F::opaque(b.zzz);
+        const bool a_inf = is_inf(a), b_inf = F::limbs_all_zero(b.z);
+        fe Z1Z1, Z1c, U1, U2, S1, S2, H, Rd, HH, HHH, Q, t, X3, Y3;
+        Jac res, bj;
+        bj.x = b.x;
+        bj.y = b.y;
+        bj.z = b.z;
+        F::sqr(Z1Z1, a.z);
+        F::mul(Z1c, Z1Z1, a.z);
+        F::mul(U1, a.x, b.zz);
+        F::mul(U2, b.x, Z1Z1);
+        F::mul(S1, a.y, b.zzz);
+        F::mul(S2, b.y, Z1c);
+        F::template sub<1>(H, U2, U1);
+        F::template sub<1>(Rd, S2, S1);
+        if (!a_inf && !b_inf && F::template is_zero_mod<16>(H)) {
+            if (F::template is_zero_mod<16>(Rd)) jdbl(res, a);
+            else set_inf(res);
+        } else {
+            opaque(a);
+            F::opaque(b.z);
+            F::opaque(H);
+            F::opaque(Rd);
+            F::opaque(U1);
+            F::opaque(S1);
+            F::sqr(HH, H);
+            F::mul(HHH, H, HH);
+            F::mul(Q, U1, HH);
+            F::sqr(X3, Rd);
+            F::template sub_b_2c<2>(X3, X3, HHH, Q);   // R^2 - H^3 - 2 U1 H^2 + 4p   (< 5.01p)
+            F::template sub<3>(t, Q, X3);
+            F::template neg<1>(S1, S1);
+            F::mul2(Y3, Rd, t, S1, HHH);                // R (U1 H^2 - X3) - S1 H^3     (< 1.01p)
+            F::mul(t, a.z, b.z);
+            F::mul(res.z, t, H);
+            res.x = X3;
+            res.y = Y3;
+        }
+        select(res, b_inf, a, res);
+        select(res, a_inf, bj, res);
+        r = res;
+    }
 };
 
 // ---- device / radix-2^29 instantiation, under the names the kernels use
@@ -228,6 +363,8 @@ KZ_HD void g1x_madd(G1X& acc, const fp_t& x2, const fp_t& y2) { G1D::madd(acc, x
 KZ_HD void g1x_add(G1X& r, const G1X& a, const G1X& b) { G1D::add(r, a, b); }
 KZ_HD void g1x_neg(G1X& r, const G1X& a) { G1D::neg(r, a); }
 KZ_HD void g1x_to_affine(G1Aff& r, const G1X& p) { G1D::to_affine(r, p); }
+using G1J = G1D::Jac;
+using G1JC = G1D::JacC;
 
 // zcash-format compression of a canonical affine point into 12 big-endian-ordered words
 // (reference serialization.go:98-100 -> gnark G1Affine.Bytes).  out[0] is the most significant

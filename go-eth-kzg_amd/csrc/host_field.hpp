@@ -71,6 +71,12 @@ struct HostFp {
         sub<KLOG>(t, t, c2);
         sub<KLOG>(r, t, c2);
     }
+    template <int KLOG>
+    static inline void sub_b_c(El& r, const El& a, const El& b, const El& c1) {
+        El t;
+        sub<KLOG>(t, a, b);
+        sub<KLOG>(r, t, c1);
+    }
     static inline void select(El& r, bool c, const El& a, const El& b) { r = c ? a : b; }
     static inline void mul2(El& r, const El& a, const El& b, const El& c, const El& d) {   // a*b + c*d
         El t1, t2;

@@ -186,7 +186,7 @@ struct Mont29 {
     }
     static KZ_HD void dbl(El& r, const El& a) { add(r, a, a); }
 
-    // r = a - b + K*M with K = 2^KLOG (KLOG in 0..4); requires b <= K*M.  No modular reduction.
+    // r = a - b + K*M with K = 2^KLOG (KLOG in 0..5); requires b <= K*M.  No modular reduction.
     template <int KLOG>
     static KZ_HD void sub(El& r, const El& a, const El& b) {
         int32_t c = 0;
@@ -208,6 +208,21 @@ struct Mont29 {
 #pragma unroll
         for (int i = 0; i < N; i++) {
             int32_t v = (int32_t)(a.l[i] - b.l[i] - 2 * c2.l[i] + P::KMOD[KLOG][i]) + c;
+            if (i < N - 1) {
+                r.l[i] = (uint32_t)v & MASK29;
+                c = v >> W29;
+            } else {
+                r.l[i] = (uint32_t)v;
+            }
+        }
+    }
+    // r = a - b - c + K*M with K = 2^KLOG; requires b + c <= K*M  (Jacobian doubling: (X + 2B)^2 - A - 4C)
+    template <int KLOG>
+    static KZ_HD void sub_b_c(El& r, const El& a, const El& b, const El& c1) {
+        int32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            int32_t v = (int32_t)(a.l[i] - b.l[i] - c1.l[i] + P::KMOD[KLOG][i]) + c;
             if (i < N - 1) {
                 r.l[i] = (uint32_t)v & MASK29;
                 c = v >> W29;

@@ -417,32 +417,38 @@ __global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __rest
     load_affine_v(p, aff + (size_t)i * 32);
     if (p.inf) return;
     // T = [|x|]P, Q = [|x|]T   (|x| = 0xd201000000010000, top bit at 63)
-    // both chains in ONE rolled loop (pass 0: T = [|x|]P, pass 1: Q = [|x|]T) with the doubling inlined, so that the running
-    // point stays in registers through the 126 doublings; the five additions per pass go through the called routine
-    G1X Q, base;
-    g1x_from_affine(base, p.x, p.y);
-    Q = base;
+    // both chains in ONE rolled loop (pass 0: T = [|x|]P, pass 1: Q = [|x|]T) with the group operations inlined, so that the
+    // running point stays in registers through the 126 doublings.  Jacobian coordinates: the chain is nothing but doublings
+    // (5 squarings + 2 multiplications each, g1.hpp jdbl) and this kernel is their latency, one lone wavefront per 64 points.
+    G1J Q;
+    G1JC base;
+    G1D::jac_cache_affine(base, p.x, p.y);
+    Q.x = p.x;
+    Q.y = p.y;
+    Fp::set_one(Q.z);
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
 #pragma unroll 1
         for (int bit = 62; bit >= 0; bit--) {
-            g1x_dbl(Q, Q);
-            if ((BLS_X_ABS >> bit) & 1) g1x_add_nv(Q, Q, base);
+            G1D::jdbl(Q, Q);
+            if ((BLS_X_ABS >> bit) & 1) G1D::jadd(Q, Q, base);
         }
-        if (pass == 0) base = Q;
+        if (pass == 0) G1D::jac_cache(base, Q);
     }
-    // phi(P) = (beta x, y) must equal -Q = (X, -Y, ZZ, ZZZ):   beta x ZZ == X  and  y ZZZ == -Y
+    // phi(P) = (beta x, y) must equal -Q = (X, -Y, Z):   beta x Z^2 == X  and  y Z^3 == -Y
     bool ok;
-    if (g1x_is_inf(Q)) {
+    if (G1D::is_inf(Q)) {
         ok = false;
     } else {
-        fp_t beta, l, r;
+        fp_t beta, l, r, zz, zzz;
         Fp::set(beta, FP_BETA);
+        Fp::sqr(zz, Q.z);
+        Fp::mul(zzz, zz, Q.z);
         Fp::mul(l, beta, p.x);
-        Fp::mul(l, l, Q.zz);
+        Fp::mul(l, l, zz);
         ok = Fp::eq_mod(l, Q.x);
-        Fp::mul(l, p.y, Q.zzz);
-        Fp::template neg<2>(r, Q.y);
+        Fp::mul(l, p.y, zzz);
+        Fp::template neg<3>(r, Q.y);
         ok = ok && Fp::eq_mod(l, r);
     }
     if (!ok) st[i] = MKZG_ERR_G1_NOT_IN_SUBGROUP;

@@ -38,6 +38,17 @@ void shim_g1_madd(uint32_t* acc, const uint32_t* x, const uint32_t* y) { G1X a; 
 void shim_g1_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { G1X x, y, r; memcpy(&x, a, 224); memcpy(&y, b, 224); g1x_add(r, x, y); memcpy(o, &r, 224); }
 void shim_g1_dbl(const uint32_t* a, uint32_t* o) { G1X x, r; memcpy(&x, a, 224); g1x_dbl(r, x); memcpy(o, &r, 224); }
 void shim_g1_set_inf(uint32_t* o) { G1X r; g1x_set_inf(r); memcpy(o, &r, 224); }
+// Jacobian accumulators: 3 x 14 limbs (x, y, z)
+void shim_g1j_from_xyzz(const uint32_t* a, uint32_t* o) { G1X x; memcpy(&x, a, 224); G1J r; G1D::jac_from_xyzz(r, x); memcpy(o, &r, 168); }
+void shim_g1j_to_xyzz(const uint32_t* a, uint32_t* o) { G1J x; memcpy(&x, a, 168); G1X r; G1D::jac_to_xyzz(r, x); memcpy(o, &r, 224); }
+void shim_g1j_set_inf(uint32_t* o) { G1J r; G1D::set_inf(r); memcpy(o, &r, 168); }
+void shim_g1j_dbl(const uint32_t* a, uint32_t* o) { G1J x, r; memcpy(&x, a, 168); G1D::jdbl(r, x); memcpy(o, &r, 168); }
+void shim_g1j_add(const uint32_t* a, const uint32_t* b, uint32_t* o) {   // b: another Jacobian accumulator
+    G1J x, y, r; memcpy(&x, a, 168); memcpy(&y, b, 168); G1JC c; G1D::jac_cache(c, y); G1D::jadd(r, x, c); memcpy(o, &r, 168);
+}
+void shim_g1j_add_affine(const uint32_t* a, const uint32_t* px, const uint32_t* py, uint32_t* o) {
+    G1J x, r; memcpy(&x, a, 168); fp_t fx, fy; Fp::set(fx, px); Fp::set(fy, py); G1JC c; G1D::jac_cache_affine(c, fx, fy); G1D::jadd(r, x, c); memcpy(o, &r, 168);
+}
 // returns compressed 48 bytes
 void shim_g1_compress(const uint32_t* a, uint8_t* out48) {
     G1X x; memcpy(&x, a, 224); G1Aff aff; g1x_to_affine(aff, x);

@@ -288,6 +288,86 @@ def test_g1_ops(shim):
     assert shim_compress(shim, acc) == compress(ref)
 
 
+def jac_value(acc, k):
+    return sum(int(acc[14 * k + i]) << (29 * i) for i in range(14))
+
+
+def jac_check_bounds(acc):
+    # the loose bounds g1.hpp states for a Jacobian accumulator
+    assert jac_value(acc, 0) < 17.01 * P and jac_value(acc, 1) < 5.01 * P and jac_value(acc, 2) < 1.01 * P
+
+
+def jac_compress(shim, j):
+    x = (C.c_uint32 * 56)()
+    shim.shim_g1j_to_xyzz(j, x)
+    # X < 8p, Y < 4p, ZZ, ZZZ < 1.01p again
+    v = [sum(int(x[14 * k + i]) << (29 * i) for i in range(14)) for k in range(4)]
+    assert v[0] < 8 * P and v[1] < 4 * P and v[2] < 1.01 * P and v[3] < 1.01 * P
+    return shim_compress(shim, x)
+
+
+def test_g1_jacobian_ops(shim):
+    """Jacobian doubling / addition against affine arithmetic in Python, every exceptional case, bounds after every step"""
+    G = (G1X, G1Y)
+    rng = random.Random(11)
+    pts = [ec_mul(rng.randrange(1, R), G) for _ in range(5)]
+    aff = lambda pt: (limbs(pt[0] * RP % P), limbs(pt[1] * RP % P))
+    J = lambda: (C.c_uint32 * 42)()
+    # XYZZ with a non-trivial ZZ -> Jacobian -> back
+    a = xyzz_from_affine(pts[0])
+    shim.shim_g1_madd(a, *aff(pts[1]))
+    ja = J()
+    shim.shim_g1j_from_xyzz(a, ja)
+    ref_a = ec_add(pts[0], pts[1])
+    assert jac_compress(shim, ja) == compress(ref_a)
+    # identity handling
+    inf = J()
+    shim.shim_g1j_set_inf(inf)
+    assert jac_compress(shim, inf) == compress(None)
+    o = J()
+    shim.shim_g1j_dbl(inf, o)
+    assert jac_compress(shim, o) == compress(None)
+    shim.shim_g1j_add(inf, ja, o)
+    assert jac_compress(shim, o) == compress(ref_a)
+    shim.shim_g1j_add(ja, inf, o)
+    assert jac_compress(shim, o) == compress(ref_a)
+    shim.shim_g1j_add(inf, inf, o)
+    assert jac_compress(shim, o) == compress(None)
+    shim.shim_g1j_add_affine(inf, *aff(pts[2]), o)
+    assert jac_compress(shim, o) == compress(pts[2])
+    # P + P and P - P through the addition
+    shim.shim_g1j_add(ja, ja, o)
+    assert jac_compress(shim, o) == compress(ec_mul(2, ref_a))
+    shim.shim_g1j_add_affine(o, *aff(ec_mul(2, ref_a)), o)
+    assert jac_compress(shim, o) == compress(ec_mul(4, ref_a))
+    neg = (ref_a[0], P - ref_a[1])
+    shim.shim_g1j_add_affine(ja, *aff(neg), o)
+    assert jac_compress(shim, o) == compress(None)
+    # long mixed chain (what a windowed multiplication does): 5 doublings, then additions of accumulators and affine points
+    acc, ref = J(), None
+    shim.shim_g1j_set_inf(acc)
+    for i in range(60):
+        for _ in range(5):
+            shim.shim_g1j_dbl(acc, acc)
+            ref = ec_add(ref, ref) if ref else None
+            jac_check_bounds(acc)
+        if i % 3 != 2:
+            shim.shim_g1j_add(acc, ja, acc)
+            ref = ec_add(ref, ref_a)
+        else:
+            shim.shim_g1j_add_affine(acc, *aff(pts[i % 5]), acc)
+            ref = ec_add(ref, pts[i % 5])
+        jac_check_bounds(acc)
+    assert jac_compress(shim, acc) == compress(ref)
+    # 126 doublings in a row (the subgroup test's chain)
+    acc = J()
+    shim.shim_g1j_from_xyzz(xyzz_from_affine(pts[3]), acc)
+    for _ in range(126):
+        shim.shim_g1j_dbl(acc, acc)
+        jac_check_bounds(acc)
+    assert jac_compress(shim, acc) == compress(ec_mul(1 << 126, pts[3]))
+
+
 def test_g1_matches_oracle(shim):
     """cross-check with the CPU oracle on k*G"""
     import oracle

@@ -132,14 +132,83 @@ __device__ __forceinline__ void sha_load_block(uint32_t w[16], int k, const uint
     }
 }
 constexpr int SHA_NBLOCKS = 2050;
-__global__ void __launch_bounds__(192) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
-    __shared__ uint4 wk[4][16][64];                 // [message block mod 4][round / 4][lane]: four W + K per 16-byte LDS access
+// The consumer splits every round over a PAIR of lanes four lanes apart: the "E" lane (DPP banks 0 and 2 of each row of 16) holds
+// (e, f, g, h), the "A" lane (banks 1 and 3) holds (a, b, c, d), and both execute the SAME instructions: per-lane rotation amounts
+// give S1(e) / S0(a), and Maj(a,b,c) = Ch(a ^ c, b, c) shares the Ch instruction.  The A lane runs ONE ROUND BEHIND the E lane:
+//     E, round q:      e' = S1(e) + Ch(e,f,g) + [h + W_q + K_q + d]        d = the A lane's c of one step ago: no hurry
+//     A, round q - 1:  a' = S0(a) + Maj(a,b,c) + [T1]                      T1 = (the E lane's e' of the PREVIOUS step) - d
+// so the bracketed addends are ready before the step starts and one three-input add ends the round for both lanes: three
+// dependent instructions per round (rotate, xor3, add3) and ten issued, against 14 issued in one lane before -- this
+// wavefront's dependent chain IS the kernel's duration.  The addend of the next step is formed during the current one:
+//     v_xad_u32   hw', R2, m_a, wk'      E: h' + W + K (next h is this g)          A: ~c + 1 = -d'   (the A lanes read W + K = 1)
+//     DPP add     E lanes: hw' += R1 of the A lane (its next c)    [row_shl:4, banks 0 and 2]
+//     DPP add     A lanes: hw  += R0 of the E lane (e' of the previous step)    [row_shr:4, banks 1 and 3; in the step that uses hw]
+// The feed-forward at the end of a block happens one step apart for the two lanes (bank-masked additions), with the additive
+// corrections the skew asks for; tools/sha_pair_model.py is the lane-level model of this exact instruction sequence, checked
+// against hashlib.  32 blobs per consumer wavefront, so a workgroup is two producers + two consumers.
+#define SHA_DPP_E " row_mask:0xf bank_mask:0x5\n\t"
+#define SHA_DPP_A " row_mask:0xf bank_mask:0xa\n\t"
+#define SHA_ID " quad_perm:[0,1,2,3]"
+#define SHA_P2B(R0, HC) "v_add_u32_dpp %[" HC "], %[" R0 "], %[" HC "] row_shr:4" SHA_DPP_A
+#define SHA_STEP_(R0, R1, R2, T, HC, HN, WN, P2B)                                       \
+    "v_alignbit_b32 %[ta], %[" R0 "], %[" R0 "], %[s1]\n\t"                              \
+    "v_alignbit_b32 %[tb], %[" R0 "], %[" R0 "], %[s2]\n\t"                              \
+    "v_alignbit_b32 %[tc], %[" R0 "], %[" R0 "], %[s3]\n\t"                              \
+    "v_bitop3_b32 %[tx], %[" R0 "], %[" R2 "], %[ma] bitop3:0x78\n\t"                    \
+    "v_bitop3_b32 %[ta], %[ta], %[tb], %[tc] bitop3:0x96\n\t"                            \
+    "v_bitop3_b32 %[tx], %[tx], %[" R1 "], %[" R2 "] bitop3:0xca\n\t"                    \
+    P2B                                                                                  \
+    "v_xad_u32 %[" HN "], %[" R2 "], %[ma], %[" WN "]\n\t"                               \
+    "v_add3_u32 %[" T "], %[tx], %[" HC "], %[ta]\n\t"                                   \
+    "v_add_u32_dpp %[" HN "], %[" R1 "], %[" HN "] row_shl:4" SHA_DPP_E
+#define SHA_STEP(R0, R1, R2, T, HC, HN, WN) SHA_STEP_(R0, R1, R2, T, HC, HN, WN, SHA_P2B(R0, HC))
+#define SHA_STEP_FIRST(R0, R1, R2, T, HC, HN, WN) SHA_STEP_(R0, R1, R2, T, HC, HN, WN, "")
+// after the first step of a block (state now in p3, p0, p1, p2; next addend in hY): the A lanes have finished the previous block
+#define SHA_BOUNDARY_A                                                                   \
+    "v_add_u32_dpp %[hs1], %[p0], %[hs1]" SHA_ID SHA_DPP_A                               \
+    "v_add_u32_dpp %[hs0], %[p3], %[hs0]" SHA_ID SHA_DPP_A                               \
+    "v_sub_u32_dpp %[hY], %[hY], %[hs3]" SHA_ID SHA_DPP_A   /* A: -d of the new block = -(c + old H3) */ \
+    "v_add_u32_dpp %[hY], %[hs2], %[hY] row_shl:4" SHA_DPP_E /* E: its next d = the A lane's c + old H2 */ \
+    "v_add_u32_dpp %[hs2], %[p1], %[hs2]" SHA_ID SHA_DPP_A                               \
+    "v_add_u32_dpp %[hs3], %[p2], %[hs3]" SHA_ID SHA_DPP_A                               \
+    "v_mov_b32_dpp %[p3], %[hs0]" SHA_ID SHA_DPP_A                                       \
+    "v_mov_b32_dpp %[p0], %[hs1]" SHA_ID SHA_DPP_A                                       \
+    "v_mov_b32_dpp %[p1], %[hs2]" SHA_ID SHA_DPP_A                                       \
+    "v_mov_b32_dpp %[p2], %[hs3]" SHA_ID SHA_DPP_A
+// after the 64th step of a block: the A lanes' addend takes the E lanes' e' before the E lanes feed forward
+#define SHA_END_BODY                                                                     \
+    "v_add_u32_dpp %[hs1], %[p1], %[hs1]" SHA_ID SHA_DPP_E                               \
+    "s_nop 0\n\t"                                                                        \
+    "v_add_u32_dpp %[hX], %[p0], %[hX] row_shr:4" SHA_DPP_A                              \
+    "v_add_u32_dpp %[hs0], %[p0], %[hs0]" SHA_ID SHA_DPP_E                               \
+    "v_add_u32_dpp %[hs2], %[p2], %[hs2]" SHA_ID SHA_DPP_E                               \
+    "v_add_u32_dpp %[hs3], %[p3], %[hs3]" SHA_ID SHA_DPP_E                               \
+    "v_mov_b32_dpp %[p0], %[hs0]" SHA_ID SHA_DPP_E                                       \
+    "v_mov_b32_dpp %[p1], %[hs1]" SHA_ID SHA_DPP_E                                       \
+    "v_mov_b32_dpp %[p2], %[hs2]" SHA_ID SHA_DPP_E                                       \
+    "v_mov_b32_dpp %[p3], %[hs3]" SHA_ID SHA_DPP_E
+// the E lanes' addend of round 0: h + W_0 + K_0 + (the A lane's c + its old H3 = d of the new block)
+#define SHA_INIT_E                                                                       \
+    "s_nop 1\n\t"                                                                        \
+    "v_mov_b32_dpp %[hX], %[p3]" SHA_ID SHA_DPP_E                                        \
+    "v_add_u32_dpp %[hX], %[w0], %[hX]" SHA_ID SHA_DPP_E                                 \
+    "v_add_u32_dpp %[hX], %[p2], %[hX] row_shl:4" SHA_DPP_E                              \
+    "v_add_u32_dpp %[hX], %[hs3], %[hX] row_shl:4" SHA_DPP_E
+#define SHA_STATE_OPS [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [hX] "+v"(hX), [hY] "+v"(hY)
+#define SHA_TMP_OPS [ta] "=&v"(ta), [tb] "=&v"(tb), [tc] "=&v"(tc), [tx] "=&v"(tx)
+#define SHA_HS_OPS [hs0] "+v"(hs0), [hs1] "+v"(hs1), [hs2] "+v"(hs2), [hs3] "+v"(hs3)
+#define SHA_CONST_OPS [ma] "v"(m_a), [s1] "v"(r1), [s2] "v"(r2), [s3] "v"(r3)
+__device__ __forceinline__ uint32_t sha_from_e_lane(uint32_t x) {   // A lanes: the value of the E lane four lanes down; E lanes: 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xA, false);   // row_shr:4
+}
+__global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
+    __shared__ uint4 wk[5][16][64];                 // [message block mod 4][round / 4][blob]: four W + K per 16-byte LDS access; [4] stays zero
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
-    const int b0 = blockIdx.x * 64 + lane;
-    const int b = b0 < n ? b0 : n - 1;              // surplus lanes shadow the last blob (they must keep the barriers)
-    const uint8_t* blob = blobs + (size_t)b * 131072;
-    const uint8_t* cm = commitments48 + (size_t)b * 48;
     if (role < 2) {
+        const int b0 = blockIdx.x * 64 + lane;
+        const int b = b0 < n ? b0 : n - 1;              // surplus lanes shadow the last blob (they must keep the barriers)
+        const uint8_t* blob = blobs + (size_t)b * 131072;
+        const uint8_t* cm = commitments48 + (size_t)b * 48;
         // producers: wave 0 expands the even message blocks, wave 1 the odd ones (the schedule is ~1.5x the instructions of
         // the rounds, so one producer per consumer would be the bottleneck)
         uint32_t wn[16];                                  // this wave's next message block, in flight while the current one is expanded
@@ -170,32 +239,67 @@ __global__ void __launch_bounds__(192) k_challenge_sha256(const uint8_t* __restr
         }
         return;
     }
-    // consumer: during step j it runs the rounds of blocks 2j-2 and 2j-1 (written in step j-1) while the producers fill 2j, 2j+1
-    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    // consumers: during step j they run the rounds of blocks 2j-2 and 2j-1 (written in step j-1) while the producers fill 2j, 2j+1
+    const bool a_side = ((lane >> 2) & 1) != 0;             // A lane: (a, b, c, d); E lane: (e, f, g, h)
+    const int col = 32 * (role - 2) + (lane >> 4) * 8 + (lane & 3) + ((lane >> 3) & 1) * 4;   // this pair's blob within the workgroup
+    const int b0 = blockIdx.x * 64 + col;
+    const uint32_t m_a = a_side ? 0xffffffffu : 0u;
+    const uint32_t r1 = a_side ? 2 : 6, r2 = a_side ? 13 : 11, r3 = a_side ? 22 : 25;
+#pragma unroll
+    for (int q = 0; q < 16; q++) wk[4][q][lane] = make_uint4(1, 1, 1, 1);      // the A lanes' "W + K": the +1 of the two's complement -d
+    // E lanes start at the initial hash value; the A lanes' first step is the (void) last round of a block before the first one:
+    // all-zero state and addend make it a no-op whose feed-forward yields the initial hash value
+    uint32_t hs0 = a_side ? 0x6a09e667u : 0x510e527fu, hs1 = a_side ? 0xbb67ae85u : 0x9b05688cu, hs2 = a_side ? 0x3c6ef372u : 0x1f83d9abu,
+             hs3 = a_side ? 0xa54ff53au : 0x5be0cd19u;
+    uint32_t p0 = a_side ? 0u : hs0, p1 = a_side ? 0u : hs1, p2 = a_side ? 0u : hs2, p3 = a_side ? 0u : hs3;
+    uint32_t hX = 0, hY = 0, ta, tb, tc, tx;
 #pragma unroll 1
     for (int j = 0; j <= SHA_NBLOCKS / 2; j++) {
         if (j >= 1) {
 #pragma unroll 1
             for (int k = 2 * j - 2; k < 2 * j; k++) {
-                const uint4 (*src)[64] = wk[k & 3];
-                uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-                uint4 wq = src[0][lane];
+                const uint4* src = a_side ? &wk[4][0][0] : &wk[k & 3][0][col];
+                uint32_t wkr[64];                                     // the block's 64 W + K words (A lane: ones), read up front
 #pragma unroll
-                for (int i = 0; i < 64; i++) {
-                    if ((i & 3) == 0 && i) wq = src[i >> 2][lane];
-                    const uint32_t wki = (i & 3) == 0 ? wq.x : (i & 3) == 1 ? wq.y : (i & 3) == 2 ? wq.z : wq.w;
-                    const uint32_t S1 = xor3(rotr(e, 6), rotr(e, 11), rotr(e, 25));
-                    const uint32_t t1 = hh + S1 + sha_ch(e, f, g) + wki;
-                    const uint32_t S0 = xor3(rotr(a, 2), rotr(a, 13), rotr(a, 22));
-                    const uint32_t t2 = S0 + sha_maj(a, bb, c);
-                    hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+                for (int q = 0; q < 16; q++) {
+                    const uint4 v = src[q * 64];
+                    wkr[4 * q] = v.x; wkr[4 * q + 1] = v.y; wkr[4 * q + 2] = v.z; wkr[4 * q + 3] = v.w;
                 }
-                h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+                asm volatile(SHA_INIT_E
+                             SHA_STEP_FIRST("p0", "p1", "p2", "p3", "hX", "hY", "w1")
+                             SHA_BOUNDARY_A
+                             : SHA_STATE_OPS, SHA_HS_OPS, SHA_TMP_OPS
+                             : SHA_CONST_OPS, [w0] "v"(wkr[0]), [w1] "v"(wkr[1]));
+                asm volatile(SHA_STEP("p3", "p0", "p1", "p2", "hY", "hX", "w2")
+                             SHA_STEP("p2", "p3", "p0", "p1", "hX", "hY", "w3")
+                             SHA_STEP("p1", "p2", "p3", "p0", "hY", "hX", "w4")
+                             : SHA_STATE_OPS, SHA_TMP_OPS
+                             : SHA_CONST_OPS, [w2] "v"(wkr[2]), [w3] "v"(wkr[3]), [w4] "v"(wkr[4]));
+#pragma unroll
+                for (int g = 1; g < 16; g++) {
+                    asm volatile(SHA_STEP("p0", "p1", "p2", "p3", "hX", "hY", "w1")
+                                 SHA_STEP("p3", "p0", "p1", "p2", "hY", "hX", "w2")
+                                 SHA_STEP("p2", "p3", "p0", "p1", "hX", "hY", "w3")
+                                 SHA_STEP("p1", "p2", "p3", "p0", "hY", "hX", "w4")
+                                 : SHA_STATE_OPS, SHA_TMP_OPS
+                                 : SHA_CONST_OPS, [w1] "v"(wkr[4 * g + 1]), [w2] "v"(wkr[4 * g + 2]), [w3] "v"(wkr[4 * g + 3]), [w4] "v"(wkr[(4 * g + 4) & 63]));
+                }
+                asm volatile(SHA_END_BODY : SHA_STATE_OPS, SHA_HS_OPS :);
             }
         }
         __syncthreads();
     }
-    if (b0 >= n) return;
+    // the A lanes' last round and feed-forward (the E lanes' registers are scratch by now; their hash words are in hs0..3)
+    asm volatile(SHA_STEP_FIRST("p0", "p1", "p2", "p3", "hX", "hY", "w1")
+                 SHA_BOUNDARY_A
+                 : SHA_STATE_OPS, SHA_HS_OPS, SHA_TMP_OPS
+                 : SHA_CONST_OPS, [w1] "v"(m_a));
+    // the A lane holds h[0..3], its E lane h[4..7]: gather the digest in the A lane
+    const uint32_t h0 = hs0, h1 = hs1, h2 = hs2, h3 = hs3;
+    const uint32_t g0 = sha_from_e_lane(hs0), g1 = sha_from_e_lane(hs1), g2 = sha_from_e_lane(hs2), g3 = sha_from_e_lane(hs3);
+    if (!a_side || b0 >= n) return;
+    const int b = b0;
+    const uint32_t h[8] = {h0, h1, h2, h3, g0, g1, g2, g3};
     // digest (big-endian h[0..7]) as little-endian words, reduced mod r (2^256 < 3r: at most two subtractions)
     uint32_t v[8];
 #pragma unroll
@@ -730,7 +834,7 @@ __global__ void __launch_bounds__(64) k_fr_to_scalars(const uint32_t* __restrict
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(192), 0, s, d_blobs, d_commitments, n, d_z);
+    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(256), 0, s, d_blobs, d_commitments, n, d_z);
 }
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);

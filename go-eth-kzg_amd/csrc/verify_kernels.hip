@@ -132,74 +132,75 @@ __device__ __forceinline__ void sha_load_block(uint32_t w[16], int k, const uint
     }
 }
 constexpr int SHA_NBLOCKS = 2050;
-// The consumer splits every round over a PAIR of lanes four lanes apart: the "E" lane (DPP banks 0 and 2 of each row of 16) holds
-// (e, f, g, h), the "A" lane (banks 1 and 3) holds (a, b, c, d), and both execute the SAME instructions: per-lane rotation amounts
-// give S1(e) / S0(a), and Maj(a,b,c) = Ch(a ^ c, b, c) shares the Ch instruction.  The A lane runs ONE ROUND BEHIND the E lane:
-//     E, round q:      e' = S1(e) + Ch(e,f,g) + [h + W_q + K_q + d]        d = the A lane's c of one step ago: no hurry
-//     A, round q - 1:  a' = S0(a) + Maj(a,b,c) + [T1]                      T1 = (the E lane's e' of the PREVIOUS step) - d
+// The consumer splits every round over a PAIR of lanes, mirror images within a row of 16 (lane i and lane 15 - i): the "E" lane
+// (lanes 0..7 of the row: DPP banks 0, 1) holds (e, f, g, h), the "A" lane (banks 2, 3) holds (a, b, c, d), and both execute the SAME
+// instructions: per-lane rotation amounts give S1(e) / S0(a), and Maj(a,b,c) = Ch(a ^ c, b, c) shares the Ch instruction.
+// The A lane runs TWO ROUNDS BEHIND the E lane:
+//     E, round q:      e' = S1(e) + Ch(e,f,g) + [h + W_q + K_q + d_q]      d_q = a_(q-3): the A lane's current "a" one step ago
+//     A, round q - 2:  a' = S0(a) + Maj(a,b,c) + [T1]                      T1 = e_(q-1) - d: the E lane's current "e" one step ago
 // so the bracketed addends are ready before the step starts and one three-input add ends the round for both lanes: three
-// dependent instructions per round (rotate, xor3, add3) and ten issued, against 14 issued in one lane before -- this
-// wavefront's dependent chain IS the kernel's duration.  The addend of the next step is formed during the current one:
+// dependent instructions per round (rotate, xor3, add3) and NINE issued, against 14 issued in one lane before -- this wavefront's
+// instruction stream IS the kernel's duration.  The addend of the next step is formed during the current one:
 //     v_xad_u32   hw', R2, m_a, wk'      E: h' + W + K (next h is this g)          A: ~c + 1 = -d'   (the A lanes read W + K = 1)
-//     DPP add     E lanes: hw' += R1 of the A lane (its next c)    [row_shl:4, banks 0 and 2]
-//     DPP add     A lanes: hw  += R0 of the E lane (e' of the previous step)    [row_shr:4, banks 1 and 3; in the step that uses hw]
-// The feed-forward at the end of a block happens one step apart for the two lanes (bank-masked additions), with the additive
-// corrections the skew asks for; tools/sha_pair_model.py is the lane-level model of this exact instruction sequence, checked
-// against hashlib.  32 blobs per consumer wavefront, so a workgroup is two producers + two consumers.
-#define SHA_DPP_E " row_mask:0xf bank_mask:0x5\n\t"
-#define SHA_DPP_A " row_mask:0xf bank_mask:0xa\n\t"
+//     DPP add     hw' += R0 of the mirror lane      E: the A lane's a = its d three rounds on     A: the E lane's e
+// (with the two-round skew both lanes want the partner's R0, hence ONE row_mirror addition).  The feed-forward at the end of a
+// block happens two steps apart for the two lanes (bank-masked additions), with the additive corrections the skew asks for;
+// tools/sha_pair_model.py is the lane-level model of this exact instruction sequence, checked against hashlib.
+// 32 blobs per consumer wavefront, so a workgroup is two producers + two consumers.
+#define SHA_DPP_E " row_mask:0xf bank_mask:0x3\n\t"
+#define SHA_DPP_A " row_mask:0xf bank_mask:0xc\n\t"
+#define SHA_DPP_ALL " row_mask:0xf bank_mask:0xf\n\t"
 #define SHA_ID " quad_perm:[0,1,2,3]"
-#define SHA_P2B(R0, HC) "v_add_u32_dpp %[" HC "], %[" R0 "], %[" HC "] row_shr:4" SHA_DPP_A
-#define SHA_STEP_(R0, R1, R2, T, HC, HN, WN, P2B)                                       \
+#define SHA_STEP(R0, R1, R2, T, HC, HN, WN)                                              \
     "v_alignbit_b32 %[ta], %[" R0 "], %[" R0 "], %[s1]\n\t"                              \
     "v_alignbit_b32 %[tb], %[" R0 "], %[" R0 "], %[s2]\n\t"                              \
     "v_alignbit_b32 %[tc], %[" R0 "], %[" R0 "], %[s3]\n\t"                              \
     "v_bitop3_b32 %[tx], %[" R0 "], %[" R2 "], %[ma] bitop3:0x78\n\t"                    \
     "v_bitop3_b32 %[ta], %[ta], %[tb], %[tc] bitop3:0x96\n\t"                            \
     "v_bitop3_b32 %[tx], %[tx], %[" R1 "], %[" R2 "] bitop3:0xca\n\t"                    \
-    P2B                                                                                  \
     "v_xad_u32 %[" HN "], %[" R2 "], %[ma], %[" WN "]\n\t"                               \
     "v_add3_u32 %[" T "], %[tx], %[" HC "], %[ta]\n\t"                                   \
-    "v_add_u32_dpp %[" HN "], %[" R1 "], %[" HN "] row_shl:4" SHA_DPP_E
-#define SHA_STEP(R0, R1, R2, T, HC, HN, WN) SHA_STEP_(R0, R1, R2, T, HC, HN, WN, SHA_P2B(R0, HC))
-#define SHA_STEP_FIRST(R0, R1, R2, T, HC, HN, WN) SHA_STEP_(R0, R1, R2, T, HC, HN, WN, "")
-// after the first step of a block (state now in p3, p0, p1, p2; next addend in hY): the A lanes have finished the previous block
+    "v_add_u32_dpp %[" HN "], %[" R0 "], %[" HN "] row_mirror" SHA_DPP_ALL
+// after step 0 of a block (next addend in hY): E: its d of round 1 is the A lane's a + old H2; A: the E lane's e was fed forward
+#define SHA_CORR0                                                                        \
+    "v_add_u32_dpp %[hY], %[hs2], %[hY] row_mirror" SHA_DPP_E                            \
+    "v_add_u32_dpp %[hY], %[ho], %[hY] row_mirror" SHA_DPP_A   /* ho = -(old H4); a mirrored operand of v_subrev is NOT permuted on gfx950 */
+// after step 1 of a block (state now in p2, p3, p0, p1; next addend in hX): the A lanes have finished the previous block
 #define SHA_BOUNDARY_A                                                                   \
-    "v_add_u32_dpp %[hs1], %[p0], %[hs1]" SHA_ID SHA_DPP_A                               \
-    "v_add_u32_dpp %[hs0], %[p3], %[hs0]" SHA_ID SHA_DPP_A                               \
-    "v_sub_u32_dpp %[hY], %[hY], %[hs3]" SHA_ID SHA_DPP_A   /* A: -d of the new block = -(c + old H3) */ \
-    "v_add_u32_dpp %[hY], %[hs2], %[hY] row_shl:4" SHA_DPP_E /* E: its next d = the A lane's c + old H2 */ \
-    "v_add_u32_dpp %[hs2], %[p1], %[hs2]" SHA_ID SHA_DPP_A                               \
-    "v_add_u32_dpp %[hs3], %[p2], %[hs3]" SHA_ID SHA_DPP_A                               \
-    "v_mov_b32_dpp %[p3], %[hs0]" SHA_ID SHA_DPP_A                                       \
-    "v_mov_b32_dpp %[p0], %[hs1]" SHA_ID SHA_DPP_A                                       \
-    "v_mov_b32_dpp %[p1], %[hs2]" SHA_ID SHA_DPP_A                                       \
-    "v_mov_b32_dpp %[p2], %[hs3]" SHA_ID SHA_DPP_A
-// after the 64th step of a block: the A lanes' addend takes the E lanes' e' before the E lanes feed forward
+    "v_add_u32_dpp %[hs2], %[p0], %[hs2]" SHA_ID SHA_DPP_A                               \
+    "v_add_u32_dpp %[hs0], %[p2], %[hs0]" SHA_ID SHA_DPP_A                               \
+    "v_add_u32_dpp %[hX], %[hs1], %[hX] row_mirror" SHA_DPP_E  /* E: d of round 2 = the A lane's a + old H1 */ \
+    "v_subrev_u32_dpp %[hX], %[hs3], %[hX]" SHA_ID SHA_DPP_A   /* A: -d of the new block = -(c + old H3) */ \
+    "v_add_u32_dpp %[hs1], %[p3], %[hs1]" SHA_ID SHA_DPP_A                               \
+    "v_add_u32_dpp %[hs3], %[p1], %[hs3]" SHA_ID SHA_DPP_A                               \
+    "v_mov_b32_dpp %[p2], %[hs0]" SHA_ID SHA_DPP_A                                       \
+    "v_mov_b32_dpp %[p0], %[hs2]" SHA_ID SHA_DPP_A                                       \
+    "v_mov_b32_dpp %[p3], %[hs1]" SHA_ID SHA_DPP_A                                       \
+    "v_mov_b32_dpp %[p1], %[hs3]" SHA_ID SHA_DPP_A
+// after the 64th step of a block: the E lanes feed forward (minus their old H4 is kept for SHA_CORR0)
 #define SHA_END_BODY                                                                     \
+    "v_sub_u32 %[ho], 0, %[hs0]\n\t"                                                     \
     "v_add_u32_dpp %[hs1], %[p1], %[hs1]" SHA_ID SHA_DPP_E                               \
-    "s_nop 0\n\t"                                                                        \
-    "v_add_u32_dpp %[hX], %[p0], %[hX] row_shr:4" SHA_DPP_A                              \
     "v_add_u32_dpp %[hs0], %[p0], %[hs0]" SHA_ID SHA_DPP_E                               \
     "v_add_u32_dpp %[hs2], %[p2], %[hs2]" SHA_ID SHA_DPP_E                               \
     "v_add_u32_dpp %[hs3], %[p3], %[hs3]" SHA_ID SHA_DPP_E                               \
-    "v_mov_b32_dpp %[p0], %[hs0]" SHA_ID SHA_DPP_E                                       \
     "v_mov_b32_dpp %[p1], %[hs1]" SHA_ID SHA_DPP_E                                       \
+    "v_mov_b32_dpp %[p0], %[hs0]" SHA_ID SHA_DPP_E                                       \
     "v_mov_b32_dpp %[p2], %[hs2]" SHA_ID SHA_DPP_E                                       \
     "v_mov_b32_dpp %[p3], %[hs3]" SHA_ID SHA_DPP_E
-// the E lanes' addend of round 0: h + W_0 + K_0 + (the A lane's c + its old H3 = d of the new block)
+// the E lanes' addend of round 0: h + W_0 + K_0 + (the A lane's b + its old H3 = d of the new block)
 #define SHA_INIT_E                                                                       \
     "s_nop 1\n\t"                                                                        \
     "v_mov_b32_dpp %[hX], %[p3]" SHA_ID SHA_DPP_E                                        \
     "v_add_u32_dpp %[hX], %[w0], %[hX]" SHA_ID SHA_DPP_E                                 \
-    "v_add_u32_dpp %[hX], %[p2], %[hX] row_shl:4" SHA_DPP_E                              \
-    "v_add_u32_dpp %[hX], %[hs3], %[hX] row_shl:4" SHA_DPP_E
+    "v_add_u32_dpp %[hX], %[p1], %[hX] row_mirror" SHA_DPP_E                             \
+    "v_add_u32_dpp %[hX], %[hs3], %[hX] row_mirror" SHA_DPP_E
 #define SHA_STATE_OPS [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [hX] "+v"(hX), [hY] "+v"(hY)
 #define SHA_TMP_OPS [ta] "=&v"(ta), [tb] "=&v"(tb), [tc] "=&v"(tc), [tx] "=&v"(tx)
-#define SHA_HS_OPS [hs0] "+v"(hs0), [hs1] "+v"(hs1), [hs2] "+v"(hs2), [hs3] "+v"(hs3)
+#define SHA_HS_OPS [hs0] "+v"(hs0), [hs1] "+v"(hs1), [hs2] "+v"(hs2), [hs3] "+v"(hs3), [ho] "+v"(ho)
 #define SHA_CONST_OPS [ma] "v"(m_a), [s1] "v"(r1), [s2] "v"(r2), [s3] "v"(r3)
-__device__ __forceinline__ uint32_t sha_from_e_lane(uint32_t x) {   // A lanes: the value of the E lane four lanes down; E lanes: 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xA, false);   // row_shr:4
+__device__ __forceinline__ uint32_t sha_from_e_lane(uint32_t x) {   // A lanes: the value of their E lane; E lanes: 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xC, false);   // row_mirror
 }
 __global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
     __shared__ uint4 wk[5][16][64];                 // [message block mod 4][round / 4][blob]: four W + K per 16-byte LDS access; [4] stays zero
@@ -240,19 +241,19 @@ __global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restr
         return;
     }
     // consumers: during step j they run the rounds of blocks 2j-2 and 2j-1 (written in step j-1) while the producers fill 2j, 2j+1
-    const bool a_side = ((lane >> 2) & 1) != 0;             // A lane: (a, b, c, d); E lane: (e, f, g, h)
-    const int col = 32 * (role - 2) + (lane >> 4) * 8 + (lane & 3) + ((lane >> 3) & 1) * 4;   // this pair's blob within the workgroup
+    const bool a_side = ((lane >> 3) & 1) != 0;             // A lane: (a, b, c, d); E lane: (e, f, g, h)
+    const int col = 32 * (role - 2) + (lane >> 4) * 8 + (a_side ? 15 - (lane & 15) : (lane & 15));   // this pair's blob within the workgroup
     const int b0 = blockIdx.x * 64 + col;
     const uint32_t m_a = a_side ? 0xffffffffu : 0u;
     const uint32_t r1 = a_side ? 2 : 6, r2 = a_side ? 13 : 11, r3 = a_side ? 22 : 25;
 #pragma unroll
     for (int q = 0; q < 16; q++) wk[4][q][lane] = make_uint4(1, 1, 1, 1);      // the A lanes' "W + K": the +1 of the two's complement -d
-    // E lanes start at the initial hash value; the A lanes' first step is the (void) last round of a block before the first one:
-    // all-zero state and addend make it a no-op whose feed-forward yields the initial hash value
+    // E lanes start at the initial hash value; the A lanes' first two steps are the (void) last rounds of a block before the first
+    // one: all-zero state and addends make them no-ops whose feed-forward yields the initial hash value
     uint32_t hs0 = a_side ? 0x6a09e667u : 0x510e527fu, hs1 = a_side ? 0xbb67ae85u : 0x9b05688cu, hs2 = a_side ? 0x3c6ef372u : 0x1f83d9abu,
              hs3 = a_side ? 0xa54ff53au : 0x5be0cd19u;
     uint32_t p0 = a_side ? 0u : hs0, p1 = a_side ? 0u : hs1, p2 = a_side ? 0u : hs2, p3 = a_side ? 0u : hs3;
-    uint32_t hX = 0, hY = 0, ta, tb, tc, tx;
+    uint32_t ho = a_side ? 0u : 0u - hs0, hX = 0, hY = 0, ta, tb, tc, tx;   // minus the E lane's H4 of one block ago
 #pragma unroll 1
     for (int j = 0; j <= SHA_NBLOCKS / 2; j++) {
         if (j >= 1) {
@@ -266,15 +267,16 @@ __global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restr
                     wkr[4 * q] = v.x; wkr[4 * q + 1] = v.y; wkr[4 * q + 2] = v.z; wkr[4 * q + 3] = v.w;
                 }
                 asm volatile(SHA_INIT_E
-                             SHA_STEP_FIRST("p0", "p1", "p2", "p3", "hX", "hY", "w1")
+                             SHA_STEP("p0", "p1", "p2", "p3", "hX", "hY", "w1")
+                             SHA_CORR0
+                             SHA_STEP("p3", "p0", "p1", "p2", "hY", "hX", "w2")
                              SHA_BOUNDARY_A
                              : SHA_STATE_OPS, SHA_HS_OPS, SHA_TMP_OPS
-                             : SHA_CONST_OPS, [w0] "v"(wkr[0]), [w1] "v"(wkr[1]));
-                asm volatile(SHA_STEP("p3", "p0", "p1", "p2", "hY", "hX", "w2")
-                             SHA_STEP("p2", "p3", "p0", "p1", "hX", "hY", "w3")
+                             : SHA_CONST_OPS, [w0] "v"(wkr[0]), [w1] "v"(wkr[1]), [w2] "v"(wkr[2]));
+                asm volatile(SHA_STEP("p2", "p3", "p0", "p1", "hX", "hY", "w3")
                              SHA_STEP("p1", "p2", "p3", "p0", "hY", "hX", "w4")
                              : SHA_STATE_OPS, SHA_TMP_OPS
-                             : SHA_CONST_OPS, [w2] "v"(wkr[2]), [w3] "v"(wkr[3]), [w4] "v"(wkr[4]));
+                             : SHA_CONST_OPS, [w3] "v"(wkr[3]), [w4] "v"(wkr[4]));
 #pragma unroll
                 for (int g = 1; g < 16; g++) {
                     asm volatile(SHA_STEP("p0", "p1", "p2", "p3", "hX", "hY", "w1")
@@ -289,11 +291,13 @@ __global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restr
         }
         __syncthreads();
     }
-    // the A lanes' last round and feed-forward (the E lanes' registers are scratch by now; their hash words are in hs0..3)
-    asm volatile(SHA_STEP_FIRST("p0", "p1", "p2", "p3", "hX", "hY", "w1")
+    // the A lanes' last two rounds and feed-forward (the E lanes' registers are scratch by now; their hash words are in hs0..3)
+    asm volatile(SHA_STEP("p0", "p1", "p2", "p3", "hX", "hY", "w1")
+                 SHA_CORR0
+                 SHA_STEP("p3", "p0", "p1", "p2", "hY", "hX", "w1")
                  SHA_BOUNDARY_A
                  : SHA_STATE_OPS, SHA_HS_OPS, SHA_TMP_OPS
-                 : SHA_CONST_OPS, [w1] "v"(m_a));
+                 : SHA_CONST_OPS, [w1] "v"(m_a & 1u));
     // the A lane holds h[0..3], its E lane h[4..7]: gather the digest in the A lane
     const uint32_t h0 = hs0, h1 = hs1, h2 = hs2, h3 = hs3;
     const uint32_t g0 = sha_from_e_lane(hs0), g1 = sha_from_e_lane(hs1), g2 = sha_from_e_lane(hs2), g3 = sha_from_e_lane(hs3);

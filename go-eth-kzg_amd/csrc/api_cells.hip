@@ -289,8 +289,7 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     hipStream_t s2 = c->side;
     HIPCHK(hipEventRecord(c->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    KT(KT_DECOMPRESS, s2, g1_decompress2_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s2));
-    KT(KT_SUBGROUP, s2, g1_subgroup_check2_device(aff_rows, (int)n_rows, st_rows, aff_q, (int)n, st_q, s2));
+    KT(KT_SUBGROUP, s2, g1_validate2_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s2));
     HIPCHK(hipEventRecord(c->ev_join, s2));
     // uploads, part 2 (host memcpy of n x 2 KiB into the pinned staging area runs while the GPU validates the points)
     {

@@ -97,8 +97,7 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     hipStream_t s2 = c->side;
     HIPCHK(hipEventRecord(c->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    KT(KT_DECOMPRESS, s2, g1_decompress2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2));
-    KT(KT_SUBGROUP, s2, g1_subgroup_check2_device(aff_c, (int)n, st_c, aff_q, (int)n, st_q, s2));
+    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2));
     HIPCHK(hipEventRecord(c->ev_join, s2));
     // 2. challenge and claimed value per blob, or caller-supplied z / y
     if (d_blobs) {
@@ -321,8 +320,7 @@ int mkzg_compute_blob_kzg_proof_batch_device(mkzg_ctx* c, const void* d_blobs, c
         // commitment must be a valid subgroup point (prove.go:56-62)
         HIPCHK(hipEventRecord(c->ev_fork, s));
         HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        g1_decompress_device(cms, (int)slice, c->d_v_aff, st_cm, c->side);
-        g1_subgroup_check_device(c->d_v_aff, (int)slice, st_cm, c->side);
+        g1_validate2_device(cms, (int)slice, c->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, c->side);
         HIPCHK(hipEventRecord(c->ev_join, c->side));
         KT(KT_SHA256, s, challenge_device(blobs, cms, (int)slice, c->d_q_z, s));
         for (size_t off = 0; off < slice; off += (size_t)c->opt_max_batch) {

@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include "g1.hpp"
 #include "msm_kernels.h"
+#include "g1_decode.hpp"
 
 namespace kzg {
 
@@ -426,60 +427,8 @@ __global__ void __launch_bounds__(64) k_g1_decompress(const uint8_t* __restrict_
     uint32_t* out_aff = out_aff_a;
     int* st = st_a;
     if (i >= n_a) { i -= n_a; in48 = in48_b; out_aff = out_aff_b; st = st_b; }
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(in48 + (size_t)i * 48);
-    uint32_t w[12];
-#pragma unroll
-    for (int q = 0; q < 12; q++) w[11 - q] = __builtin_bswap32(p[q]);
-    const uint32_t flags = w[11] >> 29;
     G1Aff a;
-    Fp::set_zero(a.x);
-    Fp::set_zero(a.y);
-    a.inf = 1;
-    int rc = 0;
-    if (!(flags & 4) || flags == 7) {
-        rc = MKZG_ERR_G1_BAD_ENCODING;
-    } else if (flags & 2) {
-        uint32_t any = w[11] & 0x1fffffffu;
-#pragma unroll
-        for (int q = 0; q < 11; q++) any |= w[q];
-        if (any) rc = MKZG_ERR_G1_BAD_ENCODING;
-    } else {
-        w[11] &= 0x1fffffffu;
-        if (Fp::words32_geq_mod(w)) {
-            rc = MKZG_ERR_G1_BAD_ENCODING;
-        } else {
-            fp_t xp, x, rhs, y, four, chk;
-            Fp::from_words32(xp, w);
-            Fp::from_plain(x, xp);
-            Fp::sqr(rhs, x);
-            Fp::mul(rhs, rhs, x);
-            Fp::set(four, FP_FOUR);
-            Fp::add(rhs, rhs, four);
-            Fp::pow_words(y, rhs, FpParams::EXP_SQRT, FpParams::BITS);
-            Fp::sqr(chk, y);
-            if (!Fp::eq_mod(chk, rhs)) {
-                rc = MKZG_ERR_G1_NOT_ON_CURVE;
-            } else {
-                fp_t yc, ypl;
-                uint32_t yw[12];
-                Fp::canon(yc, y);
-                Fp::to_plain(ypl, yc);
-                Fp::to_words32(yw, ypl);
-                bool gt = false, lt = false;
-#pragma unroll
-                for (int j = 11; j >= 0; j--) {
-                    if (!gt && !lt) {
-                        if (yw[j] > FpParams::HALF[j]) gt = true;
-                        else if (yw[j] < FpParams::HALF[j]) lt = true;
-                    }
-                }
-                if (gt != ((flags & 1) != 0)) { Fp::template neg<0>(yc, yc); Fp::reduce_once(yc, yc); }
-                Fp::canon(a.x, x);
-                a.y = yc;
-                a.inf = 0;
-            }
-        }
-    }
+    const int rc = g1_decode_lane(a, in48 + (size_t)i * 48);
     st[i] = rc;
     store_affine(out_aff + (size_t)i * 32, a);
 }

@@ -23,6 +23,7 @@
 #include <stdint.h>
 #include "g1.hpp"
 #include "verify_kernels.h"
+#include "g1_decode.hpp"
 
 namespace kzg {
 
@@ -511,19 +512,8 @@ __global__ void __launch_bounds__(EVB_T) k_blob_eval(const uint8_t* __restrict__
 // ------------------------------------------------------------------------------------------
 // G1 subgroup membership: phi(P) == -[x^2]P, one lane per affine row; st[i] |= NOT_IN_SUBGROUP
 // ------------------------------------------------------------------------------------------
-// two point arrays in one launch (commitments and proofs): the test is one 126-doubling chain per lane, i.e. latency-bound,
-// so two launches back to back cost twice the time of one
-__global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __restrict__ aff_a, int n_a, int* __restrict__ st_a,
-                                                          const uint32_t* __restrict__ aff_b, int n_b, int* __restrict__ st_b) {
-    int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_a + n_b) return;
-    const uint32_t* aff = aff_a;
-    int* st = st_a;
-    if (i >= n_a) { i -= n_a; aff = aff_b; st = st_b; }
-    if (st[i] != 0) return;
-    G1Aff p;
-    load_affine_v(p, aff + (size_t)i * 32);
-    if (p.inf) return;
+// phi(P) == -[x^2]P for a finite affine point P of the curve
+__device__ __forceinline__ bool g1_in_subgroup_lane(const G1Aff& p) {
     // T = [|x|]P, Q = [|x|]T   (|x| = 0xd201000000010000, top bit at 63)
     // both chains in ONE rolled loop (pass 0: T = [|x|]P, pass 1: Q = [|x|]T) with the group operations inlined, so that the
     // running point stays in registers through the 126 doublings.  Jacobian coordinates: the chain is nothing but doublings
@@ -559,8 +549,49 @@ __global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __rest
         Fp::template neg<3>(r, Q.y);
         ok = ok && Fp::eq_mod(l, r);
     }
-    if (!ok) st[i] = MKZG_ERR_G1_NOT_IN_SUBGROUP;
+    return ok;
 }
+// two point arrays in one launch (commitments and proofs): the test is one 126-doubling chain per lane, i.e. latency-bound,
+// so two launches back to back cost twice the time of one
+__global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __restrict__ aff_a, int n_a, int* __restrict__ st_a,
+                                                          const uint32_t* __restrict__ aff_b, int n_b, int* __restrict__ st_b) {
+    int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_a + n_b) return;
+    const uint32_t* aff = aff_a;
+    int* st = st_a;
+    if (i >= n_a) { i -= n_a; aff = aff_b; st = st_b; }
+    if (st[i] != 0) return;
+    G1Aff p;
+    load_affine_v(p, aff + (size_t)i * 32);
+    if (p.inf) return;
+    if (!g1_in_subgroup_lane(p)) st[i] = MKZG_ERR_G1_NOT_IN_SUBGROUP;
+}
+// Decoding and subgroup test of the verifiers' points in ONE launch: both are per-lane latency chains (a ~380-squaring square root,
+// then 126 doublings), and as two kernels on the side stream the second one's dispatch lands behind whatever the main stream
+// issued in between -- in VerifyCellKZGProofBatch the 16 MiB staging copy, whose blit kernel kept it waiting for 0.3 ms.
+__global__ void __launch_bounds__(64) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
+                                                    const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
+    int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_a + n_b) return;
+    const uint8_t* in48 = in48_a;
+    uint32_t* aff = aff_a;
+    int* st = st_a;
+    if (i >= n_a) { i -= n_a; in48 = in48_b; aff = aff_b; st = st_b; }
+    G1Aff p;
+    int rc = g1_decode_lane(p, in48 + (size_t)i * 48);
+    {
+        uint32_t w[32];
+#pragma unroll
+        for (int q = 0; q < 14; q++) { w[q] = p.x.l[q]; w[14 + q] = p.y.l[q]; }
+        w[28] = p.inf; w[29] = 0; w[30] = 0; w[31] = 0;
+        uint4* o = reinterpret_cast<uint4*>(aff + (size_t)i * 32);
+#pragma unroll
+        for (int q = 0; q < 8; q++) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    }
+    if (rc == 0 && !p.inf && !g1_in_subgroup_lane(p)) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
+    st[i] = rc;
+}
+
 
 // ------------------------------------------------------------------------------------------
 // RLC scalars (single workgroup): r -> r^i ; s1_i = r^i ; s3_i = r^i z_i ; e = sum r^i y_i
@@ -848,6 +879,10 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<1>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, d_quot, d_status);
 }
 void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s) { g1_subgroup_check2_device(d_aff, n, d_status, nullptr, 0, nullptr, s); }
+void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s) {
+    const int n = n_a + n_b;
+    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
+}
 void g1_subgroup_check2_device(const uint32_t* d_aff_a, int n_a, int* d_st_a, const uint32_t* d_aff_b, int n_b, int* d_st_b, hipStream_t s) {
     const int n = n_a + n_b;
     if (n > 0) hipLaunchKernelGGL(k_g1_subgroup_check, dim3((n + 63) / 64), dim3(64), 0, s, d_aff_a, n_a, d_st_a, d_aff_b, n_b, d_st_b);

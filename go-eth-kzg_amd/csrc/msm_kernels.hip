@@ -414,11 +414,9 @@ __global__ void __launch_bounds__(64, 2) k_bucket_reduce2(const uint32_t* __rest
 // ------------------------------------------------------------------------------------------
 // set-up kernels
 // ------------------------------------------------------------------------------------------
-// zcash-compressed G1 -> affine record.  Checks of gnark's SetBytes (reference
-// serialization.go:108-115): flag bits, x < p, on curve; the r-torsion check is a separate
-// kernel (k_subgroup_check) because trusted-setup points are decoded without it
-// (reference trusted_setup.go:104-117).
-// two arrays in one launch: the square root is a ~380-squaring chain per lane (latency-bound), see k_g1_subgroup_check
+// zcash-compressed G1 -> affine record (g1_decode.hpp).  No r-torsion test here: trusted-setup points are decoded
+// without it (reference trusted_setup.go:104-117); the verifiers' points go through k_g1_validate (verify_kernels.hip).
+// Two arrays in one launch: the square root is a ~380-squaring chain per lane (latency-bound).
 __global__ void __launch_bounds__(64) k_g1_decompress(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ out_aff_a, int* __restrict__ st_a,
                                                       const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ out_aff_b, int* __restrict__ st_b) {
     int i = blockIdx.x * 64 + threadIdx.x;

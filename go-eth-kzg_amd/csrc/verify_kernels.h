@@ -13,8 +13,6 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
                           int* d_status, hipStream_t s);
 // decode (gnark SetBytes checks) + subgroup test of two arrays of compressed points in one launch: affine rows and status words out
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s);
-void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s);
-void g1_subgroup_check2_device(const uint32_t* d_aff_a, int n_a, int* d_st_a, const uint32_t* d_aff_b, int n_b, int* d_st_b, hipStream_t s);   // two arrays, one launch
 // r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         hipStream_t s);

@@ -2,16 +2,17 @@
 //   VerifyBlobKZGProofBatch  reference verify.go:88-143 + internal/kzg/kzg_verify.go:111-202
 //   ComputeBlobKZGProof / ComputeKZGProof   reference prove.go:46-111 + internal/kzg/kzg_prove.go
 //
-//   k_challenge_sha256   compute_challenge (fiatshamir.go:22-33): one lane per blob streams its
-//                        131,152-byte transcript through SHA-256 (inherently serial per blob;
-//                        blobs are the parallel axis) and reduces the digest mod r.
+//   k_challenge_sha256   compute_challenge (fiatshamir.go:22-33): SHA-256 of the 131,152-byte transcript of every blob
+//                        (inherently serial per blob; blobs are the parallel axis), digest reduced mod r.  Two
+//                        producer wavefronts (message schedule) + two consumer wavefronts (rounds, a PAIR of
+//                        lanes per blob) per 64 blobs.
 //   k_blob_eval          DeserializeBlob + EvaluateLagrangePolynomial (serialization.go:134-146,
 //                        internal/domain/domain.go:193-235): one workgroup per blob, barycentric
 //                        formula over the bit-reversed 4096-domain, batch inversion per lane.
 //   k_blob_quotient      computeQuotientPoly (kzg_prove.go:53-180), both the off-domain and the
 //                        on-domain branch; output feeds the fixed-base MSM of msm_kernels.hip.
-//   k_g1_subgroup_check  the r-torsion test of gnark's SetBytes (serialization.go:108-115) as
-//                        phi(P) == -[x^2]P (Scott 2021), one lane per point.
+//   k_g1_validate        gnark's SetBytes for the verifiers' points (serialization.go:108-115): decoding
+//                        (g1_decode.hpp) and the r-torsion test as phi(P) == -[x^2]P (Scott 2021), one lane per point.
 //   k_rlc_scalars        utils.ComputePowers + the scalar folds of kzg_verify.go:141-179.
 //   k_vmsm_window        variable-base Pippenger, one workgroup per (MSM, 8-bit window): LDS
 //                        counting sort of Booth digits, one lane per bucket, wavefront-level
@@ -551,23 +552,8 @@ __device__ __forceinline__ bool g1_in_subgroup_lane(const G1Aff& p) {
     }
     return ok;
 }
-// two point arrays in one launch (commitments and proofs): the test is one 126-doubling chain per lane, i.e. latency-bound,
-// so two launches back to back cost twice the time of one
-__global__ void __launch_bounds__(64) k_g1_subgroup_check(const uint32_t* __restrict__ aff_a, int n_a, int* __restrict__ st_a,
-                                                          const uint32_t* __restrict__ aff_b, int n_b, int* __restrict__ st_b) {
-    int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_a + n_b) return;
-    const uint32_t* aff = aff_a;
-    int* st = st_a;
-    if (i >= n_a) { i -= n_a; aff = aff_b; st = st_b; }
-    if (st[i] != 0) return;
-    G1Aff p;
-    load_affine_v(p, aff + (size_t)i * 32);
-    if (p.inf) return;
-    if (!g1_in_subgroup_lane(p)) st[i] = MKZG_ERR_G1_NOT_IN_SUBGROUP;
-}
-// Decoding and subgroup test of the verifiers' points in ONE launch: both are per-lane latency chains (a ~380-squaring square root,
-// then 126 doublings), and as two kernels on the side stream the second one's dispatch lands behind whatever the main stream
+// Decoding and subgroup test of the verifiers' points in ONE launch, two point arrays (commitments and proofs) at once: both steps
+// are per-lane latency chains (a ~380-squaring square root, then 126 doublings), so launches back to back cost their sum; and as two kernels on the side stream the second one's dispatch lands behind whatever the main stream
 // issued in between -- in VerifyCellKZGProofBatch the 16 MiB staging copy, whose blit kernel kept it waiting for 0.3 ms.
 __global__ void __launch_bounds__(64) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
                                                     const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
@@ -877,15 +863,6 @@ void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_
 void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
                           int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<1>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, d_quot, d_status);
-}
-void g1_subgroup_check_device(const uint32_t* d_aff, int n, int* d_status, hipStream_t s) { g1_subgroup_check2_device(d_aff, n, d_status, nullptr, 0, nullptr, s); }
-void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s) {
-    const int n = n_a + n_b;
-    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
-}
-void g1_subgroup_check2_device(const uint32_t* d_aff_a, int n_a, int* d_st_a, const uint32_t* d_aff_b, int n_b, int* d_st_b, hipStream_t s) {
-    const int n = n_a + n_b;
-    if (n > 0) hipLaunchKernelGGL(k_g1_subgroup_check, dim3((n + 63) / 64), dim3(64), 0, s, d_aff_a, n_a, d_st_a, d_aff_b, n_b, d_st_b);
 }
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         hipStream_t s) {

@@ -864,6 +864,10 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
                           int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<1>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, d_quot, d_status);
 }
+void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s) {
+    const int n = n_a + n_b;
+    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
+}
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         hipStream_t s) {
     hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, exp_offset, d_s1, d_s3, d_e);

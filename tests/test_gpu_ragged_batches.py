@@ -1,0 +1,40 @@
+"""Batch sizes that do not fill the kernels' units (64 blobs per SHA-256 workgroup, 32 per consumer wavefront, slices of 4096 proofs):
+device-resident proof batches of ragged sizes must equal the per-blob API, and verify (reference prove.go:46-67, verify.go:88-143)."""
+import pytest
+
+from test_gpu_commit import rand_blob
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 31, 33, 63, 65, 130])
+def test_ragged_proof_batches_match_single_calls(gpu_ctx, n):
+    import torch
+    ctx = gpu_ctx
+    blobs = [rand_blob(2000 + (i % 5)) for i in range(n)]           # five distinct blobs, repeated
+    singles = {}
+    for i in range(5):
+        if i < n:
+            rc, cm = ctx.BlobToKZGCommitment(blobs[i])
+            assert rc == 0
+            rc, pr = ctx.ComputeBlobKZGProof(blobs[i], cm)
+            assert rc == 0
+            singles[i] = (cm, pr)
+    cms = b"".join(singles[i % 5][0] for i in range(n))
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cm = torch.frombuffer(bytearray(cms), dtype=torch.uint8).cuda()
+    d_pr = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.ones(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), n, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0
+    got = bytes(d_pr.cpu().numpy().tobytes())
+    for i in range(n):
+        assert got[48 * i:48 * i + 48] == singles[i % 5][1], (n, i)
+    assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), n, st) == 0
+    # one wrong proof anywhere (here: the last lane pair of the last wavefront) must be rejected
+    bad = bytearray(got)
+    bad[48 * (n - 1):48 * n] = singles[(n) % 5][1] if n > 1 and singles[(n) % 5][1] != singles[(n - 1) % 5][1] else bytes(got[:48][::-1])
+    d_bad = torch.frombuffer(bad, dtype=torch.uint8).cuda()
+    assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_bad.data_ptr(), n, st) != 0

@@ -199,7 +199,7 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* c, const void* d_bl
         KT(KT_CELLS_NTT, s, cells_from_blobs_device(blobs, (int)chunk, c->d_tw_fwd, c->d_tw_inv, c->d_coeffs, (uint8_t*)d_cells + done * 262144, d_status + done, s));
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(c->d_coeffs, (int)chunk, c->d_tw_fwd, d_status + done, c->d_fk_scalars, s));
         KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, (int)chunk, d_status + done, c->d_fk_parts, c->d_fk_results, s));
-        KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_fk_results + c->fk_cap * 128 * 64, c->d_fk_plan, (int)chunk, d_status + done, (uint8_t*)d_proofs + done * 128 * 48, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_fk_results + c->fk_cap * 128 * 64, c->d_fk_plan, (int)chunk, d_status + done, (uint8_t*)d_proofs + done * 128 * 48, c->d_fk_parts, s));
         done += chunk;
     }
     HIPCHK(hipGetLastError());
@@ -489,7 +489,7 @@ static int recover_front(mkzg_ctx* c, size_t n_blobs, const uint64_t* const* cel
     if (with_proofs) {
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(c->d_coeffs, (int)n_blobs, c->d_tw_fwd, c->d_cell_st, c->d_fk_scalars, s));
         KT(KT_FK20_MSM, s, fk20_msm_device(c->d_fk_scalars, c->d_fk_table, (int)n_blobs, c->d_cell_st, c->d_fk_parts, c->d_fk_results, s));
-        KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_fk_results + c->fk_cap * 128 * 64, c->d_fk_plan, (int)n_blobs, c->d_cell_st, c->d_fk_proofs, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(c->d_fk_results, c->d_fk_results + c->fk_cap * 128 * 64, c->d_fk_plan, (int)n_blobs, c->d_cell_st, c->d_fk_proofs, c->d_fk_parts, s));
     }
     HIPCHK(hipGetLastError());
     // device-side statuses (non-canonical field elements in the cells) join the host-side ones

@@ -21,6 +21,6 @@ void fk20_build_plan(uint32_t* plan /* FK_PLAN_WORDS, host */);
 // scalars [n][128][64][8 words] -> parts [n][128][16] XYZZ rows (scratch) -> results [n][128] XYZZ rows
 void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s);
 // results [n][128] XYZZ rows (clobbered) + tmp of the same size -> proofs [n][128][48 B]
-void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, const uint32_t* d_plan, int n, const int* d_status, uint8_t* d_proofs48, hipStream_t s);
+void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, const uint32_t* d_plan, int n, const int* d_status, uint8_t* d_proofs48, uint32_t* d_parts /* >= 1024 x n XYZZ rows */, hipStream_t s);
 
 }  // namespace kzg

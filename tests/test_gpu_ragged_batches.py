@@ -38,3 +38,40 @@ def test_ragged_proof_batches_match_single_calls(gpu_ctx, n):
     bad[48 * (n - 1):48 * n] = singles[(n) % 5][1] if n > 1 and singles[(n) % 5][1] != singles[(n - 1) % 5][1] else bytes(got[:48][::-1])
     d_bad = torch.frombuffer(bad, dtype=torch.uint8).cuda()
     assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_bad.data_ptr(), n, st) != 0
+
+
+@pytest.mark.parametrize("n", [9, 40, 65, 100])
+def test_ragged_cell_proof_batches_match_single_calls(gpu_ctx, n):
+    """ComputeCellsAndKZGProofs for n blobs in one call (G1 transforms with one LANE per blob and a uniform twiddle per wavefront:
+    partially filled wavefronts, more than one wavefront of blobs) against the per-blob entry point (one lane per TERM, per-lane
+    twiddles) -- two different code paths for fk20.go:76-124 that must agree byte for byte; one blob of the batch is invalid."""
+    import torch
+    ctx = gpu_ctx
+    distinct = [rand_blob(3000 + i) for i in range(4)]
+    singles = []
+    for b in distinct:
+        rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(b)
+        assert rc == 0
+        singles.append((b"".join(cells), b"".join(proofs)))
+    blobs = [distinct[i % 4] for i in range(n)]
+    bad_at = n // 2
+    bad = bytearray(blobs[bad_at])
+    bad[32 * 77:32 * 78] = b"\xff" * 32                                 # not a canonical field element
+    blobs[bad_at] = bytes(bad)
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cells = torch.zeros(n * 262144, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.zeros(n * 128 * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.ones(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), n, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st)
+    torch.cuda.synchronize()
+    status = d_st.cpu().tolist()
+    cells = d_cells.cpu().numpy().tobytes()
+    proofs = d_proofs.cpu().numpy().tobytes()
+    for i in range(n):
+        if i == bad_at:
+            assert status[i] != 0
+            continue
+        assert status[i] == 0, i
+        assert cells[i * 262144:(i + 1) * 262144] == singles[i % 4][0], (n, i)
+        assert proofs[i * 6144:(i + 1) * 6144] == singles[i % 4][1], (n, i)

@@ -11,10 +11,12 @@
 //     for the 32 byte-windows w and m = 1..128 (signed Booth digits) -- 4.3 GB, sized for a
 //     288 GB part -- so an MSM-64 is 64 x 32 mixed additions with no bucket reduction at all and
 //     no sort; 16 lanes share one MSM and combine with a 4-level wavefront tree.
-//   * the per-blob G1 transforms are four table-driven DFT levels with one lane per twiddle multiplication
-//     (k_g1_dft_level, below); the one-wavefront radix-2 FFT (g1_fft128_dif, points in LDS) is kept for the
-//     one-off set-up of the table.  Twiddle multiplications use the GLV endomorphism (two 128-bit halves,
-//     precomputed per twiddle) with signed 5-bit windows: 125 doublings + <= 52 additions.
+//   * the per-blob G1 transforms are table-driven DFT levels, each level = one twiddle multiplication deep (GLV endomorphism,
+//     Jacobian accumulator).  Batches (> 8 blobs): four levels of 1024 plan entries, ONE WAVEFRONT PER ENTRY and one lane per
+//     blob, so the twiddle is uniform across the wavefront (k_g1_dft_mul: width-5 NAF strings, uniform branches), the terms of
+//     an output summed by k_g1_dft_sum.  Small batches (the reference's per-blob API): two levels of 64-term outputs with one
+//     lane per TERM (k_g1_dft_level<64>: per-lane twiddles, signed 5-bit windows: 125 doublings + <= 52 additions).
+//     The one-wavefront radix-2 FFT (g1_fft128_dif, points in LDS) is kept for the one-off set-up of the table.
 // Integer modular arithmetic only -- no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -389,11 +391,11 @@ __global__ void __launch_bounds__(64) k_fk20_msm_reduce(const uint32_t* __restri
 //     level 1:  Y[j1 + r1 i2]  = sum_{i1<r1}  w^{ r2 i1 j1}        x[r2 i1 + i2]
 //     level 2:  X[j1 + r1 j2]  = sum_{i2<r2}  w^{ i2 (j1 + r1 j2)} Y[j1 + r1 i2]
 // (r1, r2) = (8, 16) for the IFFT, whose level 2 only produces j < 64, and (16, 8) for the FFT, whose level 1 skips the
-// eight i1 that address the identity padding: 1024 lanes per blob in every one of the four levels,
-// one LANE per term (each lane: one GLV scalar multiplication by a fixed power of w), the terms of an output in adjacent
-// lanes and summed with a shuffle tree.  5x the group operations of radix 2, but 4 chains deep instead of 12 and
-// 16 wavefronts per blob and level instead of one (batch 64 = one wavefront per SIMD).
-// Plan entry (one per lane): out << 16 | src << 8 | exponent (0..127, w^64 = -1).
+// eight i1 that address the identity padding: 1024 terms ("plan entries") in every one of the four levels, each one GLV scalar
+// multiplication by a fixed power of w, the terms of an output adjacent and summed with a shuffle tree.  5x the group operations
+// of radix 2, but 4 chains deep instead of 12, and 1024 independent chains per level for any batch size: k_g1_dft_mul runs one
+// WAVEFRONT per entry with the blobs in its lanes (batch 64 = one full wavefront per SIMD, the twiddle uniform in each).
+// Plan entry: out << 16 | src << 8 | exponent (0..127, w^64 = -1).
 // ------------------------------------------------------------------------------------------
 void fk20_build_plan(uint32_t* plan /* FK_PLAN_WORDS */) {
     uint32_t* p = plan;

@@ -142,6 +142,7 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->fk_ws_done) (void)hipEventDestroy(c->fk_ws_done);
+    delete c->pool;
     delete c;
 }
 
@@ -154,6 +155,7 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
         return MKZG_ERR_HIP;
     }
     mkzg_ctx* c = new mkzg_ctx();
+    c->pool = new kzg::HostPool(3);
     if (n_dev > 0 && device_ids) c->device = device_ids[0];
     else (void)hipGetDevice(&c->device);
     // reference api.go:93-95 (ErrMinSRSSize) and the fixed-size arrays of trusted_setup.go:23-27
@@ -368,10 +370,7 @@ int mkzg_blob_to_kzg_commitment_batch(mkzg_ctx* c, const uint8_t* const* blobs, 
             auto gather = [&](size_t q) {
                 for (size_t i = q * per; i < std::min(chunk, (q + 1) * per); i++) memcpy(c->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[done + i], MKZG_BYTES_PER_BLOB);
             };
-            std::vector<std::thread> th;
-            for (size_t q = 1; q < nthr; q++) th.emplace_back(gather, q);
-            gather(0);
-            for (auto& t : th) t.join();
+            c->pool->parallel((int)nthr, [&](int q) { gather((size_t)q); });
         }
         HIPCHK(hipMemcpyAsync(c->d_blobs, c->h_stage, chunk * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, c->stream));
         rc = mkzg_blob_to_kzg_commitment_batch_device(c, c->d_blobs, chunk, c->d_out, c->d_status, c->stream);

@@ -299,11 +299,7 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
         };
         if (n >= 1024) {                                          // 16 MiB for 8192 cells: four host threads
             const size_t q = (n + 3) / 4;
-            std::thread t1(gather, q, std::min(n, 2 * q)), t2(gather, std::min(n, 2 * q), std::min(n, 3 * q)), t3(gather, std::min(n, 3 * q), n);
-            gather(0, q);
-            t1.join();
-            t2.join();
-            t3.join();
+            c->pool->parallel(4, [&](int i) { gather(std::min(n, (size_t)i * q), std::min(n, (size_t)(i + 1) * q)); });
         } else {
             gather(0, n);
         }
@@ -346,11 +342,7 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     const uint32_t* wsum = h_misc + 16;
     auto horner = [&](int m) { g1h_horner_words(out->sums[m], wsum + (size_t)m * VMSM_WINDOWS * 48, VMSM_WINDOWS, VMSM_WINDOW_BITS); };
     {
-        std::thread t0([&] { horner(0); }), t1([&] { horner(1); }), t2([&] { horner(2); });
-        horner(3);
-        t0.join();
-        t1.join();
-        t2.join();
+        c->pool->parallel(4, [&](int m) { horner(m); });
     }
     return MKZG_OK;
 }
@@ -364,7 +356,7 @@ static int cell_verify_finish(mkzg_ctx* c, const CellFold& f) {
     g1h_to_affine(ps[0], f.sums[0]);
     g1h_to_affine(ps[1], rl);
     const G2Prepared* qs[2] = {&c->g2_alpha64, &c->g2_neg_gen};
-    return pairing_check_prepared_2mt(ps, qs) ? MKZG_OK : MKZG_VERIFY_FAILED;
+    return pairing_check_prepared_2mt(ps, qs, c->pool) ? MKZG_OK : MKZG_VERIFY_FAILED;
 }
 int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
                                      size_t n_cells, const uint8_t* proofs48n, size_t n_p) {

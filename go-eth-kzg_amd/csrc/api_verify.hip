@@ -162,11 +162,9 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     const uint32_t* wsum = h_misc + 16;
     auto horner = [&](int m, G1HX& out) { g1h_horner_words(out, wsum + (size_t)m * VMSM_WINDOWS * 48, VMSM_WINDOWS, VMSM_WINDOW_BITS); };
     {   // three independent 255-doubling chains: one per host thread
-        std::thread ta([&] { horner(0, out->A); });
-        std::thread tc([&] { horner(1, out->Cc); });
-        horner(2, out->D);
-        ta.join();
-        tc.join();
+        G1HX* dst[3] = {&out->D, &out->A, &out->Cc};
+        const int job[3] = {2, 0, 1};
+        c->pool->parallel(3, [&](int i) { horner(job[i], *dst[i]); });
     }
     memcpy(out->e, h_misc + 8, 32);
     c->last_host_finish_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
@@ -191,7 +189,7 @@ static int verify_finish(mkzg_ctx* c, const VerifyFold& f) {
     g1h_to_affine(ps[0], Fsum);
     g1h_to_affine(ps[1], negA);
     const G2Prepared* qs[2] = {&c->g2_gen, &c->g2_alpha};
-    bool ok = pairing_check_prepared_2mt(ps, qs);
+    bool ok = pairing_check_prepared_2mt(ps, qs, c->pool);
     c->last_host_finish_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
     return ok ? MKZG_OK : MKZG_VERIFY_FAILED;
 }

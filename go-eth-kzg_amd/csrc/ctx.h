@@ -15,6 +15,7 @@
 #include "fk20_kernels.h"
 #include "recover_kernels.h"
 #include "host_g1.hpp"
+#include "host_pool.hpp"
 
 using namespace kzg;
 
@@ -33,6 +34,7 @@ struct mkzg_ctx {
     hipStream_t side = nullptr;            // side stream: point validation runs beside SHA-256 / evaluation
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::recursive_mutex mu;
+    kzg::HostPool* pool = nullptr;         // persistent host threads for the verifiers' host steps (host_pool.hpp)
     // SRS
     std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes
     uint32_t* d_lagrange_aff = nullptr;    // 4096 affine rows, natural order of the JSON

@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 #include "host_field.hpp"
+#include "host_pool.hpp"
 
 namespace kzg {
 
@@ -495,7 +496,7 @@ inline void miller_loop_prepared(Fp12& f, const G1AffH& P, const G2Prepared& Q) 
 }
 // e(P_0, Q_0) e(P_1, Q_1) == 1 with the two Miller loops on two host threads (the shared-squaring loop below does 63 squarings +
 // 136 line products in sequence; two threads do 63 + 68 each and one extra product)
-inline bool pairing_check_prepared_2mt(const G1AffH* Ps, const G2Prepared* const* Qs);
+inline bool pairing_check_prepared_2mt(const G1AffH* Ps, const G2Prepared* const* Qs, HostPool* pool = nullptr);
 
 // prod_i e(P_i, Q_i) == 1 for prepared Q_i; pairs with an infinity member contribute 1
 inline bool pairing_check_prepared(const G1AffH* Ps, const G2Prepared* const* Qs, int n) {
@@ -521,12 +522,17 @@ inline bool pairing_check_prepared(const G1AffH* Ps, const G2Prepared* const* Qs
     return fp12::is_one(e);
 }
 
-inline bool pairing_check_prepared_2mt(const G1AffH* Ps, const G2Prepared* const* Qs) {
+inline bool pairing_check_prepared_2mt(const G1AffH* Ps, const G2Prepared* const* Qs, HostPool* pool) {
     if (Ps[0].inf || Qs[0]->inf || Ps[1].inf || Qs[1]->inf) return pairing_check_prepared(Ps, Qs, 2);
-    Fp12 f0, f1, f, e;
-    std::thread t([&] { miller_loop_prepared(f1, Ps[1], *Qs[1]); });
-    miller_loop_prepared(f0, Ps[0], *Qs[0]);
-    t.join();
+    Fp12 fs[2], f, e;
+    Fp12 &f0 = fs[0], &f1 = fs[1];
+    if (pool) {
+        pool->parallel(2, [&](int i) { miller_loop_prepared(fs[i], Ps[i], *Qs[i]); });
+    } else {
+        std::thread t([&] { miller_loop_prepared(f1, Ps[1], *Qs[1]); });
+        miller_loop_prepared(f0, Ps[0], *Qs[0]);
+        t.join();
+    }
     fp12::mul(f, f0, f1);
     fp12::conj(f, f);   // x < 0
     final_exponentiation(e, f);

@@ -63,6 +63,29 @@ int shim_cyclotomic_sqr_check(const uint8_t* p48, const uint8_t* q96) {
     if (fp6::eq(a.c0, b.c0) && fp6::eq(a.c1, b.c1)) bad += 1000;   // must differ outside the subgroup
     return bad;
 }
+// HostPool: every index of every parallel() call runs exactly once, also with several submitting threads and more tasks than
+// workers; returns the number of mistakes
+int shim_pool_selftest() {
+    HostPool pool(3);
+    std::atomic<int> bad(0);
+    auto submitter = [&](int seed) {
+        for (int rep = 0; rep < 300; rep++) {
+            const int k = 1 + (rep + seed) % 7;
+            std::vector<int> hits(k, 0);
+            pool.parallel(k, [&](int i) { hits[i] += 1 + i; });
+            for (int i = 0; i < k; i++) if (hits[i] != 1 + i) bad++;
+        }
+    };
+    std::thread a(submitter, 0), b(submitter, 3);
+    submitter(5);
+    a.join();
+    b.join();
+    HostPool none(0);                      // no workers: runs inline
+    int inl = 0;
+    none.parallel(4, [&](int i) { inl += i; });
+    if (inl != 6) bad++;
+    return bad.load();
+}
 // [k]P for compressed P, k = 32-byte little-endian words; returns affine x,y as 2x48 big-endian + inf flag
 int shim_g1_mul(const uint8_t* p48, const uint64_t* k, uint8_t* out_xy96) {
     G1AffH a;

@@ -20,7 +20,7 @@ X = -0xD201000000010000
 def shim():
     so = os.path.join(SHIM_DIR, "libpairing_shim.so")
     src = os.path.join(SHIM_DIR, "pairing_shim.cpp")
-    hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("host_pairing.hpp", "host_field.hpp", "host_g1.hpp", "g1.hpp", "mont29.hpp", "constants29.h")]
+    hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("host_pairing.hpp", "host_field.hpp", "host_g1.hpp", "host_pool.hpp", "g1.hpp", "mont29.hpp", "constants29.h")]
     if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
     return C.CDLL(so)
@@ -92,3 +92,8 @@ def test_g1_mul_matches_oracle(shim, setup):
         exp = bytearray(x.to_bytes(48, "big"))
         exp[0] |= 0x80 | (0x20 if y > (P - 1) // 2 else 0)
         assert bytes(exp) == oracle.g1_gen_mul(k)
+
+
+def test_host_pool(shim):
+    """the persistent host threads the verifiers' host steps run on (host_pool.hpp)"""
+    assert shim.shim_pool_selftest() == 0

@@ -348,6 +348,158 @@ struct G1T {
         select(res, a_inf, bj, res);
         r = res;
     }
+
+    // ------------------------------------------------------------------------------------------
+    // r-torsion test of a finite affine point of the curve: phi(P) == -[x^2]P (Scott 2021), x = -BLS_X_ABS; what gnark's
+    // G1Affine.IsInSubGroup decides under the reference's point decoding (serialization.go:108-115).
+    // ------------------------------------------------------------------------------------------
+    static KZ_HD bool in_subgroup(const fe& px, const fe& py, const fe& beta) {
+        // T = [|x|]P, Q = [|x|]T in ONE rolled loop (pass 0, pass 1) so that the running point stays in registers through the 126 doublings
+        Jac Q;
+        JacC base;
+        jac_cache_affine(base, px, py);
+        Q.x = px;
+        Q.y = py;
+        F::set_one(Q.z);
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+        for (int pass = 0; pass < 2; pass++) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+            for (int bit = 62; bit >= 0; bit--) {
+                jdbl(Q, Q);
+                if ((BLS_X_ABS >> bit) & 1) jadd(Q, Q, base);
+            }
+            if (pass == 0) jac_cache(base, Q);
+        }
+        // phi(P) = (beta x, y) must equal -Q = (X, -Y, Z):   beta x Z^2 == X  and  y Z^3 == -Y
+        if (is_inf(Q)) return false;
+        fe l, r, zz, zzz;
+        F::sqr(zz, Q.z);
+        F::mul(zzz, zz, Q.z);
+        F::mul(l, beta, px);
+        F::mul(l, l, zz);
+        bool ok = F::eq_mod(l, Q.x);
+        F::mul(l, py, zzz);
+        F::template neg<3>(r, Q.y);
+        return ok && F::eq_mod(l, r);
+    }
+
+    // The same test WITHOUT the y coordinate, from x and rhs = x^3 + 4 = y^2 alone -- so that it can run beside the square root that
+    // recovers y (both are ~1 ms latency chains per lane; k_g1_validate gives them one wavefront each).  [k](x, y) = (X_k(x), y Y_k(x)):
+    // every multiple of P is kept as (X, Y, z) meaning the Jacobian point (X, Y, Z = z y).  Then
+    //   * the doubling never sees y:  X3, Y3 depend on X, Y only and Z3 = 2 Y Z = (2 Y z) y  -- jdbl() as it is;
+    //   * the addition of two such points, written out with Z_i = z_i y and y^2 = rhs, yields (X3, y3' y, Z3) with Z3 free of y; scaling
+    //     that Jacobian triple by lambda = y gives (rhs X3, rhs^2 y3', Z3 y), the same form again;
+    //   * P itself is (x rhs, rhs^2, z = 1), and the final comparison beta x Z^2 == X, y Z^3 == -Y reads beta x z^2 rhs == X, z^3 rhs^2 == -Y.
+    // Exact for every point of the curve (identity operands, P + P, P - P handled as in jadd); y != 0 on this curve (odd group order).
+    struct JacYC {   // addition operand with zzr = z^2 rhs (= Z^2), zzzr = z zzr (Z^3 = zzzr y), zr = z rhs cached
+        fe x, y, z, zzr, zzzr, zr;
+    };
+    static KZ_HD void jy_cache(JacYC& r, const Jac& p, const fe& rhs) {
+        fe t;
+        r.x = p.x;
+        r.y = p.y;
+        r.z = p.z;
+        F::sqr(t, p.z);
+        F::mul(r.zzr, t, rhs);
+        F::mul(r.zzzr, r.zzr, p.z);
+        F::mul(r.zr, p.z, rhs);
+    }
+    static KZ_HD void jadd_y(Jac& r, const Jac& a_, const JacYC& b_, const fe& rhs_, const fe& rhs2_) {
+        Jac a = a_;
+        JacYC b = b_;
+        fe rhs = rhs_, rhs2 = rhs2_;
+        opaque(a);
+        F::opaque(b.x);
+        F::opaque(b.y);
+        F::opaque(b.z);
+        F::opaque(b.zzr);
+        F::opaque(b.zzzr);
+        F::opaque(b.zr);
+        F::opaque(rhs);
+        F::opaque(rhs2);
+        const bool a_inf = is_inf(a), b_inf = F::limbs_all_zero(b.z);
+        fe A1, zA1, U1, U2, s1, s2, H, Rd, HH, HHH, Q, t, X3, Y3;
+        Jac res, bj;
+        bj.x = b.x;
+        bj.y = b.y;
+        bj.z = b.z;
+        F::sqr(t, a.z);
+        F::mul(A1, t, rhs);                 // Z1^2
+        F::mul(zA1, A1, a.z);               // Z1^3 / y
+        F::mul(U1, a.x, b.zzr);
+        F::mul(U2, b.x, A1);
+        F::mul(s1, a.y, b.zzzr);            // S1 / y
+        F::mul(s2, b.y, zA1);               // S2 / y
+        F::template sub<1>(H, U2, U1);
+        F::template sub<1>(Rd, s2, s1);     // R / y
+        if (!a_inf && !b_inf && F::template is_zero_mod<16>(H)) {
+            if (F::template is_zero_mod<16>(Rd)) jdbl(res, a);
+            else set_inf(res);
+        } else {
+            opaque(a);
+            F::opaque(b.zr);
+            F::opaque(H);
+            F::opaque(Rd);
+            F::opaque(U1);
+            F::opaque(s1);
+            F::opaque(rhs);
+            F::opaque(rhs2);
+            F::sqr(HH, H);
+            F::mul(HHH, H, HH);
+            F::mul(Q, U1, HH);
+            F::sqr(t, Rd);
+            F::mul(X3, t, rhs);                              // R^2 = (R/y)^2 rhs
+            F::template sub_b_2c<2>(X3, X3, HHH, Q);          // - H^3 - 2 U1 H^2 + 4p   (< 5.01p)
+            F::template sub<3>(t, Q, X3);
+            F::template neg<1>(s1, s1);
+            F::mul2(Y3, Rd, t, s1, HHH);                      // Y3 / y
+            F::mul(t, a.z, b.zr);
+            F::mul(res.z, t, H);                              // Z3 = z1 z2 rhs H  (no y): becomes the new z after the scaling by y
+            F::mul(res.x, X3, rhs);
+            F::mul(res.y, Y3, rhs2);
+        }
+        select(res, b_inf, a, res);
+        select(res, a_inf, bj, res);
+        r = res;
+    }
+    static KZ_HD bool in_subgroup_yfree(const fe& px, const fe& rhs, const fe& beta) {
+        fe rhs2;
+        F::sqr(rhs2, rhs);
+        Jac Q;
+        F::mul(Q.x, px, rhs);
+        Q.y = rhs2;
+        F::set_one(Q.z);
+        JacYC base;
+        jy_cache(base, Q, rhs);
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+        for (int pass = 0; pass < 2; pass++) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+            for (int bit = 62; bit >= 0; bit--) {
+                jdbl(Q, Q);
+                if ((BLS_X_ABS >> bit) & 1) jadd_y(Q, Q, base, rhs, rhs2);
+            }
+            if (pass == 0) jy_cache(base, Q, rhs);
+        }
+        if (is_inf(Q)) return false;
+        fe l, r, zz, t;
+        F::sqr(zz, Q.z);
+        F::mul(t, zz, rhs);                 // Z^2
+        F::mul(l, beta, px);
+        F::mul(l, l, t);
+        bool ok = F::eq_mod(l, Q.x);
+        F::mul(t, zz, Q.z);
+        F::mul(l, t, rhs2);                 // y Z^3 = z^3 rhs^2
+        F::template neg<3>(r, Q.y);
+        return ok && F::eq_mod(l, r);
+    }
 };
 
 // ---- device / radix-2^29 instantiation, under the names the kernels use

@@ -513,59 +513,41 @@ __global__ void __launch_bounds__(EVB_T) k_blob_eval(const uint8_t* __restrict__
 // ------------------------------------------------------------------------------------------
 // G1 subgroup membership: phi(P) == -[x^2]P, one lane per affine row; st[i] |= NOT_IN_SUBGROUP
 // ------------------------------------------------------------------------------------------
-// phi(P) == -[x^2]P for a finite affine point P of the curve
-__device__ __forceinline__ bool g1_in_subgroup_lane(const G1Aff& p) {
-    // T = [|x|]P, Q = [|x|]T   (|x| = 0xd201000000010000, top bit at 63)
-    // both chains in ONE rolled loop (pass 0: T = [|x|]P, pass 1: Q = [|x|]T) with the group operations inlined, so that the
-    // running point stays in registers through the 126 doublings.  Jacobian coordinates: the chain is nothing but doublings
-    // (5 squarings + 2 multiplications each, g1.hpp jdbl) and this kernel is their latency, one lone wavefront per 64 points.
-    G1J Q;
-    G1JC base;
-    G1D::jac_cache_affine(base, p.x, p.y);
-    Q.x = p.x;
-    Q.y = p.y;
-    Fp::set_one(Q.z);
-#pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-#pragma unroll 1
-        for (int bit = 62; bit >= 0; bit--) {
-            G1D::jdbl(Q, Q);
-            if ((BLS_X_ABS >> bit) & 1) G1D::jadd(Q, Q, base);
-        }
-        if (pass == 0) G1D::jac_cache(base, Q);
-    }
-    // phi(P) = (beta x, y) must equal -Q = (X, -Y, Z):   beta x Z^2 == X  and  y Z^3 == -Y
-    bool ok;
-    if (G1D::is_inf(Q)) {
-        ok = false;
-    } else {
-        fp_t beta, l, r, zz, zzz;
-        Fp::set(beta, FP_BETA);
-        Fp::sqr(zz, Q.z);
-        Fp::mul(zzz, zz, Q.z);
-        Fp::mul(l, beta, p.x);
-        Fp::mul(l, l, zz);
-        ok = Fp::eq_mod(l, Q.x);
-        Fp::mul(l, p.y, zzz);
-        Fp::template neg<3>(r, Q.y);
-        ok = ok && Fp::eq_mod(l, r);
-    }
-    return ok;
-}
-// Decoding and subgroup test of the verifiers' points in ONE launch, two point arrays (commitments and proofs) at once: both steps
-// are per-lane latency chains (a ~380-squaring square root, then 126 doublings), so launches back to back cost their sum; and as two kernels on the side stream the second one's dispatch lands behind whatever the main stream
-// issued in between -- in VerifyCellKZGProofBatch the 16 MiB staging copy, whose blit kernel kept it waiting for 0.3 ms.
-__global__ void __launch_bounds__(64) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
-                                                    const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
-    int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_a + n_b) return;
+// Decoding and subgroup test of the verifiers' points in ONE launch, two point arrays (commitments and proofs) at once, and TWO
+// wavefronts per 64 points: both steps are per-lane latency chains -- a ~380-squaring square root (0.43 ms) and the 126 doublings
+// of phi(P) == -[x^2]P (0.97 ms) -- and the second does not need the first's result: G1T::in_subgroup_yfree runs on x and
+// x^3 + 4 alone.  Wave 0 decodes (gnark SetBytes, serialization.go:108-115) and writes the affine rows, wave 1 runs the r-torsion
+// test; a point that fails to decode reports that error, whatever wave 1 computed from its x.  As two kernels back to back the
+// chains cost their sum (1.41 ms) plus, on the side stream, whatever the main stream issued in between.
+__global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
+                                                     const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
+    __shared__ int sub_ok[64];                              // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    int i = blockIdx.x * 64 + lane;
+    const bool live = i < n_a + n_b;
     const uint8_t* in48 = in48_a;
     uint32_t* aff = aff_a;
     int* st = st_a;
-    if (i >= n_a) { i -= n_a; in48 = in48_b; aff = aff_b; st = st_b; }
+    if (live && i >= n_a) { i -= n_a; in48 = in48_b; aff = aff_b; st = st_b; }
+    if (role == 1) {
+        int v = 2;
+        if (live) {
+            fp_t x, rhs, beta;
+            uint32_t flags;
+            if (g1_parse_lane(x, flags, in48 + (size_t)i * 48) == 0) {
+                g1_curve_rhs(rhs, x);
+                Fp::set(beta, FP_BETA);
+                v = G1D::in_subgroup_yfree(x, rhs, beta) ? 1 : 0;
+            }
+        }
+        sub_ok[lane] = v;
+        __syncthreads();
+        return;
+    }
     G1Aff p;
-    int rc = g1_decode_lane(p, in48 + (size_t)i * 48);
-    {
+    int rc = 0;
+    if (live) {
+        rc = g1_decode_lane(p, in48 + (size_t)i * 48);
         uint32_t w[32];
 #pragma unroll
         for (int q = 0; q < 14; q++) { w[q] = p.x.l[q]; w[14 + q] = p.y.l[q]; }
@@ -574,8 +556,11 @@ __global__ void __launch_bounds__(64) k_g1_validate(const uint8_t* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 8; q++) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     }
-    if (rc == 0 && !p.inf && !g1_in_subgroup_lane(p)) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
-    st[i] = rc;
+    __syncthreads();
+    if (live) {
+        if (rc == 0 && !p.inf && sub_ok[lane] == 0) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
+        st[i] = rc;
+    }
 }
 
 
@@ -866,7 +851,7 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
 }
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s) {
     const int n = n_a + n_b;
-    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
+    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(128), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
 }
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         hipStream_t s) {

@@ -49,6 +49,13 @@ void shim_g1j_add(const uint32_t* a, const uint32_t* b, uint32_t* o) {   // b: a
 void shim_g1j_add_affine(const uint32_t* a, const uint32_t* px, const uint32_t* py, uint32_t* o) {
     G1J x, r; memcpy(&x, a, 168); fp_t fx, fy; Fp::set(fx, px); Fp::set(fy, py); G1JC c; G1D::jac_cache_affine(c, fx, fy); G1D::jadd(r, x, c); memcpy(o, &r, 168);
 }
+// r-torsion test of the affine point (x, y) (Montgomery limbs): bit 0 = with y, bit 1 = from x and y^2 alone
+int shim_g1_in_subgroup(const uint32_t* x, const uint32_t* y) {
+    fp_t fx, fy, beta, rhs;
+    Fp::set(fx, x); Fp::set(fy, y); Fp::set(beta, FP_BETA);
+    Fp::sqr(rhs, fy);
+    return (G1D::in_subgroup(fx, fy, beta) ? 1 : 0) | (G1D::in_subgroup_yfree(fx, rhs, beta) ? 2 : 0);
+}
 // returns compressed 48 bytes
 void shim_g1_compress(const uint32_t* a, uint8_t* out48) {
     G1X x; memcpy(&x, a, 224); G1Aff aff; g1x_to_affine(aff, x);

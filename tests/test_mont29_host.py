@@ -368,6 +368,32 @@ def test_g1_jacobian_ops(shim):
     assert jac_compress(shim, acc) == compress(ec_mul(1 << 126, pts[3]))
 
 
+def test_g1_subgroup_tests(shim):
+    """phi(P) == -[x^2]P with and without the y coordinate (g1.hpp in_subgroup / in_subgroup_yfree) on points inside and outside
+    the prime-order subgroup, including the order-3 points (0, +-2) that drive the chain through its exceptional cases"""
+    G = (G1X, G1Y)
+    rng = random.Random(21)
+    aff = lambda pt: (limbs(pt[0] * RP % P), limbs(pt[1] * RP % P))
+    for _ in range(4):
+        pt = ec_mul(rng.randrange(1, R), G)
+        assert shim.shim_g1_in_subgroup(*aff(pt)) == 3
+    outside = [(0, 2), (0, P - 2)]
+    while len(outside) < 6:                                     # random points of the curve: in G1 with probability 1/cofactor
+        x = rng.randrange(P)
+        rhs = (x * x * x + 4) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P == rhs:
+            outside.append((x, y))
+    for pt in outside:
+        assert ec_mul(R, pt) is not None                        # not of order r
+        assert shim.shim_g1_in_subgroup(*aff(pt)) == 0, pt
+    # h * Q lies in G1 for any curve point Q (h = cofactor): both tests must accept it
+    H_COF = 0x396c8c005555e1568c00aaab0000aaab
+    q = ec_mul(H_COF, outside[3])
+    assert q is not None and ec_mul(R, q) is None
+    assert shim.shim_g1_in_subgroup(*aff(q)) == 3
+
+
 def test_g1_matches_oracle(shim):
     """cross-check with the CPU oracle on k*G"""
     import oracle

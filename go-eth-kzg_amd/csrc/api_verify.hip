@@ -23,11 +23,12 @@ static const size_t V_MISC_WORDS = 16 + 4 * VMSM_WINDOWS * 48;
     } while (0)
 
 void free_verify_ws(mkzg_ctx* c) {
-    void* ptrs[] = {c->d_v_raw, c->d_v_aff, c->d_v_st, c->d_v_z, c->d_v_y, c->d_v_s1, c->d_v_s3, c->d_v_misc, c->d_quot, c->d_q_z, c->d_q_y, c->d_q_st};
+    void* ptrs[] = {c->d_v_raw, c->d_v_aff, c->d_v_st, c->d_v_z, c->d_v_y, c->d_v_s1, c->d_v_s3, c->d_v_misc, c->d_quot, c->d_q_z, c->d_q_y, c->d_q_st, c->d_v_coeffs};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->h_v) (void)hipHostFree(c->h_v);
     c->d_v_raw = nullptr; c->d_v_aff = nullptr; c->d_v_st = nullptr; c->d_v_z = nullptr; c->d_v_y = nullptr; c->d_v_s1 = nullptr; c->d_v_s3 = nullptr;
     c->d_v_misc = nullptr; c->d_quot = nullptr; c->d_q_z = nullptr; c->d_q_y = nullptr; c->d_q_st = nullptr; c->h_v = nullptr;
+    c->d_v_coeffs = nullptr; c->v_coeff_cap = 0;
     c->v_cap = 0; c->q_cap = 0; c->quot_cap = 0; c->h_v_bytes = 0;
 }
 int ensure_verify_ws(mkzg_ctx* c, size_t n) {
@@ -86,6 +87,18 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     if (n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
     int rc = ensure_verify_ws(c, n);
     if (rc) return rc;
+    if (d_blobs) {
+        // coefficient rows of the blobs (inverse NTT beside the challenge hash) and the NTT twiddles they need
+        rc = ensure_cells(c, 0);
+        if (rc) return rc;
+        if (n > c->v_coeff_cap) {
+            if (c->d_v_coeffs) (void)hipFree(c->d_v_coeffs);
+            c->d_v_coeffs = nullptr;
+            c->v_coeff_cap = 0;
+            HIPCHK(hipMalloc(&c->d_v_coeffs, n * 4096 * 48));
+            c->v_coeff_cap = n;
+        }
+    }
     const size_t cap = c->v_cap;
     uint32_t* aff_c = c->d_v_aff;
     uint32_t* aff_q = c->d_v_aff + cap * 32;
@@ -98,11 +111,15 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     HIPCHK(hipEventRecord(c->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
     KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2));
+    //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
+    //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions
+    if (d_blobs) KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, c->d_v_coeffs, nullptr, st_b, s2));
     HIPCHK(hipEventRecord(c->ev_join, s2));
     // 2. challenge and claimed value per blob, or caller-supplied z / y
     if (d_blobs) {
         KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, c->d_v_z, s));
-        KT(KT_EVAL, s, blob_eval_device(d_blobs, c->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, c->d_v_y, st_b, s));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+        KT(KT_EVAL, s, poly_eval_device(c->d_v_coeffs, c->d_v_z, (int)n, c->d_v_y, st_b, s));
     } else {
         // VerifyKZGProof checks y before z (verify.go:15-23); st_b ends up non-zero if either fails
         scalars_to_fr_device(d_z32, (int)n, c->d_v_z, st_b, s);

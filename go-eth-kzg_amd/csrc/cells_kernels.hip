@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(NT) k_cells_ntt(const uint8_t* __restrict__ bl
         c_fr_mul(c, c, w);
         lds_put<N>(sh, i, c);
     }
+    if (INPUT == 0 && cells == nullptr) return;      // coefficients only (the batch verifier evaluates them at the challenge)
     __syncthreads();
     // forward NTT-4096, decimation in frequency: natural in, bit-reversed out
     for (int h = N / 2; h >= 1; h >>= 1) {

@@ -94,6 +94,8 @@ struct mkzg_ctx {
     uint32_t* d_q_y = nullptr;
     int* d_q_st = nullptr;
     // ---- EIP-7594
+    uint32_t* d_v_coeffs = nullptr;        // batch verifier: coefficient rows of the blobs (v_coeff_cap x 4096 x 12 words)
+    size_t v_coeff_cap = 0;
     uint32_t* d_tw_fwd = nullptr;          // 4096 Fr rows: w_8192^j
     uint32_t* d_tw_inv = nullptr;          // 4096 Fr rows: w_8192^-j
     uint32_t* d_g1tw_fwd = nullptr;        // 64 x 8 words: w_128^j as plain scalars

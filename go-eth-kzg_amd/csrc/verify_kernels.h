@@ -11,6 +11,8 @@ void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int 
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s);
 void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
                           int* d_status, hipStream_t s);
+// y_b = f_b(z_b) from coefficient rows (n x 4096 x 12 words, as cells_from_blobs_device publishes them); blobs with a non-zero status are skipped
+void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint32_t* d_y, const int* d_status, hipStream_t s);
 // decode (gnark SetBytes checks) + subgroup test of two arrays of compressed points in one launch: affine rows and status words out
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s);
 // r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)

@@ -105,30 +105,8 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
     int* st_c = c->d_v_st;
     int* st_q = c->d_v_st + cap;
     int* st_b = c->d_v_st + 2 * cap;
-    // 1. decode + validate the points (serialization.go:108-115)
-    //    on the side stream, beside the (longer, latency-bound) SHA-256 + evaluation chain
-    hipStream_t s2 = c->side;
-    HIPCHK(hipEventRecord(c->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2));
-    //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
-    //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions
-    if (d_blobs) KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, c->d_v_coeffs, nullptr, st_b, s2));
-    HIPCHK(hipEventRecord(c->ev_join, s2));
-    // 2. challenge and claimed value per blob, or caller-supplied z / y
-    if (d_blobs) {
-        KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, c->d_v_z, s));
-        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
-        KT(KT_EVAL, s, poly_eval_device(c->d_v_coeffs, c->d_v_z, (int)n, c->d_v_y, st_b, s));
-    } else {
-        // VerifyKZGProof checks y before z (verify.go:15-23); st_b ends up non-zero if either fails
-        scalars_to_fr_device(d_z32, (int)n, c->d_v_z, st_b, s);
-        int* st_y = (int*)(c->d_v_misc + 16);   // scratch inside the window-sum area (overwritten later)
-        scalars_to_fr_device(d_y32, (int)n, c->d_v_y, st_y, s);
-        // merge: handled on the host below through a second copy
-    }
-    HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
-    // 3. random linear combination scalars (kzg_verify.go:136-141)
+    // 0. the random linear combination scalar r (kzg_verify.go:136-141) is drawn first: everything that needs r but not the
+    //    challenges runs beside the challenge hash
     uint32_t* h_misc = (uint32_t*)(c->h_v + 3 * cap * sizeof(int));
     uint8_t rbytes[32];
     if (r32) {
@@ -137,22 +115,63 @@ static int verify_fold(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_z32
         return MKZG_ERR_HIP;
     }
     memcpy(h_misc, rbytes, 32);
-    int y_bad = 0;
-    if (!d_blobs) {
-        // need the y-status before it is overwritten by the window sums
-        std::vector<int> sty(n);
-        HIPCHK(hipMemcpyAsync(sty.data(), c->d_v_misc + 16, n * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        for (int v : sty) if (v) y_bad = v;
-    }
-    HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
-    KT(KT_RLC, s, rlc_scalars_device(c->d_v_misc, c->d_v_z, c->d_v_y, (int)n, exp_offset, c->d_v_s1, c->d_v_s3, c->d_v_misc + 8, s));
-    // 4. the three MSMs of kzg_verify.go:150,225,179: sum r^i Q_i, sum r^i C_i, sum r^i z_i Q_i
-    const uint32_t* scal[3] = {c->d_v_s1, c->d_v_s1, c->d_v_s3};
-    const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
+    uint32_t* d_parts = c->d_v_misc + V_MISC_WORDS;
+    uint32_t* d_wsum = c->d_v_misc + 16;
+    const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
     int vrc = 0;
-    const int njob[3] = {(int)n, (int)n, (int)n};
-    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, c->d_v_misc + V_MISC_WORDS, c->d_v_misc + 16, s));
+    // 1. decode + validate the points (serialization.go:108-115)
+    //    on the side stream, beside the (longer, latency-bound) SHA-256 chain
+    hipStream_t s2 = c->side;
+    HIPCHK(hipEventRecord(c->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2));
+    if (d_blobs) {
+        //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
+        //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions;
+        //    the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
+        KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, c->d_v_coeffs, nullptr, st_b, s2));
+        HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s2));
+        KT(KT_RLC, s2, rlc_scalars_device(c->d_v_misc, nullptr, nullptr, (int)n, exp_offset, c->d_v_s1, nullptr, nullptr, 1, s2));
+        const uint32_t* scal[2] = {c->d_v_s1, c->d_v_s1};
+        const uint32_t* pts[2] = {aff_q, aff_c};
+        const int njob[2] = {(int)n, (int)n};
+        KT(KT_VMSM, s2, vrc = vmsm_windows_device(scal, pts, njob, 2, d_parts, d_wsum, s2));
+        if (vrc) return MKZG_ERR_BAD_ARGS;
+    }
+    HIPCHK(hipEventRecord(c->ev_join, s2));
+    // 2. challenge and claimed value per blob, or caller-supplied z / y
+    int y_bad = 0;
+    if (d_blobs) {
+        KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, c->d_v_z, s));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+        KT(KT_EVAL, s, poly_eval_device(c->d_v_coeffs, c->d_v_z, (int)n, c->d_v_y, st_b, s));
+        // 3. what depends on the challenges: r^i z_i, sum r^i y_i, and the MSM sum r^i z_i Q_i (kzg_verify.go:179)
+        KT(KT_RLC, s, rlc_scalars_device(c->d_v_misc, c->d_v_z, c->d_v_y, (int)n, exp_offset, c->d_v_s1, c->d_v_s3, c->d_v_misc + 8, 2, s));
+        const uint32_t* scal[1] = {c->d_v_s3};
+        const uint32_t* pts[1] = {aff_q};
+        const int njob[1] = {(int)n};
+        KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 1, d_parts + 2 * parts_per_job, d_wsum + 2 * wsum_per_job, s, 256));
+    } else {
+        // VerifyKZGProof checks y before z (verify.go:15-23); st_b ends up non-zero if either fails
+        scalars_to_fr_device(d_z32, (int)n, c->d_v_z, st_b, s);
+        int* st_y = (int*)(c->d_v_misc + 16);   // scratch inside the window-sum area (overwritten later)
+        scalars_to_fr_device(d_y32, (int)n, c->d_v_y, st_y, s);
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+        {
+            // need the y-status before it is overwritten by the window sums
+            std::vector<int> sty(n);
+            HIPCHK(hipMemcpyAsync(sty.data(), c->d_v_misc + 16, n * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            for (int v : sty) if (v) y_bad = v;
+        }
+        HIPCHK(hipMemcpyAsync(c->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
+        KT(KT_RLC, s, rlc_scalars_device(c->d_v_misc, c->d_v_z, c->d_v_y, (int)n, exp_offset, c->d_v_s1, c->d_v_s3, c->d_v_misc + 8, 0, s));
+        // the three MSMs of kzg_verify.go:150,225,179: sum r^i Q_i, sum r^i C_i, sum r^i z_i Q_i
+        const uint32_t* scal[3] = {c->d_v_s1, c->d_v_s1, c->d_v_s3};
+        const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
+        const int njob[3] = {(int)n, (int)n, (int)n};
+        KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
+    }
     if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     // 5. one round trip: statuses, e, window sums

@@ -17,13 +17,14 @@ void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s);
 // r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
-                        hipStream_t s);
+                        int mode /* 0 all, 1 s1 only, 2 s3 and e only */, hipStream_t s);
 // n_msm <= 4 jobs of n_per_job[m] <= 8192 (scalar, point) pairs; d_out[msm][32 windows][48 words]
 // gnark-crypto Montgomery layouts (fr.Element 4 x u64, G1Affine 12 x u64) -> plain 8-word scalars + radix-2^29 affine rows
 void gnark_to_vmsm_device(const uint32_t* d_scalars_mont, const uint32_t* d_points_mont, int n, uint32_t* d_scalars8, uint32_t* d_aff, hipStream_t s);
 constexpr int VMSM_KMAX = 8;                                        // slices of the point range per (job, window)
 constexpr size_t VMSM_PART_WORDS = (size_t)4 * 32 * VMSM_KMAX * 64;   // scratch of vmsm_windows_device (XYZZ rows)
-int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_parts, uint32_t* d_out, hipStream_t s);
+int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_parts, uint32_t* d_out, hipStream_t s,
+                        int points_per_slice = 2048 /* 2048: 8192-point jobs fill the GPU in one round of workgroups */);
 void build_roots_device(uint32_t* d_roots_brp, uint32_t* d_inv_roots_brp, int log_n, hipStream_t s);
 void scalars_to_fr_device(const uint8_t* d_in32, int n, uint32_t* d_out12, int* d_status, hipStream_t s);
 void fr_to_scalars_device(const uint32_t* d_in12, int n, uint8_t* d_out32, hipStream_t s);

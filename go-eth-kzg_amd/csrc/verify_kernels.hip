@@ -606,8 +606,9 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
 // RLC scalars (single workgroup): r -> r^i ; s1_i = r^i ; s3_i = r^i z_i ; e = sum r^i y_i
 // outputs as plain little-endian 8-word scalars
 // ------------------------------------------------------------------------------------------
+// mode 0: everything; mode 1: s1 only (does not need z, y: issued before the challenges exist); mode 2: s3 and e only
 __global__ void __launch_bounds__(EV_T) k_rlc_scalars(const uint32_t* __restrict__ r_words8, const uint32_t* __restrict__ z_in, const uint32_t* __restrict__ y_in, int n,
-                                                      uint32_t exp_offset, uint32_t* __restrict__ s1, uint32_t* __restrict__ s3, uint32_t* __restrict__ e_out) {
+                                                      uint32_t exp_offset, uint32_t* __restrict__ s1, uint32_t* __restrict__ s3, uint32_t* __restrict__ e_out, int mode) {
     __shared__ uint32_t sh[EV_T * 9];
     const int t = threadIdx.x;
     uint32_t rw[8];
@@ -633,22 +634,28 @@ __global__ void __launch_bounds__(EV_T) k_rlc_scalars(const uint32_t* __restrict
             if (e & 1) fr_mul_n(rp, rp, base);
             fr_mul_n(base, base, base);
         }
-        fr_t z, y, rz, ry, pl;
-        load_fr12(z, z_in + (size_t)i * 12);
-        load_fr12(y, y_in + (size_t)i * 12);
-        fr_mul_n(rz, rp, z);
-        fr_mul_n(ry, rp, y);
-        FrC::add(part, part, ry);
+        fr_t pl;
         uint32_t w[8];
-        Fr::to_plain(pl, rp);
-        Fr::to_words32(w, pl);
+        if (mode != 2) {
+            Fr::to_plain(pl, rp);
+            Fr::to_words32(w, pl);
 #pragma unroll
-        for (int q = 0; q < 8; q++) s1[(size_t)i * 8 + q] = w[q];
-        Fr::to_plain(pl, rz);
-        Fr::to_words32(w, pl);
+            for (int q = 0; q < 8; q++) s1[(size_t)i * 8 + q] = w[q];
+        }
+        if (mode != 1) {
+            fr_t z, y, rz, ry;
+            load_fr12(z, z_in + (size_t)i * 12);
+            load_fr12(y, y_in + (size_t)i * 12);
+            fr_mul_n(rz, rp, z);
+            fr_mul_n(ry, rp, y);
+            FrC::add(part, part, ry);
+            Fr::to_plain(pl, rz);
+            Fr::to_words32(w, pl);
 #pragma unroll
-        for (int q = 0; q < 8; q++) s3[(size_t)i * 8 + q] = w[q];
+            for (int q = 0; q < 8; q++) s3[(size_t)i * 8 + q] = w[q];
+        }
     }
+    if (mode == 1) return;
     block_sum_fr<EV_T>(part, sh);
     if (t == 0) {
         fr_t pl;
@@ -895,10 +902,11 @@ void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, in
     if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(128), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
 }
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, exp_offset, d_s1, d_s3, d_e);
+                        int mode, hipStream_t s) {
+    hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, exp_offset, d_s1, d_s3, d_e, mode);
 }
-int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_parts, uint32_t* d_out, hipStream_t s) {
+int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_parts, uint32_t* d_out, hipStream_t s,
+                        int points_per_slice) {
     if (n_msm < 1 || n_msm > 4) return -1;
     VmsmJobs jobs;
     int kmax = 1;
@@ -908,7 +916,7 @@ int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const*
         jobs.j[m].scalars = d_scalars[q];
         jobs.j[m].points = d_points[q];
         jobs.j[m].n = n_per_job[q];
-        jobs.k[m] = std::min(VMSM_KMAX, std::max(1, n_per_job[q] / 2048));   // 2048 points per slice: 8192-point jobs fill the GPU in one round of workgroups
+        jobs.k[m] = std::min(VMSM_KMAX, std::max(1, n_per_job[q] / points_per_slice));   // 2048 points per slice: 8192-point jobs fill the GPU in one round of workgroups
         if (m < n_msm) kmax = std::max(kmax, jobs.k[m]);
     }
     hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts);

@@ -755,43 +755,44 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
         if (v >> 31) Fp::template neg<0>(p.y, p.y);
         g1x_madd(acc, p.x, p.y);
     }
-    // per wave (64 buckets): S = sum B_l ; Q = sum l B_l  via suffix scan + tree.  The additions are inlined (one copy, rolled loop over
-    // the 12 rounds): the points stay in registers between rounds instead of travelling through the called routine's stack
+    // window sum = sum_k (k+1) B_k = sum over all 128 buckets of the SUFFIX sums  suffix_k = sum_{j >= k} B_j:
+    //   rounds 0-5   suffix scan inside each wavefront (64 buckets)
+    //   round  6     wavefront 0 adds wavefront 1's total to every one of its suffixes (one parallel addition, through LDS)
+    //   rounds 7-12  tree sum of the 64 suffixes of each wavefront;  then one addition of the two wavefronts' sums
+    // -- 14 additions deep; the weights never appear, so there is no 64 S_1 = six serial doublings as a (S, Q) formulation has.
+    // The additions are inlined (one copy, rolled loop): the points stay in registers between rounds.
     const int lane = t & 63, wave = t >> 6;
-    G1X Pf = acc, o, S;
+    G1X Pf = acc, o;
+    auto put_x = [&](const G1X& v) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) { xchg[i] = v.x.l[i]; xchg[14 + i] = v.y.l[i]; xchg[28 + i] = v.zz.l[i]; xchg[42 + i] = v.zzz.l[i]; }
+    };
+    auto get_x = [&](G1X& v) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) { v.x.l[i] = xchg[i]; v.y.l[i] = xchg[14 + i]; v.zz.l[i] = xchg[28 + i]; v.zzz.l[i] = xchg[42 + i]; }
+    };
 #pragma unroll 1
-    for (int round = 0; round < 12; round++) {
-        const int d = round < 6 ? (1 << round) : (32 >> (round - 6));
+    for (int round = 0; round < 13; round++) {
+        bool take;
         if (round == 6) {
-            S = Pf;                // lane 0: sum of the wave's buckets
-            if (lane == 0) g1x_set_inf(Pf);
+            if (wave == 1 && lane == 0) put_x(Pf);
+            __syncthreads();
+            get_x(o);
+            take = wave == 0;
+        } else {
+            const int d = round < 6 ? (1 << round) : (32 >> (round - 7));
+            shfl_down_xyzz_v(o, Pf, d);
+            take = round < 6 ? (lane + d < 64) : (lane < d);
         }
-        shfl_down_xyzz_v(o, Pf, d);
-        const bool take = round < 6 ? (lane + d < 64) : (lane < d);
         if (take) g1x_add(Pf, Pf, o);
     }
-    // lane 0 of each wave now holds S_w (in S) and Q_w (in Pf)
-    if (wave == 1 && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 14; i++) {
-            xchg[i] = S.x.l[i]; xchg[14 + i] = S.y.l[i]; xchg[28 + i] = S.zz.l[i]; xchg[42 + i] = S.zzz.l[i];
-            xchg[56 + i] = Pf.x.l[i]; xchg[70 + i] = Pf.y.l[i]; xchg[84 + i] = Pf.zz.l[i]; xchg[98 + i] = Pf.zzz.l[i];
-        }
-    }
+    __syncthreads();
+    if (wave == 1 && lane == 0) put_x(Pf);
     __syncthreads();
     if (t == 0) {
-        // total = sum_k (k+1) B_k = (S_0 + Q_0) + (65 S_1 + Q_1)
-        G1X S1, Q1, tot;
-#pragma unroll
-        for (int i = 0; i < 14; i++) {
-            S1.x.l[i] = xchg[i]; S1.y.l[i] = xchg[14 + i]; S1.zz.l[i] = xchg[28 + i]; S1.zzz.l[i] = xchg[42 + i];
-            Q1.x.l[i] = xchg[56 + i]; Q1.y.l[i] = xchg[70 + i]; Q1.zz.l[i] = xchg[84 + i]; Q1.zzz.l[i] = xchg[98 + i];
-        }
-        g1x_add_nv(tot, S, Pf);
-        g1x_add_nv(tot, tot, Q1);
-        g1x_add_nv(tot, tot, S1);
-        for (int q = 0; q < 6; q++) g1x_dbl_nv(S1, S1);
-        g1x_add_nv(tot, tot, S1);
+        G1X Q1, tot;
+        get_x(Q1);
+        g1x_add_nv(tot, Pf, Q1);
         uint32_t* dst = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + z) * 64;
 #pragma unroll
         for (int i = 0; i < 14; i++) { dst[i] = tot.x.l[i]; dst[14 + i] = tot.y.l[i]; dst[28 + i] = tot.zz.l[i]; dst[42 + i] = tot.zzz.l[i]; }

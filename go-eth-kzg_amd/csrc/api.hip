@@ -139,8 +139,10 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     free_cells(c);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->side2) (void)hipStreamDestroy(c->side2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_decoded) (void)hipEventDestroy(c->ev_decoded);
     if (c->fk_ws_done) (void)hipEventDestroy(c->fk_ws_done);
     delete c->pool;
     delete c;
@@ -169,8 +171,10 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_decoded, hipEventDisableTiming));
         // decode the Lagrange SRS on the device (no subgroup check: trusted_setup.go:104-117)
         uint8_t* d_raw = nullptr;
         int* d_st = nullptr;

@@ -81,7 +81,7 @@ static int ensure_cv_ws(mkzg_ctx* c, size_t n) {
     HIPCHK(hipMalloc(&c->d_cv_weights, cap * 32));
     HIPCHK(hipMalloc(&c->d_cv_partials, (size_t)CELL_INTERP_BLOCKS * 64 * 48));
     HIPCHK(hipMalloc(&c->d_cv_interp, 64 * 32));
-    HIPCHK(hipMalloc(&c->d_cv_st, cap * sizeof(int)));
+    HIPCHK(hipMalloc(&c->d_cv_st, 3 * cap * sizeof(int)));
     c->cv_cap = cap;
     return MKZG_OK;
 }
@@ -289,8 +289,17 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     hipStream_t s2 = c->side;
     HIPCHK(hipEventRecord(c->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-    KT(KT_SUBGROUP, s2, g1_validate2_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s2));
-    HIPCHK(hipEventRecord(c->ev_join, s2));
+    // Decoding (0.43 ms) and the y-free subgroup test (0.97 ms) as two launches on two streams: the MSMs below need the decoded rows
+    // only, so they start as soon as the scalars are ready instead of after the longer chain.  A point outside the subgroup is still a
+    // point of the curve (the group law is total there), and its verdict makes the call fail before any sum is looked at.
+    hipStream_t s3 = c->side2;
+    int* sub_rows = c->d_cv_st + c->cv_cap;
+    int* sub_q = c->d_cv_st + 2 * c->cv_cap;
+    HIPCHK(hipStreamWaitEvent(s3, c->ev_fork, 0));
+    KT(KT_DECOMPRESS, s2, g1_validate2_device(c->d_v_raw, (int)n_rows, aff_rows, st_rows, c->d_v_raw + cap * 48, (int)n, aff_q, st_q, s2, 1));
+    HIPCHK(hipEventRecord(c->ev_decoded, s2));
+    KT(KT_SUBGROUP, s3, g1_validate2_device(c->d_v_raw, (int)n_rows, nullptr, sub_rows, c->d_v_raw + cap * 48, (int)n, nullptr, sub_q, s3, 2));
+    HIPCHK(hipEventRecord(c->ev_join, s3));
     // uploads, part 2 (host memcpy of n x 2 KiB into the pinned staging area runs while the GPU validates the points)
     {
         const std::vector<uint8_t> zero_cell(2048, 0);           // stands in for nil entries (reported after the device work)
@@ -316,7 +325,7 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     // scalars
     KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(c->d_v_misc, exp_offset, c->d_cv_cell_idx, c->d_cv_row_idx, c->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, c->d_cv_rp,
                                                        c->d_v_s1, c->d_v_s3, c->d_cv_weights, c->d_cv_partials, c->d_cv_interp, c->d_cv_st, s));
-    HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_decoded, 0));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
     const uint32_t* scal[4] = {c->d_v_s1, c->d_cv_weights, c->d_cv_interp, c->d_v_s3};
     const uint32_t* pts[4] = {aff_q, aff_rows, c->d_monomial_aff, aff_q};
@@ -326,14 +335,23 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
     if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     int* h_st = (int*)c->h_v;
-    std::vector<int> st_cells(n);
+    std::vector<int> st_cells(n), h_sub_rows(n_rows), h_sub_q(n);
+    HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));               // the subgroup verdicts
     HIPCHK(hipMemcpyAsync(h_st, c->d_v_st, 2 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(st_cells.data(), c->d_cv_st, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_sub_rows.data(), sub_rows, n_rows * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_sub_q.data(), sub_q, n * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_misc, c->d_v_misc, V_MISC_WORDS_C * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     // error precedence of api_eip7594.go:190-213: all commitments, then all proofs, then all cells
-    for (size_t i = 0; i < n_rows; i++) if (h_st[i]) return h_st[i];
-    for (size_t i = 0; i < n; i++) if (h_st[cap + i]) return h_st[cap + i];
+    for (size_t i = 0; i < n_rows; i++) {
+        if (h_st[i]) return h_st[i];
+        if (h_sub_rows[i]) return h_sub_rows[i];
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (h_st[cap + i]) return h_st[cap + i];
+        if (h_sub_q[i]) return h_sub_q[i];
+    }
     for (size_t i = 0; i < n; i++) {
         if (i == first_nil) return MKZG_ERR_NIL_INPUT;
         if (st_cells[i]) return st_cells[i];

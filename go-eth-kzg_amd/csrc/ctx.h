@@ -32,7 +32,8 @@ struct mkzg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;          // internal stream for host-pointer entry points
     hipStream_t side = nullptr;            // side stream: point validation runs beside SHA-256 / evaluation
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side2 = nullptr;           // second side stream: the cell verifier's subgroup test beside decoding + MSMs
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_decoded = nullptr;
     std::recursive_mutex mu;
     kzg::HostPool* pool = nullptr;         // persistent host threads for the verifiers' host steps (host_pool.hpp)
     // SRS
@@ -114,7 +115,7 @@ struct mkzg_ctx {
     uint32_t* d_cv_weights = nullptr;      // cv_cap x 8 words
     uint32_t* d_cv_partials = nullptr;     // CELL_INTERP_BLOCKS x 64 Fr rows
     uint32_t* d_cv_interp = nullptr;       // 64 x 8 words
-    int* d_cv_st = nullptr;                // cv_cap
+    int* d_cv_st = nullptr;                // 3 x cv_cap: cell statuses, subgroup verdicts of the commitment rows, of the proofs
     // recovery
     bool rec_ready = false;
     size_t rec_cap = 0;                    // blobs the recovery scratch / position arrays hold

@@ -557,10 +557,13 @@ __global__ void __launch_bounds__(256) k_poly_eval(const uint32_t* __restrict__ 
 // x^3 + 4 alone.  Wave 0 decodes (gnark SetBytes, serialization.go:108-115) and writes the affine rows, wave 1 runs the r-torsion
 // test; a point that fails to decode reports that error, whatever wave 1 computed from its x.  As two kernels back to back the
 // chains cost their sum (1.41 ms) plus, on the side stream, whatever the main stream issued in between.
+// mode 0: both wavefronts, one status per point.  mode 1 / mode 2 (64 threads): only the decoding / only the r-torsion test, as two
+// launches on two streams -- for the cell verifier, whose MSMs can then start on the decoded rows while the test is still running;
+// mode 2 writes MKZG_ERR_G1_NOT_IN_SUBGROUP or 0 to ITS OWN status arrays (the caller gives the decoding's status precedence).
 __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
-                                                     const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
+                                                     const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode) {
     __shared__ int sub_ok[64];                              // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
-    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, role = mode == 0 ? (int)(threadIdx.x >> 6) : mode - 1;
     int i = blockIdx.x * 64 + lane;
     const bool live = i < n_a + n_b;
     const uint8_t* in48 = in48_a;
@@ -578,6 +581,10 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
                 v = G1D::in_subgroup_yfree(x, rhs, beta) ? 1 : 0;
             }
         }
+        if (mode == 2) {
+            if (live) st[i] = v == 0 ? MKZG_ERR_G1_NOT_IN_SUBGROUP : 0;
+            return;
+        }
         sub_ok[lane] = v;
         __syncthreads();
         return;
@@ -593,6 +600,10 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
         uint4* o = reinterpret_cast<uint4*>(aff + (size_t)i * 32);
 #pragma unroll
         for (int q = 0; q < 8; q++) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    }
+    if (mode == 1) {
+        if (live) st[i] = rc;
+        return;
     }
     __syncthreads();
     if (live) {
@@ -898,9 +909,10 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
 void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint32_t* d_y, const int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_poly_eval, dim3(n), dim3(256), 0, s, d_coeffs, d_z, d_status, d_y);
 }
-void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s) {
+void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
+                         int mode) {
     const int n = n_a + n_b;
-    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(128), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
+    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(mode == 0 ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b, mode);
 }
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         int mode, hipStream_t s) {

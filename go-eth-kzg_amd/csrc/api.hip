@@ -157,7 +157,7 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
         return MKZG_ERR_HIP;
     }
     mkzg_ctx* c = new mkzg_ctx();
-    c->pool = new kzg::HostPool(3);
+    c->pool = new kzg::HostPool(7);
     if (n_dev > 0 && device_ids) c->device = device_ids[0];
     else (void)hipGetDevice(&c->device);
     // reference api.go:93-95 (ErrMinSRSSize) and the fixed-size arrays of trusted_setup.go:23-27

@@ -306,13 +306,19 @@ static int cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n
         auto gather = [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; i++) memcpy(c->h_stage + i * 2048, cells[i] ? cells[i] : zero_cell.data(), 2048);
         };
-        if (n >= 1024) {                                          // 16 MiB for 8192 cells: four host threads
-            const size_t q = (n + 3) / 4;
-            c->pool->parallel(4, [&](int i) { gather(std::min(n, (size_t)i * q), std::min(n, (size_t)(i + 1) * q)); });
+        if (n >= 1024) {
+            // 16 MiB for 8192 cells: gathered by eight host threads in chunks of 2048 cells, each chunk's copy to the device in flight
+            // while the next one is gathered
+            const size_t chunk = 2048;
+            for (size_t lo = 0; lo < n; lo += chunk) {
+                const size_t hi = std::min(n, lo + chunk), q = (hi - lo + 7) / 8;
+                c->pool->parallel(8, [&](int i) { gather(std::min(hi, lo + (size_t)i * q), std::min(hi, lo + (size_t)(i + 1) * q)); });
+                HIPCHK(hipMemcpyAsync(c->d_cv_cells + lo * 2048, c->h_stage + lo * 2048, (hi - lo) * 2048, hipMemcpyHostToDevice, s));
+            }
         } else {
             gather(0, n);
+            HIPCHK(hipMemcpyAsync(c->d_cv_cells, c->h_stage, n * 2048, hipMemcpyHostToDevice, s));
         }
-        HIPCHK(hipMemcpyAsync(c->d_cv_cells, c->h_stage, n * 2048, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->d_cv_cell_idx, cell_indices, n * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(c->d_cv_row_idx, row_idx.data(), n * 4, hipMemcpyHostToDevice, s));
         if (r32) {

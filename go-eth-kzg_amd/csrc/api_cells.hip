@@ -113,7 +113,7 @@ int ensure_fk20(mkzg_ctx* c, size_t n) {
         c->fk_cap = 0;
         HIPCHK(hipMalloc(&c->d_fk_scalars, n * 128 * 64 * 32));
         HIPCHK(hipMalloc(&c->d_fk_results, 2 * n * 128 * 256));
-        HIPCHK(hipMalloc(&c->d_fk_parts, n * 128 * 16 * 256));
+        HIPCHK(hipMalloc(&c->d_fk_parts, n * 128 * 24 * 256));   // up to 24 partial sums per MSM (fk20_msm_device); the DFT levels reuse it (1024 rows per blob)
         HIPCHK(hipMalloc(&c->d_fk_proofs, n * 128 * 48));
         c->fk_cap = n;
     }

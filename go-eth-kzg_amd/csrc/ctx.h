@@ -129,7 +129,7 @@ struct mkzg_ctx {
     bool fk_ws_used = false;
     uint32_t* d_monomial_aff = nullptr;    // 4096 affine rows
     uint32_t* d_fk_t_aff = nullptr;        // 8192 affine rows T[k][i]
-    uint32_t* d_fk_table = nullptr;        // direct window table (4.3 GB)
+    uint32_t* d_fk_table = nullptr;        // direct window table (25.8 GB)
     size_t fk_cap = 0;
     uint32_t* d_fk_scalars = nullptr;      // fk_cap x 128 x 64 x 8 words
     uint32_t* d_fk_results = nullptr;      // 2 x fk_cap x 128 XYZZ rows (MSM results + ping-pong buffer of the G1 DFT levels)

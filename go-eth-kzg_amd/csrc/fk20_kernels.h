@@ -7,9 +7,11 @@
 
 namespace kzg {
 
-constexpr int FK_C = 8;          // window bits of the direct table
-constexpr int FK_NWIN = 32;      // byte windows of a 255-bit scalar
-constexpr int FK_NMULT = 128;    // multiples 1..128 (signed Booth digits)
+constexpr int FK_C = 11;         // window bits of the direct table
+constexpr int FK_WPL = 3;        // windows per lane of k_fk20_msm
+constexpr int FK_LANES = 8;      // lanes per MSM-64 (FK_LANES * FK_WPL = FK_NWIN windows; 64 / FK_LANES MSMs per wavefront)
+constexpr int FK_NWIN = 24;      // 11-bit windows of a 255-bit scalar (264 bits)
+constexpr int FK_NMULT = 1024;   // multiples 1..1024 (signed Booth digits)
 
 size_t fk20_table_bytes();
 // monomial SRS (4096 affine rows) -> T (8192 affine rows, [k][i]) -> direct table (fk20_table_bytes())

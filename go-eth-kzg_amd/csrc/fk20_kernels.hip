@@ -7,10 +7,10 @@
 //     h        = IFFT_128^{G1}(R)[0..63], zero-padded to 128
 //     proofs   = bitrev(FFT_128^{G1}(h))
 // MI355X-first choices:
-//   * the 8192 fixed bases T[k][i] get a DIRECT window table in HBM: D[k][i][w][m] = m 2^(8w) T
-//     for the 32 byte-windows w and m = 1..128 (signed Booth digits) -- 4.3 GB, sized for a
-//     288 GB part -- so an MSM-64 is 64 x 32 mixed additions with no bucket reduction at all and
-//     no sort; 16 lanes share one MSM and combine with a 4-level wavefront tree.
+//   * the 8192 fixed bases T[k][i] get a DIRECT window table in HBM: D[k][i][w][m] = m 2^(11w) T
+//     for the 24 eleven-bit windows w and m = 1..1024 (signed Booth digits) -- 25.8 GB, sized for a
+//     288 GB part -- so an MSM-64 is 64 x 24 mixed additions with no bucket reduction at all and
+//     no sort; 8 (batches) or 24 (few blobs) lanes share one MSM and combine with a wavefront tree.
 //   * the per-blob G1 transforms are table-driven DFT levels, each level = one twiddle multiplication deep (GLV endomorphism,
 //     Jacobian accumulator).  Batches (> 8 blobs): four levels of 1024 plan entries, ONE WAVEFRONT PER ENTRY and one lane per
 //     blob, so the twiddle is uniform across the wavefront (k_g1_dft_mul: width-5 NAF strings, uniform branches), the terms of
@@ -287,8 +287,8 @@ __global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------
-// k_fk20_msm: R[b][k] = sum_i V[b][k][i] * T[k][i] through the direct table.  16 lanes per MSM,
-// lane l handles windows 2l, 2l+1 for all 64 points; 4 MSMs per wavefront.
+// k_fk20_msm: R[b][k] = sum_i V[b][k][i] * T[k][i] through the direct table.  FK_LANES (8) lanes per MSM,
+// lane l handles windows FK_WPL l .. FK_WPL l + 2 (11 bits each) for all 64 points; 8 MSMs per wavefront, one wavefront per SIMD at batch 64.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void f_shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
 #pragma unroll
@@ -299,28 +299,39 @@ __device__ __forceinline__ void f_shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
         r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
     }
 }
-// 17-bit Booth field (two byte-windows and the bit below them) of lane `sub` for one scalar
-__device__ __forceinline__ uint32_t fk_field(const uint32_t* __restrict__ s, int sub) {
-    if (sub == 0) return (s[0] << 1) & 0x1ffffu;
-    const int bit = 16 * sub - 1, wi = bit >> 5, off = bit & 31;      // off is 15 or 31
-    const uint64_t v = ((uint64_t)(wi + 1 < 8 ? s[wi + 1] : 0u) << 32) | s[wi];
-    return (uint32_t)(v >> off) & 0x1ffffu;
+// the lane's WPL windows of one scalar plus the Booth overlap bit below them: bits [WPL FK_C sub - 1, WPL FK_C (sub + 1))
+template <int WPL>
+__device__ __forceinline__ uint64_t fk_field(const uint32_t* __restrict__ s, int sub) {
+    constexpr int W = WPL * FK_C;
+    static_assert(W + 1 <= 63, "a lane's windows plus the overlap bit must fit 64 bits");
+    const uint64_t mask = ((uint64_t)1 << (W + 1)) - 1;
+    if (sub == 0) return (((uint64_t)s[1] << 32 | s[0]) << 1) & mask;
+    const int bit = W * sub - 1, wi = bit >> 5, off = bit & 31;
+    uint64_t v = (((uint64_t)(wi + 1 < 8 ? s[wi + 1] : 0u) << 32) | s[wi]) >> off;
+    if (off + W + 1 > 64 && wi + 2 < 8) v |= (uint64_t)s[wi + 2] << (64 - off);
+    return v & mask;
 }
+// <LANES, WPL> = <8, 3>: batches (8 MSMs per wavefront, 192 additions per lane; one wavefront per SIMD at 64 blobs);
+//                <24, 1>: calls with few blobs (2 MSMs per wavefront, 64 additions per lane: a third of the latency, 64 wavefronts per blob)
+template <int LANES, int WPL>
 __global__ void __launch_bounds__(64, 2) k_fk20_msm(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ table, const int* __restrict__ status,
                                                     uint32_t* __restrict__ parts) {
+    static_assert(LANES * WPL == FK_NWIN, "lanes x windows per lane = windows of a scalar");
     // table rows travel HBM -> LDS with global_load_lds_dwordx4 while the previous row is added (see k_commit_direct_acc)
     __shared__ __attribute__((aligned(16))) uint32_t rowbuf[8 * 256];
     const int b = blockIdx.y;
     if (status[b] != 0) return;
-    const int lane = threadIdx.x, sub = lane & 15;
-    const int k = blockIdx.x * 4 + (lane >> 4);
+    const int lane = threadIdx.x, sub = lane % LANES;
+    const bool active = lane < (64 / LANES) * LANES;       // <24, 1> leaves 16 lanes without an MSM
+    const int k = blockIdx.x * (64 / LANES) + (active ? lane / LANES : 0);
     const uint32_t* sc = scalars + ((size_t)b * 128 + k) * 64 * 8;
     G1X acc;
     g1x_set_inf(acc);
-    uint32_t fld = fk_field(sc, sub), fld_next = 0;
+    uint64_t fld = fk_field<WPL>(sc, sub), fld_next = 0;
     bool cur = false, cneg = false;
+    int i = 0, ww = 0;                                    // point and window-within-lane of step t
 #pragma unroll 1
-    for (int t = 0; t <= 128; t++) {
+    for (int t = 0; t <= 64 * WPL; t++) {
         G1Aff p;
         p.inf = 1;
         if (cur) {
@@ -339,18 +350,18 @@ __global__ void __launch_bounds__(64, 2) k_fk20_msm(const uint32_t* __restrict__
             asm volatile("" : "+v"(p.inf));
         }
         bool nxt = false, nneg = false;
-        if (t < 128) {
-            const int i = t >> 1, ww = t & 1;
-            if (ww == 0 && i + 1 < 64) fld_next = fk_field(sc + (i + 1) * 8, sub);       // lands long before it is needed
-            const uint32_t v = (fld >> (8 * ww)) & 0x1ffu;
+        if (t < 64 * WPL) {
+            if (ww == 0 && i + 1 < 64) fld_next = fk_field<WPL>(sc + (i + 1) * 8, sub);       // lands long before it is needed
+            const uint32_t v = (uint32_t)(fld >> (FK_C * ww)) & ((2u << FK_C) - 1);
             int d = (int)((v + 1) >> 1);
             if (v >> FK_C) d -= (1 << FK_C);
-            if (ww == 1) fld = fld_next;
-            if (d != 0) {
+            const int wi = WPL * sub + ww, pi = i;
+            if (++ww == WPL) { ww = 0; i++; fld = fld_next; }
+            if (d != 0 && active) {
                 const int m = d < 0 ? -d : d;
                 nneg = d < 0;
                 nxt = true;
-                const uint32_t* row = table + (((size_t)(k * 64 + i) * FK_NWIN + (2 * sub + ww)) * FK_NMULT + (m - 1)) * 32;
+                const uint32_t* row = table + (((size_t)(k * 64 + pi) * FK_NWIN + wi) * FK_NMULT + (m - 1)) * 32;
 #pragma unroll
                 for (int q = 0; q < 8; q++)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + 4 * q),
@@ -364,21 +375,24 @@ __global__ void __launch_bounds__(64, 2) k_fk20_msm(const uint32_t* __restrict__
         cur = nxt;
         cneg = nneg;
     }
-    // the 16 partial sums of an MSM are combined by k_fk20_msm_reduce: any group addition here (inlined or called) makes the
+    // the FK_LANES partial sums of an MSM are combined by k_fk20_msm_reduce: any group addition here (inlined or called) makes the
     // compiler keep `acc` in scratch memory, whose loads then queue behind the row DMA on vmcnt
-    f_store_xyzz(parts + (((size_t)b * 128 + k) * 16 + sub) * 64, acc);
+    if (active) f_store_xyzz(parts + (((size_t)b * 128 + k) * LANES + sub) * 64, acc);
 }
+// LANES partial sums per MSM, padded to PAD (a power of two) lanes with the identity for the shuffle tree
+template <int LANES, int PAD>
 __global__ void __launch_bounds__(64) k_fk20_msm_reduce(const uint32_t* __restrict__ parts, const int* __restrict__ status, uint32_t* __restrict__ results) {
     const int b = blockIdx.y;
     if (status[b] != 0) return;
-    const int lane = threadIdx.x, k = blockIdx.x * 4 + (lane >> 4);
+    const int lane = threadIdx.x, k = blockIdx.x * (64 / PAD) + lane / PAD, sub = lane % PAD;
     G1X acc, o;
-    f_load_xyzz(acc, parts + (((size_t)b * 128 + k) * 16 + (lane & 15)) * 64);
-    for (int m = 8; m >= 1; m >>= 1) {
+    if (sub < LANES) f_load_xyzz(acc, parts + (((size_t)b * 128 + k) * LANES + sub) * 64);
+    else g1x_set_inf(acc);
+    for (int m = PAD / 2; m >= 1; m >>= 1) {
         f_shfl_xor_xyzz(o, acc, m);
         f_add(acc, acc, o);
     }
-    if ((lane & 15) == 0) f_store_xyzz(results + ((size_t)b * 128 + k) * 64, acc);
+    if (sub == 0) f_store_xyzz(results + ((size_t)b * 128 + k) * 64, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -519,8 +533,13 @@ __global__ void __launch_bounds__(64) k_g1_dft_sum(const uint32_t* __restrict__ 
 }
 void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_fk20_msm, dim3(32, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_parts);
-    hipLaunchKernelGGL(k_fk20_msm_reduce, dim3(32, n), dim3(64), 0, s, d_parts, d_status, d_results);
+    if (n <= FK_DIRECT_MAX_BATCH) {      // latency over occupancy: one window per lane
+        hipLaunchKernelGGL((k_fk20_msm<24, 1>), dim3(128 / 2, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_parts);
+        hipLaunchKernelGGL((k_fk20_msm_reduce<24, 32>), dim3(128 / 2, n), dim3(64), 0, s, d_parts, d_status, d_results);
+        return;
+    }
+    hipLaunchKernelGGL((k_fk20_msm<FK_LANES, FK_WPL>), dim3(128 * FK_LANES / 64, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_parts);
+    hipLaunchKernelGGL((k_fk20_msm_reduce<FK_LANES, FK_LANES>), dim3(128 * FK_LANES / 64, n), dim3(64), 0, s, d_parts, d_status, d_results);
 }
 void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, const uint32_t* d_plan, int n, const int* d_status, uint8_t* d_proofs48, uint32_t* d_parts, hipStream_t s) {
     if (n <= 0) return;

@@ -388,9 +388,10 @@ __global__ void __launch_bounds__(64) k_fk20_msm_reduce(const uint32_t* __restri
     G1X acc, o;
     if (sub < LANES) f_load_xyzz(acc, parts + (((size_t)b * 128 + k) * LANES + sub) * 64);
     else g1x_set_inf(acc);
+#pragma unroll 1
     for (int m = PAD / 2; m >= 1; m >>= 1) {
         f_shfl_xor_xyzz(o, acc, m);
-        f_add(acc, acc, o);
+        g1x_add(acc, acc, o);
     }
     if (sub == 0) f_store_xyzz(results + ((size_t)b * 128 + k) * 64, acc);
 }
@@ -527,7 +528,7 @@ __global__ void __launch_bounds__(64) k_g1_dft_sum(const uint32_t* __restrict__ 
 #pragma unroll 1
     for (int m = R / 2; m >= 1; m >>= 1) {
         f_shfl_xor_xyzz(q, p, m);
-        f_add(p, p, q);
+        g1x_add(p, p, q);                 // inlined (one copy in the rolled loop): the points stay in registers between rounds
     }
     if (live && j == 0 && status[b] == 0) f_store_xyzz(out + ((size_t)b * 128 + (plan[entry] >> 16)) * 64, p);
 }

@@ -32,7 +32,7 @@ ERR_BAD_ARGS = 17
 ERR_HIP = 100
 
 EXPORTED_SYMBOLS = [
-    "mkzg_ctx_new", "mkzg_ctx_free", "mkzg_ctx_set_option",
+    "mkzg_ctx_new", "mkzg_ctx_free", "mkzg_ctx_set_option", "mkzg_ctx_get_option",
     "mkzg_blob_to_kzg_commitment", "mkzg_blob_to_kzg_commitment_batch", "mkzg_blob_to_kzg_commitment_batch_device",
     "mkzg_commit_lagrange", "mkzg_profile_enable", "mkzg_profile_read", "mkzg_version",
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
@@ -63,6 +63,7 @@ def lib():
         L.mkzg_ctx_free.argtypes = [vp]
         L.mkzg_ctx_free.restype = None
         L.mkzg_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+        L.mkzg_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long)]
         L.mkzg_blob_to_kzg_commitment.argtypes = [vp, C.c_char_p, i32, C.c_char_p]
         L.mkzg_blob_to_kzg_commitment_batch.argtypes = [vp, C.POINTER(C.c_char_p), sz, C.c_char_p, C.POINTER(i32)]
         L.mkzg_blob_to_kzg_commitment_batch_device.argtypes = [vp, vp, sz, vp, vp, vp]
@@ -102,12 +103,16 @@ def lib():
 class Context:
     """Mirror of goethkzg.Context backed by one MI355X."""
 
-    def __init__(self, setup_path=DEFAULT_SETUP, device=None):
+    def __init__(self, setup_path=DEFAULT_SETUP, device=None, devices=None):
+        """device: one HIP device id; devices: a list of ids for a multi-device context (include/mi355kzg.h)"""
         L = lib()
         with open(setup_path, "rb") as fh:
             js = fh.read()
         h = C.c_void_p()
-        if device is None:
+        if devices is not None:
+            ids = (C.c_int * max(1, len(devices)))(*devices)
+            rc = L.mkzg_ctx_new(js, len(js), ids, len(devices), C.byref(h))
+        elif device is None:
             rc = L.mkzg_ctx_new(js, len(js), None, 0, C.byref(h))
         else:
             ids = (C.c_int * 1)(device)
@@ -129,6 +134,11 @@ class Context:
 
     def set_option(self, key, value):
         return self._L.mkzg_ctx_set_option(self._h, key.encode(), int(value))
+
+    def get_option(self, key):
+        v = C.c_long(0)
+        rc = self._L.mkzg_ctx_get_option(self._h, key.encode(), C.byref(v))
+        return v.value if rc == 0 else None
 
     # ---- EIP-4844 -------------------------------------------------------------------------
     def BlobToKZGCommitment(self, blob, num_goroutines=0):

@@ -1,6 +1,6 @@
-// api.hip -- the C ABI of libmi355kzg.so (include/mi355kzg.h): context construction and the
-// host-side mirror of go-eth-kzg's Context methods for the hot path.  Host logic only: every
-// field/group operation happens in HIP kernels (msm_kernels.hip); there is no CPU fallback.
+// api.hip -- the C ABI of libmi355kzg.so (include/mi355kzg.h): context construction, the lanes that let calls on a
+// shared context overlap, and the host-side mirror of go-eth-kzg's Context methods for commitments.  Host logic only:
+// every field/group operation happens in HIP kernels (msm_kernels.hip); there is no CPU fallback.
 //
 // Reference being mirrored (paths relative to crate-crypto/go-eth-kzg):
 //   NewContext4096            api.go:90-149   (+ trusted_setup.go:90-192 JSON / point decoding)
@@ -9,6 +9,7 @@
 //   multiexp.MultiExpG1       internal/multiexp/multiexp.go:20-50
 #include <thread>
 #include "ctx.h"
+#include "api_multi.h"
 
 // ---------------------------------------------------------------------------------------------
 // trusted-setup JSON (reference trusted_setup.go:23-27): {"g1_monomial":[...], "g1_lagrange":[...],
@@ -52,150 +53,397 @@ static bool parse_hex_array(const char* js, size_t len, const char* key, size_t 
     return false;
 }
 
-int ensure_plan(mkzg_ctx* c) {
-    if (c->plan_ready) return MKZG_OK;
-    CommitPlanSizes sz;
-    commit_plan_sizes(c->opt_c, c->opt_max_batch, &sz);
-    uint32_t* table = nullptr;
-    HIPCHK(hipMalloc(&table, sz.table_bytes));
-    for (int i = 0; i < mkzg_ctx::NSLOT; i++) {
-        CommitPlan& p = c->slots[i];
-        p.c = c->opt_c;
-        p.max_batch = c->opt_max_batch;
-        p.d_table = table;
-        HIPCHK(hipMalloc(&p.d_entries, sz.entries_bytes));
-        HIPCHK(hipMalloc(&p.d_task_off, sz.task_off_bytes));
-        HIPCHK(hipMalloc(&p.d_tasks, sz.tasks_bytes));
-        HIPCHK(hipMalloc(&p.d_ntasks, sz.ntasks_bytes));
-        HIPCHK(hipMalloc(&p.d_parts, sz.parts_bytes));
-        HIPCHK(hipMalloc(&p.d_partials, sz.partials_bytes));
-        if (!c->slot_done[i]) HIPCHK(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming));
-        if (!c->acc_done[i]) HIPCHK(hipEventCreateWithFlags(&c->acc_done[i], hipEventDisableTiming));
-        c->slot_used[i] = false;
-    }
-    c->plan = c->slots[0];
-    // api.go:131: the commit key is the bit-reversed Lagrange SRS
-    build_table_device(c->plan.c, c->d_lagrange_aff, table, 4096, 12, c->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->plan_ready = true;
+// ---------------------------------------------------------------------------------------------
+// lanes
+// ---------------------------------------------------------------------------------------------
+thread_local bool tl_hip_error = false;
+static int lane_create(Lane* L, int id) {
+    L->id = id;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    // three priorities -> three pools of hardware queues: main streams of the lanes do not share queues with side streams
+    HIPCHK(hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, greatest));
+    HIPCHK(hipStreamCreateWithPriority(&L->side, hipStreamNonBlocking, (least + greatest) / 2));
+    HIPCHK(hipStreamCreateWithPriority(&L->side2, hipStreamNonBlocking, least));
+    HIPCHK(hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L->ev_decoded, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
+    for (auto& e : L->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return MKZG_OK;
 }
-static void free_plan(mkzg_ctx* c) {
-    if (c->slots[0].d_table) (void)hipFree(c->slots[0].d_table);
-    for (int i = 0; i < mkzg_ctx::NSLOT; i++) {
-        CommitPlan& p = c->slots[i];
-        void* ptrs[] = {p.d_entries, p.d_task_off, p.d_tasks, p.d_ntasks, p.d_parts, p.d_partials};
-        for (void* q : ptrs) if (q) (void)hipFree(q);
-        p = CommitPlan();
-        c->slot_used[i] = false;
+static void free_lane_plan(Lane* L) {
+    dev_free(L->plan.d_entries); dev_free(L->plan.d_task_off); dev_free(L->plan.d_tasks); dev_free(L->plan.d_ntasks);
+    dev_free(L->plan.d_parts); dev_free(L->plan.d_partials);
+    L->plan = CommitPlan();
+    L->plan_c = 0; L->plan_batch = 0;
+}
+static void free_lane_direct(Lane* L) {
+    dev_free(L->dslot.d_parts); dev_free(L->dslot.d_bad);
+    L->dslot_batch = 0;
+}
+void free_lane(Lane* L) {
+    free_lane_plan(L);
+    free_lane_direct(L);
+    if (L->h_stage) { (void)hipHostFree(L->h_stage); L->h_stage = nullptr; }
+    if (L->h_out) { (void)hipHostFree(L->h_out); L->h_out = nullptr; }
+    if (L->h_v) { (void)hipHostFree(L->h_v); L->h_v = nullptr; }
+    L->h_stage_bytes = 0; L->h_out_items = 0; L->h_v_bytes = 0;
+    dev_free(L->d_blobs); dev_free(L->d_out); dev_free(L->d_status);
+    L->d_blobs_bytes = 0; L->d_out_items = 0;
+    dev_free(L->d_v_raw); dev_free(L->d_v_aff); dev_free(L->d_v_st); dev_free(L->d_v_z); dev_free(L->d_v_y); dev_free(L->d_v_s1); dev_free(L->d_v_s3);
+    dev_free(L->d_v_misc); dev_free(L->d_v_coeffs);
+    L->v_cap = 0; L->v_coeff_cap = 0;
+    dev_free(L->d_quot); dev_free(L->d_q_z); dev_free(L->d_q_y); dev_free(L->d_q_st);
+    L->q_cap = 0; L->quot_cap = 0;
+    dev_free(L->d_coeffs); dev_free(L->d_cells); dev_free(L->d_cell_st);
+    L->cell_cap = 0;
+    dev_free(L->d_cv_cells); dev_free(L->d_cv_cell_idx); dev_free(L->d_cv_row_idx); dev_free(L->d_cv_rp); dev_free(L->d_cv_weights); dev_free(L->d_cv_partials);
+    dev_free(L->d_cv_interp); dev_free(L->d_cv_st);
+    L->cv_cap = 0;
+    dev_free(L->d_rec_scratch); dev_free(L->d_rec_pos);
+    L->rec_cap = 0;
+    dev_free(L->d_fk_scalars); dev_free(L->d_fk_results); dev_free(L->d_fk_parts); dev_free(L->d_fk_proofs);
+    L->fk_cap = 0;
+}
+static void lane_destroy(Lane* L) {
+    free_lane(L);
+    if (L->stream) (void)hipStreamDestroy(L->stream);
+    if (L->side) (void)hipStreamDestroy(L->side);
+    if (L->side2) (void)hipStreamDestroy(L->side2);
+    hipEvent_t evs[] = {L->ev_fork, L->ev_join, L->ev_decoded, L->done};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    for (auto& e : L->ev_chunk) if (e) (void)hipEventDestroy(e);
+}
+
+Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
+    Lane* L = nullptr;
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        for (;;) {
+            for (int i = 0; i < mkzg_ctx::NLANE; i++) {
+                Lane* q = &c->lanes[i];
+                if (!q->busy && (!L || q->released_at < L->released_at)) L = q;
+            }
+            if (L) break;
+            c->cv.wait(lk);
+        }
+        L->busy = true;
     }
-    c->plan = CommitPlan();
-    c->plan_ready = false;
+    (void)hipSetDevice(c->device);
+    L->failed = false;
+    tl_hip_error = false;
+    if (L->used) (void)hipStreamWaitEvent(user_stream ? s : L->stream, L->done, 0);      // the previous owner may have returned before the GPU was done
+    return L;
 }
-// workspace hand-over between streams: the new user waits (on the device) for the previous one
-int acquire_slot(mkzg_ctx* c, hipStream_t s) {
-    const int slot = (int)(c->slot_counter++ % mkzg_ctx::NSLOT);
-    if (c->slot_used[slot] && hipStreamWaitEvent(s, c->slot_done[slot], 0) != hipSuccess) return -1;
-    c->slots[slot].wait_before_acc = (c->opt_chain_acc && c->last_acc_slot >= 0) ? c->acc_done[c->last_acc_slot] : nullptr;
-    c->slots[slot].record_after_acc = c->acc_done[slot];
-    return slot;
+void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s) {
+    if (L->failed || tl_hip_error) {       // error exit with work possibly in flight on any of the lane's streams
+        tl_hip_error = false;
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(L->stream);
+        (void)hipStreamSynchronize(L->side);
+        (void)hipStreamSynchronize(L->side2);
+        (void)hipGetLastError();
+    }
+    (void)hipEventRecord(L->done, s);
+    L->used = true;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        L->busy = false;
+        L->released_at = ++c->release_seq;
+    }
+    c->cv.notify_all();
 }
-int release_slot(mkzg_ctx* c, int slot, hipStream_t s) {
-    HIPCHK(hipEventRecord(c->slot_done[slot], s));
-    c->slot_used[slot] = true;
-    c->last_acc_slot = slot;
+void lanes_quiesce(mkzg_ctx* c) {
+    {
+        std::unique_lock<std::mutex> lk(c->mu);
+        for (int i = 0; i < mkzg_ctx::NLANE; i++) {
+            c->cv.wait(lk, [&] { return !c->lanes[i].busy; });
+            c->lanes[i].busy = true;
+        }
+    }
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+}
+void lanes_resume(mkzg_ctx* c) {
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        for (int i = 0; i < mkzg_ctx::NLANE; i++) { c->lanes[i].busy = false; c->lanes[i].used = false; }
+    }
+    c->cv.notify_all();
+}
+
+int pointer_device(const void* p) {
+    hipPointerAttribute_t a;
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (a.type != hipMemoryTypeDevice) return -1;
+    return a.device;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shared tables
+// ---------------------------------------------------------------------------------------------
+// bucket method: T[j][i] = 2^(c j) L_brp[i]   (api.go:131: the commit key is the bit-reversed Lagrange SRS)
+int ensure_commit_table(mkzg_ctx* c) {
+    std::lock_guard<std::mutex> g(c->init_mu);
+    if (c->d_commit_table && c->commit_table_c == c->opt_c) return MKZG_OK;
+    CommitPlanSizes sz;
+    commit_plan_sizes(c->opt_c, 1, &sz);
+    c->commit_table_c = 0;
+    int rc = dev_realloc(c->d_commit_table, sz.table_bytes);
+    if (rc) return rc;
+    build_table_device(c->opt_c, c->d_lagrange_aff, c->d_commit_table, 4096, 12, c->init_stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->init_stream));
+    c->commit_table_c = c->opt_c;
+    return MKZG_OK;
+}
+// Direct window table.  The table is sized for an otherwise empty 288 GB part; a drop-in must degrade, not fail: if the width asked
+// for cannot be allocated the next narrower one is tried, and when none fits the context falls back to the bucket method
+// (direct_bits_built == 0, direct_failed) -- same bytes out either way.
+static const size_t DIRECT_HEADROOM = (size_t)40 << 30;      // left free for the FK20 table (25.8 GB) and the lanes' workspaces
+int ensure_direct(mkzg_ctx* c) {
+    std::lock_guard<std::mutex> g(c->init_mu);
+    if (c->opt_direct_bits == 0 || c->direct_failed) return MKZG_OK;
+    if (c->d_direct && c->direct_bits_built) return MKZG_OK;
+    int want = c->opt_direct_bits;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    if (want < 0) want = 15;                                  // auto: the widest table that leaves the headroom free
+    for (int cb = want; cb >= 12; cb--) {
+        const size_t bytes = direct_table_bytes(cb);
+        if (c->opt_direct_bits < 0 && free_b && bytes + DIRECT_HEADROOM > free_b) continue;
+        if (free_b && bytes + ((size_t)1 << 30) > free_b) continue;               // cannot fit: do not even ask
+        const int nwin = (255 + cb - 1) / cb;
+        uint32_t* tmp = nullptr;
+        if (hipMalloc(&c->d_direct, bytes) != hipSuccess) { (void)hipGetLastError(); c->d_direct = nullptr; continue; }
+        if (hipMalloc(&tmp, (size_t)nwin * 4096 * 128) != hipSuccess) { (void)hipGetLastError(); dev_free(c->d_direct); continue; }
+        build_table_any_device(cb, c->d_lagrange_aff, tmp, 4096, 12, c->init_stream);
+        build_direct_device(cb, tmp, c->d_direct, c->init_stream);
+        const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(c->init_stream) == hipSuccess;
+        (void)hipFree(tmp);
+        if (!ok) { dev_free(c->d_direct); return MKZG_ERR_HIP; }
+        c->direct_bits_built = cb;
+        if (cb != c->opt_direct_bits && c->opt_direct_bits > 0)
+            fprintf(stderr, "[mi355kzg] direct window table: %d bits requested, %d bits fit in free HBM\n", c->opt_direct_bits, cb);
+        return MKZG_OK;
+    }
+    fprintf(stderr, "[mi355kzg] direct window table does not fit in free HBM (%.1f GB free): using the bucket method\n", (double)free_b / 1e9);
+    c->direct_failed = true;
+    c->direct_bits_built = 0;
+    return MKZG_OK;
+}
+static int ensure_lane_plan(mkzg_ctx* c, Lane* L) {
+    if (L->plan_c == c->opt_c && L->plan_batch >= c->opt_max_batch && L->plan.d_entries) { L->plan.d_table = c->d_commit_table; return MKZG_OK; }
+    free_lane_plan(L);
+    CommitPlanSizes sz;
+    commit_plan_sizes(c->opt_c, c->opt_max_batch, &sz);
+    CommitPlan& p = L->plan;
+    p.c = c->opt_c;
+    p.max_batch = c->opt_max_batch;
+    p.d_table = c->d_commit_table;
+    HIPCHK(hipMalloc(&p.d_entries, sz.entries_bytes));
+    HIPCHK(hipMalloc(&p.d_task_off, sz.task_off_bytes));
+    HIPCHK(hipMalloc(&p.d_tasks, sz.tasks_bytes));
+    HIPCHK(hipMalloc(&p.d_ntasks, sz.ntasks_bytes));
+    HIPCHK(hipMalloc(&p.d_parts, sz.parts_bytes));
+    HIPCHK(hipMalloc(&p.d_partials, sz.partials_bytes));
+    L->plan_c = c->opt_c;
+    L->plan_batch = c->opt_max_batch;
+    return MKZG_OK;
+}
+static int ensure_lane_direct(mkzg_ctx* c, Lane* L) {
+    if (L->dslot_batch >= c->opt_max_batch && L->dslot.d_parts) return MKZG_OK;
+    free_lane_direct(L);
+    HIPCHK(hipMalloc(&L->dslot.d_parts, direct_parts_bytes(c->opt_max_batch)));
+    HIPCHK(hipMalloc(&L->dslot.d_bad, direct_bad_bytes(c->opt_max_batch)));
+    L->dslot_batch = c->opt_max_batch;
+    return MKZG_OK;
+}
+
+// Commitments of n polynomials in Lagrange form against the bit-reversed Lagrange SRS, with the method the context is
+// configured for (direct window table or buckets).  input_kind 0: 32-byte big-endian scalars (blobs, canonicity checked);
+// 1: 12-word Montgomery Fr rows (quotient polynomials of the proof path).  The caller holds lane L; pieces of max_batch items
+// run back to back on s through the lane's one workspace.  ws_off: first workspace item to use (chunks of one call that run on
+// different streams take disjoint item ranges; n + ws_off <= max_batch then).
+static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, int n, int ws_off, uint8_t* d_out48n, int* d_status, hipStream_t s) {
+    KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
+    if (c->direct_bits_built) {
+        const DirectSlot ws = direct_slot_offset(L->dslot, ws_off);
+        commit_direct_device(c->direct_bits_built, c->d_direct, ws, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt);
+    } else {
+        const CommitPlan pl = commit_plan_offset(L->plan, ws_off);
+        commit_batch_device(pl, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt);
+    }
+    return MKZG_OK;
+}
+static int commit_prepare(mkzg_ctx* c, Lane* L) {
+    if (c->opt_direct_bits && !c->direct_bits_built && !c->direct_failed) {
+        int rc = ensure_direct(c);
+        if (rc) return rc;
+    }
+    if (c->direct_bits_built) return ensure_lane_direct(c, L);
+    if (!c->d_commit_table || c->commit_table_c != c->opt_c) {
+        int rc = ensure_commit_table(c);
+        if (rc) return rc;
+    }
+    return ensure_lane_plan(c, L);
+}
+int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s) {
+    int rc = commit_prepare(c, L);
+    if (rc) return rc;
+    size_t done = 0;
+    while (done < n) {
+        const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
+        commit_piece(c, L, d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, 0, d_out48n + done * 48, d_status + done, s);
+        done += chunk;
+    }
+    HIPCHK(hipGetLastError());
+    return MKZG_OK;
+}
+
+int ensure_staging(Lane* L, size_t n_items, size_t in_bytes_per_item) {
+    const size_t need = n_items * in_bytes_per_item;
+    if (L->h_stage_bytes < need) {
+        L->h_stage_bytes = 0;
+        int rc = pinned_realloc(L->h_stage, need);
+        if (rc) return rc;
+        L->h_stage_bytes = need;
+    }
+    if (L->d_blobs_bytes < need) {
+        L->d_blobs_bytes = 0;
+        int rc = dev_realloc(L->d_blobs, need);
+        if (rc) return rc;
+        L->d_blobs_bytes = need;
+    }
+    if (L->d_out_items < n_items) {
+        L->d_out_items = 0;
+        int rc = dev_realloc(L->d_out, n_items * 48);
+        if (!rc) rc = dev_realloc(L->d_status, n_items * sizeof(int));
+        if (rc) return rc;
+        L->d_out_items = n_items;
+    }
+    if (L->h_out_items < n_items) {
+        L->h_out_items = 0;
+        int rc = pinned_realloc(L->h_out, n_items * 52);
+        if (rc) return rc;
+        L->h_out_items = n_items;
+    }
+    return MKZG_OK;
+}
+
+// Host-pointer commitments, one piece of at most max_batch blobs: the blobs (Go's []*Blob: scattered, pageable) are gathered into the
+// lane's pinned staging area chunk by chunk by the host pool; chunk k's copy to the device and its kernels are in flight while chunk
+// k + 1 is gathered, chunks alternate between two streams of different priority (their accumulate kernels are grids of single-wave
+// workgroups, so a later chunk's waves fill the SIMD slots an earlier one leaves), and every chunk works in its own item range of the
+// lane's workspace.  One synchronisation at the end.
+static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, size_t n, uint8_t* out48n, int* st_out) {
+    int rc = ensure_staging(L, (size_t)c->opt_max_batch, MKZG_BYTES_PER_BLOB);
+    if (!rc) rc = commit_prepare(c, L);
+    if (rc) return rc;
+    const size_t CH = (size_t)std::max(1, c->opt_host_chunk);
+    hipStream_t ss[2] = {L->stream, L->side2};
+    const int nthr = n >= 8 ? 8 : 1;
+    HIPCHK(hipEventRecord(L->ev_fork, L->stream));
+    HIPCHK(hipStreamWaitEvent(L->side2, L->ev_fork, 0));       // the second stream inherits the lane hand-over
+    int k = 0;
+    for (size_t lo = 0; lo < n; lo += CH, k++) {
+        const size_t m = std::min(CH, n - lo);
+        hipStream_t s = ss[k & 1];
+        const size_t per = (m + nthr - 1) / nthr;
+        c->pool->parallel(nthr, [&](int q) {
+            for (size_t i = lo + (size_t)q * per; i < std::min(lo + m, lo + (size_t)(q + 1) * per); i++) memcpy(L->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB);
+        });
+        HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, m * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, s));
+        commit_piece(c, L, L->d_blobs + lo * MKZG_BYTES_PER_BLOB, MKZG_BYTES_PER_BLOB, 0, (int)m, (int)lo, L->d_out + lo * 48, L->d_status + lo, s);
+        HIPCHK(hipMemcpyAsync(L->h_out + lo * 48, L->d_out + lo * 48, m * 48, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(L->h_out + L->h_out_items * 48 + lo * 4, L->d_status + lo, m * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(L->ev_join, L->side2));
+    HIPCHK(hipStreamWaitEvent(L->stream, L->ev_join, 0));
+    HIPCHK(hipStreamSynchronize(L->stream));
+    memcpy(out48n, L->h_out, n * 48);
+    memcpy(st_out, L->h_out + L->h_out_items * 48, n * sizeof(int));
     return MKZG_OK;
 }
 
 extern "C" {
 
-const char* mkzg_version(void) { return "mi355kzg 0.1 (gfx950)"; }
+const char* mkzg_version(void) { return "mi355kzg 0.2 (gfx950)"; }
 int mkzg_valu_calibrate(mkzg_ctx* c, double* wave_instr_per_s) {
     if (!c || !wave_instr_per_s) return MKZG_ERR_BAD_ARGS;
-    std::lock_guard<std::recursive_mutex> g(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    *wave_instr_per_s = valu_calibrate_device(c->stream);
-    return *wave_instr_per_s > 0.0 ? MKZG_OK : MKZG_ERR_HIP;
+    if (!c->peers.empty()) c = c->peers[0];
+    LaneGuard G(c);
+    *wave_instr_per_s = valu_calibrate_device(G.s);
+    return *wave_instr_per_s > 0.0 ? MKZG_OK : G.fail(MKZG_ERR_HIP);
 }
 
-void mkzg_ctx_free(mkzg_ctx* c) {
+static void ctx_destroy_one(mkzg_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    free_plan(c);
-    if (c->d_lagrange_aff) (void)hipFree(c->d_lagrange_aff);
-    if (c->d_direct) (void)hipFree(c->d_direct);
-    for (int i = 0; i < mkzg_ctx::NSLOT; i++) {
-        if (c->dslots[i].d_parts) (void)hipFree(c->dslots[i].d_parts);
-        if (c->dslots[i].d_bad) (void)hipFree(c->dslots[i].d_bad);
-    }
-    if (c->d_roots_brp) (void)hipFree(c->d_roots_brp);
-    if (c->d_inv_roots_brp) (void)hipFree(c->d_inv_roots_brp);
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
-    if (c->d_blobs) (void)hipFree(c->d_blobs);
-    if (c->d_out) (void)hipFree(c->d_out);
-    if (c->d_status) (void)hipFree(c->d_status);
-    free_verify_ws(c);
-    free_cells(c);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->side2) (void)hipStreamDestroy(c->side2);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_decoded) (void)hipEventDestroy(c->ev_decoded);
-    if (c->fk_ws_done) (void)hipEventDestroy(c->fk_ws_done);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < mkzg_ctx::NLANE; i++) lane_destroy(&c->lanes[i]);
+    dev_free(c->d_lagrange_aff); dev_free(c->d_commit_table); dev_free(c->d_direct);
+    dev_free(c->d_roots_brp); dev_free(c->d_inv_roots_brp);
+    dev_free(c->d_tw_fwd); dev_free(c->d_tw_inv); dev_free(c->d_g1tw_fwd); dev_free(c->d_g1tw_inv);
+    dev_free(c->d_monomial_aff); dev_free(c->d_pow7); dev_free(c->d_ipow7); dev_free(c->d_fk_t_aff); dev_free(c->d_fk_table); dev_free(c->d_fk_plan);
+    if (c->init_stream) (void)hipStreamDestroy(c->init_stream);
     delete c->pool;
     delete c;
 }
-
-int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, mkzg_ctx** out) {
-    if (!js || !out) return MKZG_ERR_BAD_ARGS;
-    *out = nullptr;
-    int ndev_present = 0;
-    if (hipGetDeviceCount(&ndev_present) != hipSuccess || ndev_present <= 0) {
-        fprintf(stderr, "[mi355kzg] no HIP device: this library has no CPU fallback\n");
-        return MKZG_ERR_HIP;
+void mkzg_ctx_free(mkzg_ctx* c) {
+    if (!c) return;
+    if (!c->peers.empty()) {
+        for (mkzg_ctx* p : c->peers) ctx_destroy_one(p);
+        delete c->pool;
+        delete c;
+        return;
     }
+    ctx_destroy_one(c);
+}
+
+static int ctx_create_one(const char* js, size_t len, int device, mkzg_ctx** out) {
     mkzg_ctx* c = new mkzg_ctx();
-    c->pool = new kzg::HostPool(7);
-    if (n_dev > 0 && device_ids) c->device = device_ids[0];
-    else (void)hipGetDevice(&c->device);
+    const unsigned hw = std::thread::hardware_concurrency();
+    c->pool = new kzg::HostPool((int)std::min(15u, std::max(7u, hw / 4)));
+    c->device = device;
     // reference api.go:93-95 (ErrMinSRSSize) and the fixed-size arrays of trusted_setup.go:23-27
     if (!parse_hex_array(js, len, "g1_monomial", 48, c->g1_monomial) || !parse_hex_array(js, len, "g1_lagrange", 48, c->g1_lagrange) ||
         !parse_hex_array(js, len, "g2_monomial", 96, c->g2_monomial) || c->g1_monomial.size() != 4096 * 48 || c->g1_lagrange.size() != 4096 * 48 ||
         c->g2_monomial.size() < 2 * 96) {
+        delete c->pool;
         delete c;
         return MKZG_ERR_BAD_TRUSTED_SETUP;
     }
     int rc = [&]() -> int {
         HIPCHK(hipSetDevice(c->device));
-        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_decoded, hipEventDisableTiming));
+        HIPCHK(hipStreamCreateWithFlags(&c->init_stream, hipStreamNonBlocking));
+        for (int i = 0; i < mkzg_ctx::NLANE; i++) {
+            int r = lane_create(&c->lanes[i], i);
+            if (r) return r;
+        }
         // decode the Lagrange SRS on the device (no subgroup check: trusted_setup.go:104-117)
         uint8_t* d_raw = nullptr;
         int* d_st = nullptr;
         HIPCHK(hipMalloc(&d_raw, 4096 * 48));
         HIPCHK(hipMalloc(&d_st, 4096 * sizeof(int)));
         HIPCHK(hipMalloc(&c->d_lagrange_aff, 4096 * 128));
-        HIPCHK(hipMemcpyAsync(d_raw, c->g1_lagrange.data(), 4096 * 48, hipMemcpyHostToDevice, c->stream));
-        g1_decompress_device(d_raw, 4096, c->d_lagrange_aff, d_st, c->stream);
+        HIPCHK(hipMemcpyAsync(d_raw, c->g1_lagrange.data(), 4096 * 48, hipMemcpyHostToDevice, c->init_stream));
+        g1_decompress_device(d_raw, 4096, c->d_lagrange_aff, d_st, c->init_stream);
         HIPCHK(hipGetLastError());
         std::vector<int> st(4096);
-        HIPCHK(hipMemcpyAsync(st.data(), d_st, 4096 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpyAsync(st.data(), d_st, 4096 * sizeof(int), hipMemcpyDeviceToHost, c->init_stream));
+        HIPCHK(hipStreamSynchronize(c->init_stream));
         (void)hipFree(d_raw);
         (void)hipFree(d_st);
         for (int v : st) if (v) return MKZG_ERR_BAD_TRUSTED_SETUP;   // reference panics (trusted_setup.go:152-156)
         // domain of the blob polynomial, bit-reversed (api.go:127-132)
         HIPCHK(hipMalloc(&c->d_roots_brp, 4096 * 48));
         HIPCHK(hipMalloc(&c->d_inv_roots_brp, 4096 * 48));
-        build_roots_device(c->d_roots_brp, c->d_inv_roots_brp, 12, c->stream);
+        build_roots_device(c->d_roots_brp, c->d_inv_roots_brp, 12, c->init_stream);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipStreamSynchronize(c->init_stream));
         // opening key (api.go:104-123): G2 generator and [alpha]G2, Miller-loop lines prepared once
         G2Aff q0, q1;
         if (!g2_decompress(q0, c->g2_monomial.data()) || !g2_decompress(q1, c->g2_monomial.data() + 96)) return MKZG_ERR_BAD_TRUSTED_SETUP;
@@ -209,185 +457,136 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
             g2_prepare(c->g2_alpha64, q64);
             g2_prepare(c->g2_neg_gen, nq0);
         }
+        // byte-window table of the G1 generator for the [e]G of the batch verifiers (kzg_verify.go:169)
+        G1HX gen;
+        g1h_generator(gen);
+        g1h_fixed_build(c->gen_fixed, gen);
         return MKZG_OK;
     }();
-    if (rc) { mkzg_ctx_free(c); return rc; }
+    if (rc) { ctx_destroy_one(c); return rc; }
     *out = c;
     return MKZG_OK;
 }
 
-int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
-    if (!c || !key) return MKZG_ERR_BAD_ARGS;
-    std::lock_guard<std::recursive_mutex> g(c->mu);
-    (void)hipSetDevice(c->device);
+int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, mkzg_ctx** out) {
+    if (!js || !out || n_dev < 0 || (n_dev > 0 && !device_ids)) return MKZG_ERR_BAD_ARGS;
+    *out = nullptr;
+    int ndev_present = 0;
+    if (hipGetDeviceCount(&ndev_present) != hipSuccess || ndev_present <= 0) {
+        fprintf(stderr, "[mi355kzg] no HIP device: this library has no CPU fallback\n");
+        return MKZG_ERR_HIP;
+    }
+    for (int i = 0; i < n_dev; i++) if (device_ids[i] < 0 || device_ids[i] >= ndev_present) return MKZG_ERR_BAD_ARGS;
+    if (n_dev <= 1) {
+        int dev = 0;
+        if (n_dev == 1) dev = device_ids[0];
+        else (void)hipGetDevice(&dev);
+        return ctx_create_one(js, len, dev, out);
+    }
+    // several devices: a front object that owns one full context per listed device and shards batches over them (api_multi.hip)
+    mkzg_ctx* front = new mkzg_ctx();
+    front->device = device_ids[0];
+    front->pool = new kzg::HostPool(n_dev - 1);
+    for (int i = 0; i < n_dev; i++) {
+        mkzg_ctx* p = nullptr;
+        int rc = ctx_create_one(js, len, device_ids[i], &p);
+        if (rc) { mkzg_ctx_free(front); return rc; }
+        front->peers.push_back(p);
+    }
+    *out = front;
+    return MKZG_OK;
+}
+
+static int set_option_one(mkzg_ctx* c, const char* key, long value) {
     if (!strcmp(key, "msm_window")) {
         if (value < 11 || value > 13) return MKZG_ERR_BAD_ARGS;
-        if (c->opt_c != (int)value) { c->opt_c = (int)value; free_plan(c); }
+        lanes_quiesce(c);
+        c->opt_c = (int)value;
+        lanes_resume(c);
         return MKZG_OK;
     }
     if (!strcmp(key, "commit_direct_bits")) {
-        if (value != 0 && (value < 12 || value > 15)) return MKZG_ERR_BAD_ARGS;
+        if (value != 0 && value != -1 && (value < 12 || value > 15)) return MKZG_ERR_BAD_ARGS;
+        lanes_quiesce(c);
         if (c->opt_direct_bits != (int)value) {
             c->opt_direct_bits = (int)value;
-            if (c->d_direct) { (void)hipFree(c->d_direct); c->d_direct = nullptr; c->direct_bits_built = 0; }
+            dev_free(c->d_direct);
+            c->direct_bits_built = 0;
+            c->direct_failed = false;
         }
-        return MKZG_OK;
-    }
-    if (!strcmp(key, "chain_accumulate")) {
-        if (value != 0 && value != 1) return MKZG_ERR_BAD_ARGS;
-        c->opt_chain_acc = (int)value;
+        lanes_resume(c);
         return MKZG_OK;
     }
     if (!strcmp(key, "max_batch")) {
         if (value < 1 || value > 4096) return MKZG_ERR_BAD_ARGS;
-        if (c->opt_max_batch != (int)value) { c->opt_max_batch = (int)value; free_plan(c); }
+        lanes_quiesce(c);
+        c->opt_max_batch = (int)value;
+        lanes_resume(c);
+        return MKZG_OK;
+    }
+    if (!strcmp(key, "host_chunk")) {
+        if (value < 1 || value > 4096) return MKZG_ERR_BAD_ARGS;
+        c->opt_host_chunk = (int)value;
+        return MKZG_OK;
+    }
+    if (!strcmp(key, "host_sha")) {
+        if (value < -1 || value > 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_host_sha = (int)value;
         return MKZG_OK;
     }
     return MKZG_ERR_BAD_ARGS;
 }
-
-// Commitments of n polynomials in Lagrange form against the bit-reversed Lagrange SRS, with the method the context is
-// configured for (direct window table or buckets).  input_kind 0: 32-byte big-endian scalars (blobs, canonicity checked);
-// 1: 12-word Montgomery Fr rows (quotient polynomials of the proof path).  Caller holds c->mu and has set the device.
-int commit_scalars_device(mkzg_ctx* c, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s) {
-    if (c->opt_direct_bits) {
-        if (c->direct_bits_built != c->opt_direct_bits) {
-            const int cb = c->opt_direct_bits, nwin = (255 + cb - 1) / cb;
-            uint32_t* tmp = nullptr;
-            if (c->d_direct) (void)hipFree(c->d_direct);
-            c->d_direct = nullptr;
-            c->direct_bits_built = 0;
-            if (hipMalloc(&c->d_direct, direct_table_bytes(cb)) != hipSuccess) {       // e.g. 146 GB not available on this device
-                (void)hipGetLastError();
-                c->d_direct = nullptr;
-                return MKZG_ERR_HIP;
-            }
-            if (hipMalloc(&tmp, (size_t)nwin * 4096 * 128) != hipSuccess) {
-                (void)hipGetLastError();
-                (void)hipFree(c->d_direct);
-                c->d_direct = nullptr;
-                return MKZG_ERR_HIP;
-            }
-            build_table_any_device(cb, c->d_lagrange_aff, tmp, 4096, 12, c->stream);
-            build_direct_device(cb, tmp, c->d_direct, c->stream);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(c->stream));
-            (void)hipFree(tmp);
-            c->direct_bits_built = cb;
-        }
-        if (c->dslot_batch != c->opt_max_batch) {
-            HIPCHK(hipDeviceSynchronize());
-            for (int i = 0; i < mkzg_ctx::NSLOT; i++) {
-                if (c->dslots[i].d_parts) (void)hipFree(c->dslots[i].d_parts);
-                if (c->dslots[i].d_bad) (void)hipFree(c->dslots[i].d_bad);
-                c->dslots[i].d_parts = nullptr; c->dslots[i].d_bad = nullptr;
-                HIPCHK(hipMalloc(&c->dslots[i].d_parts, direct_parts_bytes(c->opt_max_batch)));
-                HIPCHK(hipMalloc(&c->dslots[i].d_bad, (size_t)c->opt_max_batch * 64 * sizeof(int)));
-                if (!c->slot_done[i]) HIPCHK(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming));
-                if (!c->acc_done[i]) HIPCHK(hipEventCreateWithFlags(&c->acc_done[i], hipEventDisableTiming));
-                c->slot_used[i] = false;
-            }
-            c->last_acc_slot = -1;
-            c->dslot_batch = c->opt_max_batch;
-        }
-        size_t done = 0;
-        while (done < n) {
-            const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
-            const int slot = (int)(c->slot_counter++ % mkzg_ctx::NSLOT);
-            if (c->slot_used[slot]) HIPCHK(hipStreamWaitEvent(s, c->slot_done[slot], 0));
-            c->dslots[slot].wait_before_acc = (c->opt_chain_acc && c->last_acc_slot >= 0) ? c->acc_done[c->last_acc_slot] : nullptr;
-            c->dslots[slot].record_after_acc = c->acc_done[slot];
-            commit_direct_device(c->opt_direct_bits, c->d_direct, c->dslots[slot], d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, d_out48n + done * 48,
-                                 d_status + done, s, c->profiling ? &c->timer : nullptr);
-            int rr = release_slot(c, slot, s);
-            if (rr) return rr;
-            done += chunk;
-        }
-        HIPCHK(hipGetLastError());
-        return MKZG_OK;
+int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
+    if (!c || !key) return MKZG_ERR_BAD_ARGS;
+    if (c->peers.empty()) return set_option_one(c, key, value);
+    for (mkzg_ctx* p : c->peers) {
+        int rc = set_option_one(p, key, value);
+        if (rc) return rc;
     }
-    int rc = ensure_plan(c);
-    if (rc) return rc;
-    size_t done = 0;
-    while (done < n) {
-        int chunk = (int)std::min<size_t>(n - done, (size_t)c->plan.max_batch);
-        const int slot = acquire_slot(c, s);
-        if (slot < 0) return MKZG_ERR_HIP;
-        commit_batch_device(c->slots[slot], d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, d_out48n + done * 48, d_status + done, s,
-                            c->profiling ? &c->timer : nullptr);
-        int rr = release_slot(c, slot, s);
-        if (rr) return rr;
-        done += chunk;
-    }
-    HIPCHK(hipGetLastError());
     return MKZG_OK;
 }
-// device-resident batch: the product's hot path
+int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
+    if (!c || !key || !value) return MKZG_ERR_BAD_ARGS;
+    const mkzg_ctx* q = c->peers.empty() ? c : c->peers[0];
+    if (!strcmp(key, "msm_window")) *value = q->opt_c;
+    else if (!strcmp(key, "commit_direct_bits")) *value = q->opt_direct_bits;
+    else if (!strcmp(key, "commit_direct_bits_effective")) *value = q->direct_bits_built;      // 0 until the first commitment builds the table, or after degrading to buckets
+    else if (!strcmp(key, "max_batch")) *value = q->opt_max_batch;
+    else if (!strcmp(key, "host_chunk")) *value = q->opt_host_chunk;
+    else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
+    else if (!strcmp(key, "devices")) *value = c->peers.empty() ? 1 : (long)c->peers.size();
+    else if (!strcmp(key, "lanes")) *value = mkzg_ctx::NLANE;
+    else return MKZG_ERR_BAD_ARGS;
+    return MKZG_OK;
+}
+
+// device-resident batch: the product's hot path.  Asynchronous on `stream`.
 int mkzg_blob_to_kzg_commitment_batch_device(mkzg_ctx* c, const void* d_blobs, size_t n, void* d_out48n, int* d_status, void* stream) {
     if (!c || (!d_blobs && n) || (!d_out48n && n) || (!d_status && n)) return MKZG_ERR_BAD_ARGS;
-    std::lock_guard<std::recursive_mutex> g(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    return commit_scalars_device(c, (const uint8_t*)d_blobs, MKZG_BYTES_PER_BLOB, 0, n, (uint8_t*)d_out48n, d_status, (hipStream_t)stream);
-}
-
-int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item) {
-    size_t need = n_items * in_bytes_per_item;
-    if (c->h_stage_bytes < need) {
-        if (c->h_stage) (void)hipHostFree(c->h_stage);
-        c->h_stage = nullptr; c->h_stage_bytes = 0;
-        HIPCHK(hipHostMalloc(&c->h_stage, need, hipHostMallocDefault));
-        c->h_stage_bytes = need;
-    }
-    if (c->d_blobs_bytes < need) {
-        if (c->d_blobs) (void)hipFree(c->d_blobs);
-        c->d_blobs = nullptr; c->d_blobs_bytes = 0;
-        HIPCHK(hipMalloc(&c->d_blobs, need));
-        c->d_blobs_bytes = need;
-    }
-    if (c->d_out_items < n_items) {
-        if (c->d_out) (void)hipFree(c->d_out);
-        if (c->d_status) (void)hipFree(c->d_status);
-        c->d_out = nullptr; c->d_status = nullptr; c->d_out_items = 0;
-        HIPCHK(hipMalloc(&c->d_out, n_items * 48));
-        HIPCHK(hipMalloc(&c->d_status, n_items * sizeof(int)));
-        c->d_out_items = n_items;
-    }
-    return MKZG_OK;
+    if (!c->peers.empty() && !(c = ctx_for_pointer(c, d_blobs))) return MKZG_ERR_BAD_ARGS;
+    if (n == 0) return MKZG_OK;
+    LaneGuard G(c, (hipStream_t)stream);
+    return G.fail(commit_scalars_device(c, G.L, (const uint8_t*)d_blobs, MKZG_BYTES_PER_BLOB, 0, n, (uint8_t*)d_out48n, d_status, G.s));
 }
 
 int mkzg_blob_to_kzg_commitment_batch(mkzg_ctx* c, const uint8_t* const* blobs, size_t n, uint8_t* out48n, int* per_item_status) {
     if (!c || (n && (!blobs || !out48n))) return MKZG_ERR_BAD_ARGS;
     if (n == 0) return MKZG_OK;
     for (size_t i = 0; i < n; i++) if (!blobs[i]) return MKZG_ERR_NIL_INPUT;      // serialization.go:135-137
+    if (!c->peers.empty()) return md_blob_to_kzg_commitment_batch(c, blobs, n, out48n, per_item_status);
     int first = MKZG_OK;
-    size_t done = 0;
-    while (done < n) {
-        std::lock_guard<std::recursive_mutex> g(c->mu);
-        HIPCHK(hipSetDevice(c->device));
-        size_t chunk = std::min<size_t>(n - done, (size_t)c->opt_max_batch);
-        int rc = ensure_staging(c, chunk, MKZG_BYTES_PER_BLOB);
-        if (rc) return rc;
-        // gather the blobs into the pinned staging area with a few host threads (33 MB for 256 blobs: a single memcpy
-        // stream takes about as long as the GPU's whole commitment pass)
-        {
-            const size_t nthr = chunk >= 32 ? 4 : 1, per = (chunk + nthr - 1) / nthr;
-            auto gather = [&](size_t q) {
-                for (size_t i = q * per; i < std::min(chunk, (q + 1) * per); i++) memcpy(c->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[done + i], MKZG_BYTES_PER_BLOB);
-            };
-            c->pool->parallel((int)nthr, [&](int q) { gather((size_t)q); });
-        }
-        HIPCHK(hipMemcpyAsync(c->d_blobs, c->h_stage, chunk * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, c->stream));
-        rc = mkzg_blob_to_kzg_commitment_batch_device(c, c->d_blobs, chunk, c->d_out, c->d_status, c->stream);
-        if (rc) return rc;
-        std::vector<int> st(chunk);
-        HIPCHK(hipMemcpyAsync(out48n + done * 48, c->d_out, chunk * 48, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(st.data(), c->d_status, chunk * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        for (size_t i = 0; i < chunk; i++) {
+    std::vector<int> st;
+    LaneGuard G(c);
+    for (size_t done = 0; done < n;) {
+        const size_t m = std::min<size_t>(n - done, (size_t)c->opt_max_batch);
+        st.resize(m);
+        int rc = commit_host_piece(c, G.L, blobs + done, m, out48n + done * 48, st.data());
+        if (rc) return G.fail(rc);
+        for (size_t i = 0; i < m; i++) {
             if (per_item_status) per_item_status[done + i] = st[i];
             if (st[i] && !first) first = st[i];
         }
-        done += chunk;
+        done += m;
     }
     return first;
 }
@@ -395,6 +594,7 @@ int mkzg_blob_to_kzg_commitment_batch(mkzg_ctx* c, const uint8_t* const* blobs, 
 int mkzg_blob_to_kzg_commitment(mkzg_ctx* c, const uint8_t* blob, int num_threads, uint8_t out48[48]) {
     if (!c || !out48) return MKZG_ERR_BAD_ARGS;
     if (!blob) return MKZG_ERR_NIL_INPUT;
+    if (!c->peers.empty()) c = c->peers[c->rr++ % c->peers.size()];
     const uint8_t* one[1] = {blob};
     int st = 0;
     int rc = mkzg_blob_to_kzg_commitment_batch(c, one, 1, out48, &st);
@@ -407,6 +607,7 @@ int mkzg_commit_lagrange(mkzg_ctx* c, const uint8_t* scalars32, size_t n, int nu
     if (!c || !out48 || (!scalars32 && n)) return MKZG_ERR_BAD_ARGS;
     if (n == 0 || n > 4096) return MKZG_ERR_INVALID_POLY_SIZE;                     // srs.go:57-59
     if (num_threads >= 1024) return MKZG_ERR_TOO_MANY_GOROUTINES;
+    if (!c->peers.empty()) c = c->peers[c->rr++ % c->peers.size()];
     std::vector<uint8_t> padded(MKZG_BYTES_PER_BLOB, 0);                             // zero scalars contribute nothing
     memcpy(padded.data(), scalars32, n * 32);
     const uint8_t* one[1] = {padded.data()};
@@ -416,23 +617,32 @@ int mkzg_commit_lagrange(mkzg_ctx* c, const uint8_t* scalars32, size_t n, int nu
 
 int mkzg_profile_enable(mkzg_ctx* c, int on) {
     if (!c) return MKZG_ERR_BAD_ARGS;
-    std::lock_guard<std::recursive_mutex> g(c->mu);
+    if (!c->peers.empty()) { for (mkzg_ctx* p : c->peers) p->profiling = on != 0; return MKZG_OK; }
     c->profiling = on != 0;
     return MKZG_OK;
 }
 int mkzg_profile_read(mkzg_ctx* c, mkzg_kernel_time* out, int cap, int reset) {
-    if (!c) return 0;
-    std::lock_guard<std::recursive_mutex> g(c->mu);
-    (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
-    c->timer.collect();
-    for (int i = 0; i < KT_COUNT && i < cap; i++) {
-        out[i].name = kKernelNames[i];
-        out[i].total_ms = c->timer.total_ms[i];
-        out[i].launches = c->timer.launches[i];
+    if (!c || (cap > 0 && !out)) return 0;
+    for (int i = 0; i < KT_COUNT && i < cap; i++) { out[i].name = kKernelNames[i]; out[i].total_ms = 0; out[i].launches = 0; }
+    std::vector<mkzg_ctx*> all = c->peers.empty() ? std::vector<mkzg_ctx*>{c} : c->peers;
+    for (mkzg_ctx* q : all) {
+        lanes_quiesce(q);
+        for (int l = 0; l < mkzg_ctx::NLANE; l++) {
+            KernelTimer& t = q->lanes[l].timer;
+            t.collect();
+            for (int i = 0; i < KT_COUNT && i < cap; i++) { out[i].total_ms += t.total_ms[i]; out[i].launches += t.launches[i]; }
+            if (reset) t.reset();
+        }
+        lanes_resume(q);
     }
-    if (reset) c->timer.reset();
     return KT_COUNT;
 }
 
 }  // extern "C"
+
+mkzg_ctx* ctx_for_pointer(mkzg_ctx* c, const void* p) {
+    if (c->peers.empty()) return c;
+    const int dev = pointer_device(p);
+    for (mkzg_ctx* q : c->peers) if (q->device == dev) return q;
+    return nullptr;
+}

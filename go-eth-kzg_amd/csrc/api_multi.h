@@ -1,0 +1,34 @@
+// api_multi.h -- internal seams between the single-device entry points and the multi-device front (api_multi.hip).
+//
+// A context created over several devices (mkzg_ctx_new with n_dev > 1) is a front object that owns one full context per device
+// (mkzg_ctx::peers).  Batch entry points with host pointers are sharded over the devices by contiguous ranges -- one host thread per
+// device -- and the two batch verifiers combine their per-device partial sums in process (the same fold / finish split that the
+// multi-process form exchanges as 512-byte records, include/mi355kzg.h); single-item calls go round-robin; device-pointer entry
+// points run on the device that owns the pointer.
+#pragma once
+#include "ctx.h"
+
+// ---- EIP-4844 batch verifier, split at its four sums (reference internal/kzg/kzg_verify.go:141-199)
+struct VerifyFold { G1HX A, Cc, D; uint32_t e[8]; };
+void verify_fold_clear(VerifyFold& f);
+void verify_fold_add(VerifyFold& acc, const VerifyFold& f);
+// host-pointer fold of n items with global exponents r^(exp_offset + i); r_le32: the batch-wide scalar as 32 little-endian bytes.
+// first_nil (may be null) receives the index of the first nil blob or n; statuses are resolved inside (reference verify.go:102-123 order).
+int sd_verify_blob_fold_host(mkzg_ctx* c, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n, uint64_t exp_offset,
+                             const uint8_t r_le32[32], VerifyFold* out);
+int sd_verify_finish(mkzg_ctx* c, const VerifyFold& f);
+int draw_rlc_scalar(uint8_t r_le32[32]);
+
+// ---- EIP-7594 cell batch verifier, split at its four group sums (reference internal/kzg_multi/kzg_verify.go:32,41,68,80)
+struct CellFold { G1HX sums[4]; };
+int sd_cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells, size_t n_cells,
+                        const uint8_t* proofs48n, size_t n_p, uint64_t exp_offset, const uint8_t* r_be32 /* null: draw */, CellFold* out);
+int sd_cell_verify_finish(mkzg_ctx* c, const CellFold& f);
+
+// ---- multi-device fronts (c->peers non-empty)
+int md_blob_to_kzg_commitment_batch(mkzg_ctx* c, const uint8_t* const* blobs, size_t n, uint8_t* out48n, int* per_item_status);
+int md_verify_blob_kzg_proof_batch(mkzg_ctx* c, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n);
+int md_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n, const uint64_t* cell_indices, const uint8_t* const* cells, const uint8_t* proofs48n, size_t n);
+int md_recover_cells_and_kzg_proofs_batch(mkzg_ctx* c, size_t n_blobs, const uint64_t* const* cell_ids, const size_t* n_ids, const uint8_t* const* const* cells,
+                                          const size_t* n_cells, uint8_t* cells_out, uint8_t* proofs_out, int* status);
+static inline mkzg_ctx* md_pick(mkzg_ctx* c) { return c->peers.empty() ? c : c->peers[c->rr++ % c->peers.size()]; }

@@ -1,10 +1,20 @@
 // ctx.h -- the context object behind the C ABI (internal to libmi355kzg.so).
+//
+// A context is what go-eth-kzg's `Context` is (reference api.go:17-28): immutable after construction and shared by any
+// number of caller threads (reference verify.go:152-169, examples_test.go:11).  Everything a call MUTATES lives in a Lane
+// (streams, events, workspaces, pinned staging); a context owns NLANE of them and a call holds exactly one from entry to
+// return, so NLANE calls run concurrently on one GPU and only the lane hand-over takes the context mutex.  What calls
+// SHARE -- the SRS-derived tables in HBM and the host-side pairing precomputation -- is built once (lazily, under init_mu)
+// and is read-only afterwards.  One context per device; a multi-device context is a primary plus one peer per further
+// device (api_multi.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -19,47 +29,57 @@
 
 using namespace kzg;
 
+// a HIP call failed on this thread since its lane was acquired: the lane's release then synchronises all of its streams (work may be
+// in flight on any of them when HIPCHK returns from the middle of a call)
+extern thread_local bool tl_hip_error;
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
         hipError_t e__ = (expr);                                                                       \
         if (e__ != hipSuccess) {                                                                       \
             fprintf(stderr, "[mi355kzg] HIP error %s at %s:%d: %s\n", hipGetErrorName(e__), __FILE__, __LINE__, #expr); \
+            tl_hip_error = true;                                                                       \
             return MKZG_ERR_HIP;                                                                       \
         }                                                                                              \
     } while (0)
 
-struct mkzg_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;          // internal stream for host-pointer entry points
-    hipStream_t side = nullptr;            // side stream: point validation runs beside SHA-256 / evaluation
-    hipStream_t side2 = nullptr;           // second side stream: the cell verifier's subgroup test beside decoding + MSMs
+// device / pinned buffers that grow on demand: the old block is released and the pointer cleared BEFORE the new allocation, so a
+// failed hipMalloc leaves a null pointer and a zero capacity behind, never a dangling one
+template <class T>
+static inline int dev_realloc(T*& p, size_t bytes) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    HIPCHK(hipMalloc(&p, bytes ? bytes : 16));
+    return MKZG_OK;
+}
+template <class T>
+static inline int pinned_realloc(T*& p, size_t bytes) {
+    if (p) { (void)hipHostFree(p); p = nullptr; }
+    HIPCHK(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault));
+    return MKZG_OK;
+}
+template <class T>
+static inline void dev_free(T*& p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+struct mkzg_ctx;
+
+// Per-call mutable state.  Owned by one call at a time (lane_acquire / lane_release in api.hip).
+struct Lane {
+    int id = 0;
+    bool busy = false;
+    uint64_t released_at = 0;              // hand-over order: the lane that has been free longest goes first
+    hipStream_t stream = nullptr;          // main stream of host-pointer entry points (device-pointer entry points bring their own)
+    hipStream_t side = nullptr;            // point validation runs beside SHA-256 / evaluation
+    hipStream_t side2 = nullptr;           // the cell verifier's subgroup test beside decoding + MSMs; second chunk stream of the host-pointer commit path
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_decoded = nullptr;
-    std::recursive_mutex mu;
-    kzg::HostPool* pool = nullptr;         // persistent host threads for the verifiers' host steps (host_pool.hpp)
-    // SRS
-    std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes
-    uint32_t* d_lagrange_aff = nullptr;    // 4096 affine rows, natural order of the JSON
-    // commit MSM: one shared table, NSLOT independent workspaces so that consecutive calls on different
-    // streams overlap (the latency-bound bucket reduction of one call hides under the accumulation of the
-    // next); slot_done[i] orders the reuse of workspace i across streams without host synchronisation
-    static constexpr int NSLOT = 2;
-    CommitPlan plan;                       // == slots[0] (kept for the single-slot users)
-    CommitPlan slots[NSLOT];
-    hipEvent_t slot_done[NSLOT] = {nullptr, nullptr};
-    bool slot_used[NSLOT] = {false, false};
-    unsigned slot_counter = 0;
-    hipEvent_t acc_done[NSLOT] = {nullptr, nullptr};   // recorded after each call's accumulate kernel
-    int last_acc_slot = -1;
-    int opt_c = 13;
-    int opt_chain_acc = 0;                 // 1: the accumulate kernel of a call waits for the previous call's accumulate kernel
-    int opt_direct_bits = 0;               // 0: bucket method; 12..15: direct-table commitment (HBM-hungry, see msm_kernels.hip)
-    uint32_t* d_direct = nullptr;
-    int direct_bits_built = 0;
-    DirectSlot dslots[NSLOT];              // direct mode workspaces (share slot_done / acc_done with the bucket mode)
+    hipEvent_t done = nullptr;             // recorded on the call's main stream at release: the next owner's stream waits for it (no host sync)
+    bool used = false;
+    // ---- commitment MSM workspaces
+    CommitPlan plan;                       // bucket method: per-lane arrays; plan.d_table points at the context's shared table
+    int plan_c = 0, plan_batch = 0;
+    DirectSlot dslot;                      // direct-table method: lane accumulators
     int dslot_batch = 0;
-    int opt_max_batch = 256;
-    bool plan_ready = false;
-    // staging
+    // ---- staging of host-pointer entry points
     uint8_t* h_stage = nullptr;            // pinned
     size_t h_stage_bytes = 0;
     uint8_t* d_blobs = nullptr;
@@ -67,16 +87,10 @@ struct mkzg_ctx {
     uint8_t* d_out = nullptr;
     int* d_status = nullptr;
     size_t d_out_items = 0;
-    // profiling
-    bool profiling = false;
-    KernelTimer timer;
-    // ---- EIP-4844 proofs / verification
-    uint32_t* d_roots_brp = nullptr;       // 4096 Fr rows (12 words), bit-reversed domain (api.go:132)
-    uint32_t* d_inv_roots_brp = nullptr;
-    G1HFixedBase gen_fixed;                // host byte-window table of the G1 generator ([e]G of the batch verifiers)
-    G2Prepared g2_gen, g2_alpha;           // prepared [1]G2, [alpha]G2 (kzg.OpeningKey, internal/kzg/srs.go:10-20)
-    G2Prepared g2_neg_gen, g2_alpha64;     // prepared -[1]G2, [alpha^64]G2 (kzgmulti.OpeningKey, internal/kzg_multi/kzg_verify.go:89-92)
-    // verify workspace, sized for v_cap proofs
+    uint8_t* h_out = nullptr;              // pinned: results of the chunked commit path (48 B + status per blob)
+    size_t h_out_items = 0;
+    hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // ---- EIP-4844 verification workspace, sized for v_cap proofs
     size_t v_cap = 0;
     uint8_t* d_v_raw = nullptr;            // 2 v_cap x 48 B   (commitments | proofs)
     uint32_t* d_v_aff = nullptr;           // 2 v_cap affine rows
@@ -85,29 +99,23 @@ struct mkzg_ctx {
     uint32_t* d_v_y = nullptr;
     uint32_t* d_v_s1 = nullptr;            // v_cap x 8 words
     uint32_t* d_v_s3 = nullptr;
-    uint32_t* d_v_misc = nullptr;          // [0..8) r, [8..16) e, [16 .. 16+3*32*48) window sums
+    uint32_t* d_v_misc = nullptr;          // [0..8) r, [8..16) e, [16 .. 16+4*32*48) window sums, then the slice sums of the MSMs
     uint8_t* h_v = nullptr;                // pinned: statuses + misc
     size_t h_v_bytes = 0;
-    // quotient workspace (proof computation), q_cap blobs
+    uint32_t* d_v_coeffs = nullptr;        // coefficient rows of the blobs (v_coeff_cap x 4096 x 12 words)
+    size_t v_coeff_cap = 0;
+    // quotient workspace (proof computation)
     size_t q_cap = 0, quot_cap = 0;        // capacities of the scalar/status arrays and of the quotient rows
-    uint32_t* d_quot = nullptr;            // q_cap x 4096 Fr rows
+    uint32_t* d_quot = nullptr;            // quot_cap x 4096 Fr rows
     uint32_t* d_q_z = nullptr;
     uint32_t* d_q_y = nullptr;
     int* d_q_st = nullptr;
     // ---- EIP-7594
-    uint32_t* d_v_coeffs = nullptr;        // batch verifier: coefficient rows of the blobs (v_coeff_cap x 4096 x 12 words)
-    size_t v_coeff_cap = 0;
-    uint32_t* d_tw_fwd = nullptr;          // 4096 Fr rows: w_8192^j
-    uint32_t* d_tw_inv = nullptr;          // 4096 Fr rows: w_8192^-j
-    uint32_t* d_g1tw_fwd = nullptr;        // 64 x 8 words: w_128^j as plain scalars
-    uint32_t* d_g1tw_inv = nullptr;
-    bool cells_ready = false;
     size_t cell_cap = 0;                   // blobs per launch for the cell paths
     uint32_t* d_coeffs = nullptr;          // cell_cap x 4096 Fr rows
     uint8_t* d_cells = nullptr;            // cell_cap x 262144 B
     int* d_cell_st = nullptr;
-    // VerifyCellKZGProofBatch workspace, cv_cap cells
-    size_t cv_cap = 0;
+    size_t cv_cap = 0;                     // VerifyCellKZGProofBatch workspace, cv_cap cells
     uint8_t* d_cv_cells = nullptr;         // cv_cap x 2048 B
     uint64_t* d_cv_cell_idx = nullptr;
     uint32_t* d_cv_row_idx = nullptr;
@@ -116,40 +124,116 @@ struct mkzg_ctx {
     uint32_t* d_cv_partials = nullptr;     // CELL_INTERP_BLOCKS x 64 Fr rows
     uint32_t* d_cv_interp = nullptr;       // 64 x 8 words
     int* d_cv_st = nullptr;                // 3 x cv_cap: cell statuses, subgroup verdicts of the commitment rows, of the proofs
-    // recovery
-    bool rec_ready = false;
     size_t rec_cap = 0;                    // blobs the recovery scratch / position arrays hold
-    uint32_t* d_pow7 = nullptr;
-    uint32_t* d_ipow7 = nullptr;
     uint32_t* d_rec_scratch = nullptr;
     int* d_rec_pos = nullptr;              // per blob 128 positions + 64 missing ids, then one count per blob
-    // FK20
-    bool fk_ready = false;
-    hipEvent_t fk_ws_done = nullptr;       // orders reuse of the cells / FK20 / recovery workspaces across streams (asynchronous entry points)
-    bool fk_ws_used = false;
-    uint32_t* d_monomial_aff = nullptr;    // 4096 affine rows
-    uint32_t* d_fk_t_aff = nullptr;        // 8192 affine rows T[k][i]
-    uint32_t* d_fk_table = nullptr;        // direct window table (25.8 GB)
     size_t fk_cap = 0;
     uint32_t* d_fk_scalars = nullptr;      // fk_cap x 128 x 64 x 8 words
-    uint32_t* d_fk_results = nullptr;      // 2 x fk_cap x 128 XYZZ rows (MSM results + ping-pong buffer of the G1 DFT levels)
-    uint32_t* d_fk_parts = nullptr;        // fk_cap x 128 x 16 XYZZ rows: per-lane partial sums of the FK20 MSMs
-    uint32_t* d_fk_plan = nullptr;         // FK_PLAN_WORDS lane descriptors of the G1 DFT levels
+    uint32_t* d_fk_results = nullptr;      // 2 x fk_cap x 128 XYZZ rows (MSM results + second buffer of the transform stage)
+    uint32_t* d_fk_parts = nullptr;        // fk_cap x 128 x 24 XYZZ rows: per-lane partial sums of the FK20 MSMs, then the transform stage's terms
     uint8_t* d_fk_proofs = nullptr;        // fk_cap x 128 x 48 B
-    // host finish timing (last call), microseconds
-    double last_host_finish_us = 0, last_verify_total_us = 0;
+    // ---- profiling (hipEvent brackets on the streams this lane's kernels are launched on)
+    KernelTimer timer;
+    double last_host_finish_us = 0;
+    bool failed = false;                   // set by an error exit: the release then synchronises every stream of the lane
 };
 
-int ensure_plan(mkzg_ctx* c);
-int acquire_slot(mkzg_ctx* c, hipStream_t s);          // returns slot index (>= 0) or -1
-int release_slot(mkzg_ctx* c, int slot, hipStream_t s);
-extern "C" int commit_scalars_device(mkzg_ctx* c, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s);
-extern "C" int ensure_staging(mkzg_ctx* c, size_t n_items, size_t in_bytes_per_item);   // defined inside api.hip's extern "C" block
-int ensure_verify_ws(mkzg_ctx* c, size_t n);
-int ensure_quot_ws(mkzg_ctx* c, size_t n, size_t n_quot);
-void free_verify_ws(mkzg_ctx* c);
-int ensure_cells(mkzg_ctx* c, size_t n);
-void free_cells(mkzg_ctx* c);
-int ensure_fk20(mkzg_ctx* c, size_t n);
-int ensure_monomial(mkzg_ctx* c);
+struct mkzg_ctx {
+    int device = 0;
+    std::vector<mkzg_ctx*> peers;          // further devices of a multi-device context (owned by this, the primary)
+    std::atomic<unsigned> rr{0};           // round-robin cursor of single-item calls over the devices
+    // ---- lanes
+    static constexpr int NLANE = 4;
+    Lane lanes[NLANE];
+    std::mutex mu;                         // lane hand-over only
+    std::condition_variable cv;
+    uint64_t release_seq = 0;
+    std::mutex init_mu;                    // lazy construction of the shared tables below
+    hipStream_t init_stream = nullptr;
+    kzg::HostPool* pool = nullptr;         // persistent host threads for the host steps (host_pool.hpp), shared by the lanes
+    // ---- options (mkzg_ctx_set_option; changed only while no call is in flight)
+    int opt_c = 13;
+    int opt_direct_bits = 0;               // 0: bucket method; 12..15: direct-table commitment (HBM-hungry, see msm_kernels.hip)
+    int opt_max_batch = 256;
+    int opt_host_chunk = 64;               // blobs per chunk of the host-pointer commitment pipeline
+    int opt_host_sha = -1;                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
+    std::atomic<bool> profiling{false};
+    // ---- SRS
+    std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes
+    uint32_t* d_lagrange_aff = nullptr;    // 4096 affine rows, natural order of the JSON
+    // ---- shared tables (read-only once built)
+    uint32_t* d_commit_table = nullptr;    // bucket method: [nwin][4096] affine rows for commit_table_c
+    int commit_table_c = 0;
+    uint32_t* d_direct = nullptr;          // direct window table
+    int direct_bits_built = 0;             // 0 with opt_direct_bits != 0 and direct_failed: degraded to the bucket method
+    bool direct_failed = false;            // the table could not be allocated at any width: stop retrying
+    uint32_t* d_roots_brp = nullptr;       // 4096 Fr rows (12 words), bit-reversed domain (api.go:132)
+    uint32_t* d_inv_roots_brp = nullptr;
+    G1HFixedBase gen_fixed;                // host byte-window table of the G1 generator ([e]G of the batch verifiers)
+    G2Prepared g2_gen, g2_alpha;           // prepared [1]G2, [alpha]G2 (kzg.OpeningKey, internal/kzg/srs.go:10-20)
+    G2Prepared g2_neg_gen, g2_alpha64;     // prepared -[1]G2, [alpha^64]G2 (kzgmulti.OpeningKey, internal/kzg_multi/kzg_verify.go:89-92)
+    std::atomic<bool> twiddles_ready{false};
+    uint32_t* d_tw_fwd = nullptr;          // 4096 Fr rows: w_8192^j
+    uint32_t* d_tw_inv = nullptr;          // 4096 Fr rows: w_8192^-j
+    uint32_t* d_g1tw_fwd = nullptr;        // 64 x 8 words: w_128^j as plain scalars
+    uint32_t* d_g1tw_inv = nullptr;
+    std::atomic<bool> monomial_ready{false};
+    uint32_t* d_monomial_aff = nullptr;    // 4096 affine rows
+    std::atomic<bool> rec_ready{false};
+    uint32_t* d_pow7 = nullptr;
+    uint32_t* d_ipow7 = nullptr;
+    std::atomic<bool> fk_ready{false};
+    uint32_t* d_fk_t_aff = nullptr;        // 8192 affine rows T[k][i]
+    uint32_t* d_fk_table = nullptr;        // direct window table of the FK20 bases (fk20_table_bytes())
+    uint32_t* d_fk_plan = nullptr;         // FK_PLAN_WORDS lane descriptors of the G1 DFT levels
+    // host finish timing (last verification call), microseconds
+    std::atomic<double> last_host_finish_us{0.0};
+};
 
+// ---- lanes (api.hip)
+// Blocks until a lane is free; the call's main stream -- the caller's (device-pointer entry points; may be the null stream) or the
+// lane's own -- is made to wait for the lane's previous user.
+Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s);
+// Hands the lane back; s = the call's main stream.  After an error exit every stream of the lane is synchronised first.
+void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s);
+// all lanes at once (option changes, profile read-out, destruction): returns with every lane owned by the caller and the device idle
+void lanes_quiesce(mkzg_ctx* c);
+void lanes_resume(mkzg_ctx* c);
+struct LaneGuard {                          // one call = one guard
+    mkzg_ctx* c;
+    Lane* L;
+    hipStream_t s;                          // the call's main stream
+    explicit LaneGuard(mkzg_ctx* c_) : c(c_), L(lane_acquire(c_, false, nullptr)), s(L->stream) {}                     // host-pointer entry points
+    LaneGuard(mkzg_ctx* c_, hipStream_t user_stream) : c(c_), L(lane_acquire(c_, true, user_stream)), s(user_stream) {}   // device-pointer entry points
+    ~LaneGuard() { if (L) lane_release(c, L, s); }
+    LaneGuard(const LaneGuard&) = delete;
+    LaneGuard& operator=(const LaneGuard&) = delete;
+    int fail(int rc) { if (L && rc != MKZG_OK) L->failed = true; return rc; }    // error exit after device work was enqueued
+};
+#define KT(kind, s, call)                                         \
+    do {                                                          \
+        const bool kt_on__ = c->profiling.load(std::memory_order_relaxed); \
+        if (kt_on__) L->timer.begin(kind, s);                     \
+        call;                                                     \
+        if (kt_on__) L->timer.end(kind, s);                       \
+    } while (0)
+
+// ---- shared tables, built once (api.hip, api_cells.hip)
+int ensure_commit_table(mkzg_ctx* c);
+int ensure_direct(mkzg_ctx* c);             // MKZG_OK also when the table cannot be had: direct_bits_built then says what is in use
+int ensure_twiddles(mkzg_ctx* c);
+int ensure_monomial(mkzg_ctx* c);
+int ensure_fk20_tables(mkzg_ctx* c);
+int ensure_rec_tables(mkzg_ctx* c);
+// ---- per-lane workspaces
+int ensure_staging(Lane* L, size_t n_items, size_t in_bytes_per_item);
+int ensure_verify_ws(Lane* L, size_t n);
+int ensure_quot_ws(Lane* L, size_t n, size_t n_quot);
+int ensure_cells_ws(Lane* L, size_t n);
+int ensure_fk20_ws(Lane* L, size_t n);
+void free_lane(Lane* L);
+// commitments of n polynomials in Lagrange form (api.hip); the caller holds lane L and runs on stream s
+int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s);
+// device a pointer lives on (-1: not a device pointer)
+int pointer_device(const void* p);
+mkzg_ctx* ctx_for_pointer(mkzg_ctx* c, const void* p);

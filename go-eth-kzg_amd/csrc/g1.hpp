@@ -104,9 +104,7 @@ struct G1T {
         F::opaque(y2);
         fe U2, S2, Pd, Rd, PP, PPP, Q, t, X3;
         F::mul(U2, x2, acc.zz);
-        KZ_SCHED_FENCE();
         F::mul(S2, y2, acc.zzz);
-        KZ_SCHED_FENCE();
         F::template sub<3>(Pd, U2, acc.x);    // U2 - X1 + 8p   in (0.99p, 9.01p)
         F::template sub<2>(Rd, S2, acc.y);    // S2 - Y1 + 4p   in (0.99p, 5.01p)
         if (F::template is_zero_mod<16>(Pd)) {
@@ -118,21 +116,14 @@ struct G1T {
         F::opaque(Pd);
         F::opaque(Rd);
         F::sqr(PP, Pd);
-        KZ_SCHED_FENCE();
         F::mul(PPP, Pd, PP);
-        KZ_SCHED_FENCE();
         F::mul(Q, acc.x, PP);
-        KZ_SCHED_FENCE();
         F::mul(acc.zz, acc.zz, PP);           // PP, Pd and X1 are dead from here on (keeps the live set small for R^2)
-        KZ_SCHED_FENCE();
         F::mul(acc.zzz, acc.zzz, PPP);
-        KZ_SCHED_FENCE();
         F::sqr(X3, Rd);
-        KZ_SCHED_FENCE();
         F::template sub_b_2c<2>(X3, X3, PPP, Q);   // R^2 - PPP - 2Q + 4p   (PPP + 2Q < 3.03p; result < 5.01p)
         F::template sub<3>(t, Q, X3);         // Q - X3 + 8p
         F::template neg<2>(S2, acc.y);        // 4p - Y1
-        KZ_SCHED_FENCE();
         F::mul2(acc.y, Rd, t, S2, PPP);       // R (Q - X3) - Y1 PPP   (< 1.01p), one reduction for both products
         acc.x = X3;
     }

@@ -1,0 +1,159 @@
+// host_sha256.hpp -- SHA-256 for the Fiat-Shamir challenge of the host-pointer verifiers (reference fiatshamir.go:22-33).
+//
+// Why the host has one at all: a blob handed over as a host pointer must cross PCIe (131 KiB, ~2.6 us at 50 GB/s) before the device
+// can hash it, and the device's hash of one transcript is a 2050-compression serial chain (2.7 ms whatever the batch size).  A host
+// core with SHA extensions hashes the same transcript in ~70 us, so a pool of cores hashes a batch WHILE it uploads and the device
+// starts from finished challenges.  Device-resident batches keep the device hash (verify_kernels.hip k_challenge_sha256).
+// The compression function comes in two forms: x86 SHA extensions (runtime-detected) and portable C.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace kzg {
+
+static const uint32_t SHA256_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74,
+    0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d,
+    0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e,
+    0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5,
+    0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+static inline uint32_t sha_ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static inline void sha256_blocks_c(uint32_t st[8], const uint8_t* p, size_t nblk) {
+    while (nblk--) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) {
+            const uint32_t s0 = sha_ror(w[i - 15], 7) ^ sha_ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = sha_ror(w[i - 2], 17) ^ sha_ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = h + (sha_ror(e, 6) ^ sha_ror(e, 11) ^ sha_ror(e, 25)) + ((e & f) ^ (~e & g)) + SHA256_K[i] + w[i];
+            const uint32_t t2 = (sha_ror(a, 2) ^ sha_ror(a, 13) ^ sha_ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
+        p += 64;
+    }
+}
+
+#if defined(__x86_64__)
+// Four rounds per sha256rnds2 pair; the message schedule of rounds 16.. from sha256msg1 / sha256msg2:
+//   W[t..t+3] = msg2(msg1(W[t-16..t-13], W[t-12..t-9]) + (W[t-7..t-4]), W[t-4..t-1])
+__attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_ni(uint32_t st[8], const uint8_t* p, size_t nblk) {
+    const __m128i BSWAP = _mm_set_epi64x(0x0c0d0e0f08090a0bLL, 0x0405060700010203LL);
+    __m128i tmp = _mm_loadu_si128((const __m128i*)&st[0]);       // d c b a
+    __m128i s1 = _mm_loadu_si128((const __m128i*)&st[4]);        // h g f e
+    tmp = _mm_shuffle_epi32(tmp, 0xB1);                          // c d a b
+    s1 = _mm_shuffle_epi32(s1, 0x1B);                            // e f g h
+    __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);                    // a b e f
+    s1 = _mm_blend_epi16(s1, tmp, 0xF0);                         // c d g h
+    while (nblk--) {
+        const __m128i save0 = s0, save1 = s1;
+        __m128i m[4];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            __m128i w;
+            if (i < 4) {
+                w = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(p + 16 * i)), BSWAP);
+            } else {
+                __m128i t = _mm_sha256msg1_epu32(m[i & 3], m[(i + 1) & 3]);
+                t = _mm_add_epi32(t, _mm_alignr_epi8(m[(i + 3) & 3], m[(i + 2) & 3], 4));
+                w = _mm_sha256msg2_epu32(t, m[(i + 3) & 3]);
+            }
+            m[i & 3] = w;
+            __m128i msg = _mm_add_epi32(w, _mm_loadu_si128((const __m128i*)&SHA256_K[4 * i]));
+            s1 = _mm_sha256rnds2_epu32(s1, s0, msg);
+            msg = _mm_shuffle_epi32(msg, 0x0E);
+            s0 = _mm_sha256rnds2_epu32(s0, s1, msg);
+        }
+        s0 = _mm_add_epi32(s0, save0);
+        s1 = _mm_add_epi32(s1, save1);
+        p += 64;
+    }
+    tmp = _mm_shuffle_epi32(s0, 0x1B);                           // f e b a
+    s1 = _mm_shuffle_epi32(s1, 0xB1);                            // d c h g
+    s0 = _mm_blend_epi16(tmp, s1, 0xF0);                         // d c b a
+    s1 = _mm_alignr_epi8(s1, tmp, 8);                            // h g f e
+    _mm_storeu_si128((__m128i*)&st[0], s0);
+    _mm_storeu_si128((__m128i*)&st[4], s1);
+}
+static inline bool sha256_have_ni() {
+    static const bool have = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+    return have;
+}
+#else
+static inline bool sha256_have_ni() { return false; }
+#endif
+
+static inline void sha256_blocks(uint32_t st[8], const uint8_t* p, size_t nblk) {
+#if defined(__x86_64__)
+    if (sha256_have_ni()) { sha256_blocks_ni(st, p, nblk); return; }
+#endif
+    sha256_blocks_c(st, p, nblk);
+}
+static inline void sha256_init(uint32_t st[8]) {
+    static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    memcpy(st, iv, sizeof(iv));
+}
+// one-shot digest (tests)
+static inline void sha256_digest(uint8_t out[32], const uint8_t* data, size_t len) {
+    uint32_t st[8];
+    sha256_init(st);
+    sha256_blocks(st, data, len / 64);
+    uint8_t tail[128] = {0};
+    const size_t rem = len % 64;
+    memcpy(tail, data + len - rem, rem);
+    tail[rem] = 0x80;
+    const size_t tl = rem + 9 <= 64 ? 64 : 128;
+    const uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha256_blocks(st, tail, tl / 64);
+    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16); out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i]; }
+}
+
+// compute_challenge (reference fiatshamir.go:22-33): SHA-256("FSBLOBVERIFY_V1_" || u128_be(4096) || blob || commitment) reduced
+// modulo r, written as 32 big-endian bytes (canonical).  The blob is hashed in place: only the first 32 and the last 32 bytes of it
+// are copied (they share a compression block with the 32-byte header and with the commitment).
+static inline void host_compute_challenge(uint8_t z32[32], const uint8_t* blob /* 131072 B */, const uint8_t commitment48[48]) {
+    uint32_t st[8];
+    sha256_init(st);
+    uint8_t blk[128];
+    memcpy(blk, "FSBLOBVERIFY_V1_", 16);
+    memset(blk + 16, 0, 16);
+    blk[30] = 0x10;                                        // 4096 = 0x1000, big-endian in the last 8 of the 16 bytes
+    memcpy(blk + 32, blob, 32);
+    sha256_blocks(st, blk, 1);
+    sha256_blocks(st, blob + 32, (131072 - 64) / 64);      // blob[32 .. 131040)
+    memset(blk, 0, sizeof(blk));
+    memcpy(blk, blob + 131072 - 32, 32);
+    memcpy(blk + 32, commitment48, 48);
+    blk[80] = 0x80;
+    const uint64_t bits = (uint64_t)(32 + 131072 + 48) * 8;
+    for (int i = 0; i < 8; i++) blk[127 - i] = (uint8_t)(bits >> (8 * i));
+    sha256_blocks(st, blk, 2);
+    // digest as a 256-bit big-endian integer, reduced mod r (r > 2^254: at most two subtractions)
+    static const uint32_t RW[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};   // little-endian words of r
+    uint32_t w[8];
+    for (int i = 0; i < 8; i++) w[i] = st[7 - i];
+    for (int pass = 0; pass < 3; pass++) {
+        bool ge = true;
+        for (int i = 7; i >= 0; i--) {
+            if (w[i] != RW[i]) { ge = w[i] > RW[i]; break; }
+        }
+        if (!ge) break;
+        uint64_t br = 0;
+        for (int i = 0; i < 8; i++) {
+            const uint64_t d = (uint64_t)w[i] - RW[i] - br;
+            w[i] = (uint32_t)d;
+            br = (d >> 32) & 1;
+        }
+    }
+    for (int i = 0; i < 8; i++) { z32[4 * i] = (uint8_t)(w[7 - i] >> 24); z32[4 * i + 1] = (uint8_t)(w[7 - i] >> 16); z32[4 * i + 2] = (uint8_t)(w[7 - i] >> 8); z32[4 * i + 3] = (uint8_t)w[7 - i]; }
+}
+
+}  // namespace kzg

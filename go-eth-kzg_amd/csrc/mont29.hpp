@@ -36,12 +36,8 @@
 // and every limb product becomes a 64x32-bit multiply (two v_mad_u64_u32 + moves instead of one).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KZ_OPAQUE32(x) asm("" : "+v"(x))
-// keeps the machine scheduler from interleaving two independent field multiplications (it would, to hide latency
-// that a second resident wavefront already hides, and pays for it with ~30 more live registers -> spills)
-#define KZ_SCHED_FENCE() do { } while (0)
 #else
 #define KZ_OPAQUE32(x) do { } while (0)
-#define KZ_SCHED_FENCE() do { } while (0)
 #endif
 
 namespace kzg {

@@ -57,12 +57,9 @@ struct CommitPlan {
     uint32_t* d_ntasks = nullptr;    // [batch]
     uint32_t* d_parts = nullptr;     // [batch][max_tasks] XYZZ partial bucket sums, bucket-major
     uint32_t* d_partials = nullptr;  // [batch][nbucket/16][2] XYZZ chunk sums
-    // cross-call pipelining: the accumulate kernel of a call waits for the accumulate kernel of the previous
-    // call (so the VALU-saturating phases run back to back) while the previous call's latency-bound
-    // reduction kernels overlap with it on another stream
-    hipEvent_t wait_before_acc = nullptr;
-    hipEvent_t record_after_acc = nullptr;
 };
+// the same workspace seen from batch item `off` on (chunks of one call run on different streams over disjoint item ranges)
+CommitPlan commit_plan_offset(const CommitPlan& pl, int off);
 
 void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz);
 // scalars: input_kind 0 = 32-byte big-endian scalars, 4096 per item, items `stride` bytes apart
@@ -79,10 +76,10 @@ void build_direct_device(int c, const uint32_t* d_table, uint32_t* d_direct, hip
 struct DirectSlot {
     uint32_t* d_parts = nullptr;
     int* d_bad = nullptr;
-    hipEvent_t wait_before_acc = nullptr;      // same cross-call chaining as CommitPlan
-    hipEvent_t record_after_acc = nullptr;
 };
 size_t direct_parts_bytes(int max_batch);
+size_t direct_bad_bytes(int max_batch);
+DirectSlot direct_slot_offset(const DirectSlot& ws, int off);
 double valu_calibrate_device(hipStream_t s);   // sustained v_mad_u64_u32 wave-instructions per second on this GPU
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48,
                           int* d_status, hipStream_t s, KernelTimer* kt);

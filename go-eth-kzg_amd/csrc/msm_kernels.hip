@@ -751,11 +751,9 @@ static void launch_commit(const CommitPlan& pl, const uint8_t* d_scalars, size_t
     if (input_kind == 0) hipLaunchKernelGGL((k_digits_sort<C, 0>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_task_off, tasks, pl.d_ntasks, d_status);
     else hipLaunchKernelGGL((k_digits_sort<C, 1>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_task_off, tasks, pl.d_ntasks, d_status);
     if (kt) kt->end(KT_DIGITS_SORT, s);
-    if (pl.wait_before_acc) (void)hipStreamWaitEvent(s, pl.wait_before_acc, 0);
     if (kt) kt->begin(KT_BUCKET_ACC, s);
     hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3(TG::MAXT / 256, n), dim3(256), 0, s, pl.d_table, pl.d_entries, tasks, pl.d_ntasks, pl.d_parts);
     if (kt) kt->end(KT_BUCKET_ACC, s);
-    if (pl.record_after_acc) (void)hipEventRecord(pl.record_after_acc, s);
     constexpr int NCHUNK = RC::NBUCKET / CHUNK;
     if (kt) kt->begin(KT_REDUCE1, s);
     hipLaunchKernelGGL((k_bucket_reduce1<C>), dim3((NCHUNK + 63) / 64, n), dim3(64), 0, s, pl.d_parts, pl.d_task_off, d_status, pl.d_partials);
@@ -802,6 +800,25 @@ void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table,
     }
 }
 size_t direct_parts_bytes(int max_batch) { return (size_t)max_batch * DPARTS * 64 * sizeof(uint32_t); }
+size_t direct_bad_bytes(int max_batch) { return (size_t)max_batch * DBLK * sizeof(int); }
+DirectSlot direct_slot_offset(const DirectSlot& ws, int off) {
+    DirectSlot o = ws;
+    o.d_parts = ws.d_parts + (size_t)off * DPARTS * 64;
+    o.d_bad = ws.d_bad + (size_t)off * DBLK;
+    return o;
+}
+CommitPlan commit_plan_offset(const CommitPlan& pl, int off) {
+    CommitPlanSizes sz;
+    commit_plan_sizes(pl.c, 1, &sz);                 // per-item sizes
+    CommitPlan o = pl;
+    o.d_entries = pl.d_entries + (size_t)off * (sz.entries_bytes / 4);
+    o.d_task_off = pl.d_task_off + (size_t)off * (sz.task_off_bytes / 4);
+    o.d_tasks = pl.d_tasks + (size_t)off * (sz.tasks_bytes / 4);
+    o.d_ntasks = pl.d_ntasks + (size_t)off * (sz.ntasks_bytes / 4);
+    o.d_parts = pl.d_parts + (size_t)off * (sz.parts_bytes / 4);
+    o.d_partials = pl.d_partials + (size_t)off * (sz.partials_bytes / 4);
+    return o;
+}
 template <int KIND>
 static void launch_direct_acc(int c, dim3 grid, hipStream_t s, const uint8_t* d_scalars, size_t stride, const uint32_t* d_direct, const DirectSlot& ws) {
     switch (c) {
@@ -814,13 +831,11 @@ static void launch_direct_acc(int c, dim3 grid, hipStream_t s, const uint8_t* d_
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status,
                           hipStream_t s, KernelTimer* kt) {
     if (n <= 0) return;
-    if (ws.wait_before_acc) (void)hipStreamWaitEvent(s, ws.wait_before_acc, 0);
     if (kt) kt->begin(KT_COMMIT_DIRECT, s);
     const dim3 grid(DBLK, n);
     if (input_kind == 0) launch_direct_acc<0>(c, grid, s, d_scalars, stride, d_direct, ws);
     else launch_direct_acc<1>(c, grid, s, d_scalars, stride, d_direct, ws);
     if (kt) kt->end(KT_COMMIT_DIRECT, s);
-    if (ws.record_after_acc) (void)hipEventRecord(ws.record_after_acc, s);
     if (kt) kt->begin(KT_COMMIT_DIRECT_FIN, s);
     hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status);
     if (kt) kt->end(KT_COMMIT_DIRECT_FIN, s);

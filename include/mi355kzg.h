@@ -13,8 +13,11 @@
  *     (HBM) pointers + a hipStream_t (as void*) and enqueue asynchronously on that stream.
  *   - return value: MKZG_OK, MKZG_VERIFY_FAILED (<-> kzg.ErrVerifyOpeningProof), or one code per
  *     reference error sentinel; MKZG_ERR_HIP for a runtime failure.  Never aborts.
- *   - a context is immutable after construction and may be shared by threads (calls that use
- *     the context's workspace are serialised internally).
+ *   - a context is immutable after construction and may be shared by threads, like the reference's Context
+ *     (api.go:17-28, examples_test.go:11): every call works in one of the context's lanes (own streams, workspaces
+ *     and pinned staging), so up to four calls per device run concurrently on the GPU; further callers wait for a lane.
+ *   - batch entry points take any batch size (pieces are cut internally; the batch verifiers fold all pieces with ONE
+ *     random scalar and finish with one pairing check).
  *   - there is NO CPU fallback: without a HIP device mkzg_ctx_new fails with MKZG_ERR_HIP.
  */
 #ifndef MI355KZG_H
@@ -51,7 +54,7 @@ enum {
     MKZG_ERR_INVALID_POLY_SIZE = 15,       /* kzg.ErrInvalidPolynomialSize */
     MKZG_ERR_BAD_TRUSTED_SETUP = 16,       /* panics / kzg.ErrMinSRSSize of api.go:90-117, trusted_setup.go */
     MKZG_ERR_BAD_ARGS = 17,
-    MKZG_ERR_HIP = 100                     /* HIP / RCCL runtime failure (no reference analogue) */
+    MKZG_ERR_HIP = 100                     /* HIP runtime failure or no usable device (no reference analogue) */
 };
 
 typedef struct mkzg_ctx mkzg_ctx;
@@ -59,15 +62,27 @@ typedef struct mkzg_ctx mkzg_ctx;
 /* ---- context ------------------------------------------------------------------------------ */
 /* NewContext4096 (reference api.go:90-149) from the JSON of trusted_setup.go:23-27
  * (`g1_monomial`, `g1_lagrange`, `g2_monomial` hex strings).  device_ids/n_dev select the HIP
- * device (n_dev == 0: current device).  One context drives one GPU; multi-GPU jobs create one
- * context per process/rank (DESIGN.md "multi-GPU"). */
+ * devices (n_dev == 0: the current device).  With n_dev > 1 the context drives all listed GPUs: host-pointer batches
+ * are sharded over them (one host thread per device, partial results of the batch verifiers combined in process),
+ * single-item calls go round-robin, device-pointer entry points run on the device that owns the pointers.  A device
+ * id that does not exist is MKZG_ERR_BAD_ARGS.  Multi-process jobs (one rank per GPU) create one single-device context
+ * per rank and use the _partial / _finish entry points below (DESIGN.md "multi-GPU"). */
 int mkzg_ctx_new(const char* trusted_setup_json, size_t len, const int* device_ids, int n_dev, mkzg_ctx** out);
 void mkzg_ctx_free(mkzg_ctx* ctx);
-/* tuning knobs before first use: "msm_window" (11..13), "max_batch" (blobs per launch), "commit_direct_bits"
- * (0 = bucket method; 12..15 = direct window table for BlobToKZGCommitment: 21 GB .. 146 GB of HBM, fewer group
- * additions, two kernels per batch), "chain_accumulate" (1 = consecutive calls' accumulate kernels run back to back
- * even when issued on different streams; 0 = no cross-call ordering). */
+/* Tuning knobs.  Changing one waits for the calls in flight on the context.
+ *   "msm_window"          11..13: window width of the bucket method
+ *   "max_batch"           blobs per launch of the commitment kernels (workspace size)
+ *   "commit_direct_bits"  0 = bucket method (library default: 10.5 MB table); 12..15 = direct window table for
+ *                         BlobToKZGCommitment / the proof MSM (21 GB .. 146 GB of HBM, fewer group additions); -1 = the widest
+ *                         table that leaves 40 GB of the device's free memory untouched.  If the table cannot be allocated the
+ *                         next narrower one is tried and finally the bucket method is used: the call still succeeds with the
+ *                         same bytes; "commit_direct_bits_effective" (get) reports what is in use.
+ *   "host_chunk"          blobs per chunk of the host-pointer commitment pipeline (gather / upload / kernels overlap per chunk)
+ *   "host_sha"            host-pointer verifiers: Fiat-Shamir challenges hashed by the host pool while the blobs upload (1),
+ *                         on the device after the upload (0), library's choice (-1, default) */
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
+/* reads an option back; also "commit_direct_bits_effective", "devices", "lanes" */
+int mkzg_ctx_get_option(mkzg_ctx* ctx, const char* key, long* value);
 
 /* ---- EIP-4844 ------------------------------------------------------------------------------ */
 /* Context.BlobToKZGCommitment (reference prove.go:13-33).  num_threads mirrors numGoRoutines:
@@ -97,7 +112,7 @@ int mkzg_verify_kzg_proof(mkzg_ctx* ctx, const uint8_t commitment48[48], const u
 int mkzg_verify_blob_kzg_proof(mkzg_ctx* ctx, const uint8_t* blob, const uint8_t commitment48[48], const uint8_t proof48[48]);
 /* Context.VerifyBlobKZGProofBatch (reference verify.go:88-143; also covers ...BatchPar, verify.go:152-169,
  * which must return the same verdict).  blobs: array of host pointers; the three counts mirror the
- * three Go slices (mismatch -> MKZG_ERR_BATCH_LENGTH).  At most 8192 proofs per call. */
+ * three Go slices (mismatch -> MKZG_ERR_BATCH_LENGTH).  Any number of proofs. */
 int mkzg_verify_blob_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n_blobs, size_t n_comm,
                                      size_t n_proofs);
 /* same, inputs contiguous in HBM; synchronises `stream` internally (the verdict needs the host pairing). */
@@ -106,7 +121,9 @@ int mkzg_verify_blob_kzg_proof_batch_device(mkzg_ctx* ctx, const void* d_blobs, 
 /* Sharded VerifyBlobKZGProofBatch for multi-GPU jobs (one context/process per GPU): every rank folds its
  * shard (global indices offset .. offset+n_local) with the batch-wide scalar r32 (32 bytes big-endian, chosen by
  * rank 0 and broadcast) into a 512-byte record; after an all-gather any rank combines the records and runs the
- * single pairing check.  Equivalent to reference internal/kzg/kzg_verify.go:111-202 on the concatenated batch. */
+ * single pairing check.  Equivalent to reference internal/kzg/kzg_verify.go:111-202 on the concatenated batch.
+ * SOUNDNESS: the index ranges [offset, offset + n_local) of the ranks must tile the batch exactly -- two items folded with
+ * the same power of r can cancel each other's errors, and the verdict is still an ordinary accept / reject. */
 int mkzg_verify_blob_kzg_proof_batch_partial_device(mkzg_ctx* ctx, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n_local,
                                                     uint64_t offset, const uint8_t r32[32], uint8_t record512[512], void* stream);
 int mkzg_verify_blob_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* records512, size_t n_records);
@@ -127,14 +144,15 @@ int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* ctx, const uint8_t* blob, int nu
 int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n, void* d_cells, void* d_proofs, int* d_status, void* stream);
 
 /* Context.VerifyCellKZGProofBatch (reference api_eip7594.go:163-214): one commitment, cell index, cell and
- * proof per entry; the four counts mirror the four Go slices.  At most 8192 cells per call. */
+ * proof per entry; the four counts mirror the four Go slices.  Any number of cells. */
 int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* commitments48n, size_t n_commitments, const uint64_t* cell_indices, size_t n_indices,
                                      const uint8_t* const* cells, size_t n_cells, const uint8_t* proofs48n, size_t n_proofs);
 /* Sharded form for multi-GPU jobs (the algebra of reference internal/kzg_multi/kzg_verify.go:16-105 split at its
  * four group sums): a rank folds ITS cells -- global positions offset .. offset + n - 1 of the batch -- with the batch-wide
  * scalar r32 (32 bytes, big-endian, reduced mod r; the same on every rank) into a 512-byte record: int32 status at 0, then
  * compressed sum r^k proof_k at 16, sum w_row C_row at 64, [I(tau)]G1 at 112, sum r^k h_k^64 proof_k at 160.  Records of all
- * ranks (all-gathered, 512 B each) go to _finish on any rank: sums are added, one pairing check decides. */
+ * ranks (all-gathered, 512 B each) go to _finish on any rank: sums are added, one pairing check decides.  As above, the
+ * ranges [offset, offset + n) of the ranks must tile the batch exactly. */
 int mkzg_verify_cell_kzg_proof_batch_partial(mkzg_ctx* ctx, const uint8_t* commitments48n, size_t n_commitments, const uint64_t* cell_indices, size_t n_indices,
                                              const uint8_t* const* cells, size_t n_cells, const uint8_t* proofs48n, size_t n_proofs, uint64_t offset,
                                              const uint8_t r32[32], uint8_t record512[512]);

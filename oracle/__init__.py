@@ -14,7 +14,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libkzg_oracle.so")
-DEFAULT_SETUP = os.path.join(os.path.dirname(HERE), "tests", "golden", "trusted_setup.json")
+DEFAULT_SETUP = os.path.join(os.path.dirname(HERE), "go-eth-kzg_amd", "trusted_setup.json")
 
 BLOB_BYTES = 131072
 CELL_BYTES = 2048

@@ -95,8 +95,30 @@ def main():
     with open(os.path.join(HERE, "consensus_pool.bin"), "wb") as fh:
         fh.write(pool)
     print(f"{n} cases, pool {len(pool)} bytes, {len(pool_index)} unique blobs/cells", file=sys.stderr)
-    # the trusted setup (data): used by the oracle, the product and every vector
-    shutil.copyfile(f"{REF}/trusted_setup.json", os.path.join(HERE, "trusted_setup.json"))
+    # one vector as raw bytes for the plain-C caller test (tests/c_abi/use_all.c): blob | commitment | blob proof of the first valid
+    # blob_to_kzg_commitment case that compute_blob_kzg_proof covers too
+    def raw(x):
+        return bytes.fromhex(x[2:]) if isinstance(x, str) and x.startswith("0x") and len(x) % 2 == 0 else None
+    done = False
+    for f in sorted(glob.glob(f"{REF}/tests/blob_to_kzg_commitment/*/*/data.yaml")):
+        with open(f) as fh:
+            d = yaml.load(fh, Loader=yaml.CSafeLoader)
+        blob, cm = raw(d["input"]["blob"]), raw(d["output"]) if d["output"] else None
+        if not blob or not cm or len(blob) != 131072 or cm[0] == 0xC0:
+            continue
+        for g in sorted(glob.glob(f"{REF}/tests/compute_blob_kzg_proof/*/*/data.yaml")):
+            with open(g) as fh:
+                e = yaml.load(fh, Loader=yaml.CSafeLoader)
+            if e["output"] and raw(e["input"]["blob"]) == blob and raw(e["input"]["commitment"]) == cm:
+                with open(os.path.join(HERE, "c_caller_vector.bin"), "wb") as fh:
+                    fh.write(blob + cm + raw(e["output"]))
+                done = True
+                break
+        if done:
+            break
+    assert done
+    # the trusted setup (data): used by the oracle, the product and every vector -- ONE copy, next to the product library
+    shutil.copyfile(f"{REF}/trusted_setup.json", os.path.join(os.path.dirname(os.path.dirname(HERE)), "go-eth-kzg_amd", "trusted_setup.json"))
 
 
 if __name__ == "__main__":

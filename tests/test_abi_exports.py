@@ -55,7 +55,7 @@ def test_c_caller_compiles_links_and_fails_cleanly(product):
     libdir = os.path.join(ROOT, "go-eth-kzg_amd")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
                            "-L", libdir, "-lmi355kzg", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "trusted_setup.json")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, os.path.join(ROOT, "go-eth-kzg_amd", "trusted_setup.json")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     import torch
     if not torch.cuda.is_available():

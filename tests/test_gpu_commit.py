@@ -125,18 +125,21 @@ def test_direct_table_mode(product, oracle_ctx, bits):
 
 
 def test_options_and_calibration(product, oracle_ctx):
-    """chain_accumulate only reorders kernels (same bytes); mkzg_valu_calibrate returns a plausible issue rate"""
+    """options only change how the work is cut (same bytes); unknown keys / values are MKZG_ERR_BAD_ARGS; mkzg_valu_calibrate returns
+    a plausible issue rate"""
     import torch
     torch.cuda.init()
-    blobs = [rand_blob(31), rand_blob(32), rand_blob(33)]
+    blobs = [rand_blob(31 + i) for i in range(7)]
     exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
-    for chain in (0, 1):
+    for chunk, batch in ((1, 2), (2, 4), (3, 256), (64, 256)):       # host-pointer pipeline: chunks per piece, pieces per call
         ctx = product.Context()
-        assert ctx.set_option("max_batch", 2) == 0
-        assert ctx.set_option("chain_accumulate", chain) == 0
-        assert ctx.set_option("chain_accumulate", 2) == 17           # MKZG_ERR_BAD_ARGS
+        assert ctx.set_option("max_batch", batch) == 0 and ctx.get_option("max_batch") == batch
+        assert ctx.set_option("host_chunk", chunk) == 0 and ctx.get_option("host_chunk") == chunk
+        assert ctx.set_option("host_chunk", 0) == 17                 # MKZG_ERR_BAD_ARGS
+        assert ctx.set_option("no_such_option", 1) == 17 and ctx.get_option("no_such_option") is None
         rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
-        assert rc == 0 and outs == exp
+        assert rc == 0 and outs == exp and st == [0] * 7
+        assert ctx.get_option("commit_direct_bits_effective") == 0 and ctx.get_option("devices") == 1 and ctx.get_option("lanes") >= 4
         ctx.close()
     ctx = product.Context()
     rate = ctx.valu_calibrate()
@@ -144,16 +147,48 @@ def test_options_and_calibration(product, oracle_ctx):
     assert rate is not None and 1e11 < rate < 2e12                   # 100 G .. 2 T wave-instructions / s
 
 
+def test_direct_table_degrades_instead_of_failing(product, oracle_ctx):
+    """a drop-in must degrade, not fail: with most of the HBM taken the 146 GB table cannot be allocated -- the library steps down to
+    a narrower table or to the bucket method and still returns the reference's bytes"""
+    import torch
+    torch.cuda.init()
+    free, total = torch.cuda.mem_get_info()
+    keep = 30 << 30                                                  # leave 30 GB: room for the 12-bit table (21.5 GB) at most
+    hog = torch.empty(max(0, free - keep), dtype=torch.uint8, device="cuda") if free > keep else None
+    blobs = [rand_blob(51), rand_blob(52)]
+    ctx = product.Context()
+    try:
+        assert ctx.set_option("commit_direct_bits", 15) == 0
+        rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
+        assert rc == 0 and st == [0, 0]
+        assert outs == [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
+        eff = ctx.get_option("commit_direct_bits_effective")
+        assert eff in (0, 12), eff                                   # never the width asked for: it cannot fit
+        # auto sizing leaves 40 GB headroom: with 30 GB free that means the bucket method
+        assert ctx.set_option("commit_direct_bits", -1) == 0
+        rc, outs2, st = ctx.BlobToKZGCommitmentBatch(blobs)
+        assert rc == 0 and outs2 == outs and ctx.get_option("commit_direct_bits_effective") == 0
+    finally:
+        ctx.close()
+        del hog
+        torch.cuda.empty_cache()
+
+
 def test_c_program_through_the_abi():
-    """tests/c_abi/use_all.c (plain C99 against include/mi355kzg.h, as cgo would bind it) commits the zero blob on the GPU"""
+    """tests/c_abi/use_all.c (plain C99 against include/mi355kzg.h, as cgo would bind it) on the GPU: the zero blob, a consensus-spec
+    commitment vector byte for byte, proof + verify accept / reject"""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src, exe, libdir = os.path.join(root, "tests", "c_abi", "use_all.c"), os.path.join(root, "tests", "c_abi", "use_all"), os.path.join(root, "go-eth-kzg_amd")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), src, "-o", exe, "-L", libdir, "-lmi355kzg",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    r = subprocess.run([exe, os.path.join(root, "tests", "golden", "trusted_setup.json")], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "commitment of the zero blob: rc=0 ok" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, os.path.join(root, "go-eth-kzg_amd", "trusted_setup.json"), os.path.join(root, "tests", "golden", "c_caller_vector.bin")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for line in ("commitment of the zero blob: rc=0 ok", "commitment vector: rc=0 ok", "proof vector: rc=0 ok", "verify valid: rc=0 ok", "verify corrupted: rc=1 ok",
+                 "batch verify valid: rc=0 ok", "batch verify corrupted: rc=1 ok"):
+        assert line in r.stdout, r.stdout + r.stderr
 
 
 def test_msm_g1_gnark_layouts(gpu_ctx):

@@ -229,38 +229,70 @@ def test_proofs_with_direct_table(product, oracle_ctx):
 
 
 def test_shared_context_from_threads(gpu_ctx, oracle_ctx):
-    """the reference's Context is shared by goroutines (verify.go:159-165); here: four host threads hammer one context with
-    different calls (ctypes drops the GIL, so they really contend for the library's mutex and workspaces)"""
+    """the reference's Context is shared by goroutines (verify.go:152-169, examples_test.go:11); here: eight host threads hammer one
+    context with different calls (ctypes drops the GIL, so the calls really overlap: more callers than lanes, every kind of entry
+    point, device-pointer and host-pointer forms mixed) and every result must equal the serial one"""
     import threading
+    import torch
     from test_gpu_commit import rand_blob
     blobs = [rand_blob(300 + i) for i in range(4)]
     exp_cm = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
     exp_pr = [oracle_ctx.compute_blob_kzg_proof(b, c)[1] for b, c in zip(blobs, exp_cm)]
+    rc, cells0, proofs0 = gpu_ctx.ComputeCellsAndKZGProofs(blobs[0])
+    assert rc == 0
+    rco, oc, op = oracle_ctx.compute_cells_and_kzg_proofs(blobs[0])
+    assert b"".join(cells0) == oc and b"".join(proofs0) == op
+    # a device-resident batch of 256 for the throughput-shaped calls
+    N = 256
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs[i % 4] for i in range(N))), dtype=torch.uint8).cuda()
+    d_cm = torch.frombuffer(bytearray(b"".join(exp_cm[i % 4] for i in range(N))), dtype=torch.uint8).cuda()
+    d_pr = torch.frombuffer(bytearray(b"".join(exp_pr[i % 4] for i in range(N))), dtype=torch.uint8).cuda()
+    d_bad = d_pr.clone()
+    d_bad[48 * 200:48 * 201] = d_pr[48 * 201:48 * 202]
+    torch.cuda.synchronize()
     errors = []
 
     def worker(k):
         try:
-            for it in range(6):
+            stream = torch.cuda.Stream()
+            d_out = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
+            d_st = torch.ones(N, dtype=torch.int32, device="cuda")
+            for it in range(8):
                 i = (k + it) % 4
-                which = (k + it) % 3
+                which = (k + it) % 7
                 if which == 0:
                     rc, cm = gpu_ctx.BlobToKZGCommitment(blobs[i])
                     assert rc == 0 and cm == exp_cm[i]
                 elif which == 1:
                     rc, pr = gpu_ctx.ComputeBlobKZGProof(blobs[i], exp_cm[i])
                     assert rc == 0 and pr == exp_pr[i]
-                else:
+                elif which == 2:
                     assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, exp_cm, exp_pr) == 0
                     bad = list(exp_pr)
                     bad[i] = exp_pr[(i + 1) % 4]
                     assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, exp_cm, bad) == 1
-        except Exception as e:      # noqa: BLE001
+                elif which == 3:
+                    assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, stream.cuda_stream) == 0
+                    assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_bad.data_ptr(), N, stream.cuda_stream) == 1
+                elif which == 4:
+                    assert gpu_ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), N, d_out.data_ptr(), d_st.data_ptr(), stream.cuda_stream) == 0
+                    stream.synchronize()
+                    assert int(d_st.abs().sum().item()) == 0 and bool((d_out == d_cm).all().item())
+                elif which == 5:
+                    ids = [0, 3, 64, 127, 1]
+                    assert gpu_ctx.VerifyCellKZGProofBatch([exp_cm[0]] * 5, ids, [cells0[j] for j in ids], [proofs0[j] for j in ids]) == 0
+                    assert gpu_ctx.VerifyCellKZGProofBatch([exp_cm[0]] * 5, ids, [cells0[j] for j in ids], [proofs0[j ^ 1] for j in ids]) == 1
+                else:
+                    half = list(range(i % 2, 128, 2))
+                    rc, rcells, rproofs = gpu_ctx.RecoverCellsAndComputeKZGProofs(half, [cells0[j] for j in half])
+                    assert rc == 0 and rcells == cells0 and rproofs == proofs0
+        except Exception:      # noqa: BLE001
             import traceback
             errors.append(traceback.format_exc())
 
-    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
     for t in ts:
         t.start()
     for t in ts:
-        t.join(timeout=600)
+        t.join(timeout=900)
     assert not errors, errors[0]

@@ -101,3 +101,249 @@ def test_cells_and_proofs_batch_64(gpu_ctx, oracle_ctx):
     assert gpu_ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st) == 0
     torch.cuda.synchronize()
     assert hashlib.sha256(d_proofs.cpu().numpy().tobytes()).hexdigest() == digest
+
+
+def _cells_of_64_blobs(gpu_ctx):
+    """64 GetRandBlob blobs (seeds 0..63) -> their commitments, 8192 cells and 8192 proofs, all produced on the device"""
+    import torch
+    NB = 64
+    blobs = _blobs(NB, 0)
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cells = torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.zeros(NB * 128 * 48, dtype=torch.uint8, device="cuda")
+    d_cm = torch.zeros(NB * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.ones(NB, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0
+    assert gpu_ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), NB, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0
+    cms = d_cm.cpu().numpy().tobytes()
+    cells = d_cells.cpu().numpy().tobytes()
+    proofs = d_proofs.cpu().numpy().tobytes()
+    return blobs, cms, cells, proofs
+
+
+def test_verify_cell_batch_8192_and_recover_64(gpu_ctx, oracle_ctx):
+    """configs[4] at BASELINE size on one GPU: VerifyCellKZGProofBatch over 64 blobs x 128 cells = 8192 (commitment, index, cell,
+    proof) tuples in blob-major order (reference bench_eip7594_test.go:45-60 scaled to SURVEY 8d's cfg 5a) and
+    RecoverCellsAndComputeKZGProofs of all 64 blobs from their even-indexed cells (bench_eip7594_test.go:62-76)."""
+    NB = 64
+    blobs, cms, cells, proofs = _cells_of_64_blobs(gpu_ctx)
+    c_list, i_list, cell_list, p_list = [], [], [], []
+    for b in range(NB):
+        for k in range(128):
+            c_list.append(cms[48 * b:48 * b + 48])
+            i_list.append(k)
+            cell_list.append(cells[b * 262144 + k * 2048:b * 262144 + (k + 1) * 2048])
+            p_list.append(proofs[(b * 128 + k) * 48:(b * 128 + k + 1) * 48])
+    assert len(c_list) == 8192
+    # parity anchors: three blobs' commitments, cells and proofs against the oracle
+    for b in (0, 31, 63):
+        assert oracle_ctx.blob_to_kzg_commitment(blobs[b]) == (0, cms[48 * b:48 * b + 48])
+        rc, ec, ep = oracle_ctx.compute_cells_and_kzg_proofs(blobs[b])
+        assert rc == 0 and ec == cells[b * 262144:(b + 1) * 262144] and ep == proofs[b * 6144:(b + 1) * 6144]
+    assert gpu_ctx.VerifyCellKZGProofBatch(c_list, i_list, cell_list, p_list) == 0
+    # one swapped cell anywhere -> verification failure (not an input error)
+    for victim in (0, 4100, 8191):
+        bad = list(cell_list)
+        other = victim ^ 1
+        bad[victim], bad[other] = bad[other], bad[victim]
+        assert gpu_ctx.VerifyCellKZGProofBatch(c_list, i_list, bad, p_list) == 1
+    # a proof with the compression flag cleared -> decoding error
+    badp = list(p_list)
+    badp[5000] = bytes([badp[5000][0] & 0x7F]) + badp[5000][1:]
+    assert gpu_ctx.VerifyCellKZGProofBatch(c_list, i_list, cell_list, badp) == 11
+    # a cell holding a field element >= r -> non-canonical scalar
+    badc = list(cell_list)
+    badc[8000] = badc[8000][:32 * 17] + b"\xff" * 32 + badc[8000][32 * 18:]
+    assert gpu_ctx.VerifyCellKZGProofBatch(c_list, i_list, badc, p_list) == 3
+    # order independence: the same tuples cell-major (the commitments no longer arrive in runs) still verify
+    perm = [b * 128 + k for k in range(128) for b in range(NB)]
+    assert gpu_ctx.VerifyCellKZGProofBatch([c_list[i] for i in perm], [i_list[i] for i in perm], [cell_list[i] for i in perm], [p_list[i] for i in perm]) == 0
+
+    # ---- recovery of all 64 blobs from their 64 even-indexed cells, one batch call
+    ids = list(range(0, 128, 2))
+    jobs = [(ids, [cell_list[b * 128 + i] for i in ids]) for b in range(NB)]
+    rc, res = gpu_ctx.RecoverCellsAndComputeKZGProofsBatch(jobs)
+    assert rc == 0 and len(res) == NB
+    for b in range(NB):
+        st, oc, op = res[b]
+        assert st == 0
+        assert b"".join(oc) == cells[b * 262144:(b + 1) * 262144], b          # round trip: erase -> recover == the encoder's output
+        assert b"".join(op) == proofs[b * 6144:(b + 1) * 6144], b
+    for b in (1, 40, 62):                                                      # and bit-exact against the oracle's own recovery
+        rc, ec, ep = oracle_ctx.recover_cells_and_kzg_proofs(ids, jobs[b][1])
+        assert rc == 0 and ec == b"".join(res[b][1]) and ep == b"".join(res[b][2])
+
+
+def test_commitment_batch_256_direct_table_c15(product, oracle_ctx):
+    """configs[1] exactly as bench.py runs it: 256 blobs through the 15-bit direct window table (146 GB), device-resident,
+    on the two prioritised streams bench.py alternates over -- every 8th commitment against the oracle, all of them against the
+    bucket method (the two methods share no kernel)."""
+    import torch
+    torch.cuda.init()
+    B = 256
+    blobs = _blobs(B, 0)
+    ctx = product.Context()
+    try:
+        assert ctx.set_option("max_batch", B) == 0
+        d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+        d_ref = torch.zeros(B * 48, dtype=torch.uint8, device="cuda")
+        d_st = torch.ones(B, dtype=torch.int32, device="cuda")
+        assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), B, d_ref.data_ptr(), d_st.data_ptr(), 0) == 0      # bucket method
+        torch.cuda.synchronize()
+        assert int(d_st.abs().sum().item()) == 0
+        assert ctx.set_option("commit_direct_bits", 15) == 0
+        streams = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)]
+        outs = [torch.zeros(B * 48, dtype=torch.uint8, device="cuda") for _ in streams]
+        sts = [torch.ones(B, dtype=torch.int32, device="cuda") for _ in streams]
+        for rep in range(4):
+            i = rep % 2
+            assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), B, outs[i].data_ptr(), sts[i].data_ptr(), streams[i].cuda_stream) == 0
+        torch.cuda.synchronize()
+        assert ctx.get_option("commit_direct_bits_effective") == 15, "the 146 GB table was not available on this box"
+        for i in range(2):
+            assert int(sts[i].abs().sum().item()) == 0
+            assert bool((outs[i] == d_ref).all().item())
+        out = outs[0].cpu().numpy().tobytes()
+        idx = list(range(0, B, 8))
+        rc, exp, _ = oracle_ctx.blob_to_kzg_commitment_batch(b"".join(blobs[i] for i in idx), len(idx))
+        assert rc == 0
+        for k, i in enumerate(idx):
+            assert out[48 * i:48 * i + 48] == exp[48 * k:48 * k + 48], i
+    finally:
+        ctx.close()
+
+
+def test_batches_beyond_8192(gpu_ctx):
+    """the reference's batch verifiers take any length (verify.go:88-143, api_eip7594.go:163-214); here batches above the MSM
+    kernels' 8192-point jobs are cut into pieces that share ONE random scalar and carry global exponents.  8193 items: the last
+    piece holds a single item."""
+    import torch
+    NB, N = 64, 8193
+    blobs, cms, cells, proofs = _cells_of_64_blobs(gpu_ctx)
+    # ---- VerifyBlobKZGProofBatch over 8193 device-resident (blob, commitment, proof) triples (the 64 blobs, repeated)
+    d_blobs64 = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cm64 = torch.frombuffer(bytearray(cms), dtype=torch.uint8).cuda()
+    d_pr64 = torch.zeros(NB * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(NB, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_ctx.compute_blob_kzg_proof_batch_device(d_blobs64.data_ptr(), d_cm64.data_ptr(), NB, d_pr64.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0
+    idx = torch.arange(N, device="cuda") % NB
+    d_blobs = d_blobs64.view(NB, 131072)[idx].contiguous().view(-1)
+    d_cm = d_cm64.view(NB, 48)[idx].contiguous().view(-1)
+    d_pr = d_pr64.view(NB, 48)[idx].contiguous().view(-1)
+    torch.cuda.synchronize()
+    assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st) == 0
+    for victim in (8192, 8191, 0):                      # the lone item of the last piece, the last of the first piece, the first
+        bad = d_pr.clone()
+        other = (victim + 1) % NB
+        bad[48 * victim:48 * victim + 48] = d_pr64[48 * other:48 * other + 48]
+        assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), bad.data_ptr(), N, st) == 1, victim
+    badc = d_cm.clone()
+    badc[48 * 8192] = 0x00
+    assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), badc.data_ptr(), d_pr.data_ptr(), N, st) == 11
+    # two items swapped ACROSS the piece boundary: every piece on its own would still see valid-looking inputs of the right kind;
+    # only the global exponents / the single r make the batch fail
+    sw = d_pr.clone()
+    sw[48 * 8191:48 * 8192], sw[48 * 8192:48 * 8193] = d_pr[48 * 8192:48 * 8193].clone(), d_pr[48 * 8191:48 * 8192].clone()
+    assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), sw.data_ptr(), N, st) == 1
+    del d_blobs, bad, badc, sw
+    # ---- the same through the host-pointer entry point (Go's []*Blob): 2100 items = two staging pieces
+    host_blobs = [blobs[i % NB] for i in range(2100)]
+    pr64 = d_pr64.cpu().numpy().tobytes()
+    h_cms = [cms[48 * (i % NB):48 * (i % NB) + 48] for i in range(2100)]
+    h_prs = [pr64[48 * (i % NB):48 * (i % NB) + 48] for i in range(2100)]
+    assert gpu_ctx.VerifyBlobKZGProofBatch(host_blobs, h_cms, h_prs) == 0
+    h_bad = list(h_prs)
+    h_bad[2099] = h_prs[0]
+    assert gpu_ctx.VerifyBlobKZGProofBatch(host_blobs, h_cms, h_bad) == 1
+    h_nil = list(host_blobs)
+    h_nil[2050] = None
+    assert gpu_ctx.VerifyBlobKZGProofBatch(h_nil, h_cms, h_prs) == 6          # ErrDeserializeNilInput
+    # ---- VerifyCellKZGProofBatch over 8193 cells: the 8192 of the 64 blobs plus one of them again
+    c_list, i_list, cell_list, p_list = [], [], [], []
+    for b in range(NB):
+        for k in range(128):
+            c_list.append(cms[48 * b:48 * b + 48])
+            i_list.append(k)
+            cell_list.append(cells[b * 262144 + k * 2048:b * 262144 + (k + 1) * 2048])
+            p_list.append(proofs[(b * 128 + k) * 48:(b * 128 + k + 1) * 48])
+    c_list.append(c_list[77]); i_list.append(i_list[77]); cell_list.append(cell_list[77]); p_list.append(p_list[77])
+    assert len(c_list) == N
+    assert gpu_ctx.VerifyCellKZGProofBatch(c_list, i_list, cell_list, p_list) == 0
+    badl = list(cell_list)
+    badl[8192] = cell_list[78]
+    assert gpu_ctx.VerifyCellKZGProofBatch(c_list, i_list, badl, p_list) == 1
+    badl = list(cell_list)
+    badl[8191], badl[8192] = cell_list[8192], cell_list[8191]
+    assert gpu_ctx.VerifyCellKZGProofBatch(c_list, i_list, badl, p_list) == 1
+    badi = list(i_list)
+    badi[8192] = 128
+    assert gpu_ctx.VerifyCellKZGProofBatch(c_list, badi, cell_list, p_list) == 4           # ErrInvalidCellID
+
+
+def test_multi_device_context_on_one_gpu(product, oracle_ctx):
+    """mkzg_ctx_new with n_dev > 1: one context that shards host-pointer batches over the listed devices and combines the batch
+    verifiers' partial sums in process.  A 1-GPU box lists device 0 twice -- two full per-device contexts on the same GPU, which
+    exercises the whole orchestration (shard bounds, per-device threads, in-process fold / finish, error precedence)."""
+    import torch
+    torch.cuda.init()
+    assert product.lib().mkzg_ctx_new(b"{}", 2, (product.C.c_int * 2)(0, 99), 2, product.C.byref(product.C.c_void_p())) == 17      # no such device
+    ctx = product.Context(devices=[0, 0])
+    try:
+        assert ctx.get_option("devices") == 2
+        blobs = _blobs(7, 500)
+        exp_cm = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
+        rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
+        assert rc == 0 and outs == exp_cm and st == [0] * 7
+        bad = bytearray(blobs[5])
+        bad[64:96] = b"\xff" * 32
+        rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs[:5] + [bytes(bad)] + blobs[6:])
+        assert rc == 3 and st == [0, 0, 0, 0, 0, 3, 0] and outs[6] == exp_cm[6]
+        exp_pr = []
+        for b, c in zip(blobs, exp_cm):
+            rc, pr = ctx.ComputeBlobKZGProof(b, c)                    # single-item calls go round-robin over the devices
+            assert rc == 0 and pr == oracle_ctx.compute_blob_kzg_proof(b, c)[1]
+            exp_pr.append(pr)
+        assert ctx.VerifyBlobKZGProofBatch(blobs, exp_cm, exp_pr) == 0
+        swapped = list(exp_pr)
+        swapped[2], swapped[5] = swapped[5], swapped[2]                # one item on each device's shard
+        assert ctx.VerifyBlobKZGProofBatch(blobs, exp_cm, swapped) == 1
+        assert ctx.VerifyBlobKZGProofBatch(blobs[:5] + [bytes(bad)] + blobs[6:], exp_cm, exp_pr) == 3
+        assert ctx.VerifyBlobKZGProofBatch(blobs, exp_cm, exp_pr[:6]) == 2
+        for i in range(7):
+            assert ctx.VerifyBlobKZGProof(blobs[i], exp_cm[i], exp_pr[i]) == 0
+        # cells: two blobs, 20 tuples cut 10 / 10 over the devices
+        tuples = []
+        for bi in (0, 1):
+            rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blobs[bi])
+            assert rc == 0
+            rco, oc, op = oracle_ctx.compute_cells_and_kzg_proofs(blobs[bi])
+            assert b"".join(cells) == oc and b"".join(proofs) == op
+            for ci in (0, 5, 64, 127, 33, 2, 90, 91, 92, 1):
+                tuples.append((exp_cm[bi], ci, cells[ci], proofs[ci]))
+        cols = lambda t: ([x[0] for x in t], [x[1] for x in t], [x[2] for x in t], [x[3] for x in t])
+        assert ctx.VerifyCellKZGProofBatch(*cols(tuples)) == 0
+        badt = list(tuples)
+        badt[3] = (badt[3][0], badt[3][1], badt[3][2], badt[14][3])
+        assert ctx.VerifyCellKZGProofBatch(*cols(badt)) == 1
+        # recovery batch sharded by blob
+        ids = list(range(1, 128, 2))
+        jobs = []
+        full = []
+        for bi in (0, 1, 2):
+            rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blobs[bi])
+            full.append((cells, proofs))
+            jobs.append((ids, [cells[i] for i in ids]))
+        rc, res = ctx.RecoverCellsAndComputeKZGProofsBatch(jobs)
+        assert rc == 0
+        for bi in range(3):
+            assert res[bi][0] == 0 and res[bi][1] == full[bi][0] and res[bi][2] == full[bi][1]
+    finally:
+        ctx.close()

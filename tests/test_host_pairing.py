@@ -28,7 +28,7 @@ def shim():
 
 @pytest.fixture(scope="module")
 def setup():
-    with open(os.path.join(ROOT, "tests", "golden", "trusted_setup.json")) as fh:
+    with open(os.path.join(ROOT, "go-eth-kzg_amd", "trusted_setup.json")) as fh:
         js = json.load(fh)
     g1 = [bytes.fromhex(x[2:]) for x in js["g1_monomial"][:16]]
     g2 = [bytes.fromhex(x[2:]) for x in js["g2_monomial"][:16]]

@@ -1,0 +1,69 @@
+"""CPU tests of the product's host SHA-256 (go-eth-kzg_amd/csrc/host_sha256.hpp): both compression functions against hashlib over the
+block-boundary lengths, and host_compute_challenge against the reference's own KAT (fiatshamir_test.go:14-25), against a
+restatement of fiatshamir.go:22-33 with hashlib, and against the oracle."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM_DIR = os.path.join(ROOT, "tests", "host_shim")
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def shim():
+    so = os.path.join(SHIM_DIR, "libsha_shim.so")
+    src = os.path.join(SHIM_DIR, "sha_shim.cpp")
+    hdr = os.path.join(ROOT, "go-eth-kzg_amd", "csrc", "host_sha256.hpp")
+    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    L = C.CDLL(so)
+    L.shim_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    L.shim_sha256_c.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    L.shim_challenge.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    return L
+
+
+def test_sha256_against_hashlib(shim):
+    data = bytes((i * 131 + 7) & 0xFF for i in range(4096))
+    for n in [0, 1, 3, 55, 56, 57, 63, 64, 65, 119, 120, 127, 128, 129, 1000, 4096]:
+        for fn in (shim.shim_sha256, shim.shim_sha256_c):
+            out = C.create_string_buffer(32)
+            fn(data[:n], n, out)
+            assert out.raw == hashlib.sha256(data[:n]).digest(), (n, fn)
+
+
+def _challenge(blob, cm):
+    """fiatshamir.go:22-33 restated with hashlib"""
+    d = hashlib.sha256(b"FSBLOBVERIFY_V1_" + (0).to_bytes(8, "big") + (4096).to_bytes(8, "big") + blob + cm).digest()
+    return (int.from_bytes(d, "big") % R).to_bytes(32, "big")
+
+
+def test_challenge_kat_and_oracle(shim):
+    import oracle
+    out = C.create_string_buffer(32)
+    # the reference's interop / regression value (fiatshamir_test.go:14-25): zero blob, commitment = the identity
+    shim.shim_challenge(bytes(131072), bytes([0xC0]) + bytes(47), out)
+    assert out.raw == bytes.fromhex("04b7b22af63d2b2f1ced8d550560e5d1e4b01e355903dee22781e87826856096")
+    blobs = [bytes(131072), oracle.rand_blob(5), oracle.rand_blob(6), (R - 1).to_bytes(32, "big") * 4096]
+    cms = [bytes([0xC0]) + bytes(47), bytes(range(48)), b"\xff" * 48, bytes(48)]
+    for b, c in zip(blobs, cms):
+        shim.shim_challenge(b, c, out)
+        assert out.raw == _challenge(b, c)
+        assert out.raw == oracle.compute_challenge(b, c)
+        assert int.from_bytes(out.raw, "big") < R
+    # digests at and above r are reduced: search a few inputs whose raw digest exceeds r (about half of all do)
+    seen_big = 0
+    for s in range(8):
+        b = oracle.rand_blob(100 + s)
+        d = hashlib.sha256(b"FSBLOBVERIFY_V1_" + (0).to_bytes(8, "big") + (4096).to_bytes(8, "big") + b + cms[1]).digest()
+        if int.from_bytes(d, "big") >= R:
+            seen_big += 1
+            if int.from_bytes(d, "big") >= 2 * R:
+                seen_big += 100
+        shim.shim_challenge(b, cms[1], out)
+        assert out.raw == _challenge(b, cms[1])
+    assert seen_big >= 1

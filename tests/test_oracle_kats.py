@@ -116,7 +116,7 @@ def test_fk20_against_naive_proofs(tmp_path):
     # insecure SRS (internal/kzg_multi/srs.go:113-141): monomial [s^i]G, Lagrange [L_i(s)]G (natural root order)
     g1_mono = [oracle.g1_gen_mul(pow(s, i, R)) for i in range(n)]
     g1_lag = [oracle.g1_gen_mul(l) for l in lagrange_at(domain(n), s)]
-    with open(os.path.join(HERE, "golden", "trusted_setup.json")) as fh:
+    with open(os.path.join(os.path.dirname(HERE), "go-eth-kzg_amd", "trusted_setup.json")) as fh:
         g2 = json.load(fh)["g2_monomial"]          # unused by the proving path; only decoded
     setup = {"g1_monomial": ["0x" + p.hex() for p in g1_mono], "g1_lagrange": ["0x" + p.hex() for p in g1_lag], "g2_monomial": g2}
     path = tmp_path / "insecure_setup.json"

@@ -7,6 +7,7 @@
 //   Context.BlobToKZGCommitment  prove.go:13-33
 //   kzg.CommitKey.Commit      internal/kzg/srs.go:56-62
 //   multiexp.MultiExpG1       internal/multiexp/multiexp.go:20-50
+#include <functional>
 #include <thread>
 #include "ctx.h"
 #include "api_multi.h"
@@ -65,6 +66,8 @@ static int lane_create(Lane* L, int id) {
     HIPCHK(hipStreamCreateWithPriority(&L->stream, hipStreamNonBlocking, greatest));
     HIPCHK(hipStreamCreateWithPriority(&L->side, hipStreamNonBlocking, (least + greatest) / 2));
     HIPCHK(hipStreamCreateWithPriority(&L->side2, hipStreamNonBlocking, least));
+    for (auto& a : L->aux) HIPCHK(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, (least + greatest) / 2));
+    for (auto& e : L->ev_cs) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L->ev_decoded, hipEventDisableTiming));
@@ -111,23 +114,36 @@ static void lane_destroy(Lane* L) {
     if (L->stream) (void)hipStreamDestroy(L->stream);
     if (L->side) (void)hipStreamDestroy(L->side);
     if (L->side2) (void)hipStreamDestroy(L->side2);
+    for (auto& a : L->aux) if (a) (void)hipStreamDestroy(a);
+    for (auto& e : L->ev_cs) if (e) (void)hipEventDestroy(e);
     hipEvent_t evs[] = {L->ev_fork, L->ev_join, L->ev_decoded, L->done};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& e : L->ev_chunk) if (e) (void)hipEventDestroy(e);
 }
 
+// Which free lane: the most recently used one whose previous call has finished on the GPU (its workspaces are allocated and warm; a lone
+// synchronous caller therefore keeps to one lane), and only if every free lane still has work in flight -- asynchronous callers issuing
+// faster than the GPU retires -- the one released longest ago, whose work ends soonest.  Consecutive asynchronous calls thus alternate
+// between lanes and overlap, as the two-workspace scheme of the commitment path always did.
 Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
     Lane* L = nullptr;
     {
         std::unique_lock<std::mutex> lk(c->mu);
         for (;;) {
+            Lane* idle = nullptr;
+            Lane* oldest = nullptr;
             for (int i = 0; i < mkzg_ctx::NLANE; i++) {
                 Lane* q = &c->lanes[i];
-                if (!q->busy && (!L || q->released_at < L->released_at)) L = q;
+                if (q->busy) continue;
+                if (!oldest || q->released_at < oldest->released_at) oldest = q;
+                const bool finished = !q->used || hipEventQuery(q->done) == hipSuccess;
+                if (finished && (!idle || q->released_at > idle->released_at)) idle = q;
             }
+            L = idle ? idle : oldest;
             if (L) break;
             c->cv.wait(lk);
         }
+        (void)hipGetLastError();           // hipEventQuery reports hipErrorNotReady through the sticky error too
         L->busy = true;
     }
     (void)hipSetDevice(c->device);
@@ -143,6 +159,7 @@ void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s) {
         (void)hipStreamSynchronize(L->stream);
         (void)hipStreamSynchronize(L->side);
         (void)hipStreamSynchronize(L->side2);
+        for (auto& a : L->aux) (void)hipStreamSynchronize(a);
         (void)hipGetLastError();
     }
     (void)hipEventRecord(L->done, s);
@@ -332,37 +349,91 @@ int ensure_staging(Lane* L, size_t n_items, size_t in_bytes_per_item) {
     return MKZG_OK;
 }
 
-// Host-pointer commitments, one piece of at most max_batch blobs: the blobs (Go's []*Blob: scattered, pageable) are gathered into the
-// lane's pinned staging area chunk by chunk by the host pool; chunk k's copy to the device and its kernels are in flight while chunk
-// k + 1 is gathered, chunks alternate between two streams of different priority (their accumulate kernels are grids of single-wave
-// workgroups, so a later chunk's waves fill the SIMD slots an earlier one leaves), and every chunk works in its own item range of the
-// lane's workspace.  One synchronisation at the end.
+// Host-pointer commitments, one piece of at most max_batch blobs.  The blobs (Go's []*Blob: scattered, pageable) are gathered into the
+// lane's pinned staging area by the host pool, which runs AHEAD of the calling thread: the gather tasks of all chunks are queued at
+// once, the caller waits for chunk k's tasks only and issues chunk k's device work while chunks k + 1.. are still being gathered.
+//   direct table : every chunk gets its own accumulate launch on one of four compute streams -- the accumulate kernels are grids of
+//                  single-wave workgroups, so the chunks run side by side as they arrive (four 64-blob chunks = the 2048 wavefronts
+//                  of one 256-blob launch), each in its own item range of the lane's workspace; the first chunk is a small one so
+//                  that the GPU starts early, and ONE finish launch follows the last chunk.  With host_zero_copy the kernel reads its
+//                  scalars straight from the pinned staging area (every wavefront fetches 2 KB per 17 table additions: the PCIe link is
+//                  asked for ~25 GB/s spread over the kernel's duration), which takes the explicit copy off the critical path;
+//                  otherwise each chunk is copied on the lane's copy stream and its kernel waits for that copy.
+//   bucket method: its four kernels per launch are latency-bound on small batches, so ONE launch over the piece follows the last copy.
+// One synchronisation at the end.
 static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, size_t n, uint8_t* out48n, int* st_out) {
     int rc = ensure_staging(L, (size_t)c->opt_max_batch, MKZG_BYTES_PER_BLOB);
     if (!rc) rc = commit_prepare(c, L);
     if (rc) return rc;
+    const bool direct = c->direct_bits_built != 0, zc = direct && c->opt_host_zero_copy != 0;
+    KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
     const size_t CH = (size_t)std::max(1, c->opt_host_chunk);
-    hipStream_t ss[2] = {L->stream, L->side2};
-    const int nthr = n >= 8 ? 8 : 1;
-    HIPCHK(hipEventRecord(L->ev_fork, L->stream));
-    HIPCHK(hipStreamWaitEvent(L->side2, L->ev_fork, 0));       // the second stream inherits the lane hand-over
-    int k = 0;
-    for (size_t lo = 0; lo < n; lo += CH, k++) {
-        const size_t m = std::min(CH, n - lo);
-        hipStream_t s = ss[k & 1];
-        const size_t per = (m + nthr - 1) / nthr;
-        c->pool->parallel(nthr, [&](int q) {
-            for (size_t i = lo + (size_t)q * per; i < std::min(lo + m, lo + (size_t)(q + 1) * per); i++) memcpy(L->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB);
-        });
-        HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, m * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, s));
-        commit_piece(c, L, L->d_blobs + lo * MKZG_BYTES_PER_BLOB, MKZG_BYTES_PER_BLOB, 0, (int)m, (int)lo, L->d_out + lo * 48, L->d_status + lo, s);
-        HIPCHK(hipMemcpyAsync(L->h_out + lo * 48, L->d_out + lo * 48, m * 48, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(L->h_out + L->h_out_items * 48 + lo * 4, L->d_status + lo, m * sizeof(int), hipMemcpyDeviceToHost, s));
+    hipStream_t copy = L->side, cs[4] = {L->stream, L->side2, L->aux[0], L->aux[1]};
+    bool cs_used[4] = {true, false, false, false};
+    // chunk plan
+    struct Chunk { size_t lo, m; };
+    std::vector<Chunk> plan;
+    for (size_t lo = 0; lo < n;) {
+        size_t m = std::min(n - lo, (plan.empty() && direct && CH >= 32) ? CH / 2 : CH);
+        if (n - lo - m < CH / 2 + 1 && n - lo <= CH + CH / 2) m = n - lo;          // no tiny tail chunk: the last one takes up to 1.5 chunks
+        plan.push_back({lo, m});
+        lo += m;
     }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(L->ev_join, L->side2));
-    HIPCHK(hipStreamWaitEvent(L->stream, L->ev_join, 0));
-    HIPCHK(hipStreamSynchronize(L->stream));
+    // gather tasks: TPC per chunk, queued in chunk order
+    const int TPC = n >= 8 ? 4 : 1;
+    const int ntask = (int)plan.size() * TPC;
+    std::vector<std::atomic<int>> left(plan.size());
+    for (auto& a : left) a.store(TPC, std::memory_order_relaxed);
+    std::atomic<int> all_left(ntask);
+    const std::function<void(int)> gather = [&](int t) {
+        const Chunk& ch = plan[(size_t)(t / TPC)];
+        const int q = t % TPC;
+        const size_t per = (ch.m + TPC - 1) / TPC;
+        for (size_t i = ch.lo + (size_t)q * per; i < std::min(ch.lo + ch.m, ch.lo + (size_t)(q + 1) * per); i++) memcpy(L->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB);
+        left[(size_t)(t / TPC)].fetch_sub(1, std::memory_order_release);
+    };
+    c->pool->run_async(ntask, gather, &all_left);
+    // every exit path below must wait for the gather tasks: they reference this frame
+    auto drain = [&] { while (all_left.load(std::memory_order_acquire) != 0) std::this_thread::yield(); };
+    rc = [&]() -> int {
+        HIPCHK(hipEventRecord(L->ev_fork, L->stream));
+        if (!zc) HIPCHK(hipStreamWaitEvent(copy, L->ev_fork, 0));           // every stream of the call inherits the lane hand-over
+        for (size_t k = 0; k < plan.size(); k++) {
+            const size_t lo = plan[k].lo, m = plan[k].m;
+            while (left[k].load(std::memory_order_acquire) != 0) std::this_thread::yield();
+            if (!zc) HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, m * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, copy));
+            if (direct) {
+                const int q = (int)(k & 3);
+                hipStream_t s = cs[q];
+                if (!cs_used[q]) { HIPCHK(hipStreamWaitEvent(s, L->ev_fork, 0)); cs_used[q] = true; }
+                if (!zc) {
+                    HIPCHK(hipEventRecord(L->ev_chunk[k & 7], copy));
+                    HIPCHK(hipStreamWaitEvent(s, L->ev_chunk[k & 7], 0));
+                }
+                const uint8_t* src = (zc ? L->h_stage : L->d_blobs) + lo * MKZG_BYTES_PER_BLOB;
+                commit_direct_acc_device(c->direct_bits_built, c->d_direct, direct_slot_offset(L->dslot, (int)lo), src, MKZG_BYTES_PER_BLOB, 0, (int)m, s, kt);
+            }
+        }
+        // join the compute streams (direct) / the copy stream into the lane's main stream
+        for (int q = 1; q < 4; q++) {
+            if (!cs_used[q]) continue;
+            HIPCHK(hipEventRecord(L->ev_cs[q], cs[q]));
+            HIPCHK(hipStreamWaitEvent(L->stream, L->ev_cs[q], 0));
+        }
+        if (!zc) {
+            HIPCHK(hipEventRecord(L->ev_cs[0], copy));
+            HIPCHK(hipStreamWaitEvent(L->stream, L->ev_cs[0], 0));
+        }
+        if (direct) commit_direct_fin_device(L->dslot, (int)n, L->d_out, L->d_status, L->stream, kt);
+        else commit_piece(c, L, L->d_blobs, MKZG_BYTES_PER_BLOB, 0, (int)n, 0, L->d_out, L->d_status, L->stream);
+        HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, n * 48, hipMemcpyDeviceToHost, L->stream));
+        HIPCHK(hipMemcpyAsync(L->h_out + L->h_out_items * 48, L->d_status, n * sizeof(int), hipMemcpyDeviceToHost, L->stream));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(L->stream));
+        return MKZG_OK;
+    }();
+    drain();
+    if (rc) return rc;
     memcpy(out48n, L->h_out, n * 48);
     memcpy(st_out, L->h_out + L->h_out_items * 48, n * sizeof(int));
     return MKZG_OK;
@@ -403,10 +474,23 @@ void mkzg_ctx_free(mkzg_ctx* c) {
     ctx_destroy_one(c);
 }
 
+// CPUs this process may really burn: the hardware threads capped by the cgroup CPU quota (a container can show 256 and grant 16)
+static unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        unsigned long period = 0;
+        if (fscanf(f, "%31s %lu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const unsigned long quota = strtoul(q, nullptr, 10);
+            if (quota >= period) n = std::min<unsigned>(n, (unsigned)(quota / period));
+        }
+        fclose(f);
+    }
+    return n;
+}
 static int ctx_create_one(const char* js, size_t len, int device, mkzg_ctx** out) {
     mkzg_ctx* c = new mkzg_ctx();
-    const unsigned hw = std::thread::hardware_concurrency();
-    c->pool = new kzg::HostPool((int)std::min(15u, std::max(7u, hw / 4)));
+    c->pool = new kzg::HostPool((int)std::min(15u, std::max(3u, usable_cpus() - 1)));
     c->device = device;
     // reference api.go:93-95 (ErrMinSRSSize) and the fixed-size arrays of trusted_setup.go:23-27
     if (!parse_hex_array(js, len, "g1_monomial", 48, c->g1_monomial) || !parse_hex_array(js, len, "g1_lagrange", 48, c->g1_lagrange) ||
@@ -529,6 +613,11 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         c->opt_host_chunk = (int)value;
         return MKZG_OK;
     }
+    if (!strcmp(key, "host_zero_copy")) {
+        if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_host_zero_copy = (int)value;
+        return MKZG_OK;
+    }
     if (!strcmp(key, "host_sha")) {
         if (value < -1 || value > 1) return MKZG_ERR_BAD_ARGS;
         c->opt_host_sha = (int)value;
@@ -554,6 +643,7 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "max_batch")) *value = q->opt_max_batch;
     else if (!strcmp(key, "host_chunk")) *value = q->opt_host_chunk;
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
+    else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
     else if (!strcmp(key, "devices")) *value = c->peers.empty() ? 1 : (long)c->peers.size();
     else if (!strcmp(key, "lanes")) *value = mkzg_ctx::NLANE;
     else return MKZG_ERR_BAD_ARGS;

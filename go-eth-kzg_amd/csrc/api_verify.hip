@@ -10,6 +10,7 @@
 // the next call's challenge hash does (reference verify.go:152-169 gets that from goroutines).
 #include <sys/random.h>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include "ctx.h"
 #include "api_multi.h"
@@ -265,20 +266,35 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
     memcpy(h_pts + m * 48, proofs48n, m * 48);
     HIPCHK(hipMemcpyAsync(L->d_v_raw, h_pts, m * 48, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(L->d_v_raw + L->v_cap * 48, h_pts + m * 48, m * 48, hipMemcpyHostToDevice, s));
-    const size_t CH = 64;
-    const int nthr = m >= 16 ? 8 : 1;
-    for (size_t lo = 0; lo < m; lo += CH) {
-        const size_t hi = std::min(m, lo + CH), per = (hi - lo + nthr - 1) / nthr;
-        c->pool->parallel(nthr, [&](int q) {
-            for (size_t i = lo + (size_t)q * per; i < std::min(hi, lo + (size_t)(q + 1) * per); i++) {
-                uint8_t* dst = L->h_stage + i * MKZG_BYTES_PER_BLOB;
-                if (blobs[i]) memcpy(dst, blobs[i], MKZG_BYTES_PER_BLOB);
-                else memset(dst, 0, MKZG_BYTES_PER_BLOB);
-                if (hsha) host_compute_challenge(h_z + i * 32, dst, commitments48n + i * 48);
-            }
-        });
-        HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, (hi - lo) * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, s));
-    }
+    // the gather runs ahead on the host pool (all chunks' tasks queued at once); this thread waits for chunk k only and puts its copy in flight
+    const size_t CH = 128;
+    const size_t nch = (m + CH - 1) / CH;
+    const int TPC = m >= 16 ? 4 : 1;
+    std::vector<std::atomic<int>> left(nch);
+    for (auto& a : left) a.store(TPC, std::memory_order_relaxed);
+    std::atomic<int> all_left((int)nch * TPC);
+    const std::function<void(int)> gather = [&](int t) {
+        const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(m, lo + CH), per = (hi - lo + TPC - 1) / TPC;
+        const size_t q = (size_t)(t % TPC);
+        for (size_t i = lo + q * per; i < std::min(hi, lo + (q + 1) * per); i++) {
+            uint8_t* dst = L->h_stage + i * MKZG_BYTES_PER_BLOB;
+            if (blobs[i]) memcpy(dst, blobs[i], MKZG_BYTES_PER_BLOB);
+            else memset(dst, 0, MKZG_BYTES_PER_BLOB);
+            if (hsha) host_compute_challenge(h_z + i * 32, dst, commitments48n + i * 48);
+        }
+        left[k].fetch_sub(1, std::memory_order_release);
+    };
+    c->pool->run_async((int)nch * TPC, gather, &all_left);
+    rc = [&]() -> int {
+        for (size_t k = 0; k < nch; k++) {
+            const size_t lo = k * CH, hi = std::min(m, lo + CH);
+            while (left[k].load(std::memory_order_acquire) != 0) std::this_thread::yield();
+            HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, (hi - lo) * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, s));
+        }
+        return MKZG_OK;
+    }();
+    while (all_left.load(std::memory_order_acquire) != 0) std::this_thread::yield();          // the tasks reference this frame
+    if (rc) return rc;
     if (hsha) HIPCHK(hipMemcpyAsync(d_z, h_z, m * 32, hipMemcpyHostToDevice, s));
     rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out);
     if (first_nil < m) {

@@ -70,7 +70,9 @@ struct Lane {
     uint64_t released_at = 0;              // hand-over order: the lane that has been free longest goes first
     hipStream_t stream = nullptr;          // main stream of host-pointer entry points (device-pointer entry points bring their own)
     hipStream_t side = nullptr;            // point validation runs beside SHA-256 / evaluation
-    hipStream_t side2 = nullptr;           // the cell verifier's subgroup test beside decoding + MSMs; second chunk stream of the host-pointer commit path
+    hipStream_t side2 = nullptr;           // the cell verifier's subgroup test beside decoding + MSMs
+    hipStream_t aux[2] = {nullptr, nullptr};   // with stream and side2: the four compute streams of the host-pointer commit pipeline
+    hipEvent_t ev_cs[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_decoded = nullptr;
     hipEvent_t done = nullptr;             // recorded on the call's main stream at release: the next owner's stream waits for it (no host sync)
     bool used = false;
@@ -155,7 +157,8 @@ struct mkzg_ctx {
     int opt_c = 13;
     int opt_direct_bits = 0;               // 0: bucket method; 12..15: direct-table commitment (HBM-hungry, see msm_kernels.hip)
     int opt_max_batch = 256;
-    int opt_host_chunk = 64;               // blobs per chunk of the host-pointer commitment pipeline
+    int opt_host_chunk = 128;              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
+    int opt_host_zero_copy = 1;            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
     int opt_host_sha = -1;                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
     std::atomic<bool> profiling{false};
     // ---- SRS

@@ -26,6 +26,20 @@ class HostPool {
         cv_.notify_all();
         for (auto& t : th_) t.join();
     }
+    int size() const { return (int)th_.size(); }
+    // f(0), ..., f(k-1) on the workers only; returns at once.  *left must be k on entry and reaches 0 when all have finished
+    // (the caller keeps f and left alive until then).  With no workers the tasks run here.
+    void run_async(int k, const std::function<void(int)>& f, std::atomic<int>* left) {
+        if (th_.empty()) {
+            for (int i = 0; i < k; i++) { f(i); left->fetch_sub(1, std::memory_order_release); }
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (int i = 0; i < k; i++) q_.emplace_back([&f, left, i] { f(i); left->fetch_sub(1, std::memory_order_release); });
+        }
+        cv_.notify_all();
+    }
     HostPool(const HostPool&) = delete;
     HostPool& operator=(const HostPool&) = delete;
 

@@ -81,6 +81,8 @@ size_t direct_parts_bytes(int max_batch);
 size_t direct_bad_bytes(int max_batch);
 DirectSlot direct_slot_offset(const DirectSlot& ws, int off);
 double valu_calibrate_device(hipStream_t s);   // sustained v_mad_u64_u32 wave-instructions per second on this GPU
+void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, hipStream_t s, KernelTimer* kt);
+void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt);
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48,
                           int* d_status, hipStream_t s, KernelTimer* kt);
 

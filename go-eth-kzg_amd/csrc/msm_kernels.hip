@@ -828,17 +828,27 @@ static void launch_direct_acc(int c, dim3 grid, hipStream_t s, const uint8_t* d_
         default: hipLaunchKernelGGL((k_commit_direct_acc<15, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
     }
 }
-void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status,
-                          hipStream_t s, KernelTimer* kt) {
+// the two halves of a direct-table commitment: accumulate (VALU-bound, one single-wave workgroup per 512 scalars) and finish
+// (one wavefront per blob: sum of the lane accumulators, inversion, compression).  Callers that feed the accumulate kernel in chunks
+// on several streams (host-pointer pipeline) run ONE finish over all items afterwards.
+void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, hipStream_t s, KernelTimer* kt) {
     if (n <= 0) return;
     if (kt) kt->begin(KT_COMMIT_DIRECT, s);
     const dim3 grid(DBLK, n);
     if (input_kind == 0) launch_direct_acc<0>(c, grid, s, d_scalars, stride, d_direct, ws);
     else launch_direct_acc<1>(c, grid, s, d_scalars, stride, d_direct, ws);
     if (kt) kt->end(KT_COMMIT_DIRECT, s);
+}
+void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
+    if (n <= 0) return;
     if (kt) kt->begin(KT_COMMIT_DIRECT_FIN, s);
     hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status);
     if (kt) kt->end(KT_COMMIT_DIRECT_FIN, s);
+}
+void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status,
+                          hipStream_t s, KernelTimer* kt) {
+    commit_direct_acc_device(c, d_direct, ws, d_scalars, stride, input_kind, n, s, kt);
+    commit_direct_fin_device(ws, n, d_out48, d_status, s, kt);
 }
 void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz) {
     const int nwin = (255 + c - 1) / c, nb = 1 << (c - 1);

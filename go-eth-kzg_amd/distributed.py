@@ -1,82 +1,98 @@
 """Multi-GPU orchestration of the batch verifiers (one process per GPU, torch.distributed).
 
-VerifyCellKZGProofBatch shards the same way (verify_cell_kzg_proof_batch_sharded): cells are cut into contiguous ranges,
-a rank folds its cells with r^(offset+k) into four partial G1 sums (proofs, weighted commitments, [I(tau)], weighted
-proofs -- reference internal/kzg_multi/kzg_verify.go:32,41,68,80), and the 512-byte records are all-gathered.
+Commitments / proofs / cells / recovery shard by blob with no collective at all.  The two batch verifiers have ONE exchange step
+each:
 
-Commitments / proofs / cells shard by blob with no collective at all.  VerifyBlobKZGProofBatch has ONE
-exchange step: rank 0 draws the RLC scalar r and broadcasts 32 bytes; every rank folds its
-contiguous shard with the global exponents r^(offset+i) into a 512-byte record (three partial G1 sums, one
-Fr sum, a status word); the records are all-gathered (RCCL over xGMI on GPUs; < 4 KB in total, purely
-latency-bound) and every rank -- or just rank 0 -- adds them and runs the single pairing check.  RCCL has
-no group-element reduction operator, hence gather-then-add instead of all-reduce.
+  VerifyBlobKZGProofBatch   rank 0 draws the RLC scalar r and broadcasts 32 bytes; every rank folds its contiguous shard with the
+                            global exponents r^(offset+i) into a 512-byte record (three partial G1 sums, one Fr sum, a status word);
+  VerifyCellKZGProofBatch   the same with four partial G1 sums (proofs, weighted commitments, [I(tau)], weighted proofs -- reference
+                            internal/kzg_multi/kzg_verify.go:32,41,68,80);
+
+the records are all-gathered (RCCL over xGMI on GPUs; < 4 KB in total, purely latency-bound) and every rank adds them and runs the
+single pairing check.  RCCL has no group-element reduction operator, hence gather-then-add instead of all-reduce.
+
+SOUNDNESS of the random linear combination needs every item of the global batch folded with its OWN power of r: the ranks' index
+ranges must tile [0, n_total) exactly.  The offsets are therefore never taken on trust from a caller's idea of the split: every rank
+contributes the size of the shard it actually holds, the sizes are all-gathered, and offset(rank) is their prefix sum.
 
 The `engine` argument is anything with
-    partial(shard, offset, r32) -> (rc, record_bytes_512)      and      finish(list_of_records) -> rc
-The product engine (`ProductEngine`) calls the C ABI on device-resident shards; tests on CPU plug an
-oracle-backed engine to exercise this orchestration with the gloo backend.
+    partial(shard, offset, r32) -> (rc, record_bytes_512)      and      finish(list_of_records) -> rc          (blobs)
+    cell_partial(shard, offset, r32) -> (rc, record)           and      cell_finish(list_of_records) -> rc     (cells)
+The product engine (`ProductEngine`) calls the C ABI; tests on CPU plug an oracle-backed engine to exercise this orchestration with
+the gloo backend.
 """
 import os
 
 
 def shard_bounds(n_total, world, rank):
-    """contiguous ranges [lo, hi) -- blob i goes to rank i * world // n (reference has no sharding)"""
+    """contiguous ranges [lo, hi) -- a convenience for callers that cut a global batch (reference has no sharding)"""
     base, rem = divmod(n_total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def verify_blob_kzg_proof_batch_sharded(engine, shard, n_total, dist=None, device=None):
-    """Collective call: every rank passes its own shard (any object the engine understands) of a global
-    batch of n_total proofs.  Returns the same rc on every rank (0 ok, 1 verification failed, >1 input error)."""
+def _exchange_setup(n_local, n_total, dist, device):
+    """-> (world, rank, offset of this rank's shard, r32).  One all_gather of the shard sizes, one broadcast of r."""
     import torch
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    lo, hi = shard_bounds(n_total, world, rank)
     dev = device if device is not None else torch.device("cpu")
-    # 1. the batch-wide scalar: chosen by rank 0, 32 bytes broadcast
+    if world > 1:
+        mine = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, mine)
+        sizes = [int(t.item()) for t in sizes]
+    else:
+        sizes = [int(n_local)]
+    if n_total is not None and sum(sizes) != int(n_total):
+        raise ValueError(f"shards hold {sum(sizes)} items in total, the batch was announced as {n_total}: the index ranges would not tile it")
+    offset = sum(sizes[:rank])
+    # the batch-wide scalar: chosen by rank 0, 32 bytes broadcast
     r = torch.zeros(32, dtype=torch.uint8, device=dev)
     if rank == 0:
         r = torch.frombuffer(bytearray(os.urandom(32)), dtype=torch.uint8).to(dev)
     if world > 1:
         dist.broadcast(r, src=0)
-    r32 = bytes(r.cpu().tolist())
-    # 2. local fold
-    rc, rec = engine.partial(shard, lo, r32)
-    # 3. the one exchange step
-    mine = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
-    if world > 1:
-        allr = [torch.zeros(512, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        records = [bytes(t.cpu().tolist()) for t in allr]
-    else:
-        records = [rec]
-    # 4. combine + pairing (identical on every rank; cheap, and avoids a second broadcast)
-    return engine.finish(records)
+    return world, rank, offset, bytes(r.cpu().tolist()), dev
 
 
-def verify_cell_kzg_proof_batch_sharded(engine, shard, n_total, dist=None, device=None):
-    """Collective call: every rank passes its own contiguous shard (commitments, cell_indices, cells, proofs) of a global
-    batch of n_total cells; `engine` needs cell_partial(shard, offset, r32) and cell_finish(records).  Same rc on every rank."""
+def _gather_records(rec, world, dist, dev):
     import torch
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
-    lo, hi = shard_bounds(n_total, world, rank)
-    dev = device if device is not None else torch.device("cpu")
-    r = torch.zeros(32, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        r = torch.frombuffer(bytearray(os.urandom(32)), dtype=torch.uint8).to(dev)
-    if world > 1:
-        dist.broadcast(r, src=0)
-    rc, rec = engine.cell_partial(shard, lo, bytes(r.cpu().tolist()))
+    if world == 1:
+        return [rec]
     mine = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
-    if world > 1:
-        allr = [torch.zeros(512, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        records = [bytes(t.cpu().tolist()) for t in allr]
-    else:
-        records = [rec]
-    return engine.cell_finish(records)
+    allr = [torch.zeros(512, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    return [bytes(t.cpu().tolist()) for t in allr]
+
+
+def _shard_len(shard, n_local):
+    if n_local is not None:
+        return int(n_local)
+    first = shard[0]
+    if hasattr(first, "__len__"):
+        return len(first)
+    raise ValueError("n_local is required when the shard is not a tuple of sequences")
+
+
+def verify_blob_kzg_proof_batch_sharded(engine, shard, n_total=None, dist=None, device=None, n_local=None):
+    """Collective call: every rank passes its own shard (any object the engine understands) of a global batch.  n_local: items in this
+    rank's shard (default: len(shard[0]); the product engine's shard carries it explicitly).  Returns the same rc on every rank
+    (0 ok, 1 verification failed, >1 input error)."""
+    if n_local is None and len(shard) == 5 and isinstance(shard[3], int):
+        n_local = shard[3]                       # ProductEngine: (d_blobs, d_commitments, d_proofs, n_local, stream)
+    world, rank, offset, r32, dev = _exchange_setup(_shard_len(shard, n_local), n_total, dist, device)
+    rc, rec = engine.partial(shard, offset, r32)       # rc also travels in the record's status word
+    # combine + pairing (identical on every rank; cheap, and avoids a second broadcast)
+    return engine.finish(_gather_records(rec, world, dist, dev))
+
+
+def verify_cell_kzg_proof_batch_sharded(engine, shard, n_total=None, dist=None, device=None, n_local=None):
+    """Collective call: every rank passes its own contiguous shard (commitments, cell_indices, cells, proofs) of a global batch of cells;
+    `engine` needs cell_partial(shard, offset, r32) and cell_finish(records).  Same rc on every rank."""
+    world, rank, offset, r32, dev = _exchange_setup(_shard_len(shard, n_local), n_total, dist, device)
+    rc, rec = engine.cell_partial(shard, offset, r32)
+    return engine.cell_finish(_gather_records(rec, world, dist, dev))
 
 
 class ProductEngine:

@@ -48,6 +48,7 @@ def lib():
         L.kzgo_ctx_free.restype = None
         L.kzgo_blob_to_kzg_commitment.argtypes = [vp, u8p, u8p]
         L.kzgo_blob_to_kzg_commitment_batch.argtypes = [vp, u8p, sz, u8p, vp]
+        L.kzgo_blob_to_kzg_commitment_batch_threads.argtypes = [vp, u8p, sz, u8p, vp, i32]
         L.kzgo_compute_kzg_proof.argtypes = [vp, u8p, u8p, u8p, u8p]
         L.kzgo_compute_blob_kzg_proof.argtypes = [vp, u8p, u8p, u8p]
         L.kzgo_verify_kzg_proof.argtypes = [vp, u8p, u8p, u8p, u8p]
@@ -124,10 +125,11 @@ class OracleContext:
         rc = self._L.kzgo_blob_to_kzg_commitment(self._h, bytes(blob), out)
         return rc, (out.raw if rc == 0 else None)
 
-    def blob_to_kzg_commitment_batch(self, blobs_concat, n):
+    def blob_to_kzg_commitment_batch(self, blobs_concat, n, threads=0):
+        """OpenMP over blobs; threads = 0: the OpenMP default"""
         out = _buf(48 * n)
         st = (C.c_int * n)()
-        rc = self._L.kzgo_blob_to_kzg_commitment_batch(self._h, blobs_concat, n, out, C.cast(st, C.c_void_p))
+        rc = self._L.kzgo_blob_to_kzg_commitment_batch_threads(self._h, blobs_concat, n, out, C.cast(st, C.c_void_p), int(threads))
         return rc, out.raw, list(st)
 
     def compute_kzg_proof(self, blob, z):

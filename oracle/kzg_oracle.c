@@ -16,6 +16,7 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <omp.h>
 #include <string.h>
 #include <stdio.h>
 #include "field.h"
@@ -155,13 +156,20 @@ static void domain_ifft_g1(const domain_t *d, g1j_t *v) {
 /* Stands in for gnark's G1Affine.MultiExp reached through reference
  * internal/multiexp/multiexp.go:20-26: sum_i s_i * P_i.  Bucket (Pippenger) method with
  * signed window digits; the result is independent of the window size. */
+/* per-thread scratch that grows on demand and is reused by the next call (the CPU baseline commits thousands of blobs per thread) */
+static void *tls_scratch(int slot, size_t bytes) {
+    static __thread void *buf[2];
+    static __thread size_t cap[2];
+    if (cap[slot] < bytes) { free(buf[slot]); buf[slot] = malloc(bytes); cap[slot] = bytes; }
+    return buf[slot];
+}
 static void msm_g1(g1j_t *out, const fr_t *scalars, const g1a_t *points, size_t n) {
     g1j_set_inf(out);
     if (n == 0) return;
     int c = n < 4 ? 1 : n < 32 ? 3 : n < 256 ? 5 : n < 2048 ? 8 : n < 16384 ? 10 : 12;
     int nwin = (256 + c - 1) / c + 1;
     size_t nb = (size_t)1 << (c - 1);
-    int32_t *digits = malloc(n * nwin * sizeof(int32_t));
+    int32_t *digits = tls_scratch(0, n * nwin * sizeof(int32_t));
     for (size_t i = 0; i < n; i++) {
         u64 v[5]; fr_to_plain(v, &scalars[i]); v[4] = 0;
         int carry = 0;
@@ -177,7 +185,7 @@ static void msm_g1(g1j_t *out, const fr_t *scalars, const g1a_t *points, size_t 
             digits[i * nwin + w] = d;
         }
     }
-    g1j_t *buckets = malloc(nb * sizeof(g1j_t));
+    g1j_t *buckets = tls_scratch(1, nb * sizeof(g1j_t));
     for (int w = nwin - 1; w >= 0; w--) {
         for (int k = 0; k < c; k++) g1j_dbl(out, out);
         for (size_t b = 0; b < nb; b++) g1j_set_inf(&buckets[b]);
@@ -190,7 +198,6 @@ static void msm_g1(g1j_t *out, const fr_t *scalars, const g1a_t *points, size_t 
         for (size_t b = nb; b-- > 0;) { g1j_add(&run, &run, &buckets[b]); g1j_add(&sum, &sum, &run); }
         g1j_add(out, out, &sum);
     }
-    free(buckets); free(digits);
 }
 
 /* ------------------------------------------------------------------ context */
@@ -328,10 +335,12 @@ KZGO_EXPORT int kzgo_blob_to_kzg_commitment(const kzgo_ctx *c, const uint8_t *bl
     free(poly);
     return KZG_OK;
 }
-/* batch helper for the CPU baseline: independent blobs across OpenMP threads */
-KZGO_EXPORT int kzgo_blob_to_kzg_commitment_batch(const kzgo_ctx *c, const uint8_t *blobs, size_t n, uint8_t *out48, int *status) {
+/* batch helper for the CPU baseline: independent blobs across `threads` OpenMP threads (0: the OpenMP default).  The caller picks
+ * the count from the CPUs it may really use -- a cgroup quota of 16 CPUs under 256 visible ones makes the OpenMP default thrash. */
+KZGO_EXPORT int kzgo_blob_to_kzg_commitment_batch_threads(const kzgo_ctx *c, const uint8_t *blobs, size_t n, uint8_t *out48, int *status, int threads) {
     int any = 0;
-    #pragma omp parallel for schedule(dynamic) reduction(|:any)
+    if (threads <= 0) threads = omp_get_max_threads();
+    #pragma omp parallel for schedule(dynamic) reduction(|:any) num_threads(threads)
     for (size_t i = 0; i < n; i++) {
         int rc = kzgo_blob_to_kzg_commitment(c, blobs + i * BLOB_BYTES, out48 + 48 * i);
         if (status) status[i] = rc;
@@ -339,6 +348,10 @@ KZGO_EXPORT int kzgo_blob_to_kzg_commitment_batch(const kzgo_ctx *c, const uint8
     }
     return any ? KZG_ERR_BAD_ARGS : KZG_OK;
 }
+KZGO_EXPORT int kzgo_blob_to_kzg_commitment_batch(const kzgo_ctx *c, const uint8_t *blobs, size_t n, uint8_t *out48, int *status) {
+    return kzgo_blob_to_kzg_commitment_batch_threads(c, blobs, n, out48, status, 0);
+}
+KZGO_EXPORT int kzgo_omp_max_threads(void) { return omp_get_max_threads(); }
 
 /* reference internal/kzg/kzg_prove.go:14-180 */
 static void compute_quotient(fr_t *q, const domain_t *d, const fr_t *f, int64_t index, const fr_t *fz, const fr_t *z) {

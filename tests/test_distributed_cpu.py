@@ -51,6 +51,19 @@ def _worker(rank, world, port, q):
         lo, hi = D.shard_bounds(n_total, world, rank)
         out = {}
         out["valid"] = D.verify_blob_kzg_proof_batch_sharded(OracleEngine(), (blobs[lo:hi], cms[lo:hi], prs[lo:hi]), n_total, dist)
+        # a caller that cuts the batch differently (1 + 4 instead of 3 + 2): the offsets come from the all-gathered shard sizes, not
+        # from an assumed split, so every item still meets its own power of r
+        ulo, uhi = (0, 1) if rank == 0 else (1, n_total)
+        out["uneven"] = D.verify_blob_kzg_proof_batch_sharded(OracleEngine(), (blobs[ulo:uhi], cms[ulo:uhi], prs[ulo:uhi]), n_total, dist)
+        ubad = list(prs)
+        ubad[0], ubad[1] = ubad[1], ubad[0]             # swapped across the rank boundary of the uneven cut
+        out["uneven_corrupt"] = D.verify_blob_kzg_proof_batch_sharded(OracleEngine(), (blobs[ulo:uhi], cms[ulo:uhi], ubad[ulo:uhi]), n_total, dist)
+        # shards that do not add up to the announced batch are refused before anything is folded
+        try:
+            D.verify_blob_kzg_proof_batch_sharded(OracleEngine(), (blobs[lo:hi], cms[lo:hi], prs[lo:hi]), n_total + 1, dist)
+            out["mismatch"] = "accepted"
+        except ValueError:
+            out["mismatch"] = "refused"
         bad = list(prs)
         bad[3], bad[4] = bad[4], bad[3]
         out["corrupt"] = D.verify_blob_kzg_proof_batch_sharded(OracleEngine(), (blobs[lo:hi], cms[lo:hi], bad[lo:hi]), n_total, dist)
@@ -117,6 +130,7 @@ def test_sharded_verify_gloo_world2():
         assert res[r]["valid"] == 0 and res[r]["single"] == 0
         assert res[r]["corrupt"] == 1
         assert res[r]["noncanonical"] == 3
+        assert res[r]["uneven"] == 0 and res[r]["uneven_corrupt"] == 1 and res[r]["mismatch"] == "refused"
         assert res[r]["cells_valid"] == 0 and res[r]["cells_single"] == 0
         assert res[r]["cells_corrupt"] == 1
         assert res[r]["cells_noncanonical"] == 3

@@ -131,15 +131,18 @@ def test_options_and_calibration(product, oracle_ctx):
     torch.cuda.init()
     blobs = [rand_blob(31 + i) for i in range(7)]
     exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
-    for chunk, batch in ((1, 2), (2, 4), (3, 256), (64, 256)):       # host-pointer pipeline: chunks per piece, pieces per call
+    for chunk, batch, zc in ((1, 2, 0), (2, 4, 1), (3, 256, 0), (3, 256, 1), (64, 256, 1)):       # host-pointer pipeline: chunks per piece, pieces per call
         ctx = product.Context()
         assert ctx.set_option("max_batch", batch) == 0 and ctx.get_option("max_batch") == batch
         assert ctx.set_option("host_chunk", chunk) == 0 and ctx.get_option("host_chunk") == chunk
+        assert ctx.set_option("host_zero_copy", zc) == 0 and ctx.get_option("host_zero_copy") == zc
+        if chunk == 3:
+            assert ctx.set_option("commit_direct_bits", 12) == 0     # the chunked accumulate launches exist in direct-table mode only
         assert ctx.set_option("host_chunk", 0) == 17                 # MKZG_ERR_BAD_ARGS
         assert ctx.set_option("no_such_option", 1) == 17 and ctx.get_option("no_such_option") is None
         rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
         assert rc == 0 and outs == exp and st == [0] * 7
-        assert ctx.get_option("commit_direct_bits_effective") == 0 and ctx.get_option("devices") == 1 and ctx.get_option("lanes") >= 4
+        assert ctx.get_option("commit_direct_bits_effective") == (12 if chunk == 3 else 0) and ctx.get_option("devices") == 1 and ctx.get_option("lanes") >= 4
         ctx.close()
     ctx = product.Context()
     rate = ctx.valu_calibrate()

@@ -1,43 +1,64 @@
 #!/usr/bin/env python3
-"""tools/bench_host_path.py -- PCIe-inclusive rate of the host-pointer entry point
-mkzg_blob_to_kzg_commitment_batch (blobs in pageable host memory -> commitments in host memory), next to the
-device-resident rate bench.py reports.  Run on the GPU box."""
-import hashlib, json, os, struct, sys, time
+"""Host-pointer (drop-in) commitment path: mkzg_blob_to_kzg_commitment_batch on 256 scattered pageable blobs at the C ABI,
+A/B over the pipeline's options (zero-copy reads of the pinned staging area, chunk size), one and two callers.  GPU box."""
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from __graft_entry__ import load_product
-R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-
-
-def rand_blob(seed):
-    out = bytearray()
-    for i in range(0, 131072, 32):
-        out += (int.from_bytes(hashlib.sha256(struct.pack(">q", seed + i)).digest(), "big") % R).to_bytes(32, "big")
-    return bytes(out)
+from bench import rand_blob, load_product, BLOB  # noqa: E402
 
 
 def main():
     import torch
     torch.cuda.init()
+    bits = int(sys.argv[1]) if len(sys.argv) > 1 else 15
     kzg = load_product()
-    res = {}
-    for bits in (0, 15):
-        ctx = kzg.Context()
-        ctx.set_option("max_batch", 256)
-        if bits:
-            ctx.set_option("commit_direct_bits", bits)
-        blobs = [rand_blob(s) for s in range(256)]
-        rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)          # warm-up (tables)
-        assert rc == 0
-        reps = 5
-        t0 = time.perf_counter()
+    ctx = kzg.Context(device=0)
+    ctx.set_option("commit_direct_bits", bits)
+    n = 256
+    blobs = [rand_blob(s % 32) for s in range(n)]
+    keep = [ctypes.create_string_buffer(b, BLOB) for b in blobs]
+    arr = (ctypes.c_char_p * n)(*[ctypes.cast(k, ctypes.c_char_p) for k in keep])
+    L = kzg.lib()
+    ref = None
+    out = {}
+
+    def caller(reps, res):
+        o = ctypes.create_string_buffer(48 * n)
+        st = (ctypes.c_int * n)()
         for _ in range(reps):
-            rc, outs2, st = ctx.BlobToKZGCommitmentBatch(blobs)
-        dt = (time.perf_counter() - t0) / reps
-        assert outs2 == outs
-        res["direct15" if bits else "bucket13"] = {"ms_per_256_blobs_host_to_host": round(dt * 1e3, 3), "blobs_per_s": round(256 / dt, 1)}
-        ctx.close()
-    print(json.dumps(res))
+            assert L.mkzg_blob_to_kzg_commitment_batch(ctx._h, arr, n, o, st) == 0
+        res.append(o.raw)
+
+    for zc in (0, 1):
+        for chunk in (32, 64, 128, 256):
+            ctx.set_option("host_zero_copy", zc)
+            ctx.set_option("host_chunk", chunk)
+            res = []
+            caller(3, res)
+            ref = ref or res[0]
+            assert res[0] == ref
+            reps = 10
+            t0 = time.perf_counter()
+            caller(reps, res)
+            dt1 = (time.perf_counter() - t0) / reps
+            ts = [threading.Thread(target=caller, args=(reps, res)) for _ in range(2)]
+            t0 = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            dt2 = (time.perf_counter() - t0) / (2 * reps)
+            assert all(r == ref for r in res)
+            out[f"zc{zc}_chunk{chunk}"] = {"ms_one_caller": round(dt1 * 1e3, 3), "blobs_per_s_one": round(n / dt1), "blobs_per_s_two": round(n / dt2)}
+            print(f"zc{zc}_chunk{chunk}", out[f"zc{zc}_chunk{chunk}"], flush=True)
+    print(json.dumps(out))
+    ctx.close()
 
 
 if __name__ == "__main__":

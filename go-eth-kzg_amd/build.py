@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmi355kzg.so")
 SOURCES = ["api.hip", "api_verify.hip", "api_cells.hip", "api_multi.hip", "msm_kernels.hip", "verify_kernels.hip", "cells_kernels.hip", "fk20_kernels.hip", "recover_kernels.hip"]
-HEADERS = ["mont29.hpp", "modinv30.hpp", "g1.hpp", "constants29.h", "msm_kernels.h", "verify_kernels.h", "cells_kernels.h", "fk20_kernels.h", "recover_kernels.h", "ctx.h", "api_multi.h", "host_pool.hpp", "host_sha256.hpp", "g1_decode.hpp", "host_field.hpp", "host_pairing.hpp", "host_g1.hpp",
+HEADERS = ["mont29.hpp", "modinv30.hpp", "g1.hpp", "constants29.h", "msm_kernels.h", "verify_kernels.h", "cells_kernels.h", "fk20_kernels.h", "fk20_toom.h", "recover_kernels.h", "ctx.h", "api_multi.h", "host_pool.hpp", "host_sha256.hpp", "g1_decode.hpp", "host_field.hpp", "host_pairing.hpp", "host_g1.hpp",
            os.path.join("..", "..", "include", "mi355kzg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -29,6 +29,9 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(os.path.join(CSRC, "constants29.h")):
         subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_constants.py")])
+    # generated, not tracked (600 KB of digit strings): the FK20 transform stage's fixed scalars and network programs
+    if _stale(os.path.join(CSRC, "fk20_toom.h"), [os.path.join(CSRC, "gen_fk20_toom.py")]):
+        subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_fk20_toom.py")], stdout=subprocess.DEVNULL)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     for s in SOURCES:

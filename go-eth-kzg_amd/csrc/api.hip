@@ -342,7 +342,7 @@ int ensure_staging(Lane* L, size_t n_items, size_t in_bytes_per_item) {
     }
     if (L->h_out_items < n_items) {
         L->h_out_items = 0;
-        int rc = pinned_realloc(L->h_out, n_items * 52);
+        int rc = pinned_realloc(L->h_out, n_items * 52 + 256);          // 48 B + status per item; the single-proof calls park a few more words
         if (rc) return rc;
         L->h_out_items = n_items;
     }
@@ -458,7 +458,7 @@ static void ctx_destroy_one(mkzg_ctx* c) {
     dev_free(c->d_lagrange_aff); dev_free(c->d_commit_table); dev_free(c->d_direct);
     dev_free(c->d_roots_brp); dev_free(c->d_inv_roots_brp);
     dev_free(c->d_tw_fwd); dev_free(c->d_tw_inv); dev_free(c->d_g1tw_fwd); dev_free(c->d_g1tw_inv);
-    dev_free(c->d_monomial_aff); dev_free(c->d_pow7); dev_free(c->d_ipow7); dev_free(c->d_fk_t_aff); dev_free(c->d_fk_table); dev_free(c->d_fk_plan);
+    dev_free(c->d_monomial_aff); dev_free(c->d_pow7); dev_free(c->d_ipow7); dev_free(c->d_fk_t_aff); dev_free(c->d_fk_table);
     if (c->init_stream) (void)hipStreamDestroy(c->init_stream);
     delete c->pool;
     delete c;

@@ -72,14 +72,6 @@ int ensure_fk20_tables(mkzg_ctx* c) {
     if (!rc) rc = dev_realloc(c->d_fk_table, fk20_table_bytes());
     if (rc) return rc;
     fk20_setup_device(c->d_monomial_aff, c->d_g1tw_fwd, c->d_fk_t_aff, c->d_fk_table, c->init_stream);
-    {
-        std::vector<uint32_t> plan(FK_PLAN_WORDS);
-        fk20_build_plan(plan.data());
-        rc = dev_realloc(c->d_fk_plan, FK_PLAN_WORDS * sizeof(uint32_t));
-        if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(c->d_fk_plan, plan.data(), FK_PLAN_WORDS * sizeof(uint32_t), hipMemcpyHostToDevice, c->init_stream));
-        HIPCHK(hipStreamSynchronize(c->init_stream));
-    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->init_stream));
     c->fk_ready.store(true, std::memory_order_release);
@@ -121,7 +113,7 @@ int ensure_fk20_ws(Lane* L, size_t n) {
     L->fk_cap = 0;
     rc = dev_realloc(L->d_fk_scalars, n * 128 * 64 * 32);
     if (!rc) rc = dev_realloc(L->d_fk_results, 2 * n * 128 * 256);
-    if (!rc) rc = dev_realloc(L->d_fk_parts, n * 128 * 24 * 256);
+    if (!rc) rc = dev_realloc(L->d_fk_parts, n * fk20_parts_rows() * 256);
     if (!rc) rc = dev_realloc(L->d_fk_proofs, n * 128 * 48);
     if (rc) return rc;
     L->fk_cap = n;
@@ -166,7 +158,7 @@ static int cells_and_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs,
         KT(KT_CELLS_NTT, s, cells_from_blobs_device(blobs, (int)chunk, c->d_tw_fwd, c->d_tw_inv, L->d_coeffs, d_cells + done * 262144, d_status + done, s));
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(L->d_coeffs, (int)chunk, c->d_tw_fwd, d_status + done, L->d_fk_scalars, s));
         KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, (int)chunk, d_status + done, L->d_fk_parts, L->d_fk_results, s));
-        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, c->d_fk_plan, (int)chunk, d_status + done, d_proofs + done * 128 * 48, L->d_fk_parts, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)chunk, d_status + done, d_proofs + done * 128 * 48, L->d_fk_parts, s));
         done += chunk;
     }
     HIPCHK(hipGetLastError());
@@ -494,7 +486,7 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
     if (with_proofs) {
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(L->d_coeffs, (int)n_blobs, c->d_tw_fwd, L->d_cell_st, L->d_fk_scalars, s));
         KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, (int)n_blobs, L->d_cell_st, L->d_fk_parts, L->d_fk_results, s));
-        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, c->d_fk_plan, (int)n_blobs, L->d_cell_st, L->d_fk_proofs, L->d_fk_parts, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)n_blobs, L->d_cell_st, L->d_fk_proofs, L->d_fk_parts, s));
     }
     HIPCHK(hipGetLastError());
     // device-side statuses (non-canonical field elements in the cells) join the host-side ones

@@ -10,7 +10,7 @@
 //                   input evaluations) and ONE coset NTT-4096 (shift w_8192) whose decimation-
 //                   in-frequency output order is exactly the bit-reversed order the cells use.
 //   k_fk20_scalars  the 64 circulant-row NTT-128s of FK20 (reference fk20.go:100-124,
-//                   toeplitz.go:17-29,95-107), transposed, scaled by 1/128 and exported as plain
+//                   toeplitz.go:17-29,95-107), transposed, scaled by 1/2 and exported as plain
 //                   scalars for the fixed-base MSMs.
 // Twiddles come from precomputed tables (the reference recomputes them by running products,
 // internal/domain/fft.go:118-137).  Integer modular arithmetic only -- no MFMA.
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(NT) k_cells_first_half(const uint32_t* __restr
 // ------------------------------------------------------------------------------------------
 // k_fk20_scalars: per blob, the 64 circulant rows of FK20 and their NTT-128s.
 //   row i (i < 64):  circ_i[0] = c[4095 - i];  circ_i[64 + j] = c[64 j - i - 1] (j = 1..63); else 0
-//   V_i = NTT_128(circ_i) / 128    (the 1/128 of the later G1 inverse FFT is folded in here)
+//   V_i = NTT_128(circ_i) / 2      (the transform stage of fk20_kernels.hip works on u / 2, where u = sum_i V_i T_i as the reference has it)
 //   out: scalars[b][k][i] as 8 plain little-endian words   (k < 128 outputs, i < 64 rows)
 // One 1024-thread workgroup per blob; all 64 x 128 elements live in LDS (64 transforms side by side).
 // ------------------------------------------------------------------------------------------
@@ -279,12 +279,12 @@ __global__ void __launch_bounds__(NT) k_fk20_scalars(const uint32_t* __restrict_
     const int b = blockIdx.x, t = threadIdx.x;
     if (status[b] != 0) return;
     const uint32_t* c = coeffs + (size_t)b * 4096 * 12;
-    fr_t inv128;
+    fr_t inv128;       // the scale folded into the scalars: 1/2
     {
-        // 1/128 = 32 * (1/4096)
+        // 1/2 = 2048 * (1/4096)
         fr_t x;
         Fr::set(x, FR_INV_4096);
-        for (int s = 0; s < 5; s++) FrC::add(x, x, x);
+        for (int s = 0; s < 11; s++) FrC::add(x, x, x);
         inv128 = x;
     }
     uint32_t* out = scalars + (size_t)b * 128 * 64 * 8;

@@ -188,7 +188,6 @@ struct mkzg_ctx {
     std::atomic<bool> fk_ready{false};
     uint32_t* d_fk_t_aff = nullptr;        // 8192 affine rows T[k][i]
     uint32_t* d_fk_table = nullptr;        // direct window table of the FK20 bases (fk20_table_bytes())
-    uint32_t* d_fk_plan = nullptr;         // FK_PLAN_WORDS lane descriptors of the G1 DFT levels
     // host finish timing (last verification call), microseconds
     std::atomic<double> last_host_finish_us{0.0};
 };

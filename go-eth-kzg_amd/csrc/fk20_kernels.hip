@@ -11,17 +11,19 @@
 //     for the 24 eleven-bit windows w and m = 1..1024 (signed Booth digits) -- 25.8 GB, sized for a
 //     288 GB part -- so an MSM-64 is 64 x 24 mixed additions with no bucket reduction at all and
 //     no sort; 8 (batches) or 24 (few blobs) lanes share one MSM and combine with a wavefront tree.
-//   * the per-blob G1 transforms are table-driven DFT levels, each level = one twiddle multiplication deep (GLV endomorphism,
-//     Jacobian accumulator).  Batches (> 8 blobs): four levels of 1024 plan entries, ONE WAVEFRONT PER ENTRY and one lane per
-//     blob, so the twiddle is uniform across the wavefront (k_g1_dft_mul: width-5 NAF strings, uniform branches), the terms of
-//     an output summed by k_g1_dft_sum.  Small batches (the reference's per-blob API): two levels of 64-term outputs with one
-//     lane per TERM (k_g1_dft_level<64>: per-lane twiddles, signed 5-bit windows: 125 doublings + <= 52 additions).
+//   * the two per-blob G1 transforms (IFFT_128, truncate, FFT_128) are ONE fixed linear map: P = u/2 + c (*) u, two 64 x 64 Toeplitz
+//     products with fixed scalars.  They run as a three-level Toom-Cook network in transposed form (gen_fk20_toom.py): additions and
+//     doublings of points (k_fk20_pre), 686 INDEPENDENT scalar multiplications by fixed scalars (k_fk20_toom_mul: one wavefront per
+//     scalar, one lane per blob, GLV + width-5 NAF, Jacobian accumulator), additions again (k_fk20_post) -- one multiplication deep,
+//     where the radix-2 G1 FFTs of the reference (internal/domain/fft.go:49-92) are fourteen deep.
 //     The one-wavefront radix-2 FFT (g1_fft128_dif, points in LDS) is kept for the one-off set-up of the table.
 // Integer modular arithmetic only -- no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "g1.hpp"
 #include "fk20_kernels.h"
+#include "fk20_toom.h"
 
 namespace kzg {
 
@@ -138,11 +140,11 @@ __device__ __noinline__ void f_mul_glv(G1X& r, const G1X& p, const uint32_t* kk)
     G1D::jac_to_xyzz(r, acc);
 }
 
-// r = [w^e]p for the WHOLE wavefront (e = 1..63 uniform; batch kernels with lane = blob): the twiddle's GLV halves as width-5
-// NAF strings (constants29.h G1TW_WNAF_FWD), so control flow is uniform, an addition happens only at the ~1/6 of the bit positions
-// with a non-zero digit (43 additions on average against 52 with per-lane fixed windows) and the table holds the 8 odd multiples
-// instead of 16.  Same Jacobian accumulator and cached-Z table entries as f_mul_glv.
-__device__ __noinline__ void f_mul_wnaf(G1X& r, const G1X& p, int e) {
+// r = [k]p for the WHOLE wavefront (k uniform; lane = blob): the scalar's GLV halves as width-5 NAF strings (fk20_toom.h
+// FK20_TOOM_WNAF), so control flow is uniform, an addition happens only at the ~1/6 of the bit positions with a non-zero digit
+// (43 additions on average against 52 with per-lane fixed windows) and the table holds the 8 odd multiples instead of 16.
+// Same Jacobian accumulator and cached-Z table entries as f_mul_glv.
+__device__ __noinline__ void f_mul_wnaf(G1X& r, const G1X& p, const uint32_t* __restrict__ row) {
     G1JC tbl[8];                                  // (2j + 1) p
     {
         G1J run, two;
@@ -164,7 +166,6 @@ __device__ __noinline__ void f_mul_wnaf(G1X& r, const G1X& p, int e) {
     Fp::set(beta, FP_BETA);
     G1J acc;
     G1D::set_inf(acc);
-    const uint32_t* row = G1TW_WNAF_FWD[e];
     bool started = false;
 #pragma unroll 1
     for (int i = 130; i >= 0; i--) {
@@ -397,81 +398,105 @@ __global__ void __launch_bounds__(64) k_fk20_msm_reduce(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// The two G1 transforms of a blob, IFFT_128 -> keep h[0..63] -> FFT_128 (fk20.go:76-90, toeplitz.go:95-125).
-//
-// A twiddle multiplication of a G1 point is a 128-doubling chain (~2.3 ms for a lone wavefront), so a radix-2
-// transform with one wavefront per blob is 12 such chains back to back per blob: latency-bound, 3/4 of the SIMDs idle
-// at batch 64.  Here each transform is TWO table-driven levels of a 16 x 8 Cooley-Tukey split with the twiddle
-// merged into the small DFT's coefficients,
-//     level 1:  Y[j1 + r1 i2]  = sum_{i1<r1}  w^{ r2 i1 j1}        x[r2 i1 + i2]
-//     level 2:  X[j1 + r1 j2]  = sum_{i2<r2}  w^{ i2 (j1 + r1 j2)} Y[j1 + r1 i2]
-// (r1, r2) = (8, 16) for the IFFT, whose level 2 only produces j < 64, and (16, 8) for the FFT, whose level 1 skips the
-// eight i1 that address the identity padding: 1024 terms ("plan entries") in every one of the four levels, each one GLV scalar
-// multiplication by a fixed power of w, the terms of an output adjacent and summed with a shuffle tree.  5x the group operations
-// of radix 2, but 4 chains deep instead of 12, and 1024 independent chains per level for any batch size: k_g1_dft_mul runs one
-// WAVEFRONT per entry with the blobs in its lanes (batch 64 = one full wavefront per SIMD, the twiddle uniform in each).
-// Plan entry: out << 16 | src << 8 | exponent (0..127, w^64 = -1).
+// The two G1 transforms of a blob, IFFT_128 -> keep h[0..63] -> FFT_128 (fk20.go:76-90, toeplitz.go:95-125), as the Toom-Cook
+// network of gen_fk20_toom.py.  With u' = u / 2 (the 1/2 is folded into the MSM's scalars, cells_kernels.hip k_fk20_scalars):
+//     P[2a]     = u'[2a]     + sum_b gE[(a - b) mod 64] u'[2b + 1]        block 0: even outputs from odd inputs
+//     P[2a + 1] = u'[2a + 1] + sum_b gO[(a - b) mod 64] u'[2b]            block 1: odd outputs from even inputs
+// Each 64 x 64 product: three "pre" levels (an axis of 4 becomes an axis of 7: sums of inputs with coefficients 1, 2, 4, 8 and
+// signs), 343 multiplications by fixed scalars, three "post" levels (7 back to 4).  Every level is one launch with one LANE per
+// (blob, element) and the evaluation point / output index uniform per workgroup (blockIdx.y), so a wavefront runs one straight-line
+// program of at most ten group operations.  Point rows between levels: [entry][blob] (a wavefront's lanes read adjacent rows).
+// FULL_WAVES: every wavefront of these kernels runs with all 64 lanes active, lanes beyond the work repeating another lane's and
+// storing nothing.  Measured on gfx950 (tools/ubench_lanes.hip, profiles/r02_ubench_lanes.txt): a dependent chain issues one
+// instruction per ~5.9 cycles with more than 32 active lanes in the wavefront but per ~7.9 with 32 or fewer, and once the whole chip
+// holds fewer than ~8200 active lanes the figure grows with the number of resident wavefronts -- 19.6 cycles at one sparse wavefront
+// per SIMD.  A single-blob call ran this stage's 686 one-lane wavefronts at 4.7 ms; with full wavefronts it takes the 1.7 ms of a batch.
 // ------------------------------------------------------------------------------------------
-void fk20_build_plan(uint32_t* plan /* FK_PLAN_WORDS */) {
-    uint32_t* p = plan;
-    // IFFT as 8 x 16:  level 1: 128 outputs x 8 terms, Y[j1 + 8 i2] = sum_{i1<8} w^{-16 i1 j1} x[16 i1 + i2]
-    for (int i2 = 0; i2 < 16; i2++) for (int j1 = 0; j1 < 8; j1++) for (int i1 = 0; i1 < 8; i1++)
-        *p++ = (uint32_t)(j1 + 8 * i2) << 16 | (uint32_t)(16 * i1 + i2) << 8 | (uint32_t)((128 * 8 - 16 * i1 * j1) & 127);
-    // IFFT level 2: outputs j = j1 + 8 j2 < 64 only, 16 terms, exponent -(i2 j)
-    for (int j = 0; j < 64; j++) for (int i2 = 0; i2 < 16; i2++)
-        *p++ = (uint32_t)j << 16 | (uint32_t)((j & 7) + 8 * i2) << 8 | (uint32_t)((128 * 8 - i2 * j) & 127);
-    // FFT level 1: inputs x[8 i1 + i2] with i1 < 8 (upper half is the identity), exponent 8 i1 j1
-    for (int i2 = 0; i2 < 8; i2++) for (int j1 = 0; j1 < 16; j1++) for (int i1 = 0; i1 < 8; i1++)
-        *p++ = (uint32_t)(j1 + 16 * i2) << 16 | (uint32_t)(8 * i1 + i2) << 8 | (uint32_t)((8 * i1 * j1) & 127);
-    // FFT level 2: 128 outputs x 8 terms, exponent i2 j
-    for (int j = 0; j < 128; j++) for (int i2 = 0; i2 < 8; i2++)
-        *p++ = (uint32_t)j << 16 | (uint32_t)((j & 15) + 16 * i2) << 8 | (uint32_t)((i2 * j) & 127);
-    // Small batches (latency matters more than work): each transform as ONE level, 64 terms per lane group.
-    // direct IFFT: h[j] = sum_{i<128} w^{-ij} x[i] for j < 64, as two 64-term halves written to slots j and j + 64
-    for (int half = 0; half < 2; half++) for (int j = 0; j < 64; j++) for (int t = 0; t < 64; t++) {
-        const int i = 64 * half + t;
-        *p++ = (uint32_t)(j + 64 * half) << 16 | (uint32_t)i << 8 | (uint32_t)((128 * 64 - i * j) & 127);
-    }
-    // direct FFT: X[j] = sum_{i<64} w^{ij} h[i]
-    for (int j = 0; j < 128; j++) for (int i = 0; i < 64; i++)
-        *p++ = (uint32_t)j << 16 | (uint32_t)i << 8 | (uint32_t)((i * j) & 127);
-}
-static_assert(FK_PLAN_WORDS == 128 * 8 + 64 * 16 + 128 * 8 + 128 * 8 + 128 * 64 + 128 * 64, "plan size");
-constexpr int FK_PLAN_DIRECT = 128 * 8 + 64 * 16 + 128 * 8 + 128 * 8;       // offset of the direct plans
-
-template <int R>
-__global__ void __launch_bounds__(64) k_g1_dft_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ plan,
-                                                     const int* __restrict__ status) {
-    const int b = blockIdx.y;
-    if (status[b] != 0) return;
-    const uint32_t e = plan[blockIdx.x * 64 + threadIdx.x];
-    const int o = (int)(e >> 16), src = (int)((e >> 8) & 0xff), ex = (int)(e & 0xff);
-    G1X p;
-    f_load_xyzz(p, in + ((size_t)b * 128 + src) * 64);
-    if (ex & 63) {
-        uint32_t kw[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) kw[q] = G1TW_GLV_FWD[ex & 63][q];
-        f_mul_glv(p, p, kw);
-    }
-    if (ex & 64) g1x_neg(p, p);
-    G1X q;
+__device__ __forceinline__ void toom_run(G1X& acc, const uint8_t* __restrict__ prog, const uint32_t* const* __restrict__ src) {
+    // src[x]: row of operand x (4 or 7 of them)
 #pragma unroll 1
-    for (int m = R / 2; m >= 1; m >>= 1) {
-        f_shfl_xor_xyzz(q, p, m);
-        f_add(p, p, q);
+    for (int i = 0; i < FK20_PROG_LEN; i++) {
+        const int code = prog[i], op = code & 15, x = code >> 4;
+        if (op == 7) break;
+        if (op == 0) {
+            f_load_xyzz(acc, src[x]);
+        } else if (op == 3) {
+            g1x_dbl(acc, acc);
+        } else if (op == 4) {
+            g1x_neg(acc, acc);
+        } else {
+            G1X t;
+            f_load_xyzz(t, src[x]);
+            if (op == 2) g1x_neg(t, t);
+            g1x_add(acc, acc, t);
+        }
     }
-    if ((threadIdx.x & (R - 1)) == 0) f_store_xyzz(out + ((size_t)b * 128 + o) * 64, p);
 }
-// h[j] = a[j] + a[j + 64] (the two halves of the direct IFFT), j < 64
-__global__ void __launch_bounds__(64) k_g1_fold_halves(uint32_t* __restrict__ x, const int* __restrict__ status) {
-    const int b = blockIdx.x, j = threadIdx.x;
+// pre level: out[blk][p][r][q] = sum_j e_r[j] in[blk][p][j][q]   (r = blockIdx.y).  FIRST: in = u' rows [b][128], block blk reads the
+// inputs of the other parity, (p, j, q) = (0, j, q) -> element 16 j + q.
+template <bool FIRST>
+__global__ void __launch_bounds__(64) k_fk20_pre(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const int* __restrict__ status, int n, int npre, int npost) {
+    const int r = blockIdx.y;
+    const size_t glane = (size_t)blockIdx.x * 64 + threadIdx.x, total = (size_t)n * 2 * npre * npost;
+    const bool live = glane < total;
+    const size_t lane = live ? glane : glane % total;      // surplus lanes of the last wavefront shadow other lanes (FULL_WAVES below)
+    const int b = (int)(lane % n);
+    size_t item = lane / n;
+    const int q = (int)(item % npost);
+    item /= npost;
+    const int p = (int)(item % npre), blk = (int)(item / npre);
     if (status[b] != 0) return;
-    G1X p, q;
-    f_load_xyzz(p, x + ((size_t)b * 128 + j) * 64);
-    f_load_xyzz(q, x + ((size_t)b * 128 + j + 64) * 64);
-    f_add(p, p, q);
-    f_store_xyzz(x + ((size_t)b * 128 + j) * 64, p);
+    const uint32_t* src[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (FIRST) src[j] = in + ((size_t)b * 128 + 2 * (j * npost + q) + (1 - blk)) * 64;
+        else src[j] = in + (((((size_t)blk * npre + p) * 4 + j) * npost + q) * n + b) * 64;
+    }
+    G1X acc;
+    toom_run(acc, FK20_PRE_PROG[r], src);
+    if (live) f_store_xyzz(out + (((((size_t)blk * npre + p) * 7 + r) * npost + q) * n + b) * 64, acc);
+}
+// post level: out[blk][p][A][q] = sum_r e_r[3 - A] in[blk][p][r][q]   (A = blockIdx.y).  LAST: (p, A, q) = (0, A, q) -> element
+// a = 16 A + q of the block's output; the result plus u' goes to rows [b][128] at index 2 a + blk.
+template <bool LAST>
+__global__ void __launch_bounds__(64) k_fk20_post(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ u, const int* __restrict__ status, int n,
+                                                  int npre, int npost) {
+    const int A = blockIdx.y;
+    const size_t glane = (size_t)blockIdx.x * 64 + threadIdx.x, total = (size_t)n * 2 * npre * npost;
+    const bool live = glane < total;
+    const size_t lane = live ? glane : glane % total;
+    const int b = (int)(lane % n);
+    size_t item = lane / n;
+    const int q = (int)(item % npost);
+    item /= npost;
+    const int p = (int)(item % npre), blk = (int)(item / npre);
+    if (status[b] != 0) return;
+    const uint32_t* src[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) src[r] = in + (((((size_t)blk * npre + p) * 7 + r) * npost + q) * n + b) * 64;
+    G1X acc;
+    toom_run(acc, FK20_POST_PROG[A], src);
+    if (LAST) {
+        const size_t j = (size_t)b * 128 + 2 * (A * npost + q) + blk;
+        G1X t;
+        f_load_xyzz(t, u + j * 64);
+        g1x_add(acc, acc, t);
+        if (live) f_store_xyzz(out + j * 64, acc);
+    } else if (live) {
+        f_store_xyzz(out + (((((size_t)blk * npre + p) * 4 + A) * npost + q) * n + b) * 64, acc);
+    }
+}
+// the 686 products: one WAVEFRONT per fixed scalar (blockIdx.x), one lane per blob -- uniform control flow through the digit string
+__global__ void __launch_bounds__(64) k_fk20_toom_mul(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const int* __restrict__ status, int n) {
+    const int glane = blockIdx.y * 64 + threadIdx.x;
+    const bool live = glane < n;
+    const int b = live ? glane : glane % n;            // FULL_WAVES: surplus lanes repeat a blob and store nothing
+    if (status[b] != 0) return;
+    const size_t row = ((size_t)blockIdx.x * n + b) * 64;
+    G1X p;
+    f_load_xyzz(p, in + row);
+    f_mul_wnaf(p, p, FK20_TOOM_WNAF[blockIdx.x]);
+    if (live) f_store_xyzz(out + row, p);
 }
 // proofs[i] = X[brev7(i)] (fk20.go:90), affine, compressed
 __global__ void __launch_bounds__(64) k_fk20_finish(const uint32_t* __restrict__ x, const int* __restrict__ status, uint8_t* __restrict__ proofs48) {
@@ -496,42 +521,6 @@ void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fw
     const size_t n = (size_t)8192 * FK_NWIN;
     hipLaunchKernelGGL(k_fk20_setup_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_t_aff, d_table, 8192);
 }
-// Batch form of a DFT level (calls with more than FK_DIRECT_MAX_BATCH blobs): one WAVEFRONT per plan entry, one LANE per blob, so
-// that the twiddle is uniform across the wavefront (f_mul_wnaf); the products go to part[entry][blob] and k_g1_dft_sum adds the R
-// terms of every output (R adjacent lanes, shuffle tree) -- two launches per level instead of one, ~11 % fewer field multiplications.
-__global__ void __launch_bounds__(64) k_g1_dft_mul(const uint32_t* __restrict__ in, uint32_t* __restrict__ part, const uint32_t* __restrict__ plan,
-                                                   const int* __restrict__ status, int n) {
-    const int b = blockIdx.y * 64 + threadIdx.x;
-    if (b >= n || status[b] != 0) return;
-    const uint32_t e = plan[blockIdx.x];
-    const int src = (int)((e >> 8) & 0xff), ex = (int)(e & 0xff);
-    G1X p;
-    f_load_xyzz(p, in + ((size_t)b * 128 + src) * 64);
-    if (ex & 63) f_mul_wnaf(p, p, ex & 63);
-    if (ex & 64) g1x_neg(p, p);
-    f_store_xyzz(part + ((size_t)blockIdx.x * n + b) * 64, p);
-}
-template <int R>
-__global__ void __launch_bounds__(64) k_g1_dft_sum(const uint32_t* __restrict__ part, uint32_t* __restrict__ out, const uint32_t* __restrict__ plan,
-                                                   const int* __restrict__ status, int n, int n_out) {
-    // lanes: (blob, output, term) with the term fastest; surplus lanes of the last workgroup shadow the last output (shuffles need them)
-    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-    const int j = (int)(t & (R - 1));
-    size_t rest = t / R;
-    const size_t total = (size_t)n * n_out;
-    const bool live = rest < total;
-    if (!live) rest = total - 1;
-    const int oi = (int)(rest % n_out), b = (int)(rest / n_out);
-    const int entry = oi * R + j;
-    G1X p, q;
-    f_load_xyzz(p, part + ((size_t)entry * n + b) * 64);
-#pragma unroll 1
-    for (int m = R / 2; m >= 1; m >>= 1) {
-        f_shfl_xor_xyzz(q, p, m);
-        g1x_add(p, p, q);                 // inlined (one copy in the rolled loop): the points stay in registers between rounds
-    }
-    if (live && j == 0 && status[b] == 0) f_store_xyzz(out + ((size_t)b * 128 + (plan[entry] >> 16)) * 64, p);
-}
 void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s) {
     if (n <= 0) return;
     if (n <= FK_DIRECT_MAX_BATCH) {      // latency over occupancy: one window per lane
@@ -542,37 +531,24 @@ void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, 
     hipLaunchKernelGGL((k_fk20_msm<FK_LANES, FK_WPL>), dim3(128 * FK_LANES / 64, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_parts);
     hipLaunchKernelGGL((k_fk20_msm_reduce<FK_LANES, FK_LANES>), dim3(128 * FK_LANES / 64, n), dim3(64), 0, s, d_parts, d_status, d_results);
 }
-void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, const uint32_t* d_plan, int n, const int* d_status, uint8_t* d_proofs48, uint32_t* d_parts, hipStream_t s) {
+// MSM results u' [n][128] XYZZ rows in d_results -> proofs [n][128][48 B].  d_tmp: n x 128 rows (the transformed points before
+// compression); d_parts: the two buffers of the network, 2 x 686 x n rows (fk20_parts_rows() per blob).
+void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_status, uint8_t* d_proofs48, uint32_t* d_parts, hipStream_t s) {
     if (n <= 0) return;
-    const uint32_t* pl = d_plan;
-    if (n <= FK_DIRECT_MAX_BATCH) {
-        // two chains deep instead of four, 4x the group operations: the right trade while the GPU is mostly idle
-        pl += FK_PLAN_DIRECT;
-        hipLaunchKernelGGL((k_g1_dft_level<64>), dim3(128, n), dim3(64), 0, s, d_results, d_tmp, pl, d_status);
-        hipLaunchKernelGGL(k_g1_fold_halves, dim3(n), dim3(64), 0, s, d_tmp, d_status);
-        pl += 128 * 64;
-        hipLaunchKernelGGL((k_g1_dft_level<64>), dim3(128, n), dim3(64), 0, s, d_tmp, d_results, pl, d_status);
-        hipLaunchKernelGGL(k_fk20_finish, dim3(2, n), dim3(64), 0, s, d_results, d_status, d_proofs48);
-        return;
-    }
-    // four levels of 1024 plan entries each; d_parts (the MSM's slice sums, consumed by now: n x 128 x 16 XYZZ rows) holds the
-    // 1024 x n products of a level
-    const dim3 gm(1024, (n + 63) / 64);
-    auto sum_grid = [&](int n_out, int R) { return dim3((unsigned)(((size_t)n * n_out * R + 63) / 64)); };
-    hipLaunchKernelGGL(k_g1_dft_mul, gm, dim3(64), 0, s, d_results, d_parts, pl, d_status, n);
-    hipLaunchKernelGGL((k_g1_dft_sum<8>), sum_grid(128, 8), dim3(64), 0, s, d_parts, d_tmp, pl, d_status, n, 128);
-    pl += 128 * 8;
-    hipLaunchKernelGGL(k_g1_dft_mul, gm, dim3(64), 0, s, d_tmp, d_parts, pl, d_status, n);
-    hipLaunchKernelGGL((k_g1_dft_sum<16>), sum_grid(64, 16), dim3(64), 0, s, d_parts, d_results, pl, d_status, n, 64);    // h[0..63] -> d_results[0..63]
-    pl += 64 * 16;
-    hipLaunchKernelGGL(k_g1_dft_mul, gm, dim3(64), 0, s, d_results, d_parts, pl, d_status, n);
-    hipLaunchKernelGGL((k_g1_dft_sum<8>), sum_grid(128, 8), dim3(64), 0, s, d_parts, d_tmp, pl, d_status, n, 128);
-    pl += 128 * 8;
-    hipLaunchKernelGGL(k_g1_dft_mul, gm, dim3(64), 0, s, d_tmp, d_parts, pl, d_status, n);
-    hipLaunchKernelGGL((k_g1_dft_sum<8>), sum_grid(128, 8), dim3(64), 0, s, d_parts, d_results, pl, d_status, n, 128);
-    hipLaunchKernelGGL(k_fk20_finish, dim3(2, n), dim3(64), 0, s, d_results, d_status, d_proofs48);
+    uint32_t* bufA = d_parts;
+    uint32_t* bufB = d_parts + (size_t)686 * n * 64;
+    auto grid = [&](int npre, int npost, int ny) { return dim3((unsigned)(((size_t)n * 2 * npre * npost + 63) / 64), (unsigned)ny); };
+    hipLaunchKernelGGL((k_fk20_pre<true>), grid(1, 16, 7), dim3(64), 0, s, d_results, bufA, d_status, n, 1, 16);
+    hipLaunchKernelGGL((k_fk20_pre<false>), grid(7, 4, 7), dim3(64), 0, s, bufA, bufB, d_status, n, 7, 4);
+    hipLaunchKernelGGL((k_fk20_pre<false>), grid(49, 1, 7), dim3(64), 0, s, bufB, bufA, d_status, n, 49, 1);
+    hipLaunchKernelGGL(k_fk20_toom_mul, dim3(686, (n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
+    hipLaunchKernelGGL((k_fk20_post<false>), grid(49, 1, 4), dim3(64), 0, s, bufB, bufA, nullptr, d_status, n, 49, 1);
+    hipLaunchKernelGGL((k_fk20_post<false>), grid(7, 4, 4), dim3(64), 0, s, bufA, bufB, nullptr, d_status, n, 7, 4);
+    hipLaunchKernelGGL((k_fk20_post<true>), grid(1, 16, 4), dim3(64), 0, s, bufB, d_tmp, d_results, d_status, n, 1, 16);
+    hipLaunchKernelGGL(k_fk20_finish, dim3(2, n), dim3(64), 0, s, d_tmp, d_status, d_proofs48);
 }
 
 size_t fk20_table_bytes() { return (size_t)8192 * FK_NWIN * FK_NMULT * 128; }
+size_t fk20_parts_rows() { return (size_t)128 * FK_NWIN; }      // per blob: the MSM's lane partial sums (128 x 24 rows); the transform stage needs 2 x 686 of them
 
 }  // namespace kzg

@@ -352,6 +352,15 @@ __device__ __forceinline__ void shfl_down_xyzz(G1X& r, const G1X& a, int d) {
     }
 }
 
+__device__ __forceinline__ void bcast0_xyzz(G1X& a) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        a.x.l[i] = __shfl(a.x.l[i], 0);
+        a.y.l[i] = __shfl(a.y.l[i], 0);
+        a.zz.l[i] = __shfl(a.zz.l[i], 0);
+        a.zzz.l[i] = __shfl(a.zzz.l[i], 0);
+    }
+}
 // ------------------------------------------------------------------------------------------
 // kernel R2: one wavefront per blob finishes  sum_k (k+1) B_k = sum_t T_t + 16 sum_t t S_t,
 // converts to affine and writes the 48-byte compressed commitment.
@@ -395,8 +404,11 @@ __global__ void __launch_bounds__(64, 2) k_bucket_reduce2(const uint32_t* __rest
         shfl_down_xyzz(o, X, d);
         if (lane < d) g1x_add_ni(X, X, o);
     }
-    if (lane == 0) {
-        // total = X + (16 M) * P
+    {
+        // total = X + (16 M) * P, held by lane 0 after the trees: broadcast, then every lane runs the serial tail (doublings, inversion,
+        // compression) and lane 0 stores -- a wavefront with one active lane issues slower on gfx950 (fk20_kernels.hip FULL_WAVES)
+        bcast0_xyzz(X);
+        bcast0_xyzz(P);
         int sh = 4;
         for (int m = M; m > 1; m >>= 1) sh++;
         for (int q = 0; q < sh; q++) g1x_dbl_ni(P, P);
@@ -405,9 +417,11 @@ __global__ void __launch_bounds__(64, 2) k_bucket_reduce2(const uint32_t* __rest
         g1x_to_affine(a, X);
         uint32_t w[12];
         g1_compress_words(w, a);
-        uint32_t* o32 = reinterpret_cast<uint32_t*>(out48 + (size_t)b * 48);
+        if (lane == 0) {
+            uint32_t* o32 = reinterpret_cast<uint32_t*>(out48 + (size_t)b * 48);
 #pragma unroll
-        for (int i = 0; i < 12; i++) o32[i] = __builtin_bswap32(w[i]);
+            for (int i = 0; i < 12; i++) o32[i] = __builtin_bswap32(w[i]);
+        }
     }
 }
 
@@ -684,12 +698,14 @@ __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __r
         shfl_xor_xyzz(o, acc, m);
         g1x_add(acc, acc, o);
     }
+    // after the xor butterfly every lane holds the sum: all of them run the inversion and the compression (a wavefront with one
+    // active lane issues slower on gfx950, see fk20_kernels.hip FULL_WAVES), lane 0 stores
+    G1Aff a;
+    g1x_to_affine(a, acc);
+    uint32_t w12[12];
+    g1_compress_words(w12, a);
     if (lane == 0) {
         status[b] = 0;
-        G1Aff a;
-        g1x_to_affine(a, acc);
-        uint32_t w12[12];
-        g1_compress_words(w12, a);
         uint32_t* o32 = reinterpret_cast<uint32_t*>(out48 + (size_t)b * 48);
 #pragma unroll
         for (int i = 0; i < 12; i++) o32[i] = __builtin_bswap32(w12[i]);

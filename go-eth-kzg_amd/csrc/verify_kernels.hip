@@ -560,53 +560,55 @@ __global__ void __launch_bounds__(256) k_poly_eval(const uint32_t* __restrict__ 
 // mode 0: both wavefronts, one status per point.  mode 1 / mode 2 (64 threads): only the decoding / only the r-torsion test, as two
 // launches on two streams -- for the cell verifier, whose MSMs can then start on the decoded rows while the test is still running;
 // mode 2 writes MKZG_ERR_G1_NOT_IN_SUBGROUP or 0 to ITS OWN status arrays (the caller gives the decoding's status precedence).
+// Every wavefront runs with all 64 lanes active (FULL_WAVES, see fk20_kernels.hip: sparse wavefronts issue up to 3x slower on gfx950):
+// lanes beyond the points shadow another point and store nothing -- a single-proof verification has one or two points.
 __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
                                                      const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode) {
     __shared__ int sub_ok[64];                              // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
     const int lane = threadIdx.x & 63, role = mode == 0 ? (int)(threadIdx.x >> 6) : mode - 1;
+    const int total = n_a + n_b;
     int i = blockIdx.x * 64 + lane;
-    const bool live = i < n_a + n_b;
+    const bool live = i < total;
+    if (!live) i %= total;
     const uint8_t* in48 = in48_a;
     uint32_t* aff = aff_a;
     int* st = st_a;
-    if (live && i >= n_a) { i -= n_a; in48 = in48_b; aff = aff_b; st = st_b; }
-    if (role == 1) {
-        int v = 2;
-        if (live) {
-            fp_t x, rhs, beta;
-            uint32_t flags;
-            if (g1_parse_lane(x, flags, in48 + (size_t)i * 48) == 0) {
-                g1_curve_rhs(rhs, x);
-                Fp::set(beta, FP_BETA);
-                v = G1D::in_subgroup_yfree(x, rhs, beta) ? 1 : 0;
-            }
-        }
-        if (mode == 2) {
-            if (live) st[i] = v == 0 ? MKZG_ERR_G1_NOT_IN_SUBGROUP : 0;
-            return;
-        }
-        sub_ok[lane] = v;
-        __syncthreads();
-        return;
-    }
+    if (i >= n_a) { i -= n_a; in48 = in48_b; aff = aff_b; st = st_b; }
+    int v = 2, rc = 0;
     G1Aff p;
-    int rc = 0;
-    if (live) {
+    p.inf = 1;
+    if (role == 1) {
+        fp_t x, rhs, beta;
+        uint32_t flags;
+        if (g1_parse_lane(x, flags, in48 + (size_t)i * 48) == 0) {
+            g1_curve_rhs(rhs, x);
+            Fp::set(beta, FP_BETA);
+            v = G1D::in_subgroup_yfree(x, rhs, beta) ? 1 : 0;
+        }
+    } else {
         rc = g1_decode_lane(p, in48 + (size_t)i * 48);
-        uint32_t w[32];
+        if (live) {
+            uint32_t w[32];
 #pragma unroll
-        for (int q = 0; q < 14; q++) { w[q] = p.x.l[q]; w[14 + q] = p.y.l[q]; }
-        w[28] = p.inf; w[29] = 0; w[30] = 0; w[31] = 0;
-        uint4* o = reinterpret_cast<uint4*>(aff + (size_t)i * 32);
+            for (int q = 0; q < 14; q++) { w[q] = p.x.l[q]; w[14 + q] = p.y.l[q]; }
+            w[28] = p.inf; w[29] = 0; w[30] = 0; w[31] = 0;
+            uint4* o = reinterpret_cast<uint4*>(aff + (size_t)i * 32);
 #pragma unroll
-        for (int q = 0; q < 8; q++) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+            for (int q = 0; q < 8; q++) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        }
     }
-    if (mode == 1) {
+    if (mode == 1) {                                        // decoding only (64 threads, all role 0)
         if (live) st[i] = rc;
         return;
     }
+    if (mode == 2) {                                        // r-torsion test only (64 threads, all role 1), its own status arrays
+        if (live) st[i] = v == 0 ? MKZG_ERR_G1_NOT_IN_SUBGROUP : 0;
+        return;
+    }
+    // mode 0: both wavefronts meet at ONE barrier; the decoding wavefront then joins the two verdicts
+    if (role == 1) sub_ok[lane] = v;
     __syncthreads();
-    if (live) {
+    if (role == 0 && live) {
         if (rc == 0 && !p.inf && sub_ok[lane] == 0) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
         st[i] = rc;
     }

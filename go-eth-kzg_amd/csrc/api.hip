@@ -121,30 +121,34 @@ static void lane_destroy(Lane* L) {
     for (auto& e : L->ev_chunk) if (e) (void)hipEventDestroy(e);
 }
 
-// Which free lane: the most recently used one whose previous call has finished on the GPU (its workspaces are allocated and warm; a lone
-// synchronous caller therefore keeps to one lane), and only if every free lane still has work in flight -- asynchronous callers issuing
-// faster than the GPU retires -- the one released longest ago, whose work ends soonest.  Consecutive asynchronous calls thus alternate
-// between lanes and overlap, as the two-workspace scheme of the commitment path always did.
+// Which free lane: (1) the most recently used one whose previous call has finished on the GPU -- its workspaces are allocated and
+// warm, so a lone synchronous caller keeps to one lane; (2) else a lane that has been used before, the one released longest ago (its
+// work ends soonest: asynchronous callers issuing faster than the GPU retires alternate between lanes and overlap, as the
+// two-workspace scheme of the commitment path always did); (3) a lane never used -- cold: its first call allocates -- only when
+// every warm lane is taken.
 Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
     Lane* L = nullptr;
     {
         std::unique_lock<std::mutex> lk(c->mu);
         for (;;) {
             Lane* idle = nullptr;
-            Lane* oldest = nullptr;
+            Lane* warm = nullptr;
+            Lane* cold = nullptr;
             for (int i = 0; i < mkzg_ctx::NLANE; i++) {
                 Lane* q = &c->lanes[i];
                 if (q->busy) continue;
-                if (!oldest || q->released_at < oldest->released_at) oldest = q;
+                if (!q->warm) { if (!cold) cold = q; continue; }
+                if (!warm || q->released_at < warm->released_at) warm = q;
                 const bool finished = !q->used || hipEventQuery(q->done) == hipSuccess;
                 if (finished && (!idle || q->released_at > idle->released_at)) idle = q;
             }
-            L = idle ? idle : oldest;
+            L = idle ? idle : (cold && user_stream ? cold : (warm ? warm : cold));
             if (L) break;
             c->cv.wait(lk);
         }
         (void)hipGetLastError();           // hipEventQuery reports hipErrorNotReady through the sticky error too
         L->busy = true;
+        L->warm = true;
     }
     (void)hipSetDevice(c->device);
     L->failed = false;

@@ -76,6 +76,7 @@ struct Lane {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_decoded = nullptr;
     hipEvent_t done = nullptr;             // recorded on the call's main stream at release: the next owner's stream waits for it (no host sync)
     bool used = false;
+    bool warm = false;                     // has run a call before (workspaces allocated)
     // ---- commitment MSM workspaces
     CommitPlan plan;                       // bucket method: per-lane arrays; plan.d_table points at the context's shared table
     int plan_c = 0, plan_batch = 0;
@@ -145,7 +146,7 @@ struct mkzg_ctx {
     std::vector<mkzg_ctx*> peers;          // further devices of a multi-device context (owned by this, the primary)
     std::atomic<unsigned> rr{0};           // round-robin cursor of single-item calls over the devices
     // ---- lanes
-    static constexpr int NLANE = 4;
+    static constexpr int NLANE = 8;
     Lane lanes[NLANE];
     std::mutex mu;                         // lane hand-over only
     std::condition_variable cv;

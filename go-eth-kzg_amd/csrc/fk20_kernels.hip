@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(64) k_fk20_setup_fft(const uint32_t* __restric
     }
 }
 
-// set-up, step 2: D[(k*64+i)][w][m-1] = m * 2^(8w) * T[k][i], affine rows.  One lane per (point, window).
+// set-up, step 2: D[(k*64+i)][w][m-1] = m * 2^(11 w) * T[k][i] (FK_C = 11), affine rows.  One lane per (point, window).
 __global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restrict__ t_aff, uint32_t* __restrict__ table, int n_points) {
     const size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (gid >= (size_t)n_points * FK_NWIN) return;

@@ -456,6 +456,7 @@ int mkzg_valu_calibrate(mkzg_ctx* c, double* wave_instr_per_s) {
 
 static void ctx_destroy_one(mkzg_ctx* c) {
     if (!c) return;
+    if (c->init_stream) lanes_quiesce(c);           // calls still in flight on other threads finish first
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < mkzg_ctx::NLANE; i++) lane_destroy(&c->lanes[i]);

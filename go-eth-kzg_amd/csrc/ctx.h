@@ -167,10 +167,10 @@ struct mkzg_ctx {
     uint32_t* d_lagrange_aff = nullptr;    // 4096 affine rows, natural order of the JSON
     // ---- shared tables (read-only once built)
     uint32_t* d_commit_table = nullptr;    // bucket method: [nwin][4096] affine rows for commit_table_c
-    int commit_table_c = 0;
+    std::atomic<int> commit_table_c{0};    // published (release) after the table is complete; readers acquire before touching d_commit_table
     uint32_t* d_direct = nullptr;          // direct window table
-    int direct_bits_built = 0;             // 0 with opt_direct_bits != 0 and direct_failed: degraded to the bucket method
-    bool direct_failed = false;            // the table could not be allocated at any width: stop retrying
+    std::atomic<int> direct_bits_built{0}; // 0 with opt_direct_bits != 0 and direct_failed: degraded to the bucket method (published after the build)
+    std::atomic<bool> direct_failed{false}; // the table could not be allocated at any width: stop retrying
     uint32_t* d_roots_brp = nullptr;       // 4096 Fr rows (12 words), bit-reversed domain (api.go:132)
     uint32_t* d_inv_roots_brp = nullptr;
     G1HFixedBase gen_fixed;                // host byte-window table of the G1 generator ([e]G of the batch verifiers)

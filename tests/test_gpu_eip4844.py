@@ -296,3 +296,61 @@ def test_shared_context_from_threads(gpu_ctx, oracle_ctx):
     for t in ts:
         t.join(timeout=900)
     assert not errors, errors[0]
+
+
+def test_first_calls_race_on_a_fresh_context(product, oracle_ctx):
+    """every shared table of a context is built lazily by the first call that needs it; here eight threads make their FIRST calls on a
+    brand-new context at the same moment -- commitments, proofs, cells with proofs, recovery, both batch verifiers -- so the lazy
+    construction (twiddles, monomial SRS, commitment table, FK20 table, recovery tables) is raced from every side, and every result must
+    still equal the oracle's"""
+    import threading
+    from test_gpu_commit import rand_blob
+    import torch
+    torch.cuda.init()
+    blob = rand_blob(777)
+    rc, cm = oracle_ctx.blob_to_kzg_commitment(blob)
+    rc, pr = oracle_ctx.compute_blob_kzg_proof(blob, cm)
+    rc, ocells, oproofs = oracle_ctx.compute_cells_and_kzg_proofs(blob)
+    cells = [ocells[i * 2048:(i + 1) * 2048] for i in range(128)]
+    proofs = [oproofs[i * 48:(i + 1) * 48] for i in range(128)]
+    ctx = product.Context()
+    errors = []
+    gate = threading.Barrier(8)
+
+    def worker(k):
+        try:
+            gate.wait()
+            if k == 0:
+                assert ctx.BlobToKZGCommitment(blob) == (0, cm)
+            elif k == 1:
+                assert ctx.ComputeBlobKZGProof(blob, cm) == (0, pr)
+            elif k == 2:
+                rc, c2, p2 = ctx.ComputeCellsAndKZGProofs(blob)
+                assert rc == 0 and c2 == cells and p2 == proofs
+            elif k == 3:
+                ids = list(range(0, 128, 2))
+                rc, c2, p2 = ctx.RecoverCellsAndComputeKZGProofs(ids, [cells[i] for i in ids])
+                assert rc == 0 and c2 == cells and p2 == proofs
+            elif k == 4:
+                assert ctx.VerifyBlobKZGProofBatch([blob, blob], [cm, cm], [pr, pr]) == 0
+            elif k == 5:
+                ids = [0, 1, 64, 127]
+                assert ctx.VerifyCellKZGProofBatch([cm] * 4, ids, [cells[i] for i in ids], [proofs[i] for i in ids]) == 0
+            elif k == 6:
+                rc, c2 = ctx.ComputeCells(blob)
+                assert rc == 0 and c2 == cells
+            else:
+                ids = list(range(1, 128, 2))
+                rc, c2 = ctx.RecoverCells(ids, [cells[i] for i in ids])
+                assert rc == 0 and c2 == cells
+        except Exception:      # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=900)
+    ctx.close()
+    assert not errors, errors[0]

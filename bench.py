@@ -92,7 +92,7 @@ def parse_args():
     ap.add_argument("--window", type=int, default=0, help="MSM window bits override (11..13)")
     ap.add_argument("--direct-bits", type=int, default=15,
                     help="commit_direct_bits option: 0 = bucket method (0.5 GB table), 12..15 = direct window table (15: 146 GB of the 288 GB HBM)")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate over (1 = strictly serial steps)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps alternate over (1 = strictly serial steps)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents (roofline section is then empty)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drop-in", action="store_true")

@@ -6,6 +6,7 @@
 // All field work happens in cells_kernels.hip / fk20_kernels.hip / recover_kernels.hip; the host stages bytes, orders the
 // reference's checks and finishes the verifier with one pairing.  Every call works in one Lane (ctx.h).
 #include <sys/random.h>
+#include <functional>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -307,27 +308,35 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     HIPCHK(hipEventRecord(L->ev_decoded, s2));
     KT(KT_SUBGROUP, s3, g1_validate2_device(L->d_v_raw, (int)n_rows, nullptr, sub_rows, L->d_v_raw + cap * 48, (int)n, nullptr, sub_q, s3, 2));
     HIPCHK(hipEventRecord(L->ev_join, s3));
-    // uploads, part 2 (host memcpy of n x 2 KiB into the pinned staging area runs while the GPU validates the points)
+    // uploads, part 2: the cells (n x 2 KiB, scattered host pointers) are gathered into the pinned staging area by the host pool running
+    // AHEAD of this thread -- all chunks' tasks queued at once -- while the GPU validates the points; this thread waits for chunk k only
+    // and puts its copy in flight
     {
-        auto gather = [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; i++) {
+        const size_t CH = 2048;
+        const size_t nch = (n + CH - 1) / CH;
+        const int TPC = n >= 256 ? 4 : 1;
+        std::vector<std::atomic<int>> left(nch);
+        for (auto& a : left) a.store(TPC, std::memory_order_relaxed);
+        std::atomic<int> all_left((int)nch * TPC);
+        const std::function<void(int)> gather = [&](int t) {
+            const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(n, lo + CH), per = (hi - lo + TPC - 1) / TPC, q = (size_t)(t % TPC);
+            for (size_t i = lo + q * per; i < std::min(hi, lo + (q + 1) * per); i++) {
                 if (cells[i]) memcpy(L->h_stage + i * 2048, cells[i], 2048);
                 else memset(L->h_stage + i * 2048, 0, 2048);           // stands in for nil entries (reported after the device work)
             }
+            left[k].fetch_sub(1, std::memory_order_release);
         };
-        if (n >= 1024) {
-            // 16 MiB for 8192 cells: gathered by eight host threads in chunks of 2048 cells, each chunk's copy to the device in flight
-            // while the next one is gathered
-            const size_t chunk = 2048;
-            for (size_t lo = 0; lo < n; lo += chunk) {
-                const size_t hi = std::min(n, lo + chunk), q = (hi - lo + 7) / 8;
-                c->pool->parallel(8, [&](int i) { gather(std::min(hi, lo + (size_t)i * q), std::min(hi, lo + (size_t)(i + 1) * q)); });
+        c->pool->run_async((int)nch * TPC, gather, &all_left);
+        int urc = [&]() -> int {
+            for (size_t k = 0; k < nch; k++) {
+                const size_t lo = k * CH, hi = std::min(n, lo + CH);
+                while (left[k].load(std::memory_order_acquire) != 0) std::this_thread::yield();
                 HIPCHK(hipMemcpyAsync(L->d_cv_cells + lo * 2048, L->h_stage + lo * 2048, (hi - lo) * 2048, hipMemcpyHostToDevice, s));
             }
-        } else {
-            gather(0, n);
-            HIPCHK(hipMemcpyAsync(L->d_cv_cells, L->h_stage, n * 2048, hipMemcpyHostToDevice, s));
-        }
+            return MKZG_OK;
+        }();
+        while (all_left.load(std::memory_order_acquire) != 0) std::this_thread::yield();          // the tasks reference this frame
+        if (urc) return urc;
         HIPCHK(hipMemcpyAsync(L->d_cv_cell_idx, h_cidx, n * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(L->d_cv_row_idx, h_ridx, n * 4, hipMemcpyHostToDevice, s));
         memcpy(h_misc, r_words, 32);
@@ -590,16 +599,30 @@ int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* c, size_t n_blobs, const u
         const size_t m = std::min<size_t>(64, n_blobs - done);
         int rc = recover_front(c, L, m, cell_ids + done, n_ids + done, cells + done, n_cells + done, true, status + done);
         if (rc) return G.fail(rc);
-        // runs of good blobs leave in one copy each
+        // good blobs leave through the lane's pinned staging area (a device-to-pageable copy is staged by the runtime at a fraction of
+        // the PCIe rate): one device copy per run of good blobs, then the host pool spreads them to the caller's buffers
+        rc = ensure_staging(L, 1, m * (262144 + 128 * 48));
+        if (rc) return G.fail(rc);
+        uint8_t* h_cells = L->h_stage;
+        uint8_t* h_proofs = L->h_stage + m * 262144;
         for (size_t b = 0; b < m;) {
             if (status[done + b]) { if (!first) first = status[done + b]; b++; continue; }
             size_t e = b;
             while (e < m && !status[done + e]) e++;
-            HIPCHK(hipMemcpyAsync(cells_out + (done + b) * 262144, L->d_cells + b * 262144, (e - b) * 262144, hipMemcpyDeviceToHost, G.s));
-            HIPCHK(hipMemcpyAsync(proofs_out + (done + b) * 128 * 48, L->d_fk_proofs + b * 128 * 48, (e - b) * 128 * 48, hipMemcpyDeviceToHost, G.s));
+            HIPCHK(hipMemcpyAsync(h_cells + b * 262144, L->d_cells + b * 262144, (e - b) * 262144, hipMemcpyDeviceToHost, G.s));
+            HIPCHK(hipMemcpyAsync(h_proofs + b * 128 * 48, L->d_fk_proofs + b * 128 * 48, (e - b) * 128 * 48, hipMemcpyDeviceToHost, G.s));
             b = e;
         }
         HIPCHK(hipStreamSynchronize(G.s));
+        const int nthr = m >= 8 ? 8 : 1;
+        const size_t per = (m + nthr - 1) / nthr;
+        c->pool->parallel(nthr, [&](int q) {
+            for (size_t b = (size_t)q * per; b < std::min(m, (size_t)(q + 1) * per); b++) {
+                if (status[done + b]) continue;
+                memcpy(cells_out + (done + b) * 262144, h_cells + b * 262144, 262144);
+                memcpy(proofs_out + (done + b) * 128 * 48, h_proofs + b * 128 * 48, 128 * 48);
+            }
+        });
     }
     return first;
 }

@@ -16,6 +16,7 @@
 // Integer modular arithmetic only -- no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "mont29.hpp"
 #include "recover_kernels.h"
 
@@ -129,10 +130,16 @@ __global__ void __launch_bounds__(256) k_recover_tables(uint32_t* __restrict__ p
 //   inv_zc[j] = 1 / S(7^64 w_128^j)     (= 1 / FFT_coset(Z)[j'])
 // All stage kernels take the blob in blockIdx.y: per blob 192 ints of positions (cell_pos[128] | missing[64]), one count of missing
 // cells, RECOVER_SCRATCH_WORDS of scratch, 4096 coefficient rows and one status word.
-__global__ void __launch_bounds__(128) k_recover_vanishing(const int* __restrict__ pos_all, const int* __restrict__ n_missing_all, const uint32_t* __restrict__ tw_fwd,
+// VAN_COPIES x 128 threads per blob: the 128 evaluation points once per copy, copies beyond the first shadow it and store nothing.
+// Why: 64 blobs x 128 lanes = 8192 active lanes is exactly where gfx950 drops into its sparse-wavefront mode (fk20_kernels.hip
+// FULL_WAVES), and that mode outlasts the kernel: the next chip-filling launch (k_fk20_msm, 0.5 ms later) then ran at 3.6 ms instead
+// of 2.0 (measured by skipping kernels one at a time, tools/bench_recover.py).
+constexpr int VAN_COPIES = 4;
+__global__ void __launch_bounds__(128 * VAN_COPIES) k_recover_vanishing(const int* __restrict__ pos_all, const int* __restrict__ n_missing_all, const uint32_t* __restrict__ tw_fwd,
                                                            const uint32_t* __restrict__ pow7, uint32_t* __restrict__ scratch_all) {
     __shared__ uint32_t sz[2][65 * 9];
-    const int t = threadIdx.x, blob = blockIdx.y;
+    const int t = threadIdx.x & 127, blob = blockIdx.y;
+    const bool live = threadIdx.x < 128;
     const uint32_t* missing = reinterpret_cast<const uint32_t*>(pos_all + (size_t)blob * 192 + 128);
     const int n_missing = n_missing_all[blob];
     uint32_t* zeval = scratch_all + (size_t)blob * RECOVER_SCRATCH_WORDS;
@@ -165,7 +172,7 @@ __global__ void __launch_bounds__(128) k_recover_vanishing(const int* __restrict
             if (t <= m) get(cur, t, lo);
             r_mul(lo, lo, x);
             FrC::sub(v, hi, lo);
-            put(cur ^ 1, t, v);
+            if (live) put(cur ^ 1, t, v);
         }
         __syncthreads();
         cur ^= 1;
@@ -185,11 +192,11 @@ __global__ void __launch_bounds__(128) k_recover_vanishing(const int* __restrict
         r_mul(a1, a1, x1);
         FrC::add(a1, a1, cj);
     }
-    r_store_fr12(zeval + (size_t)t * 12, a0);
+    if (live) r_store_fr12(zeval + (size_t)t * 12, a0);
     fr_t inv;
     Fr::inv(inv, a1);                       // divsteps (modinv30.hpp): ~10x cheaper than the Fermat exponentiation
     Fr::reduce_once(inv, inv);
-    r_store_fr12(inv_zc + (size_t)t * 12, inv);
+    if (live) r_store_fr12(inv_zc + (size_t)t * 12, inv);
 }
 
 // stage A: dz_br = DIF-IFFT_8192( E . Zeval ) without the 1/8192, E[j] = ext[brev13(j)] from the cells
@@ -370,7 +377,7 @@ void recover_coeffs_device(const uint8_t* d_cells, const int* d_pos, const int* 
     // scratch per blob: zeval 128 rows | inv_zc 128 rows | buf0 8192 rows | buf1 8192 rows
     const size_t lds = 9 * 4096 * 4;
     (void)hipMemsetAsync(d_status, 0, (size_t)n_blobs * sizeof(int), s);
-    hipLaunchKernelGGL(k_recover_vanishing, dim3(1, n_blobs), dim3(128), 0, s, d_pos, d_n_missing, d_tw_fwd, d_pow7, d_scratch);
+    hipLaunchKernelGGL(k_recover_vanishing, dim3(1, n_blobs), dim3(128 * VAN_COPIES), 0, s, d_pos, d_n_missing, d_tw_fwd, d_pow7, d_scratch);
     hipLaunchKernelGGL(k_recover_stage_a, dim3(2, n_blobs), dim3(RNT), lds, s, d_cells, d_pos, d_scratch, d_tw_inv, d_status);
     hipLaunchKernelGGL(k_recover_stage_b1, dim3(2, n_blobs), dim3(RNT), lds, s, d_scratch, d_pow7, d_tw_fwd, d_status);
     hipLaunchKernelGGL(k_recover_stage_c, dim3(16, n_blobs), dim3(256), 0, s, d_scratch, d_tw_fwd, d_status);

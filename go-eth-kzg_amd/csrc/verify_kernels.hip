@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stdint.h>
+#include <stdlib.h>
 #include "g1.hpp"
 #include "verify_kernels.h"
 #include "g1_decode.hpp"

@@ -23,7 +23,16 @@ def main():
     h_pin = torch.empty(17 << 20, dtype=torch.uint8).pin_memory()
     d_tmp = torch.empty(17 << 20, dtype=torch.uint8, device="cuda")
 
+    rcells = None
+
     def compute(pre):
+        nonlocal rcells
+        if pre.startswith("recover"):
+            if rcells is None:
+                rc, rcells = ctx.ComputeCells(blobs[0])
+            ids = list(range(0, 128, 2))
+            for _ in range(int(pre[7:] or 1)):
+                ctx.RecoverCells(ids, [rcells[i] for i in ids])
         if pre == "h2d":
             d_tmp[:8 << 20].copy_(h_pin[:8 << 20], non_blocking=True)
         elif pre == "d2h":
@@ -40,7 +49,7 @@ def main():
         return round(p["k_fk20_msm"][0], 3)
 
     compute("none")
-    for pre in ("none", "h2d", "d2h", "gap", "gap10", "none"):
+    for pre in ("none", "recover1", "recover3", "gap10", "none"):
         print(pre, [compute(pre) for _ in range(4)], flush=True)
     ctx.close()
 

@@ -99,6 +99,7 @@ def parse_args():
     ap.add_argument("--verify-batch", type=int, default=1024, help="configs[2]: proofs per VerifyBlobKZGProofBatch call per GPU (0 = skip)")
     ap.add_argument("--verify-steps", type=int, default=3)
     ap.add_argument("--verify-inflight", type=int, default=8, help="caller threads of the sustained-rate leg (one call in flight each)")
+    ap.add_argument("--fk20-bits", type=int, default=11, help="window width of the FK20 fixed-base table: 11 (25.8 GB, default) or 13 (86 GB: 17% fewer additions but TLB-bound gathers, measured no faster; falls back to 11 if HBM is short)")
     ap.add_argument("--cell-blobs", type=int, default=64, help="configs[3]/[4]: blobs per GPU for the EIP-7594 legs (64 x 128 = 8192 cells; 0 = skip)")
     return ap.parse_args()
 
@@ -507,6 +508,7 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
     sharded over the ranks with one exchange step -- and RecoverCellsAndComputeKZGProofs of NB blobs per GPU from their even cells,
     sharded by blob with no collective).  SURVEY.md 8d: seeds 0..63, blob-major tuples, even-indexed cells."""
     NB = args.cell_blobs
+    assert ctx.set_option("fk20_bits", args.fk20_bits) == 0
     blobs = [rand_blob(rank * NB + s) for s in range(NB)]
     d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
     d_cells = torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda")
@@ -528,7 +530,7 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile_read(reset=True)
-    out["compute_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s_per_gpu": round(NB / dt, 1),
+    out["compute_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "fk20_table_bits": ctx.get_option("fk20_bits_effective"), "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s_per_gpu": round(NB / dt, 1),
                                            "kernels_ms": {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3)}
     assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), NB, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
     torch.cuda.synchronize()

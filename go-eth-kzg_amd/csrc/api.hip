@@ -613,6 +613,21 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         lanes_resume(c);
         return MKZG_OK;
     }
+    if (!strcmp(key, "fk20_bits")) {
+        if (value != 11 && value != 13) return MKZG_ERR_BAD_ARGS;
+        lanes_quiesce(c);
+        if (c->opt_fk20_bits != (int)value) {
+            c->opt_fk20_bits = (int)value;
+            if (c->fk_ready.load() && c->fk20_bits_built != (int)value) {      // rebuilt by the next call that needs it
+                dev_free(c->d_fk_table);
+                dev_free(c->d_fk_t_aff);
+                c->fk20_bits_built = 0;
+                c->fk_ready.store(false);
+            }
+        }
+        lanes_resume(c);
+        return MKZG_OK;
+    }
     if (!strcmp(key, "host_chunk")) {
         if (value < 1 || value > 4096) return MKZG_ERR_BAD_ARGS;
         c->opt_host_chunk = (int)value;
@@ -646,6 +661,8 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "commit_direct_bits")) *value = q->opt_direct_bits;
     else if (!strcmp(key, "commit_direct_bits_effective")) *value = q->direct_bits_built;      // 0 until the first commitment builds the table, or after degrading to buckets
     else if (!strcmp(key, "max_batch")) *value = q->opt_max_batch;
+    else if (!strcmp(key, "fk20_bits")) *value = q->opt_fk20_bits;
+    else if (!strcmp(key, "fk20_bits_effective")) *value = q->fk20_bits_built;                   // 0 until the first call that needs the table
     else if (!strcmp(key, "host_chunk")) *value = q->opt_host_chunk;
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;

@@ -70,9 +70,25 @@ int ensure_fk20_tables(mkzg_ctx* c) {
     std::lock_guard<std::mutex> g(c->init_mu);
     if (c->fk_ready.load(std::memory_order_relaxed)) return MKZG_OK;
     rc = dev_realloc(c->d_fk_t_aff, 8192 * 128);
-    if (!rc) rc = dev_realloc(c->d_fk_table, fk20_table_bytes());
     if (rc) return rc;
-    fk20_setup_device(c->d_monomial_aff, c->d_g1tw_fwd, c->d_fk_t_aff, c->d_fk_table, c->init_stream);
+    // 13-bit windows (86 GB) if asked for and available, else 11-bit ones (25.8 GB): same bytes out either way
+    int bits = c->opt_fk20_bits == 13 ? 13 : 11;
+    if (bits == 13) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if ((free_b && fk20_table_bytes(13) + ((size_t)8 << 30) > free_b) || hipMalloc(&c->d_fk_table, fk20_table_bytes(13)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->d_fk_table = nullptr;
+            fprintf(stderr, "[mi355kzg] FK20 table with 13-bit windows (86 GB) does not fit in free HBM: using 11-bit windows\n");
+            bits = 11;
+        }
+    }
+    if (bits == 11) {
+        rc = dev_realloc(c->d_fk_table, fk20_table_bytes(11));
+        if (rc) return rc;
+    }
+    c->fk20_bits_built = bits;
+    fk20_setup_device(c->d_monomial_aff, c->d_g1tw_fwd, c->d_fk_t_aff, c->d_fk_table, bits, c->init_stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->init_stream));
     c->fk_ready.store(true, std::memory_order_release);
@@ -158,7 +174,7 @@ static int cells_and_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs,
         const uint8_t* blobs = d_blobs + done * MKZG_BYTES_PER_BLOB;
         KT(KT_CELLS_NTT, s, cells_from_blobs_device(blobs, (int)chunk, c->d_tw_fwd, c->d_tw_inv, L->d_coeffs, d_cells + done * 262144, d_status + done, s));
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(L->d_coeffs, (int)chunk, c->d_tw_fwd, d_status + done, L->d_fk_scalars, s));
-        KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, (int)chunk, d_status + done, L->d_fk_parts, L->d_fk_results, s));
+        KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, c->fk20_bits_built, (int)chunk, d_status + done, L->d_fk_parts, L->d_fk_results, s));
         KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)chunk, d_status + done, d_proofs + done * 128 * 48, L->d_fk_parts, s));
         done += chunk;
     }
@@ -494,7 +510,7 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
     KT(KT_CELLS_NTT, s, cells_from_coeffs_device(L->d_coeffs, (int)n_blobs, c->d_tw_fwd, c->d_tw_inv, L->d_cells, L->d_cell_st, s));
     if (with_proofs) {
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(L->d_coeffs, (int)n_blobs, c->d_tw_fwd, L->d_cell_st, L->d_fk_scalars, s));
-        KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, (int)n_blobs, L->d_cell_st, L->d_fk_parts, L->d_fk_results, s));
+        KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, c->fk20_bits_built, (int)n_blobs, L->d_cell_st, L->d_fk_parts, L->d_fk_results, s));
         KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)n_blobs, L->d_cell_st, L->d_fk_proofs, L->d_fk_parts, s));
     }
     HIPCHK(hipGetLastError());

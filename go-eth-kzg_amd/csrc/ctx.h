@@ -158,6 +158,7 @@ struct mkzg_ctx {
     int opt_c = 13;
     int opt_direct_bits = 0;               // 0: bucket method; 12..15: direct-table commitment (HBM-hungry, see msm_kernels.hip)
     int opt_max_batch = 256;
+    int opt_fk20_bits = 11;                // window width of the FK20 direct table: 11 (25.8 GB) or 13 (86 GB, 17 % fewer additions per MSM)
     int opt_host_chunk = 128;              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
     int opt_host_zero_copy = 1;            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
     int opt_host_sha = -1;                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
@@ -188,7 +189,8 @@ struct mkzg_ctx {
     uint32_t* d_ipow7 = nullptr;
     std::atomic<bool> fk_ready{false};
     uint32_t* d_fk_t_aff = nullptr;        // 8192 affine rows T[k][i]
-    uint32_t* d_fk_table = nullptr;        // direct window table of the FK20 bases (fk20_table_bytes())
+    uint32_t* d_fk_table = nullptr;        // direct window table of the FK20 bases (fk20_table_bytes(fk20_bits_built))
+    int fk20_bits_built = 0;
     // host finish timing (last verification call), microseconds
     std::atomic<double> last_host_finish_us{0.0};
 };

@@ -261,25 +261,26 @@ __global__ void __launch_bounds__(64) k_fk20_setup_fft(const uint32_t* __restric
     }
 }
 
-// set-up, step 2: D[(k*64+i)][w][m-1] = m * 2^(11 w) * T[k][i] (FK_C = 11), affine rows.  One lane per (point, window).
-__global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restrict__ t_aff, uint32_t* __restrict__ table, int n_points) {
+// set-up, step 2: D[(k*64+i)][w][m-1] = m * 2^(C w) * T[k][i] for the nwin = ceil(256 / C) windows and m = 1 .. 2^(C-1), affine rows.
+// One lane per (point, window).
+__global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restrict__ t_aff, uint32_t* __restrict__ table, int n_points, int cbits, int nwin) {
     const size_t gid = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (gid >= (size_t)n_points * FK_NWIN) return;
-    const int pt = (int)(gid / FK_NWIN), w = (int)(gid % FK_NWIN);
+    if (gid >= (size_t)n_points * nwin) return;
+    const int pt = (int)(gid / nwin), w = (int)(gid % nwin), nmult = 1 << (cbits - 1);
     G1Aff base;
     f_load_affine(base, t_aff + (size_t)pt * 32);
-    uint32_t* dst = table + ((size_t)pt * FK_NWIN + w) * FK_NMULT * 32;
+    uint32_t* dst = table + ((size_t)pt * nwin + w) * nmult * 32;
     if (base.inf) {
-        for (int m = 0; m < FK_NMULT; m++) f_store_affine(dst + (size_t)m * 32, base);
+        for (int m = 0; m < nmult; m++) f_store_affine(dst + (size_t)m * 32, base);
         return;
     }
     G1X b;
     g1x_from_affine(b, base.x, base.y);
-    for (int q = 0; q < FK_C * w; q++) f_dbl(b, b);
+    for (int q = 0; q < cbits * w; q++) f_dbl(b, b);
     f_to_affine(base, b);
     G1X acc;
     g1x_set_inf(acc);
-    for (int m = 0; m < FK_NMULT; m++) {
+    for (int m = 0; m < nmult; m++) {
         f_madd(acc, base.x, base.y);
         G1Aff a;
         f_to_affine(a, acc);
@@ -288,8 +289,12 @@ __global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------
-// k_fk20_msm: R[b][k] = sum_i V[b][k][i] * T[k][i] through the direct table.  FK_LANES (8) lanes per MSM,
-// lane l handles windows FK_WPL l .. FK_WPL l + 2 (11 bits each) for all 64 points; 8 MSMs per wavefront, one wavefront per SIMD at batch 64.
+// k_fk20_msm: R[b][k] = sum_i V[b][k][i] * T[k][i] through the direct table of C-bit windows (NWIN = ceil(256 / C) signed Booth
+// digits per scalar).  An MSM-64 is shared by LW x LP lanes: lane (wg, pg) adds the rows of windows WPL wg .. WPL wg + WPL - 1 for the
+// points 64/LP pg .. 64/LP (pg + 1) - 1, so every lane of every configuration walks the same number of additions:
+//   C = 11: <8, 1, 3> batches (8 MSMs per wavefront, 192 additions per lane; one wavefront per SIMD at 64 blobs), <24, 1, 1> few blobs
+//   C = 13: <4, 2, 5> batches (160 additions per lane), <10, 2, 2> few blobs (64 additions per lane)
+// k_fk20_msm_reduce adds the lanes of an MSM.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void f_shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
 #pragma unroll
@@ -300,83 +305,112 @@ __device__ __forceinline__ void f_shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
         r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
     }
 }
-// the lane's WPL windows of one scalar plus the Booth overlap bit below them: bits [WPL FK_C sub - 1, WPL FK_C (sub + 1))
-template <int WPL>
-__device__ __forceinline__ uint64_t fk_field(const uint32_t* __restrict__ s, int sub) {
-    constexpr int W = WPL * FK_C;
-    static_assert(W + 1 <= 63, "a lane's windows plus the overlap bit must fit 64 bits");
-    const uint64_t mask = ((uint64_t)1 << (W + 1)) - 1;
-    if (sub == 0) return (((uint64_t)s[1] << 32 | s[0]) << 1) & mask;
-    const int bit = W * sub - 1, wi = bit >> 5, off = bit & 31;
-    uint64_t v = (((uint64_t)(wi + 1 < 8 ? s[wi + 1] : 0u) << 32) | s[wi]) >> off;
-    if (off + W + 1 > 64 && wi + 2 < 8) v |= (uint64_t)s[wi + 2] << (64 - off);
-    return v & mask;
+// signed Booth digit w of a 256-bit scalar s[8] (little-endian words): bits [C w - 1, C w + C), value in [-2^(C-1), 2^(C-1)]
+template <int C>
+__device__ __forceinline__ int fk_digit(const uint32_t s[8], int w) {
+    const int bit = C * w - 1;
+    uint32_t v;
+    if (bit < 0) {
+        v = (s[0] << 1) & ((2u << C) - 1);
+    } else {
+        const int wi = bit >> 5, off = bit & 31;
+        uint64_t x = wi < 8 ? (uint64_t)s[wi] : 0ull;
+        if (wi + 1 < 8) x |= (uint64_t)s[wi + 1] << 32;
+        v = (uint32_t)(x >> off) & ((2u << C) - 1);
+    }
+    int d = (int)((v + 1) >> 1);
+    if (v >> C) d -= (1 << C);
+    return d;
 }
-// <LANES, WPL> = <8, 3>: batches (8 MSMs per wavefront, 192 additions per lane; one wavefront per SIMD at 64 blobs);
-//                <24, 1>: calls with few blobs (2 MSMs per wavefront, 64 additions per lane: a third of the latency, 64 wavefronts per blob)
-template <int LANES, int WPL>
+template <int C, int LW, int LP, int WPL>
 __global__ void __launch_bounds__(64, 2) k_fk20_msm(const uint32_t* __restrict__ scalars, const uint32_t* __restrict__ table, const int* __restrict__ status,
                                                     uint32_t* __restrict__ parts) {
-    static_assert(LANES * WPL == FK_NWIN, "lanes x windows per lane = windows of a scalar");
-    // table rows travel HBM -> LDS with global_load_lds_dwordx4 while the previous row is added (see k_commit_direct_acc)
-    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[8 * 256];
+    constexpr int NWIN = (256 + C - 1) / C, NMULT = 1 << (C - 1), LANES = LW * LP, PPL = 64 / LP;      // C NWIN >= 256: the top Booth digit of a scalar < 2^255 is not negative
+    static_assert(LW * WPL == NWIN && LP * PPL == 64, "lanes x windows per lane = windows of a scalar; point groups tile the 64 points");
+    constexpr int NSTEP = PPL * WPL;
+    // Table rows travel HBM -> LDS with global_load_lds_dwordx4 (no VGPR destination) TWO additions ahead of their use, in two row
+    // buffers: with one wavefront per SIMD (batch 64) a lane has nothing else to hide a row's latency behind, and over the 86 GB table
+    // of 13-bit windows a random row takes longer than one addition (measured: one row ahead, 14.4 us per step against 10.4).
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[2][8 * 256];
     const int b = blockIdx.y;
     if (status[b] != 0) return;
-    const int lane = threadIdx.x, sub = lane % LANES;
-    const bool active = lane < (64 / LANES) * LANES;       // <24, 1> leaves 16 lanes without an MSM
-    const int k = blockIdx.x * (64 / LANES) + (active ? lane / LANES : 0);
-    const uint32_t* sc = scalars + ((size_t)b * 128 + k) * 64 * 8;
+    const int lane = threadIdx.x, sub = lane % LANES, wg = sub % LW, pg = sub / LW;
+    const int k0 = blockIdx.x * (64 / LANES) + lane / LANES;
+    const bool active = lane < (64 / LANES) * LANES && k0 < 128;       // e.g. <24, 1, 1> leaves 16 lanes without an MSM; 20-lane groups do not divide 128
+    const int k = active ? k0 : 0;
+    const uint32_t* sc = scalars + (((size_t)b * 128 + k) * 64 + (size_t)pg * PPL) * 8;      // this lane's first point
     G1X acc;
     g1x_set_inf(acc);
-    uint64_t fld = fk_field<WPL>(sc, sub), fld_next = 0;
-    bool cur = false, cneg = false;
-    int i = 0, ww = 0;                                    // point and window-within-lane of step t
+    // step u = (point i, window ww) of this lane; its digit and row address are computed when its DMA is issued, two steps early
+    auto load_scalar = [&](uint32_t w8[8], int i) {
+        const uint4 a = *reinterpret_cast<const uint4*>(sc + i * 8), c4 = *reinterpret_cast<const uint4*>(sc + i * 8 + 4);
+        w8[0] = a.x; w8[1] = a.y; w8[2] = a.z; w8[3] = a.w; w8[4] = c4.x; w8[5] = c4.y; w8[6] = c4.z; w8[7] = c4.w;
+    };
+    uint32_t cur_s[8], nxt_s[8];
+    load_scalar(cur_s, 0);
+    load_scalar(nxt_s, PPL > 1 ? 1 : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int iu = 0, wu = 0;                                    // point / window of the next step to ISSUE
+    unsigned pend = 0;                                     // bit q: the row of step (t + q) is in flight / landed; bit 4 + q: it is to be subtracted
+    auto issue = [&](int slot, int q) {                    // issue the DMA of step (iu, wu) into row buffer `slot`; q = distance to its use (1 or 2)
+        const int wi = WPL * wg + wu, pi = pg * PPL + iu;
+        const int d = fk_digit<C>(cur_s, wi);
+        if (++wu == WPL) {
+            wu = 0;
+            iu++;
+#pragma unroll
+            for (int z = 0; z < 8; z++) cur_s[z] = nxt_s[z];
+            if (iu + 1 < PPL) load_scalar(nxt_s, iu + 1);  // two VMEM loads, issued BEFORE this step's row: retired by the wait that retires the row before it
+        }
+        if (d != 0 && active) {
+            const int m = d < 0 ? -d : d;
+            pend |= (1u << q) | ((d < 0 ? 1u : 0u) << (4 + q));
+            const uint32_t* row = table + (((size_t)(k * 64 + pi) * NWIN + wi) * NMULT + (m - 1)) * 32;
+#pragma unroll
+            for (int z = 0; z < 8; z++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + 4 * z),
+                                                 (__attribute__((address_space(3))) void*)(rowbuf[slot] + z * 256), 16, 0, 0);
+        } else {
+            // keep the in-flight count per step constant (the wait below counts operations): eight harmless reads of this lane's row slot
+#pragma unroll
+            for (int z = 0; z < 8; z++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(table + 4 * z),
+                                                 (__attribute__((address_space(3))) void*)(rowbuf[slot] + z * 256), 16, 0, 0);
+        }
+    };
+    issue(0, 0);                                           // step 0 -> buffer 0
+    if (NSTEP > 1) issue(1, 1);                            // step 1 -> buffer 1
 #pragma unroll 1
-    for (int t = 0; t <= 64 * WPL; t++) {
+    for (int t = 0; t < NSTEP; t++) {
+        // everything but the eight most recent operations (the row of step t + 1) has landed: the row of step t and any scalar loads
+        if (t + 1 < NSTEP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         G1Aff p;
         p.inf = 1;
-        if (cur) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool have = (pend & 1u) != 0, neg = (pend & 16u) != 0;
+        if (have) {
+            const uint32_t* rb = rowbuf[t & 1];
             uint32_t rw[32];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                const uint4 v = *reinterpret_cast<const uint4*>(rowbuf + q * 256 + lane * 4);
+                const uint4 v = *reinterpret_cast<const uint4*>(rb + q * 256 + lane * 4);
                 rw[4 * q] = v.x; rw[4 * q + 1] = v.y; rw[4 * q + 2] = v.z; rw[4 * q + 3] = v.w;
             }
 #pragma unroll
             for (int q = 0; q < 14; q++) { p.x.l[q] = rw[q]; p.y.l[q] = rw[14 + q]; }
             p.inf = rw[28];
 #pragma unroll
-            for (int q = 0; q < 14; q++) asm volatile("" : "+v"(p.x.l[q]), "+v"(p.y.l[q]));
+            for (int q = 0; q < 14; q++) asm volatile("" : "+v"(p.x.l[q]), "+v"(p.y.l[q]));      // LDS reads retired before the buffer is refilled
             asm volatile("" : "+v"(p.inf));
         }
-        bool nxt = false, nneg = false;
-        if (t < 64 * WPL) {
-            if (ww == 0 && i + 1 < 64) fld_next = fk_field<WPL>(sc + (i + 1) * 8, sub);       // lands long before it is needed
-            const uint32_t v = (uint32_t)(fld >> (FK_C * ww)) & ((2u << FK_C) - 1);
-            int d = (int)((v + 1) >> 1);
-            if (v >> FK_C) d -= (1 << FK_C);
-            const int wi = WPL * sub + ww, pi = i;
-            if (++ww == WPL) { ww = 0; i++; fld = fld_next; }
-            if (d != 0 && active) {
-                const int m = d < 0 ? -d : d;
-                nneg = d < 0;
-                nxt = true;
-                const uint32_t* row = table + (((size_t)(k * 64 + pi) * FK_NWIN + wi) * FK_NMULT + (m - 1)) * 32;
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + 4 * q),
-                                                     (__attribute__((address_space(3))) void*)(rowbuf + q * 256), 16, 0, 0);
-            }
-        }
+        pend = ((pend >> 1) & 0x7u) | (((pend >> 5) & 0x7u) << 4);
+        if (t + 2 < NSTEP) issue(t & 1, 1);                // the buffer just read takes the row of step t + 2 (bit 1 after the shift = step t + 2 seen from t + 1)
         if (!p.inf) {
-            if (cneg) Fp::template neg<0>(p.y, p.y);
+            if (neg) Fp::template neg<0>(p.y, p.y);
             g1x_madd(acc, p.x, p.y);
         }
-        cur = nxt;
-        cneg = nneg;
     }
-    // the FK_LANES partial sums of an MSM are combined by k_fk20_msm_reduce: any group addition here (inlined or called) makes the
+    // the lanes' partial sums of an MSM are combined by k_fk20_msm_reduce: any group addition here (inlined or called) makes the
     // compiler keep `acc` in scratch memory, whose loads then queue behind the row DMA on vmcnt
     if (active) f_store_xyzz(parts + (((size_t)b * 128 + k) * LANES + sub) * 64, acc);
 }
@@ -516,20 +550,29 @@ __global__ void __launch_bounds__(64) k_fk20_finish(const uint32_t* __restrict__
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fwd, uint32_t* d_t_aff, uint32_t* d_table, hipStream_t s) {
+void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fwd, uint32_t* d_t_aff, uint32_t* d_table, int cbits, hipStream_t s) {
     hipLaunchKernelGGL(k_fk20_setup_fft, dim3(64), dim3(64), 0, s, d_monomial_aff, d_g1tw_fwd, d_t_aff);
-    const size_t n = (size_t)8192 * FK_NWIN;
-    hipLaunchKernelGGL(k_fk20_setup_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_t_aff, d_table, 8192);
+    const int nwin = fk20_nwin(cbits);
+    const size_t n = (size_t)8192 * nwin;
+    hipLaunchKernelGGL(k_fk20_setup_table, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_t_aff, d_table, 8192, cbits, nwin);
 }
-void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s) {
+template <int C, int LW, int LP, int WPL, int PAD>
+static void launch_fk_msm(const uint32_t* d_scalars, const uint32_t* d_table, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s) {
+    constexpr int LANES = LW * LP, PER = 64 / LANES;       // MSMs per wavefront
+    const dim3 grid((128 + PER - 1) / PER, n);
+    hipLaunchKernelGGL((k_fk20_msm<C, LW, LP, WPL>), grid, dim3(64), 0, s, d_scalars, d_table, d_status, d_parts);
+    hipLaunchKernelGGL((k_fk20_msm_reduce<LANES, PAD>), dim3((128 + 64 / PAD - 1) / (64 / PAD), n), dim3(64), 0, s, d_parts, d_status, d_results);
+}
+void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int cbits, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s) {
     if (n <= 0) return;
-    if (n <= FK_DIRECT_MAX_BATCH) {      // latency over occupancy: one window per lane
-        hipLaunchKernelGGL((k_fk20_msm<24, 1>), dim3(128 / 2, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_parts);
-        hipLaunchKernelGGL((k_fk20_msm_reduce<24, 32>), dim3(128 / 2, n), dim3(64), 0, s, d_parts, d_status, d_results);
-        return;
+    const bool few = n <= FK_DIRECT_MAX_BATCH;      // latency over occupancy: one or two windows per lane
+    if (cbits == 13) {
+        if (few) launch_fk_msm<13, 10, 2, 2, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+        else launch_fk_msm<13, 4, 2, 5, 8>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+    } else {
+        if (few) launch_fk_msm<11, 24, 1, 1, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+        else launch_fk_msm<11, 8, 1, 3, 8>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
     }
-    hipLaunchKernelGGL((k_fk20_msm<FK_LANES, FK_WPL>), dim3(128 * FK_LANES / 64, n), dim3(64), 0, s, d_scalars, d_table, d_status, d_parts);
-    hipLaunchKernelGGL((k_fk20_msm_reduce<FK_LANES, FK_LANES>), dim3(128 * FK_LANES / 64, n), dim3(64), 0, s, d_parts, d_status, d_results);
 }
 // MSM results u' [n][128] XYZZ rows in d_results -> proofs [n][128][48 B].  d_tmp: n x 128 rows (the transformed points before
 // compression); d_parts: the two buffers of the network, 2 x 686 x n rows (fk20_parts_rows() per blob).
@@ -548,7 +591,8 @@ void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_
     hipLaunchKernelGGL(k_fk20_finish, dim3(2, n), dim3(64), 0, s, d_tmp, d_status, d_proofs48);
 }
 
-size_t fk20_table_bytes() { return (size_t)8192 * FK_NWIN * FK_NMULT * 128; }
-size_t fk20_parts_rows() { return (size_t)128 * FK_NWIN; }      // per blob: the MSM's lane partial sums (128 x 24 rows); the transform stage needs 2 x 686 of them
+int fk20_nwin(int cbits) { return (256 + cbits - 1) / cbits; }
+size_t fk20_table_bytes(int cbits) { return (size_t)8192 * fk20_nwin(cbits) * ((size_t)1 << (cbits - 1)) * 128; }
+size_t fk20_parts_rows() { return (size_t)128 * 24; }      // per blob: the MSM's lane partial sums (at most 128 x 24 rows); the transform stage needs 2 x 686 of them
 
 }  // namespace kzg

@@ -77,13 +77,16 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         table that leaves 40 GB of the device's free memory untouched.  If the table cannot be allocated the
  *                         next narrower one is tried and finally the bucket method is used: the call still succeeds with the
  *                         same bytes; "commit_direct_bits_effective" (get) reports what is in use.
+ *   "fk20_bits"           window width of the FK20 fixed-base table: 11 (default, 25.8 GB) or 13 (86 GB: 20 instead of 24 group additions
+ *                         per scalar in the 128 MSMs of ComputeCellsAndKZGProofs / recovery); falls back to 11 when the HBM is short
+ *                         ("fk20_bits_effective" reports what is in use)
  *   "host_chunk"          blobs per chunk of the host-pointer commitment pipeline (gather / upload / kernels overlap per chunk; 128)
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
  *   "host_sha"            host-pointer verifiers: Fiat-Shamir challenges hashed by the host pool while the blobs upload (1),
  *                         on the device after the upload (0), library's choice (-1, default) */
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
-/* reads an option back; also "commit_direct_bits_effective", "devices", "lanes" */
+/* reads an option back; also "commit_direct_bits_effective", "fk20_bits_effective", "devices", "lanes" */
 int mkzg_ctx_get_option(mkzg_ctx* ctx, const char* key, long* value);
 
 /* ---- EIP-4844 ------------------------------------------------------------------------------ */

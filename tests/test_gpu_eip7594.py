@@ -1,7 +1,7 @@
 """GPU parity tests of the EIP-7594 paths through the C ABI (reference consensus_specs_test.go:361-519)."""
 import pytest
 
-from test_gpu_commit import rand_blob
+from test_gpu_commit import R, rand_blob
 
 pytestmark = pytest.mark.gpu
 
@@ -235,3 +235,36 @@ def test_cells_and_proofs_async_on_two_streams(gpu_ctx, oracle_ctx):
         for i, b in enumerate(blobs):
             rc, oc, op = oracle_ctx.compute_cells_and_kzg_proofs(b)
             assert rc == 0 and cb[i * 262144:(i + 1) * 262144] == oc and pb[i * 6144:(i + 1) * 6144] == op
+
+
+def test_fk20_table_widths_agree(product, oracle_ctx):
+    """fk20_bits 11 (default) and 13 (86 GB table, 20 instead of 24 additions per scalar) give the oracle's bytes, for one blob (few-blob
+    lane layout) and for a batch (batch lane layout); switching the option rebuilds the table"""
+    import torch
+    torch.cuda.init()
+    blobs = [rand_blob(900 + i) for i in range(12)] + [bytes(131072), (R - 1).to_bytes(32, "big") * 4096]
+    exp = [oracle_ctx.compute_cells_and_kzg_proofs(b) for b in blobs[:2] + blobs[-2:]]
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    n = len(blobs)
+    outs = {}
+    ctx = product.Context()
+    try:
+        for bits in (13, 11, 13):
+            assert ctx.set_option("fk20_bits", bits) == 0
+            assert ctx.set_option("fk20_bits", 12) == 17
+            rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blobs[0])
+            assert rc == 0 and ctx.get_option("fk20_bits_effective") == bits
+            assert b"".join(cells) == exp[0][1] and b"".join(proofs) == exp[0][2]
+            d_cells = torch.zeros(n * 262144, dtype=torch.uint8, device="cuda")
+            d_proofs = torch.zeros(n * 128 * 48, dtype=torch.uint8, device="cuda")
+            d_st = torch.ones(n, dtype=torch.int32, device="cuda")
+            assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), n, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), 0) == 0
+            torch.cuda.synchronize()
+            assert int(d_st.abs().sum().item()) == 0
+            pr = d_proofs.cpu().numpy().tobytes()
+            for j, b in enumerate([0, 1, n - 2, n - 1]):
+                assert pr[b * 6144:(b + 1) * 6144] == exp[j][2], (bits, b)
+            outs[bits] = pr
+        assert outs[11] == outs[13]
+    finally:
+        ctx.close()

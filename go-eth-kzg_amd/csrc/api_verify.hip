@@ -245,15 +245,18 @@ static int verify_device_all(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const
 // threads hash each transcript right after copying it (the blob is then still in their cache) and the device skips its own hash.
 // A nil blob stands in as the zero blob and is reported with the reference's precedence afterwards.
 // ---------------------------------------------------------------------------------------------
-static bool use_host_sha(const mkzg_ctx* c) {
+// auto: the device hash is a latency chain of 2050 compressions per blob -- 2.7 ms whether the call brings 1 blob or 1024 -- while a host
+// core with SHA-NI hashes a blob in ~70 us: up to 8 blobs per pool thread the host is the shorter path (a single VerifyBlobKZGProof or
+// ComputeBlobKZGProof saves 2.6 ms); from there on the device hash of the resident batch beats the 16-CPU box.
+static bool use_host_sha(const mkzg_ctx* c, size_t m) {
     if (c->opt_host_sha >= 0) return c->opt_host_sha != 0;
-    return false;        // measured on the 16-CPU GPU box: the device hash of a resident batch beats 16 cores of SHA-NI
+    return m <= 8 * (size_t)std::max(1, c->pool->size());
 }
 static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t m, uint32_t exp_offset,
                            const uint8_t* r_le32, VerifyFold* out, int* rc_nil /* out: MKZG_ERR_NIL_INPUT precedence result, or 0 */) {
     *rc_nil = 0;
     hipStream_t s = L->stream;
-    const bool hsha = use_host_sha(c);
+    const bool hsha = use_host_sha(c, m);
     int rc = ensure_staging(L, m, MKZG_BYTES_PER_BLOB + 128);
     if (!rc) rc = ensure_verify_ws(L, m);
     if (rc) return rc;
@@ -269,7 +272,7 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
     // the gather runs ahead on the host pool (all chunks' tasks queued at once); this thread waits for chunk k only and puts its copy in flight
     const size_t CH = 128;
     const size_t nch = (m + CH - 1) / CH;
-    const int TPC = m >= 16 ? 4 : 1;
+    const int TPC = hsha ? (int)std::min<size_t>(std::min(m, CH), (size_t)std::max(1, c->pool->size())) : (m >= 16 ? 4 : 1);
     std::vector<std::atomic<int>> left(nch);
     for (auto& a : left) a.store(TPC, std::memory_order_relaxed);
     std::atomic<int> all_left((int)nch * TPC);
@@ -416,7 +419,9 @@ int mkzg_verify_kzg_proof(mkzg_ctx* c, const uint8_t commitment48[48], const uin
 // ---- proofs -------------------------------------------------------------------------------
 // Context.ComputeBlobKZGProof for a device-resident batch (reference prove.go:46-77 per item):
 // status[i] receives the per-item code; proofs of failed items are undefined.
-static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_commitments48, size_t n, uint8_t* d_proofs48, int* d_status, hipStream_t s) {
+// d_z32: the challenges when the caller hashed the transcripts on the host (n x 32 B big-endian, canonical), else nullptr.
+static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_commitments48, size_t n, uint8_t* d_proofs48, int* d_status, hipStream_t s,
+                                      const uint8_t* d_z32 = nullptr) {
     // Slices of up to 4096 proofs.  Per slice the latency-bound stages run ONCE over the whole slice -- Fiat-Shamir challenges
     // (a 2050-compression chain per blob whatever the count) on the caller's stream, commitment decoding + subgroup checks on the
     // side stream -- and only the quotient + MSM stage is cut into max_batch pieces (its workspace is 196 KB per blob).
@@ -436,7 +441,8 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         HIPCHK(hipStreamWaitEvent(L->side, L->ev_fork, 0));
         g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, L->side);
         HIPCHK(hipEventRecord(L->ev_join, L->side));
-        KT(KT_SHA256, s, challenge_device(blobs, cms, (int)slice, L->d_q_z, s));
+        if (d_z32) scalars_to_fr_device(d_z32 + done * 32, (int)slice, L->d_q_z, L->d_v_st + 3 * L->v_cap, s);
+        else KT(KT_SHA256, s, challenge_device(blobs, cms, (int)slice, L->d_q_z, s));
         for (size_t off = 0; off < slice; off += (size_t)c->opt_max_batch) {
             const size_t chunk = std::min<size_t>(slice - off, (size_t)c->opt_max_batch);
             KT(KT_QUOTIENT, s, blob_quotient_device(blobs + off * MKZG_BYTES_PER_BLOB, L->d_q_z + off * 12, c->d_roots_brp, c->d_inv_roots_brp, (int)chunk, L->d_q_y + off * 12,
@@ -478,8 +484,10 @@ int mkzg_compute_blob_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t 
     if (rc) return G.fail(rc);
     memcpy(L->h_stage, blob, MKZG_BYTES_PER_BLOB);
     memcpy(L->h_stage + MKZG_BYTES_PER_BLOB, commitment48, 48);
-    HIPCHK(hipMemcpyAsync(L->d_blobs, L->h_stage, MKZG_BYTES_PER_BLOB + 48, hipMemcpyHostToDevice, G.s));
-    rc = compute_blob_proofs_device(c, L, L->d_blobs, L->d_blobs + MKZG_BYTES_PER_BLOB, 1, L->d_out, L->d_status, G.s);
+    const bool hsha = use_host_sha(c, 1);                      // one transcript: ~70 us on this thread instead of the 2.7 ms device chain
+    if (hsha) host_compute_challenge(L->h_stage + MKZG_BYTES_PER_BLOB + 64, L->h_stage, commitment48);
+    HIPCHK(hipMemcpyAsync(L->d_blobs, L->h_stage, MKZG_BYTES_PER_BLOB + 96, hipMemcpyHostToDevice, G.s));
+    rc = compute_blob_proofs_device(c, L, L->d_blobs, L->d_blobs + MKZG_BYTES_PER_BLOB, 1, L->d_out, L->d_status, G.s, hsha ? L->d_blobs + MKZG_BYTES_PER_BLOB + 64 : nullptr);
     if (rc) return G.fail(rc);
     HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, 48, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(L->h_out + 48, L->d_status, sizeof(int), hipMemcpyDeviceToHost, G.s));

@@ -457,15 +457,33 @@ struct G1T {
         select(res, a_inf, bj, res);
         r = res;
     }
-    static KZ_HD bool in_subgroup_yfree(const fe& px, const fe& rhs, const fe& beta) {
-        fe rhs2;
+    // the chain's start (P as (x rhs, rhs^2, z = 1) with its cached operand) and its verdict, shared with the lane-quad form of the
+    // chain in verify_kernels.hip (k_g1_validate)
+    static KZ_HD void yfree_start(Jac& Q, JacYC& base, fe& rhs2, const fe& px, const fe& rhs) {
         F::sqr(rhs2, rhs);
-        Jac Q;
         F::mul(Q.x, px, rhs);
         Q.y = rhs2;
         F::set_one(Q.z);
-        JacYC base;
         jy_cache(base, Q, rhs);
+    }
+    static KZ_HD bool yfree_verdict(const Jac& Q, const fe& px, const fe& rhs, const fe& rhs2, const fe& beta) {
+        if (is_inf(Q)) return false;
+        fe l, r, zz, t;
+        F::sqr(zz, Q.z);
+        F::mul(t, zz, rhs);                 // Z^2
+        F::mul(l, beta, px);
+        F::mul(l, l, t);
+        bool ok = F::eq_mod(l, Q.x);
+        F::mul(t, zz, Q.z);
+        F::mul(l, t, rhs2);                 // y Z^3 = z^3 rhs^2
+        F::template neg<3>(r, Q.y);
+        return ok && F::eq_mod(l, r);
+    }
+    static KZ_HD bool in_subgroup_yfree(const fe& px, const fe& rhs, const fe& beta) {
+        fe rhs2;
+        Jac Q;
+        JacYC base;
+        yfree_start(Q, base, rhs2, px, rhs);
 #ifdef __HIP_DEVICE_COMPILE__
 #pragma unroll 1
 #endif
@@ -479,17 +497,7 @@ struct G1T {
             }
             if (pass == 0) jy_cache(base, Q, rhs);
         }
-        if (is_inf(Q)) return false;
-        fe l, r, zz, t;
-        F::sqr(zz, Q.z);
-        F::mul(t, zz, rhs);                 // Z^2
-        F::mul(l, beta, px);
-        F::mul(l, l, t);
-        bool ok = F::eq_mod(l, Q.x);
-        F::mul(t, zz, Q.z);
-        F::mul(l, t, rhs2);                 // y Z^3 = z^3 rhs^2
-        F::template neg<3>(r, Q.y);
-        return ok && F::eq_mod(l, r);
+        return yfree_verdict(Q, px, rhs, rhs2, beta);
     }
 };
 

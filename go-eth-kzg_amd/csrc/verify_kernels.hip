@@ -552,25 +552,90 @@ __global__ void __launch_bounds__(256) k_poly_eval(const uint32_t* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // G1 subgroup membership: phi(P) == -[x^2]P, one lane per affine row; st[i] |= NOT_IN_SUBGROUP
 // ------------------------------------------------------------------------------------------
-// Decoding and subgroup test of the verifiers' points in ONE launch, two point arrays (commitments and proofs) at once, and TWO
-// wavefronts per 64 points: both steps are per-lane latency chains -- a ~380-squaring square root (0.43 ms) and the 126 doublings
-// of phi(P) == -[x^2]P (0.97 ms) -- and the second does not need the first's result: G1T::in_subgroup_yfree runs on x and
-// x^3 + 4 alone.  Wave 0 decodes (gnark SetBytes, serialization.go:108-115) and writes the affine rows, wave 1 runs the r-torsion
-// test; a point that fails to decode reports that error, whatever wave 1 computed from its x.  As two kernels back to back the
-// chains cost their sum (1.41 ms) plus, on the side stream, whatever the main stream issued in between.
-// mode 0: both wavefronts, one status per point.  mode 1 / mode 2 (64 threads): only the decoding / only the r-torsion test, as two
-// launches on two streams -- for the cell verifier, whose MSMs can then start on the decoded rows while the test is still running;
-// mode 2 writes MKZG_ERR_G1_NOT_IN_SUBGROUP or 0 to ITS OWN status arrays (the caller gives the decoding's status precedence).
-// Every wavefront runs with all 64 lanes active (FULL_WAVES, see fk20_kernels.hip: sparse wavefronts issue up to 3x slower on gfx950):
-// lanes beyond the points shadow another point and store nothing -- a single-proof verification has one or two points.
+// Decoding and subgroup test of the verifiers' points in ONE launch, two point arrays (commitments and proofs) at once.  Both steps
+// are per-point latency chains -- a ~380-squaring square root (0.43 ms) and the 126 doublings of phi(P) == -[x^2]P -- and the second
+// does not need the first's result: the y-free form of the test (g1.hpp) runs on x and x^3 + 4 alone.  So one wavefront decodes
+// (gnark SetBytes, serialization.go:108-115) and writes the affine rows while another runs the r-torsion test; a point that fails to
+// decode reports that error, whatever the test computed from its x.
+//
+// The test's chain is shortened by giving every point a QUAD of lanes (jdbl_quad): the a = 0 doubling is 7 field multiplications in
+// three dependent levels -- {X^2, Y^2, 2Y Z}, {(3X^2)^2, (2Y^2)^2, (X + 2Y^2)^2}, {3X^2 (D - X3)} -- so three lanes of the quad take
+// one product of a level each (operands picked by role with v_cndmask, results passed with quad_perm DPP moves, ~84 of each per
+// doubling against ~1400 instructions of products) and the chain is 3 multiplications deep per doubling instead of 7: 0.97 -> 0.6 ms
+// for the launch, on every verifier's critical path.  All four lanes hold the same (X, Y, Z) before and after; the ten additions of
+// the chain run replicated.  A block is 16 points: with 2048 points (a 1024-blob batch) that is 128 blocks of two wavefronts,
+// one wavefront per SIMD.
+// mode 0: both wavefronts, one status per point.  mode 1 (64 threads, 64 points per block) / mode 2 (64 threads, 16 points per
+// block): only the decoding / only the r-torsion test, as two launches on two streams -- for the cell verifier, whose MSMs can
+// then start on the decoded rows while the test is still running; mode 2 writes MKZG_ERR_G1_NOT_IN_SUBGROUP or 0 to ITS OWN status
+// arrays (the caller gives the decoding's status precedence).
+// Every wavefront runs with all 64 lanes active (FULL_WAVES, see fk20_kernels.hip: sparse wavefronts issue up to 3x slower on gfx950,
+// and the DPP moves read every lane of a quad): lanes beyond the points shadow another point and store nothing.
+template <int K>
+__device__ __forceinline__ void quad_bcast(fp_t& r, const fp_t& a) {
+#pragma unroll
+    for (int q = 0; q < 14; q++) r.l[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)a.l[q], (int)a.l[q], K * 0x55, 0xf, 0xf, false);
+}
+// p = 2p, the same values as G1D::jdbl (dbl-2009-l with 2Y^2 formed up front), one product per lane and level
+__device__ __forceinline__ void jdbl_quad(G1J& p, bool role1, bool role2) {
+    G1D::opaque(p);
+    fp_t U, a, b, M1, M2, t, B2, T, E, A, EE, C4, D, X3, Y3;
+    Fp::dbl(U, p.y);
+    Fp::select(a, role1, p.y, p.x);
+    Fp::select(a, role2, U, a);
+    Fp::select(b, role1, p.y, p.x);
+    Fp::select(b, role2, p.z, b);
+    Fp::mul(M1, a, b);                        // lanes 0, 3: X^2      lane 1: Y^2      lane 2: 2Y Z  (all-zero limbs for the identity)
+    quad_bcast<1>(t, M1);
+    Fp::dbl(B2, t);                           // 2 Y^2            (< 2.01p)
+    Fp::add(T, p.x, B2);                      //                   (< 19.1p)
+    Fp::triple(E, M1);                        // lanes 0, 3: 3 X^2
+    Fp::select(a, role1, B2, E);
+    Fp::select(a, role2, T, a);
+    Fp::sqr(M2, a);                           // lanes 0, 3: E^2      lane 1: 4 Y^4    lane 2: (X + 2Y^2)^2
+    quad_bcast<0>(A, M1);
+    quad_bcast<0>(EE, M2);
+    quad_bcast<1>(C4, M2);
+    quad_bcast<2>(T, M2);
+    quad_bcast<2>(p.z, M1);
+    Fp::template sub_b_c<2>(D, T, A, C4);     // D = 4 X Y^2 + 4p  (< 5.01p)
+    Fp::triple(E, A);
+    Fp::template sub_2c<4>(X3, EE, D);        // E^2 - 2D + 16p    (< 17.01p)
+    Fp::template sub<5>(t, D, X3);            // D - X3 + 32p      (< 37.1p)
+    Fp::mul(Y3, E, t);
+    Fp::template sub_2c<2>(p.y, Y3, C4);      // E (D - X3) - 8 Y^4 + 4p   (< 5.01p)
+    p.x = X3;
+}
+// G1D::in_subgroup_yfree with the doublings on a lane quad; every lane of the quad returns the verdict
+__device__ __forceinline__ bool in_subgroup_yfree_quad(const fp_t& px, const fp_t& rhs, const fp_t& beta, int role) {
+    fp_t rhs2;
+    G1J Q;
+    G1D::JacYC base;
+    G1D::yfree_start(Q, base, rhs2, px, rhs);
+    const bool role1 = role == 1, role2 = role == 2;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+        for (int bit = 62; bit >= 0; bit--) {
+            jdbl_quad(Q, role1, role2);
+            if ((BLS_X_ABS >> bit) & 1) G1D::jadd_y(Q, Q, base, rhs, rhs2);
+        }
+        if (pass == 0) G1D::jy_cache(base, Q, rhs);
+    }
+    return G1D::yfree_verdict(Q, px, rhs, rhs2, beta);
+}
+static const int VAL_PB = 16;                               // points per block of the r-torsion test (a quad of lanes each)
 __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
                                                      const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode) {
-    __shared__ int sub_ok[64];                              // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
+    __shared__ int sub_ok[VAL_PB];                          // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
     const int lane = threadIdx.x & 63, role = mode == 0 ? (int)(threadIdx.x >> 6) : mode - 1;
     const int total = n_a + n_b;
-    int i = blockIdx.x * 64 + lane;
-    const bool live = i < total;
-    if (!live) i %= total;
+    // which point: the test gives a quad per point (16 per wavefront); the decoding a lane per point -- 64 per block on its own
+    // (mode 1), the block's 16 (copied four times over the wavefront) beside the test (mode 0)
+    const int slot = role == 1 ? lane >> 2 : (mode == 1 ? lane : lane & (VAL_PB - 1));
+    int i = blockIdx.x * (mode == 1 ? 64 : VAL_PB) + slot;
+    const bool live = i < total && (role == 1 ? (lane & 3) == 0 : (mode == 1 || lane < VAL_PB));
+    if (i >= total) i %= total;
     const uint8_t* in48 = in48_a;
     uint32_t* aff = aff_a;
     int* st = st_a;
@@ -581,10 +646,10 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
     if (role == 1) {
         fp_t x, rhs, beta;
         uint32_t flags;
-        if (g1_parse_lane(x, flags, in48 + (size_t)i * 48) == 0) {
+        if (g1_parse_lane(x, flags, in48 + (size_t)i * 48) == 0) {        // uniform over the quad: its lanes read the same point
             g1_curve_rhs(rhs, x);
             Fp::set(beta, FP_BETA);
-            v = G1D::in_subgroup_yfree(x, rhs, beta) ? 1 : 0;
+            v = in_subgroup_yfree_quad(x, rhs, beta, lane & 3) ? 1 : 0;
         }
     } else {
         rc = g1_decode_lane(p, in48 + (size_t)i * 48);
@@ -607,10 +672,10 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
         return;
     }
     // mode 0: both wavefronts meet at ONE barrier; the decoding wavefront then joins the two verdicts
-    if (role == 1) sub_ok[lane] = v;
+    if (role == 1 && (lane & 3) == 0) sub_ok[slot] = v;
     __syncthreads();
     if (role == 0 && live) {
-        if (rc == 0 && !p.inf && sub_ok[lane] == 0) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
+        if (rc == 0 && !p.inf && sub_ok[slot] == 0) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
         st[i] = rc;
     }
 }
@@ -915,7 +980,9 @@ void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
                          int mode) {
     const int n = n_a + n_b;
-    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + 63) / 64), dim3(mode == 0 ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b, mode);
+    const int per_block = mode == 1 ? 64 : VAL_PB;
+    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + per_block - 1) / per_block), dim3(mode == 0 ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b,
+                                  d_st_b, mode);
 }
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         int mode, hipStream_t s) {

@@ -78,13 +78,15 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         next narrower one is tried and finally the bucket method is used: the call still succeeds with the
  *                         same bytes; "commit_direct_bits_effective" (get) reports what is in use.
  *   "fk20_bits"           window width of the FK20 fixed-base table: 11 (default, 25.8 GB) or 13 (86 GB: 20 instead of 24 group additions
- *                         per scalar in the 128 MSMs of ComputeCellsAndKZGProofs / recovery); falls back to 11 when the HBM is short
- *                         ("fk20_bits_effective" reports what is in use)
+ *                         per scalar in the 128 MSMs of ComputeCellsAndKZGProofs / recovery, but its gathers over 86 GB are TLB-bound: measured
+ *                         no faster on MI355X); falls back to 11 when the HBM is short ("fk20_bits_effective" reports what is in use)
  *   "host_chunk"          blobs per chunk of the host-pointer commitment pipeline (gather / upload / kernels overlap per chunk; 128)
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
  *   "host_sha"            host-pointer verifiers: Fiat-Shamir challenges hashed by the host pool while the blobs upload (1),
- *                         on the device after the upload (0), library's choice (-1, default) */
+ *                         on the device after the upload (0), library's choice (-1, default: the host for calls of up to 8 blobs per pool
+ *                         thread -- a 70 us hash per blob instead of the device's 2.7 ms chain -- and the device above that);
+ *                         ComputeBlobKZGProof follows the same switch */
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
 /* reads an option back; also "commit_direct_bits_effective", "fk20_bits_effective", "devices", "lanes" */
 int mkzg_ctx_get_option(mkzg_ctx* ctx, const char* key, long* value);

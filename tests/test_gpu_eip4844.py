@@ -47,7 +47,17 @@ def test_compute_kzg_proof(vectors, gpu_ctx):
     assert n_ok > 30
 
 
-def test_compute_blob_kzg_proof(vectors, gpu_ctx):
+@pytest.fixture(params=[-1, 0, 1], ids=["sha_auto", "sha_device", "sha_host"])
+def hash_place(request, gpu_ctx):
+    """Where the Fiat-Shamir transcript is hashed (option host_sha): by default the host pool takes small calls and the device large ones,
+    so the vectors -- all small -- run under each setting."""
+    assert gpu_ctx.set_option("host_sha", request.param) == 0
+    yield gpu_ctx
+    assert gpu_ctx.set_option("host_sha", -1) == 0
+
+
+def test_compute_blob_kzg_proof(vectors, hash_place):
+    gpu_ctx = hash_place
     n_ok = 0
     for c in vectors.cases("compute_blob_kzg_proof"):
         blob, cm = vectors.val(c["input"]["blob"]), vectors.val(c["input"]["commitment"])
@@ -78,7 +88,8 @@ def test_verify_kzg_proof(vectors, gpu_ctx):
     assert n > 100
 
 
-def test_verify_blob_kzg_proof(vectors, gpu_ctx):
+def test_verify_blob_kzg_proof(vectors, hash_place):
+    gpu_ctx = hash_place
     for c in vectors.cases("verify_blob_kzg_proof"):
         i = c["input"]
         blob, cm, pr = (vectors.val(i[k]) for k in ("blob", "commitment", "proof"))
@@ -89,7 +100,8 @@ def test_verify_blob_kzg_proof(vectors, gpu_ctx):
         _check_verifier(gpu_ctx.VerifyBlobKZGProof(blob, cm, pr), exp, c["name"])
 
 
-def test_verify_blob_kzg_proof_batch(vectors, gpu_ctx):
+def test_verify_blob_kzg_proof_batch(vectors, hash_place):
+    gpu_ctx = hash_place
     for c in vectors.cases("verify_blob_kzg_proof_batch"):
         i = c["input"]
         blobs, cms, prs = (vectors.val(i[k]) for k in ("blobs", "commitments", "proofs"))

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmi355kzg.so")
 SOURCES = ["api.hip", "api_verify.hip", "api_cells.hip", "api_multi.hip", "msm_kernels.hip", "verify_kernels.hip", "cells_kernels.hip", "fk20_kernels.hip", "recover_kernels.hip"]
-HEADERS = ["mont29.hpp", "modinv30.hpp", "g1.hpp", "constants29.h", "msm_kernels.h", "verify_kernels.h", "cells_kernels.h", "fk20_kernels.h", "fk20_toom.h", "recover_kernels.h", "ctx.h", "api_multi.h", "host_pool.hpp", "host_sha256.hpp", "g1_decode.hpp", "host_field.hpp", "host_pairing.hpp", "host_g1.hpp",
+HEADERS = ["mont29.hpp", "modinv30.hpp", "g1.hpp", "g1_quad.hpp", "constants29.h", "msm_kernels.h", "verify_kernels.h", "cells_kernels.h", "fk20_kernels.h", "fk20_toom.h", "recover_kernels.h", "ctx.h", "api_multi.h", "host_pool.hpp", "host_sha256.hpp", "g1_decode.hpp", "host_field.hpp", "host_pairing.hpp", "host_g1.hpp",
            os.path.join("..", "..", "include", "mi355kzg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 

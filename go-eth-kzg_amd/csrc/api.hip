@@ -290,7 +290,9 @@ static int ensure_lane_direct(mkzg_ctx* c, Lane* L) {
 static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, int n, int ws_off, uint8_t* d_out48n, int* d_status, hipStream_t s) {
     KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
     if (c->direct_bits_built) {
-        const DirectSlot ws = direct_slot_offset(L->dslot, ws_off);
+        DirectSlot slot = L->dslot;
+        slot.k = ws_off ? 8 : direct_pick_k(n, L->dslot_batch);          // a call of few blobs spreads each over more lanes
+        const DirectSlot ws = direct_slot_offset(slot, ws_off);
         commit_direct_device(c->direct_bits_built, c->d_direct, ws, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt);
     } else {
         const CommitPlan pl = commit_plan_offset(L->plan, ws_off);
@@ -370,6 +372,8 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
     if (!rc) rc = commit_prepare(c, L);
     if (rc) return rc;
     const bool direct = c->direct_bits_built != 0, zc = direct && c->opt_host_zero_copy != 0;
+    DirectSlot dslot = L->dslot;
+    if (direct) dslot.k = direct_pick_k((int)n, L->dslot_batch);
     KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
     const size_t CH = (size_t)std::max(1, c->opt_host_chunk);
     hipStream_t copy = L->side, cs[4] = {L->stream, L->side2, L->aux[0], L->aux[1]};
@@ -415,7 +419,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
                     HIPCHK(hipStreamWaitEvent(s, L->ev_chunk[k & 7], 0));
                 }
                 const uint8_t* src = (zc ? L->h_stage : L->d_blobs) + lo * MKZG_BYTES_PER_BLOB;
-                commit_direct_acc_device(c->direct_bits_built, c->d_direct, direct_slot_offset(L->dslot, (int)lo), src, MKZG_BYTES_PER_BLOB, 0, (int)m, s, kt);
+                commit_direct_acc_device(c->direct_bits_built, c->d_direct, direct_slot_offset(dslot, (int)lo), src, MKZG_BYTES_PER_BLOB, 0, (int)m, s, kt);
             }
         }
         // join the compute streams (direct) / the copy stream into the lane's main stream
@@ -428,7 +432,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
             HIPCHK(hipEventRecord(L->ev_cs[0], copy));
             HIPCHK(hipStreamWaitEvent(L->stream, L->ev_cs[0], 0));
         }
-        if (direct) commit_direct_fin_device(L->dslot, (int)n, L->d_out, L->d_status, L->stream, kt);
+        if (direct) commit_direct_fin_device(dslot, (int)n, L->d_out, L->d_status, L->stream, kt);
         else commit_piece(c, L, L->d_blobs, MKZG_BYTES_PER_BLOB, 0, (int)n, 0, L->d_out, L->d_status, L->stream);
         HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, n * 48, hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipMemcpyAsync(L->h_out + L->h_out_items * 48, L->d_status, n * sizeof(int), hipMemcpyDeviceToHost, L->stream));

@@ -13,6 +13,7 @@ size_t fk20_table_bytes(int cbits);
 // monomial SRS (4096 affine rows) -> T (8192 affine rows, [k][i]) -> direct table (fk20_table_bytes(cbits))
 void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fwd, uint32_t* d_t_aff, uint32_t* d_table, int cbits, hipStream_t s);
 constexpr int FK_DIRECT_MAX_BATCH = 8;   // up to this many blobs per call the MSM runs one window per lane (latency over occupancy)
+constexpr int FK_QUAD_MAX_BATCH = 16;    // up to this many blobs per call the 686 products of the transform network run on a quad of lanes each
 size_t fk20_parts_rows();        // XYZZ rows of scratch per blob shared by the MSM and the transform stage
 
 // scalars [n][128][64][8 words] -> parts [n][128][16] XYZZ rows (scratch) -> results [n][128] XYZZ rows

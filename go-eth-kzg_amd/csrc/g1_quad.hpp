@@ -1,0 +1,134 @@
+// g1_quad.hpp -- the Jacobian group law of g1.hpp on a QUAD of lanes per point (device only).
+//
+// Where a call brings too few points to fill the chip, what the caller waits for is the length of ONE dependent chain of field
+// multiplications: the 126 doublings of the r-torsion test behind every decoded point (reference serialization.go:108-115 ->
+// gnark IsInSubGroup), the 130 doublings of each fixed-scalar product of the FK20 network for a single blob (fk20.go:76-124).
+// A doubling is 7 multiplications but only 3 deep, an addition 13 but only 5 deep.  So four adjacent lanes take one point: all four
+// hold the same coordinates, every level each lane forms ONE product -- operands picked by its role with v_cndmask -- and the
+// results travel with quad_perm DPP moves (full rate, no LDS).  Same values as G1D::jdbl / G1D::jadd (up to the bound of Y3 in
+// the addition, noted there); the exceptional cases are decided on replicated values, so a quad never diverges.
+// Requires all four lanes of a quad to be active together (the kernels run FULL_WAVES).
+#pragma once
+#include "g1.hpp"
+
+namespace kzg {
+
+template <int K>
+__device__ __forceinline__ void quad_bcast(fp_t& r, const fp_t& a) {
+#pragma unroll
+    for (int q = 0; q < 14; q++) r.l[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)a.l[q], (int)a.l[q], K * 0x55, 0xf, 0xf, false);
+}
+struct QuadRole {
+    bool r0, r1, r2, r3;
+    __device__ __forceinline__ explicit QuadRole(int lane) : r0((lane & 3) == 0), r1((lane & 3) == 1), r2((lane & 3) == 2), r3((lane & 3) == 3) {}
+};
+// r = role 0 ? v0 : role 1 ? v1 : role 2 ? v2 : v3
+__device__ __forceinline__ void quad_pick(fp_t& r, const QuadRole& q, const fp_t& v0, const fp_t& v1, const fp_t& v2, const fp_t& v3) {
+    Fp::select(r, q.r2, v2, v3);
+    Fp::select(r, q.r1, v1, r);
+    Fp::select(r, q.r0, v0, r);
+}
+
+// p = 2p: G1D::jdbl (dbl-2009-l with 2Y^2 formed up front) in three levels {X^2, Y^2, 2Y Z}, {(3X^2)^2, (2Y^2)^2, (X + 2Y^2)^2},
+// {3X^2 (D - X3)}; the identity (Z = all-zero limbs) stays the identity
+__device__ __forceinline__ void jdbl_quad(G1J& p, const QuadRole& q) {
+    G1D::opaque(p);
+    fp_t U, a, b, M1, M2, t, B2, T, E, A, EE, C4, D, X3, Y3;
+    Fp::dbl(U, p.y);
+    Fp::select(a, q.r1, p.y, p.x);
+    Fp::select(a, q.r2, U, a);
+    Fp::select(b, q.r1, p.y, p.x);
+    Fp::select(b, q.r2, p.z, b);
+    Fp::mul(M1, a, b);                        // lanes 0, 3: X^2      lane 1: Y^2      lane 2: 2Y Z
+    quad_bcast<1>(t, M1);
+    Fp::dbl(B2, t);                           // 2 Y^2            (< 2.01p)
+    Fp::add(T, p.x, B2);                      //                   (< 19.1p)
+    Fp::triple(E, M1);                        // lanes 0, 3: 3 X^2
+    Fp::select(a, q.r1, B2, E);
+    Fp::select(a, q.r2, T, a);
+    Fp::sqr(M2, a);                           // lanes 0, 3: E^2      lane 1: 4 Y^4    lane 2: (X + 2Y^2)^2
+    quad_bcast<0>(A, M1);
+    quad_bcast<0>(EE, M2);
+    quad_bcast<1>(C4, M2);
+    quad_bcast<2>(T, M2);
+    quad_bcast<2>(p.z, M1);
+    Fp::template sub_b_c<2>(D, T, A, C4);     // D = 4 X Y^2 + 4p  (< 5.01p)
+    Fp::triple(E, A);
+    Fp::template sub_2c<4>(X3, EE, D);        // E^2 - 2D + 16p    (< 17.01p)
+    Fp::template sub<5>(t, D, X3);            // D - X3 + 32p      (< 37.1p)
+    Fp::mul(Y3, E, t);
+    Fp::template sub_2c<2>(p.y, Y3, C4);      // E (D - X3) - 8 Y^4 + 4p   (< 5.01p)
+    p.x = X3;
+}
+
+// a = a + b: G1D::jadd (add-2007-bl, b's Z^2 and Z^3 cached) in five levels
+//   {Z1^2, X1 Z2^2, Y1 Z2^3, Z1 Z2}, {Z1^3, X2 Z1^2}, {Y2 Z1^3, H^2, Z1 Z2 H}, {H^3, U1 H^2, R^2}, {R (U1 H^2 - X3), -S1 H^3};
+// Y3 is the sum of the last two products (< 2.02p where G1D::jadd's fused product gives < 1.01p; the Jacobian bound is Y < 5.01p).
+__device__ __forceinline__ void jadd_quad(G1J& a, const G1JC& b_, const QuadRole& q) {
+    G1JC b = b_;
+    G1D::opaque(a);
+    Fp::opaque(b.x);
+    Fp::opaque(b.y);
+    Fp::opaque(b.z);
+    Fp::opaque(b.zz);
+    Fp::opaque(b.zzz);
+    const bool a_inf = G1D::is_inf(a), b_inf = Fp::limbs_all_zero(b.z);
+    fp_t oa, ob, M1, M2, M3, M4, M5, Z1Z1, U1, U2, S1, S2, H, Rd, HH, HHH, Q, RR, t, X3;
+    G1J res, bj;
+    bj.x = b.x;
+    bj.y = b.y;
+    bj.z = b.z;
+    quad_pick(oa, q, a.z, a.x, a.y, a.z);
+    quad_pick(ob, q, a.z, b.zz, b.zzz, b.z);
+    Fp::mul(M1, oa, ob);                      // Z1^2 | U1 = X1 Z2^2 | S1 = Y1 Z2^3 | Z1 Z2
+    quad_bcast<0>(Z1Z1, M1);
+    Fp::select(oa, q.r0, a.z, b.x);
+    Fp::mul(M2, oa, Z1Z1);                    // Z1^3 | U2 = X2 Z1^2 (lanes 1..3)
+    quad_bcast<1>(U2, M2);
+    quad_bcast<1>(U1, M1);
+    Fp::template sub<1>(H, U2, U1);
+    Fp::select(oa, q.r0, b.y, H);
+    Fp::select(oa, q.r3, M1, oa);
+    Fp::select(ob, q.r0, M2, H);
+    Fp::mul(M3, oa, ob);                      // S2 = Y2 Z1^3 | H^2 | H^2 | Z1 Z2 H
+    quad_bcast<0>(S2, M3);
+    quad_bcast<2>(S1, M1);
+    Fp::template sub<1>(Rd, S2, S1);
+    if (!a_inf && !b_inf && Fp::template is_zero_mod<16>(H)) {
+        if (Fp::template is_zero_mod<16>(Rd)) {
+            res = a;
+            jdbl_quad(res, q);
+        } else {
+            G1D::set_inf(res);
+        }
+    } else {
+        Fp::opaque(H);
+        Fp::opaque(Rd);
+        Fp::opaque(U1);
+        Fp::opaque(S1);
+        quad_bcast<1>(HH, M3);
+        Fp::select(oa, q.r0, H, U1);
+        Fp::select(oa, q.r2, Rd, oa);
+        Fp::select(ob, q.r2, Rd, HH);
+        Fp::mul(M4, oa, ob);                  // H^3 | Q = U1 H^2 | R^2 | (Q again)
+        quad_bcast<0>(HHH, M4);
+        quad_bcast<1>(Q, M4);
+        quad_bcast<2>(RR, M4);
+        Fp::template sub_b_2c<2>(X3, RR, HHH, Q);   // R^2 - H^3 - 2 U1 H^2 + 4p   (< 5.01p)
+        Fp::template sub<3>(t, Q, X3);
+        Fp::template neg<1>(S1, S1);
+        Fp::select(oa, q.r0, Rd, S1);
+        Fp::select(ob, q.r0, t, HHH);
+        Fp::mul(M5, oa, ob);                  // R (U1 H^2 - X3) | -S1 H^3 (lanes 1..3)
+        quad_bcast<0>(t, M5);
+        quad_bcast<1>(S2, M5);
+        Fp::add(res.y, t, S2);
+        quad_bcast<3>(res.z, M3);
+        res.x = X3;
+    }
+    G1D::select(res, b_inf, a, res);
+    G1D::select(res, a_inf, bj, res);
+    a = res;
+}
+
+}  // namespace kzg

@@ -76,7 +76,9 @@ void build_direct_device(int c, const uint32_t* d_table, uint32_t* d_direct, hip
 struct DirectSlot {
     uint32_t* d_parts = nullptr;
     int* d_bad = nullptr;
+    int k = 8;                 // scalars per lane of the accumulate kernel (8, 4, 2, 1): 4096 / k partial sums per blob; see direct_pick_k
 };
+int direct_pick_k(int n, int max_batch);
 size_t direct_parts_bytes(int max_batch);
 size_t direct_bad_bytes(int max_batch);
 DirectSlot direct_slot_offset(const DirectSlot& ws, int off);

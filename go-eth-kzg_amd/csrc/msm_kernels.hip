@@ -564,8 +564,9 @@ __global__ void __launch_bounds__(64, 2) k_build_direct_level(uint32_t* __restri
 #define MKZG_DTA 64
 #endif
 constexpr int DTA = MKZG_DTA; // threads per accumulate workgroup, 8 points per lane (64: single-wave workgroups, any free wave slot takes one)
-constexpr int DBLK = 4096 / (8 * DTA);   // accumulate workgroups per blob
-constexpr int DPARTS = 512;   // lane accumulators per blob (64-word XYZZ records)
+constexpr int DPARTS = 512;   // lane accumulators per blob (64-word XYZZ records) at 8 scalars per lane: what the workspace is sized for
+constexpr int DBAD = 4096 / DTA;   // stride of a blob's bad-scalar flags (one per accumulate workgroup, at most 4096 / DTA of them)
+static_assert(DTA == 64, "the partial-sum layout below (64 parts per accumulate workgroup, folded by one wavefront) assumes single-wave workgroups");
 __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
 #pragma unroll
     for (int i = 0; i < 14; i++) {
@@ -575,13 +576,15 @@ __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
         r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
     }
 }
-// Accumulate: grid (DBLK, n blobs).  Each lane walks its 8 scalars window by window (the 256-bit scalar is a
+// Accumulate: grid (4096 / (K * DTA), n blobs).  Each lane walks its K scalars window by window (the 256-bit scalar is a
 // shift register: static register indices only), prefetching the table row of window j+1 while the row of
-// window j is added.  When C divides 255 the signed recoding has no spare top window; scalars with bit 254
+// window j is added.  K = 8 is the throughput shape (256 blobs fill the chip twice over with 136 additions per lane); calls of
+// fewer blobs spread each blob over more lanes (K = 4, 2, 1: 4096 lanes per blob, 17 additions each) and pay for it with the
+// log-depth fold of the partial sums below -- the caller of one blob waits for 17 + 12 dependent additions instead of 136 + 14.  When C divides 255 the signed recoding has no spare top window; scalars with bit 254
 // set are replaced by r - s (top digit then <= 2^(C-1)) and every digit sign is flipped.
 template <int C, int INPUT_KIND>     // INPUT_KIND 0: 32-byte big-endian scalars (blobs); 1: 12-word Montgomery Fr rows (quotient polynomials)
 __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, const uint32_t* __restrict__ direct,
-                                                            uint32_t* __restrict__ parts, int* __restrict__ bad_flags) {
+                                                            uint32_t* __restrict__ parts, int* __restrict__ bad_flags, int K) {
     using RC = Recode<C>;
     constexpr bool TIGHT = (C * RC::NWIN < 256);
     __shared__ __attribute__((aligned(16))) uint32_t rowbuf[(DTA / 64) * 8 * 256];     // 32 KB: one table row per lane
@@ -592,8 +595,8 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
     G1X acc;
     g1x_set_inf(acc);
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) {
-        const int i = (half * 8 + k) * DTA + t;
+    for (int k = 0; k < K; k++) {
+        const int i = (half * K + k) * DTA + t;
         uint32_t w[8];
         if (INPUT_KIND == 0) {
             load_scalar_be(w, scalars + (size_t)b * scalar_stride_bytes + (size_t)i * 32);
@@ -671,27 +674,47 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
             cneg = nneg;
         }
     }
-    store_xyzz(parts + ((size_t)b * DPARTS + half * DTA + t) * 64, acc);
+    store_xyzz(parts + (((size_t)b * gridDim.x + half) * DTA + t) * 64, acc);
     const int anybad = __syncthreads_or(bad);
-    if (t == 0) bad_flags[b * DBLK + half] = anybad;
+    if (t == 0) bad_flags[b * DBAD + half] = anybad;
+}
+// Fold (K < 8): one wavefront per accumulate workgroup sums its 64 lane accumulators with an xor butterfly and leaves the sum in
+// the workgroup's first record; the finish kernel then meets 4096 / (64 K) records per blob, 64 apart.
+__global__ void __launch_bounds__(64, 2) k_commit_direct_fold(uint32_t* __restrict__ parts) {
+    const size_t base = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64;
+    G1X acc, o;
+    load_xyzz(acc, parts + (base + threadIdx.x) * 64);
+#pragma unroll 1
+    for (int m = 32; m >= 1; m >>= 1) {
+        shfl_xor_xyzz(o, acc, m);
+        g1x_add(acc, acc, o);
+    }
+    if (threadIdx.x == 0) store_xyzz(parts + base * 64, acc);
 }
 // Finish: one wavefront per blob sums the 512 lane accumulators (8 per lane, then an xor butterfly), converts to
 // affine and writes the compressed commitment.  Tiny and latency-bound: it runs beside the next accumulate kernel.
+// folded (K < 8): the blob's nblk records sit 64 apart (k_commit_direct_fold); lanes beyond them start from the identity.
 __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __restrict__ parts, const int* __restrict__ bad_flags, uint8_t* __restrict__ out48,
-                                                          int* __restrict__ status) {
+                                                          int* __restrict__ status, int nblk, int folded) {
     const int b = blockIdx.x, lane = threadIdx.x;
     int anybad = 0;
-    for (int q = 0; q < DBLK; q++) anybad |= bad_flags[b * DBLK + q];
+    for (int q = 0; q < nblk; q++) anybad |= bad_flags[b * DBAD + q];
     if (anybad) {
         if (lane == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
         return;
     }
     G1X acc, o;
-    load_xyzz(acc, parts + ((size_t)b * DPARTS + lane) * 64);
+    const size_t base = (size_t)b * nblk * 64;
+    if (folded) {
+        g1x_set_inf(acc);
+        if (lane < nblk) load_xyzz(acc, parts + (base + (size_t)lane * 64) * 64);
+    } else {
+        load_xyzz(acc, parts + (base + lane) * 64);
 #pragma unroll 1
-    for (int q = 1; q < DPARTS / 64; q++) {
-        load_xyzz(o, parts + ((size_t)b * DPARTS + q * 64 + lane) * 64);
-        g1x_add(acc, acc, o);
+        for (int q = 1; q < nblk; q++) {
+            load_xyzz(o, parts + (base + q * 64 + lane) * 64);
+            g1x_add(acc, acc, o);
+        }
     }
 #pragma unroll 1
     for (int m = 32; m >= 1; m >>= 1) {
@@ -816,12 +839,19 @@ void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table,
     }
 }
 size_t direct_parts_bytes(int max_batch) { return (size_t)max_batch * DPARTS * 64 * sizeof(uint32_t); }
-size_t direct_bad_bytes(int max_batch) { return (size_t)max_batch * DBLK * sizeof(int); }
+size_t direct_bad_bytes(int max_batch) { return (size_t)max_batch * DBAD * sizeof(int); }
 DirectSlot direct_slot_offset(const DirectSlot& ws, int off) {
     DirectSlot o = ws;
-    o.d_parts = ws.d_parts + (size_t)off * DPARTS * 64;
-    o.d_bad = ws.d_bad + (size_t)off * DBLK;
+    o.d_parts = ws.d_parts + (size_t)off * (4096 / ws.k) * 64;
+    o.d_bad = ws.d_bad + (size_t)off * DBAD;
     return o;
+}
+// scalars per lane for a call of n blobs through a workspace sized for max_batch: the fewest (most lanes per blob, shortest chain)
+// whose partial sums fit the workspace and whose wavefronts still find a free slot each (two per SIMD)
+int direct_pick_k(int n, int max_batch) {
+    for (int k = 1; k < 8; k *= 2)
+        if ((size_t)n * (4096 / k) <= (size_t)max_batch * DPARTS && n * (4096 / k) / 64 <= 2048) return k;
+    return 8;
 }
 CommitPlan commit_plan_offset(const CommitPlan& pl, int off) {
     CommitPlanSizes sz;
@@ -838,10 +868,10 @@ CommitPlan commit_plan_offset(const CommitPlan& pl, int off) {
 template <int KIND>
 static void launch_direct_acc(int c, dim3 grid, hipStream_t s, const uint8_t* d_scalars, size_t stride, const uint32_t* d_direct, const DirectSlot& ws) {
     switch (c) {
-        case 12: hipLaunchKernelGGL((k_commit_direct_acc<12, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
-        case 13: hipLaunchKernelGGL((k_commit_direct_acc<13, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
-        case 14: hipLaunchKernelGGL((k_commit_direct_acc<14, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
-        default: hipLaunchKernelGGL((k_commit_direct_acc<15, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad); break;
+        case 12: hipLaunchKernelGGL((k_commit_direct_acc<12, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k); break;
+        case 13: hipLaunchKernelGGL((k_commit_direct_acc<13, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k); break;
+        case 14: hipLaunchKernelGGL((k_commit_direct_acc<14, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k); break;
+        default: hipLaunchKernelGGL((k_commit_direct_acc<15, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k); break;
     }
 }
 // the two halves of a direct-table commitment: accumulate (VALU-bound, one single-wave workgroup per 512 scalars) and finish
@@ -850,15 +880,16 @@ static void launch_direct_acc(int c, dim3 grid, hipStream_t s, const uint8_t* d_
 void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, hipStream_t s, KernelTimer* kt) {
     if (n <= 0) return;
     if (kt) kt->begin(KT_COMMIT_DIRECT, s);
-    const dim3 grid(DBLK, n);
+    const dim3 grid(4096 / (ws.k * DTA), n);
     if (input_kind == 0) launch_direct_acc<0>(c, grid, s, d_scalars, stride, d_direct, ws);
     else launch_direct_acc<1>(c, grid, s, d_scalars, stride, d_direct, ws);
+    if (ws.k < 8) hipLaunchKernelGGL(k_commit_direct_fold, grid, dim3(64), 0, s, ws.d_parts);
     if (kt) kt->end(KT_COMMIT_DIRECT, s);
 }
 void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
     if (n <= 0) return;
     if (kt) kt->begin(KT_COMMIT_DIRECT_FIN, s);
-    hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status);
+    hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, 4096 / (ws.k * DTA), ws.k < 8 ? 1 : 0);
     if (kt) kt->end(KT_COMMIT_DIRECT_FIN, s);
 }
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status,

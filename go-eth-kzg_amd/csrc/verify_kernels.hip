@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "g1.hpp"
+#include "g1_quad.hpp"
 #include "verify_kernels.h"
 #include "g1_decode.hpp"
 
@@ -558,11 +559,10 @@ __global__ void __launch_bounds__(256) k_poly_eval(const uint32_t* __restrict__ 
 // (gnark SetBytes, serialization.go:108-115) and writes the affine rows while another runs the r-torsion test; a point that fails to
 // decode reports that error, whatever the test computed from its x.
 //
-// The test's chain is shortened by giving every point a QUAD of lanes (jdbl_quad): the a = 0 doubling is 7 field multiplications in
-// three dependent levels -- {X^2, Y^2, 2Y Z}, {(3X^2)^2, (2Y^2)^2, (X + 2Y^2)^2}, {3X^2 (D - X3)} -- so three lanes of the quad take
-// one product of a level each (operands picked by role with v_cndmask, results passed with quad_perm DPP moves, ~84 of each per
-// doubling against ~1400 instructions of products) and the chain is 3 multiplications deep per doubling instead of 7: 0.97 -> 0.6 ms
-// for the launch, on every verifier's critical path.  All four lanes hold the same (X, Y, Z) before and after; the ten additions of
+// The test's chain is shortened by giving every point a QUAD of lanes (g1_quad.hpp): the a = 0 doubling is 7 field multiplications
+// in three dependent levels, so three lanes of the quad take one product of a level each (operands picked by role with v_cndmask,
+// results passed with quad_perm DPP moves, ~84 of each per doubling against ~1400 instructions of products) and the chain is 3
+// multiplications deep per doubling instead of 7: 1.02 -> 0.68 ms for the launch, on every verifier's critical path.  All four lanes hold the same (X, Y, Z) before and after; the ten additions of
 // the chain run replicated.  A block is 16 points: with 2048 points (a 1024-blob batch) that is 128 blocks of two wavefronts,
 // one wavefront per SIMD.
 // mode 0: both wavefronts, one status per point.  mode 1 (64 threads, 64 points per block) / mode 2 (64 threads, 16 points per
@@ -571,53 +571,18 @@ __global__ void __launch_bounds__(256) k_poly_eval(const uint32_t* __restrict__ 
 // arrays (the caller gives the decoding's status precedence).
 // Every wavefront runs with all 64 lanes active (FULL_WAVES, see fk20_kernels.hip: sparse wavefronts issue up to 3x slower on gfx950,
 // and the DPP moves read every lane of a quad): lanes beyond the points shadow another point and store nothing.
-template <int K>
-__device__ __forceinline__ void quad_bcast(fp_t& r, const fp_t& a) {
-#pragma unroll
-    for (int q = 0; q < 14; q++) r.l[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)a.l[q], (int)a.l[q], K * 0x55, 0xf, 0xf, false);
-}
-// p = 2p, the same values as G1D::jdbl (dbl-2009-l with 2Y^2 formed up front), one product per lane and level
-__device__ __forceinline__ void jdbl_quad(G1J& p, bool role1, bool role2) {
-    G1D::opaque(p);
-    fp_t U, a, b, M1, M2, t, B2, T, E, A, EE, C4, D, X3, Y3;
-    Fp::dbl(U, p.y);
-    Fp::select(a, role1, p.y, p.x);
-    Fp::select(a, role2, U, a);
-    Fp::select(b, role1, p.y, p.x);
-    Fp::select(b, role2, p.z, b);
-    Fp::mul(M1, a, b);                        // lanes 0, 3: X^2      lane 1: Y^2      lane 2: 2Y Z  (all-zero limbs for the identity)
-    quad_bcast<1>(t, M1);
-    Fp::dbl(B2, t);                           // 2 Y^2            (< 2.01p)
-    Fp::add(T, p.x, B2);                      //                   (< 19.1p)
-    Fp::triple(E, M1);                        // lanes 0, 3: 3 X^2
-    Fp::select(a, role1, B2, E);
-    Fp::select(a, role2, T, a);
-    Fp::sqr(M2, a);                           // lanes 0, 3: E^2      lane 1: 4 Y^4    lane 2: (X + 2Y^2)^2
-    quad_bcast<0>(A, M1);
-    quad_bcast<0>(EE, M2);
-    quad_bcast<1>(C4, M2);
-    quad_bcast<2>(T, M2);
-    quad_bcast<2>(p.z, M1);
-    Fp::template sub_b_c<2>(D, T, A, C4);     // D = 4 X Y^2 + 4p  (< 5.01p)
-    Fp::triple(E, A);
-    Fp::template sub_2c<4>(X3, EE, D);        // E^2 - 2D + 16p    (< 17.01p)
-    Fp::template sub<5>(t, D, X3);            // D - X3 + 32p      (< 37.1p)
-    Fp::mul(Y3, E, t);
-    Fp::template sub_2c<2>(p.y, Y3, C4);      // E (D - X3) - 8 Y^4 + 4p   (< 5.01p)
-    p.x = X3;
-}
 // G1D::in_subgroup_yfree with the doublings on a lane quad; every lane of the quad returns the verdict
 __device__ __forceinline__ bool in_subgroup_yfree_quad(const fp_t& px, const fp_t& rhs, const fp_t& beta, int role) {
     fp_t rhs2;
     G1J Q;
     G1D::JacYC base;
     G1D::yfree_start(Q, base, rhs2, px, rhs);
-    const bool role1 = role == 1, role2 = role == 2;
+    const QuadRole qr(role);
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {
 #pragma unroll 1
         for (int bit = 62; bit >= 0; bit--) {
-            jdbl_quad(Q, role1, role2);
+            jdbl_quad(Q, qr);
             if ((BLS_X_ABS >> bit) & 1) G1D::jadd_y(Q, Q, base, rhs, rhs2);
         }
         if (pass == 0) G1D::jy_cache(base, Q, rhs);

@@ -124,6 +124,44 @@ def test_direct_table_mode(product, oracle_ctx, bits):
     ctx.close()
 
 
+def test_direct_table_lane_shapes(product, oracle_ctx):
+    """The direct-table commitment spreads a blob over 512 lanes (8 scalars each) in a full batch and over 1024, 2048 or 4096 lanes
+    in calls of fewer blobs (msm_kernels.hip direct_pick_k: 1..32 blobs -> 1 scalar per lane, ..64 -> 2, ..128 -> 4), with a fold of
+    the partial sums in between: every shape gives the oracle's bytes, an invalid blob is reported at its index."""
+    import torch
+    torch.cuda.init()
+    distinct = [rand_blob(400 + i) for i in range(5)] + [bytes(131072)]
+    exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in distinct]
+    ctx = product.Context()
+    assert ctx.set_option("commit_direct_bits", 12) == 0
+    for n in (1, 2, 20, 32, 33, 64, 65, 128, 129):
+        blobs = [distinct[i % 6] for i in range(n)]
+        bad_at = n // 2 if n > 2 else None
+        if bad_at is not None:
+            bad = bytearray(blobs[bad_at])
+            bad[32 * 4095:] = R.to_bytes(32, "big")
+            blobs[bad_at] = bytes(bad)
+        rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)                     # host-pointer pipeline (chunked accumulate launches)
+        assert rc == (3 if bad_at is not None else 0), n
+        for i in range(n):
+            if i == bad_at:
+                assert st[i] == 3
+            else:
+                assert st[i] == 0 and outs[i] == exp[i % 6], (n, i)
+        d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()       # device-resident entry
+        d_out = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+        d_st = torch.ones(n, dtype=torch.int32, device="cuda")
+        ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), n, d_out.data_ptr(), d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out_b, st_d = d_out.cpu().numpy().tobytes(), d_st.cpu().tolist()
+        for i in range(n):
+            if i == bad_at:
+                assert st_d[i] == 3
+            else:
+                assert st_d[i] == 0 and out_b[48 * i:48 * i + 48] == exp[i % 6], (n, i)
+    ctx.close()
+
+
 def test_options_and_calibration(product, oracle_ctx):
     """options only change how the work is cut (same bytes); unknown keys / values are MKZG_ERR_BAD_ARGS; mkzg_valu_calibrate returns
     a plausible issue rate"""

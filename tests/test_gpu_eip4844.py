@@ -88,6 +88,46 @@ def test_verify_kzg_proof(vectors, gpu_ctx):
     assert n > 100
 
 
+def test_points_outside_the_subgroup(gpu_ctx):
+    """The decoder's r-torsion test (k_g1_validate: phi(P) == -[x^2]P without y, doublings on a lane quad per point) on curve points
+    inside and outside G1 through VerifyKZGProof: the order-3 points (0, +-2) drive the chain through the identity, random curve
+    points lie outside with probability 1 - 1/cofactor, h * Q lies inside for any Q.  Reference: serialization.go:108-115."""
+    import random
+    from test_mont29_host import P, R, G1X, G1Y, ec_mul, compress
+    NOT_IN_SUBGROUP = 13                                        # MKZG_ERR_G1_NOT_IN_SUBGROUP
+    rng = random.Random(77)
+    outside = [(0, 2), (0, P - 2)]
+    while len(outside) < 8:
+        x = rng.randrange(P)
+        rhs = (x * x * x + 4) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P == rhs:
+            outside.append((x, y))
+    good = compress(ec_mul(5, (G1X, G1Y)))
+    z, y32 = (3).to_bytes(32, "big"), (4).to_bytes(32, "big")
+    for pt in outside:
+        assert ec_mul(R, pt) is not None
+        assert gpu_ctx.VerifyKZGProof(compress(pt), z, y32, good) == NOT_IN_SUBGROUP, pt
+        assert gpu_ctx.VerifyKZGProof(good, z, y32, compress(pt)) == NOT_IN_SUBGROUP, pt
+    H_COF = 0x396c8c005555e1568c00aaab0000aaab
+    for pt in outside[2:5]:
+        q = ec_mul(H_COF, pt)
+        assert q is not None and ec_mul(R, q) is None
+        assert gpu_ctx.VerifyKZGProof(compress(q), z, y32, good) == VERIFY_FAILED            # decodes, in G1; the proof is simply wrong
+    # a batch that mixes them: the first offender's error wins (verify.go:102-123)
+    blob = rand_blob(5)
+    rc, cm = gpu_ctx.BlobToKZGCommitment(blob)
+    rc, pr = gpu_ctx.ComputeBlobKZGProof(blob, cm)
+    assert rc == 0
+    n = 40
+    cms, prs = [cm] * n, [pr] * n
+    assert gpu_ctx.VerifyBlobKZGProofBatch([blob] * n, cms, prs) == 0
+    for at in (0, 15, 16, 39):
+        bad = list(prs)
+        bad[at] = compress(outside[at % len(outside)])
+        assert gpu_ctx.VerifyBlobKZGProofBatch([blob] * n, cms, bad) == NOT_IN_SUBGROUP, at
+
+
 def test_verify_blob_kzg_proof(vectors, hash_place):
     gpu_ctx = hash_place
     for c in vectors.cases("verify_blob_kzg_proof"):
@@ -269,6 +309,7 @@ def test_shared_context_from_threads(gpu_ctx, oracle_ctx):
             stream = torch.cuda.Stream()
             d_out = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
             d_st = torch.ones(N, dtype=torch.int32, device="cuda")
+            torch.cuda.current_stream().synchronize()      # the fills above ran on this thread's default stream, the calls below use `stream`
             for it in range(8):
                 i = (k + it) % 4
                 which = (k + it) % 7

@@ -200,6 +200,7 @@ def test_commitment_batch_256_direct_table_c15(product, oracle_ctx):
         streams = [torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)]
         outs = [torch.zeros(B * 48, dtype=torch.uint8, device="cuda") for _ in streams]
         sts = [torch.ones(B, dtype=torch.int32, device="cuda") for _ in streams]
+        torch.cuda.synchronize()            # the fills ran on the default stream; the calls below run on their own streams
         for rep in range(4):
             i = rep % 2
             assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), B, outs[i].data_ptr(), sts[i].data_ptr(), streams[i].cuda_stream) == 0

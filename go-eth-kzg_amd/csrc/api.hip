@@ -149,6 +149,7 @@ Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
         (void)hipGetLastError();           // hipEventQuery reports hipErrorNotReady through the sticky error too
         L->busy = true;
         L->warm = true;
+        c->lanes_busy.fetch_add(1, std::memory_order_relaxed);
     }
     (void)hipSetDevice(c->device);
     L->failed = false;
@@ -172,6 +173,7 @@ void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s) {
         std::lock_guard<std::mutex> g(c->mu);
         L->busy = false;
         L->released_at = ++c->release_seq;
+        c->lanes_busy.fetch_sub(1, std::memory_order_relaxed);
     }
     c->cv.notify_all();
 }
@@ -647,6 +649,11 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         c->opt_host_sha = (int)value;
         return MKZG_OK;
     }
+    if (!strcmp(key, "verify_shape")) {
+        if (value < -1 || value > 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_verify_shape = (int)value;
+        return MKZG_OK;
+    }
     return MKZG_ERR_BAD_ARGS;
 }
 int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
@@ -669,6 +676,7 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "fk20_bits_effective")) *value = q->fk20_bits_built;                   // 0 until the first call that needs the table
     else if (!strcmp(key, "host_chunk")) *value = q->opt_host_chunk;
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
+    else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
     else if (!strcmp(key, "devices")) *value = c->peers.empty() ? 1 : (long)c->peers.size();
     else if (!strcmp(key, "lanes")) *value = mkzg_ctx::NLANE;

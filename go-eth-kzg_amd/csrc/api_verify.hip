@@ -83,12 +83,24 @@ int draw_rlc_scalar(uint8_t r_le32[32]) { return getrandom(r_le32, 32, 0) == 32 
 // Device work + Horner: A = sum r^i Q_i, Cc = sum r^i C_i, D = sum r^i z_i Q_i, e = sum r^i y_i with i = exp_offset + local index.
 // n <= VMSM_MAX_N; larger batches are cut by the callers and folded piece by piece with one r.
 // ---------------------------------------------------------------------------------------------
+// Two shapes of the blob verifier, same results.  LATENCY (a caller waits for this one call): everything that does not need the
+// challenge runs beside the 2.7 ms SHA-256 chain -- among it an inverse NTT of every blob, so that y = f(z) is a short Horner pass
+// once z is known -- and the subgroup tests take a quad of lanes per point.  THROUGHPUT (other calls share the chip, the chain
+// lengths hide behind them): y by the barycentric formula straight from the blob (domain.go:193-235 -- 2.1x fewer instructions than
+// inverse NTT + Horner, and no 201 MB of coefficients written and read back), one lane per point in the subgroup tests (2.1x fewer
+// again), and all of it on ONE stream.  By default a call takes the throughput shape when at least two other calls are in flight on the
+// context.
+static bool throughput_shape(const mkzg_ctx* c) {
+    if (c->opt_verify_shape >= 0) return c->opt_verify_shape == 1;
+    return c->lanes_busy.load(std::memory_order_relaxed) >= 3;
+}
 static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
                        uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out) {
     if (n == 0 || n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
     int rc = ensure_verify_ws(L, n);
     if (rc) return rc;
-    if (d_blobs) {
+    const bool tp = throughput_shape(c);
+    if (d_blobs && !tp) {
         // coefficient rows of the blobs (inverse NTT beside the challenge hash) and the NTT twiddles they need
         rc = ensure_twiddles(c);
         if (rc) return rc;
@@ -115,15 +127,18 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     int vrc = 0;
     // 1. decode + validate the points (serialization.go:108-115)
     //    on the side stream, beside the (longer, latency-bound) SHA-256 chain
-    hipStream_t s2 = L->side;
+    //    (throughput shape: on the call's own stream, ahead of the hash -- HIP multiplexes all streams of the process onto a few hardware
+    //    queues, in order within each, so a side stream's short kernels would wait behind some other call's 3 ms hash kernel and a
+    //    context with eight calls in flight had two of them progressing; one stream per call keeps one queue per call)
+    hipStream_t s2 = tp ? s : L->side;
     HIPCHK(hipEventRecord(L->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(s2, L->ev_fork, 0));
-    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2));
+    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? 3 : 0));
     if (d_blobs) {
         //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
         //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions;
         //    the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
-        KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s2));
+        if (!tp) KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s2));
         HIPCHK(hipMemcpyAsync(L->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s2));
         KT(KT_RLC, s2, rlc_scalars_device(L->d_v_misc, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
         const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
@@ -139,7 +154,8 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         if (d_z32) scalars_to_fr_device(d_z32, (int)n, L->d_v_z, st_x, s);          // challenges hashed on the host (canonical by construction)
         else KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, L->d_v_z, s));
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
-        KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
+        if (tp) KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, s));
+        else KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
         // 3. what depends on the challenges: r^i z_i, sum r^i y_i, and the MSM sum r^i z_i Q_i (kzg_verify.go:179)
         KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
         const uint32_t* scal[1] = {L->d_v_s3};

@@ -148,6 +148,7 @@ struct mkzg_ctx {
     // ---- lanes
     static constexpr int NLANE = 8;
     Lane lanes[NLANE];
+    std::atomic<int> lanes_busy{0};        // calls in flight on this context right now
     std::mutex mu;                         // lane hand-over only
     std::condition_variable cv;
     uint64_t release_seq = 0;
@@ -161,6 +162,7 @@ struct mkzg_ctx {
     int opt_fk20_bits = 11;                // window width of the FK20 direct table: 11 (25.8 GB) or 13 (86 GB, 17 % fewer additions per MSM)
     int opt_host_chunk = 128;              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
     int opt_host_zero_copy = 1;            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
+    int opt_verify_shape = -1;             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
     int opt_host_sha = -1;                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
     std::atomic<bool> profiling{false};
     // ---- SRS

@@ -15,7 +15,7 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
 void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint32_t* d_y, const int* d_status, hipStream_t s);
 // decode (gnark SetBytes checks) + subgroup test of two arrays of compressed points in one launch: affine rows and status words out
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
-                         int mode = 0 /* 0: decode + subgroup test; 1: decode only; 2: subgroup test only, verdicts to d_st_* */);
+                         int mode = 0 /* 0: decode + subgroup test (a lane quad per point); 1: decode only; 2: subgroup test only, verdicts to d_st_*; 3: as 0, one lane per point */);
 // r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         int mode /* 0 all, 1 s1 only, 2 s3 and e only */, hipStream_t s);

@@ -568,7 +568,9 @@ __global__ void __launch_bounds__(256) k_poly_eval(const uint32_t* __restrict__ 
 // mode 0: both wavefronts, one status per point.  mode 1 (64 threads, 64 points per block) / mode 2 (64 threads, 16 points per
 // block): only the decoding / only the r-torsion test, as two launches on two streams -- for the cell verifier, whose MSMs can
 // then start on the decoded rows while the test is still running; mode 2 writes MKZG_ERR_G1_NOT_IN_SUBGROUP or 0 to ITS OWN status
-// arrays (the caller gives the decoding's status precedence).
+// arrays (the caller gives the decoding's status precedence).  mode 3: as mode 0 with ONE lane per point in the test and 64 points
+// per block -- the quad form spends 2.1x the instructions for its shorter chain, which a context that has several calls in flight
+// (the chip is shared, nobody waits for one chain) does not want (api_verify.hip throughput_shape).
 // Every wavefront runs with all 64 lanes active (FULL_WAVES, see fk20_kernels.hip: sparse wavefronts issue up to 3x slower on gfx950,
 // and the DPP moves read every lane of a quad): lanes beyond the points shadow another point and store nothing.
 // G1D::in_subgroup_yfree with the doublings on a lane quad; every lane of the quad returns the verdict
@@ -592,14 +594,16 @@ __device__ __forceinline__ bool in_subgroup_yfree_quad(const fp_t& px, const fp_
 static const int VAL_PB = 16;                               // points per block of the r-torsion test (a quad of lanes each)
 __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
                                                      const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode) {
-    __shared__ int sub_ok[VAL_PB];                          // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
-    const int lane = threadIdx.x & 63, role = mode == 0 ? (int)(threadIdx.x >> 6) : mode - 1;
+    __shared__ int sub_ok[64];                              // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
+    const bool wide = mode == 3, both = mode == 0 || wide;
+    const int lane = threadIdx.x & 63, role = both ? (int)(threadIdx.x >> 6) : mode - 1;
     const int total = n_a + n_b;
-    // which point: the test gives a quad per point (16 per wavefront); the decoding a lane per point -- 64 per block on its own
-    // (mode 1), the block's 16 (copied four times over the wavefront) beside the test (mode 0)
-    const int slot = role == 1 ? lane >> 2 : (mode == 1 ? lane : lane & (VAL_PB - 1));
-    int i = blockIdx.x * (mode == 1 ? 64 : VAL_PB) + slot;
-    const bool live = i < total && (role == 1 ? (lane & 3) == 0 : (mode == 1 || lane < VAL_PB));
+    // which point: the test gives a quad per point (16 per wavefront) unless wide; the decoding a lane per point -- 64 per block on
+    // its own (mode 1) or beside the wide test (mode 3), the block's 16 (copied four times over the wavefront) beside the quad test
+    const int per_block = (mode == 1 || wide) ? 64 : VAL_PB;
+    const int slot = wide ? lane : (role == 1 ? lane >> 2 : (mode == 1 ? lane : lane & (VAL_PB - 1)));
+    int i = blockIdx.x * per_block + slot;
+    const bool live = i < total && (wide ? true : (role == 1 ? (lane & 3) == 0 : (mode == 1 || lane < VAL_PB)));
     if (i >= total) i %= total;
     const uint8_t* in48 = in48_a;
     uint32_t* aff = aff_a;
@@ -614,7 +618,8 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
         if (g1_parse_lane(x, flags, in48 + (size_t)i * 48) == 0) {        // uniform over the quad: its lanes read the same point
             g1_curve_rhs(rhs, x);
             Fp::set(beta, FP_BETA);
-            v = in_subgroup_yfree_quad(x, rhs, beta, lane & 3) ? 1 : 0;
+            if (wide) v = G1D::in_subgroup_yfree(x, rhs, beta) ? 1 : 0;
+            else v = in_subgroup_yfree_quad(x, rhs, beta, lane & 3) ? 1 : 0;
         }
     } else {
         rc = g1_decode_lane(p, in48 + (size_t)i * 48);
@@ -636,8 +641,8 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
         if (live) st[i] = v == 0 ? MKZG_ERR_G1_NOT_IN_SUBGROUP : 0;
         return;
     }
-    // mode 0: both wavefronts meet at ONE barrier; the decoding wavefront then joins the two verdicts
-    if (role == 1 && (lane & 3) == 0) sub_ok[slot] = v;
+    // modes 0, 3: both wavefronts meet at ONE barrier; the decoding wavefront then joins the two verdicts
+    if (role == 1 && (wide || (lane & 3) == 0)) sub_ok[slot] = v;
     __syncthreads();
     if (role == 0 && live) {
         if (rc == 0 && !p.inf && sub_ok[slot] == 0) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
@@ -945,8 +950,8 @@ void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
                          int mode) {
     const int n = n_a + n_b;
-    const int per_block = mode == 1 ? 64 : VAL_PB;
-    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + per_block - 1) / per_block), dim3(mode == 0 ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b,
+    const int per_block = (mode == 1 || mode == 3) ? 64 : VAL_PB;
+    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + per_block - 1) / per_block), dim3((mode == 0 || mode == 3) ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b,
                                   d_st_b, mode);
 }
 void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,

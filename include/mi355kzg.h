@@ -86,7 +86,11 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *   "host_sha"            host-pointer verifiers: Fiat-Shamir challenges hashed by the host pool while the blobs upload (1),
  *                         on the device after the upload (0), library's choice (-1, default: the host for calls of up to 8 blobs per pool
  *                         thread -- a 70 us hash per blob instead of the device's 2.7 ms chain -- and the device above that);
- *                         ComputeBlobKZGProof follows the same switch */
+ *                         ComputeBlobKZGProof follows the same switch
+ *   "verify_shape"        VerifyBlobKZGProofBatch: 0 = latency shape (inverse NTT of the blobs beside the challenge hash, then a short
+ *                         Horner pass; a quad of lanes per point in the subgroup tests), 1 = throughput shape (barycentric evaluation
+ *                         straight from the blobs, one lane per point: half the instructions, longer dependent chains), -1 (default)
+ *                         = throughput shape when at least two other calls are in flight on the context.  Same results either way. */
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
 /* reads an option back; also "commit_direct_bits_effective", "fk20_bits_effective", "devices", "lanes" */
 int mkzg_ctx_get_option(mkzg_ctx* ctx, const char* key, long* value);

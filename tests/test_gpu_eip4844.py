@@ -47,13 +47,16 @@ def test_compute_kzg_proof(vectors, gpu_ctx):
     assert n_ok > 30
 
 
-@pytest.fixture(params=[-1, 0, 1], ids=["sha_auto", "sha_device", "sha_host"])
+@pytest.fixture(params=[(-1, -1), (0, 0), (1, 1), (0, 1)], ids=["defaults", "sha_device-latency_shape", "sha_host-throughput_shape", "sha_device-throughput_shape"])
 def hash_place(request, gpu_ctx):
-    """Where the Fiat-Shamir transcript is hashed (option host_sha): by default the host pool takes small calls and the device large ones,
-    so the vectors -- all small -- run under each setting."""
-    assert gpu_ctx.set_option("host_sha", request.param) == 0
+    """Where the Fiat-Shamir transcript is hashed (option host_sha: by default the host pool takes small calls and the device large
+    ones) and which shape the verifier takes (option verify_shape: inverse NTT + Horner and quad subgroup tests for a lone call,
+    barycentric evaluation and one lane per point when several calls share the chip): the vectors run under each setting."""
+    assert gpu_ctx.set_option("host_sha", request.param[0]) == 0
+    assert gpu_ctx.set_option("verify_shape", request.param[1]) == 0
     yield gpu_ctx
     assert gpu_ctx.set_option("host_sha", -1) == 0
+    assert gpu_ctx.set_option("verify_shape", -1) == 0
 
 
 def test_compute_blob_kzg_proof(vectors, hash_place):

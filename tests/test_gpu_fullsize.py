@@ -65,15 +65,23 @@ def test_verify_batch_1024(gpu_ctx, oracle_ctx):
     pr = bytes(d_pr.cpu().tolist())
     for i in (0, 513, 1023):
         assert pr[48 * i:48 * i + 48] == oracle_ctx.compute_blob_kzg_proof(blobs[i], cm[48 * i:48 * i + 48])[1]
-    assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st) == 0
-    for victim in (0, 700, 1023):        # one corrupted proof anywhere must reject the whole batch
-        bad = d_pr.clone()
-        other = (victim + 1) % N
-        bad[48 * victim:48 * victim + 48] = d_pr[48 * other:48 * other + 48]
-        assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), bad.data_ptr(), N, st) == 1
-    badc = d_cm.clone()
-    badc[0] = 0x00                        # compressed flag cleared -> decoding error, not a verification failure
-    assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), badc.data_ptr(), d_pr.data_ptr(), N, st) == 11
+    badb = d_blobs.clone()
+    badb[131072 * 900 + 32 * 17:131072 * 900 + 32 * 18] = 0xff           # blob 900 holds a non-canonical field element
+    try:
+        for shape in (0, 1):                 # the lone-call shape and the shape calls take when they share the chip (option verify_shape)
+            assert gpu_ctx.set_option("verify_shape", shape) == 0
+            assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st) == 0
+            for victim in (0, 700, 1023):        # one corrupted proof anywhere must reject the whole batch
+                bad = d_pr.clone()
+                other = (victim + 1) % N
+                bad[48 * victim:48 * victim + 48] = d_pr[48 * other:48 * other + 48]
+                assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), bad.data_ptr(), N, st) == 1
+            badc = d_cm.clone()
+            badc[0] = 0x00                        # compressed flag cleared -> decoding error, not a verification failure
+            assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), badc.data_ptr(), d_pr.data_ptr(), N, st) == 11
+            assert gpu_ctx.verify_blob_kzg_proof_batch_device(badb.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st) == 3
+    finally:
+        assert gpu_ctx.set_option("verify_shape", -1) == 0
 
 
 def test_cells_and_proofs_batch_64(gpu_ctx, oracle_ctx):

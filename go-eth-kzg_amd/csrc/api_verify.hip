@@ -90,6 +90,72 @@ int draw_rlc_scalar(uint8_t r_le32[32]) { return getrandom(r_le32, 32, 0) == 32 
 // inverse NTT + Horner, and no 201 MB of coefficients written and read back), one lane per point in the subgroup tests (2.1x fewer
 // again), and all of it on ONE stream.  By default a call takes the throughput shape when at least two other calls are in flight on the
 // context.
+// Hash rounds (throughput shape).  The challenge kernel is a 2.7 ms dependent chain per blob whatever the batch, and HIP runs all the
+// streams of a process through a handful of in-order hardware queues: eight calls in flight, each with its own hash launch, held every
+// queue for 3 ms at a time and a context verified ~0.65 M blobs/s however many callers it had.  So calls that find other calls in
+// flight do not launch the hash themselves: they join the ROUND that is forming.  The first caller to find no round forming opens one
+// and leads it: it waits until the round before the previous one has finished (on the host; whoever arrives meanwhile joins), closes
+// the round and launches ONE kernel over all its jobs on one of the context's two hash streams (rounds alternate, two are in flight)
+// -- streams of the lowest priority, so that no other stream of the process shares their queues.  Everyone then waits for the round on the host (the call is synchronous anyway; a device-side wait
+// would hold the call's own queue, and with it whatever else HIP mapped there) and carries on in its own stream.
+static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipEvent_t ready, std::shared_ptr<HashRound>* out) {
+    std::shared_ptr<HashRound> r, prev;
+    bool leader = false;
+    {
+        std::unique_lock<std::mutex> lk(c->hash_mu);
+        for (auto& hs : c->hash_stream) {
+            if (hs) continue;
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, least) != hipSuccess) { hs = nullptr; (void)hipGetLastError(); return MKZG_ERR_HIP; }
+        }
+        if (c->hash_forming && c->hash_forming->jobs.count >= SHA_MAX_JOBS) return MKZG_ERR_BAD_ARGS;     // cannot happen: one job per lane
+        if (!c->hash_forming) {
+            c->hash_forming = std::make_shared<HashRound>();
+            prev = c->hash_prev2;
+            leader = true;
+        }
+        r = c->hash_forming;
+        const int j = r->jobs.count++;
+        r->jobs.blobs[j] = d_blobs;
+        r->jobs.commitments[j] = d_commitments;
+        r->jobs.z_out[j] = d_z;
+        r->jobs.n[j] = n;
+        r->ready[j] = ready;
+        if (leader && prev) c->hash_cv.wait(lk, [&] { return prev->launched; });
+    }
+    if (leader) {
+        if (prev && prev->done) (void)hipEventSynchronize(prev->done);       // the launch two rounds back has finished: its stream is free
+        hipStream_t hs;
+        {
+            std::lock_guard<std::mutex> g(c->hash_mu);
+            c->hash_forming.reset();                                           // closed: later arrivals open the next round
+            c->hash_prev2 = c->hash_prev;
+            c->hash_prev = r;
+            hs = c->hash_stream[c->hash_rounds++ & 1];
+        }
+        int rc = MKZG_OK;
+        if (hipEventCreateWithFlags(&r->done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { r->done = nullptr; rc = MKZG_ERR_HIP; }
+        for (int j = 0; j < r->jobs.count && !rc; j++)
+            if (hipStreamWaitEvent(hs, r->ready[j], 0) != hipSuccess) rc = MKZG_ERR_HIP;
+        if (!rc) {
+            challenge_jobs_device(r->jobs, hs);
+            if (hipGetLastError() != hipSuccess || hipEventRecord(r->done, hs) != hipSuccess) rc = MKZG_ERR_HIP;
+        }
+        if (rc) (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> g(c->hash_mu);
+            r->rc = rc;
+            r->launched = true;
+        }
+        c->hash_cv.notify_all();
+    } else {
+        std::unique_lock<std::mutex> lk(c->hash_mu);
+        c->hash_cv.wait(lk, [&] { return r->launched; });
+    }
+    *out = r;
+    return r->rc;
+}
 static bool throughput_shape(const mkzg_ctx* c) {
     if (c->opt_verify_shape >= 0) return c->opt_verify_shape == 1;
     return c->lanes_busy.load(std::memory_order_relaxed) >= 3;
@@ -151,8 +217,16 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     // 2. challenge and claimed value per blob, or caller-supplied z / y
     int y_bad = 0;
     if (d_blobs) {
-        if (d_z32) scalars_to_fr_device(d_z32, (int)n, L->d_v_z, st_x, s);          // challenges hashed on the host (canonical by construction)
-        else KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, L->d_v_z, s));
+        if (d_z32) {
+            scalars_to_fr_device(d_z32, (int)n, L->d_v_z, st_x, s);          // challenges hashed on the host (canonical by construction)
+        } else if (tp) {
+            std::shared_ptr<HashRound> round;                                // the hash of this call and of whoever else is waiting for one
+            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->ev_fork, &round);   // ev_fork: recorded on s before any of this call's kernels
+            if (round && round->done) HIPCHK(hipEventSynchronize(round->done));
+            if (rc) return rc;
+        } else {
+            KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, L->d_v_z, s));
+        }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
         if (tp) KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, s));
         else KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <algorithm>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -141,14 +142,30 @@ struct Lane {
     bool failed = false;                   // set by an error exit: the release then synchronises every stream of the lane
 };
 
+// One launch of the Fiat-Shamir hash kernel for all the calls that were waiting for one (api_verify.hip hash_round_join)
+struct HashRound {
+    kzg::ShaJobs jobs{};
+    hipEvent_t ready[kzg::SHA_MAX_JOBS] = {};   // per job: its inputs are ready on the call's stream
+    hipEvent_t done = nullptr;                  // the launch has finished
+    bool launched = false;
+    int rc = 0;
+    ~HashRound() { if (done) (void)hipEventDestroy(done); }
+};
+
 struct mkzg_ctx {
     int device = 0;
     std::vector<mkzg_ctx*> peers;          // further devices of a multi-device context (owned by this, the primary)
     std::atomic<unsigned> rr{0};           // round-robin cursor of single-item calls over the devices
     // ---- lanes
-    static constexpr int NLANE = 8;
+    static constexpr int NLANE = 16;
     Lane lanes[NLANE];
     std::atomic<int> lanes_busy{0};        // calls in flight on this context right now
+    // ---- hash rounds (throughput shape of the blob verifier)
+    std::mutex hash_mu;
+    std::condition_variable hash_cv;
+    std::shared_ptr<HashRound> hash_forming, hash_prev, hash_prev2;   // the round being filled, the last two launched
+    hipStream_t hash_stream[2] = {nullptr, nullptr};                    // rounds alternate between them: two in flight
+    uint64_t hash_rounds = 0;
     std::mutex mu;                         // lane hand-over only
     std::condition_variable cv;
     uint64_t release_seq = 0;

@@ -8,6 +8,17 @@ namespace kzg {
 
 // Fr rows are 12 words (9 limbs + padding), affine G1 rows 32 words, as in msm_kernels.hip.
 void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s);
+// the same for up to SHA_MAX_JOBS (blobs, commitments, n, z) jobs -- one per call in flight -- in ONE launch; every n > 0
+constexpr int SHA_MAX_JOBS = 16;
+struct ShaJobs {
+    const uint8_t* blobs[SHA_MAX_JOBS];
+    const uint8_t* commitments[SHA_MAX_JOBS];
+    uint32_t* z_out[SHA_MAX_JOBS];
+    int n[SHA_MAX_JOBS];
+    int first_block[SHA_MAX_JOBS];
+    int count;
+};
+void challenge_jobs_device(ShaJobs& jobs, hipStream_t s);
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s);
 void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
                           int* d_status, hipStream_t s);

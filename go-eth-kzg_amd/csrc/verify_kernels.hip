@@ -206,11 +206,15 @@ constexpr int SHA_NBLOCKS = 2050;
 __device__ __forceinline__ uint32_t sha_from_e_lane(uint32_t x) {   // A lanes: the value of their E lane; E lanes: 0
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xC, false);   // row_mirror
 }
-__global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
+// the body for one workgroup: blobs blk * 64 .. blk * 64 + 63 of one (blobs, commitments, n, z_out) job
+__device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out, int blk) {
     __shared__ uint4 wk[5][16][64];                 // [message block mod 4][round / 4][blob]: four W + K per 16-byte LDS access; [4] stays zero
+    // every verifier call waits for this chain and it needs few issue slots: its wavefronts go first on their SIMDs (beside the other
+    // kernels of eight calls in flight a launch took 3.8 ms instead of 2.7 without this)
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
     if (role < 2) {
-        const int b0 = blockIdx.x * 64 + lane;
+        const int b0 = blk * 64 + lane;
         const int b = b0 < n ? b0 : n - 1;              // surplus lanes shadow the last blob (they must keep the barriers)
         const uint8_t* blob = blobs + (size_t)b * 131072;
         const uint8_t* cm = commitments48 + (size_t)b * 48;
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restr
     // consumers: during step j they run the rounds of blocks 2j-2 and 2j-1 (written in step j-1) while the producers fill 2j, 2j+1
     const bool a_side = ((lane >> 3) & 1) != 0;             // A lane: (a, b, c, d); E lane: (e, f, g, h)
     const int col = 32 * (role - 2) + (lane >> 4) * 8 + (a_side ? 15 - (lane & 15) : (lane & 15));   // this pair's blob within the workgroup
-    const int b0 = blockIdx.x * 64 + col;
+    const int b0 = blk * 64 + col;
     const uint32_t m_a = a_side ? 0xffffffffu : 0u;
     const uint32_t r1 = a_side ? 2 : 6, r2 = a_side ? 13 : 11, r3 = a_side ? 22 : 25;
 #pragma unroll
@@ -326,6 +330,17 @@ __global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restr
     fr_t z;
     fr_from_words(z, v);
     store_fr12(z_out + (size_t)b * 12, z);
+}
+__global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
+    sha_challenge_block(blobs, commitments48, n, z_out, (int)blockIdx.x);
+}
+// the challenges of SEVERAL calls in one launch (api_verify.hip, the hash rounds of the throughput shape): the chain is 2.7 ms long
+// whatever the number of blobs, and a launch holds its hardware queue for that long -- calls that arrive together share one
+__global__ void __launch_bounds__(256) k_challenge_sha256_jobs(ShaJobs jobs) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.first_block[j + 1]) j++;
+    sha_challenge_block(jobs.blobs[j], jobs.commitments[j], jobs.n[j], jobs.z_out[j], (int)blockIdx.x - jobs.first_block[j]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -936,6 +951,14 @@ __global__ void __launch_bounds__(64) k_fr_to_scalars(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------
 void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(256), 0, s, d_blobs, d_commitments, n, d_z);
+}
+void challenge_jobs_device(ShaJobs& jobs, hipStream_t s) {
+    int blocks = 0;
+    for (int j = 0; j < jobs.count; j++) {
+        jobs.first_block[j] = blocks;
+        blocks += (jobs.n[j] + 63) / 64;
+    }
+    if (blocks > 0) hipLaunchKernelGGL(k_challenge_sha256_jobs, dim3(blocks), dim3(256), 0, s, jobs);
 }
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);

@@ -92,13 +92,13 @@ def parse_args():
     ap.add_argument("--window", type=int, default=0, help="MSM window bits override (11..13)")
     ap.add_argument("--direct-bits", type=int, default=15,
                     help="commit_direct_bits option: 0 = bucket method (0.5 GB table), 12..15 = direct window table (15: 146 GB of the 288 GB HBM)")
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps alternate over (1 = strictly serial steps)")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate over (1 = strictly serial steps)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents (roofline section is then empty)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drop-in", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=1024, help="configs[2]: proofs per VerifyBlobKZGProofBatch call per GPU (0 = skip)")
     ap.add_argument("--verify-steps", type=int, default=3)
-    ap.add_argument("--verify-inflight", type=int, default=8, help="caller threads of the sustained-rate leg (one call in flight each)")
+    ap.add_argument("--verify-inflight", type=int, default=16, help="caller threads of the sustained-rate leg (one call in flight each; a context has 16 lanes)")
     ap.add_argument("--fk20-bits", type=int, default=11, help="window width of the FK20 fixed-base table: 11 (25.8 GB, default) or 13 (86 GB: 17% fewer additions but TLB-bound gathers, measured no faster; falls back to 11 if HBM is short)")
     ap.add_argument("--cell-blobs", type=int, default=64, help="configs[3]/[4]: blobs per GPU for the EIP-7594 legs (64 x 128 = 8192 cells; 0 = skip)")
     return ap.parse_args()
@@ -472,7 +472,8 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(algo / (dom[1] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(algo / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": pm.get("traffic_bytes")}}
     # sustained rate: K caller threads on one shared context, one call in flight each (reference verify.go:152-169: the Context is
-    # shared by goroutines).  Each call works in its own lane; the challenge hash of one call runs beside the host finish of another.
+    # shared by goroutines).  Each call works in its own lane; calls that find others in flight take the throughput shape (barycentric
+    # evaluation, one stream per call) and share hash launches (api_verify.hip hash_round_join).
     K = args.verify_inflight
     if world == 1 and K > 1:
         reps = max(2, args.verify_steps)
@@ -498,6 +499,7 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
             dtk = time.perf_counter() - t0
         assert not errs, errs[0]
         out["sustained"] = {"callers": K, "calls": K * (reps + 1), "blobs_per_s": round(K * (reps + 1) * N / dtk, 1), "ms_per_call_amortised": round(dtk / (K * (reps + 1)) * 1e3, 3),
+                            "shape": "throughput shape: shared hash rounds, barycentric evaluation, one stream per call (option verify_shape -1)",
                             "note": "verdicts identical to the serial calls (each caller also submits one corrupted batch, which must be rejected)"}
     out["value"] = out.get("sustained", {}).get("blobs_per_s", out["single_call"]["blobs_per_s"])
     return out

@@ -204,14 +204,17 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
         //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions;
         //    the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
-        if (!tp) KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s2));
+        //    (throughput shape: none of that -- the three MSMs go out as ONE launch after the challenge, see below)
         HIPCHK(hipMemcpyAsync(L->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s2));
-        KT(KT_RLC, s2, rlc_scalars_device(L->d_v_misc, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
-        const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
-        const uint32_t* pts[2] = {aff_q, aff_c};
-        const int njob[2] = {(int)n, (int)n};
-        KT(KT_VMSM, s2, vrc = vmsm_windows_device(scal, pts, njob, 2, d_parts, d_wsum, s2));
-        if (vrc) return MKZG_ERR_BAD_ARGS;
+        if (!tp) {
+            KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s2));
+            KT(KT_RLC, s2, rlc_scalars_device(L->d_v_misc, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
+            const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
+            const uint32_t* pts[2] = {aff_q, aff_c};
+            const int njob[2] = {(int)n, (int)n};
+            KT(KT_VMSM, s2, vrc = vmsm_windows_device(scal, pts, njob, 2, d_parts, d_wsum, s2));
+            if (vrc) return MKZG_ERR_BAD_ARGS;
+        }
     }
     HIPCHK(hipEventRecord(L->ev_join, s2));
     // 2. challenge and claimed value per blob, or caller-supplied z / y
@@ -228,14 +231,24 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, L->d_v_z, s));
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
-        if (tp) KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, s));
-        else KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
-        // 3. what depends on the challenges: r^i z_i, sum r^i y_i, and the MSM sum r^i z_i Q_i (kzg_verify.go:179)
-        KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
-        const uint32_t* scal[1] = {L->d_v_s3};
-        const uint32_t* pts[1] = {aff_q};
-        const int njob[1] = {(int)n};
-        KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 1, d_parts + 2 * parts_per_job, d_wsum + 2 * wsum_per_job, s, 256));
+        if (tp) {
+            // throughput shape: every launch is time on the call's hardware queue, which it shares with other calls' streams -- one
+            // scalar kernel and ONE launch for the three MSMs of kzg_verify.go:150,225,179 instead of two of each
+            KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, s));
+            KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
+            const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
+            const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
+            const int njob[3] = {(int)n, (int)n, (int)n};
+            KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
+        } else {
+            KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
+            // 3. what depends on the challenges: r^i z_i, sum r^i y_i, and the MSM sum r^i z_i Q_i (kzg_verify.go:179)
+            KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
+            const uint32_t* scal[1] = {L->d_v_s3};
+            const uint32_t* pts[1] = {aff_q};
+            const int njob[1] = {(int)n};
+            KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 1, d_parts + 2 * parts_per_job, d_wsum + 2 * wsum_per_job, s, 256));
+        }
     } else {
         // VerifyKZGProof checks y before z (verify.go:15-23); st_b ends up non-zero if either fails
         scalars_to_fr_device(d_z32, (int)n, L->d_v_z, st_b, s);

@@ -38,13 +38,13 @@ def main():
         ts = [threading.Thread(target=caller, args=(k, reps)) for k in range(K)]
         torch.cuda.synchronize()
         time.sleep(0.05)
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         for t in ts:
             t.start()
         for t in ts:
             t.join()
-        dt = time.perf_counter() - t0
-        print(f"trial {trial}: {K} callers x {reps} calls: {K * reps * N / dt:.0f} blobs/s, {1e3 * dt / (K * reps):.3f} ms per call amortised", flush=True)
+        dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+        print(f"trial {trial}: {K} callers x {reps} calls: {K * reps * N / dt:.0f} blobs/s, {1e3 * dt / (K * reps):.3f} ms per call amortised; host CPUs busy {cpu / dt:.1f}", flush=True)
     ctx.close()
 
 

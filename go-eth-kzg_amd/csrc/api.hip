@@ -153,6 +153,7 @@ Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
     }
     (void)hipSetDevice(c->device);
     L->failed = false;
+    L->drained = false;
     tl_hip_error = false;
     if (L->used) (void)hipStreamWaitEvent(user_stream ? s : L->stream, L->done, 0);      // the previous owner may have returned before the GPU was done
     return L;
@@ -167,8 +168,15 @@ void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s) {
         for (auto& a : L->aux) (void)hipStreamSynchronize(a);
         (void)hipGetLastError();
     }
-    (void)hipEventRecord(L->done, s);
-    L->used = true;
+    // a call that has waited for its last device work on the host hands on an idle lane: no event, and the next acquire does not have to
+    // guess from hipEventQuery (an event recorded microseconds ago reads "not ready", and the caller would be sent to a cold lane --
+    // a synchronous caller looping over one context walked through all the lanes that way, allocating workspaces in each)
+    if (L->drained) {
+        L->used = false;
+    } else {
+        (void)hipEventRecord(L->done, s);
+        L->used = true;
+    }
     {
         std::lock_guard<std::mutex> g(c->mu);
         L->busy = false;
@@ -440,6 +448,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
         HIPCHK(hipMemcpyAsync(L->h_out + L->h_out_items * 48, L->d_status, n * sizeof(int), hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(L->stream));
+        L->drained = true;                  // every stream of the call was joined into L->stream above
         return MKZG_OK;
     }();
     drain();

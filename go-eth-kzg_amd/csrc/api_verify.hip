@@ -275,6 +275,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     HIPCHK(hipMemcpyAsync(h_st, L->d_v_st, 3 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    L->drained = true;                      // the side stream was joined into s above; nothing of this call is left on the device
     if (d_blobs) {
         for (size_t i = 0; i < n; i++) {                           // verify.go:102-123 order: commitment, proof, blob
             if (h_st[i]) return h_st[i];
@@ -595,6 +596,7 @@ int mkzg_compute_blob_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t 
     HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, 48, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(L->h_out + 48, L->d_status, sizeof(int), hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipStreamSynchronize(G.s));
+    L->drained = true;
     int st = 0;
     memcpy(&st, L->h_out + 48, sizeof(int));
     if (st) return st;
@@ -629,6 +631,7 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     HIPCHK(hipMemcpyAsync(L->h_out + 80, L->d_q_st, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(L->h_out + 84, st_z, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    L->drained = true;
     int stb = 0, stz = 0;
     memcpy(&stb, L->h_out + 80, sizeof(int));
     memcpy(&stz, L->h_out + 84, sizeof(int));

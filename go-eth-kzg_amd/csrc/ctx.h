@@ -140,6 +140,7 @@ struct Lane {
     KernelTimer timer;
     double last_host_finish_us = 0;
     bool failed = false;                   // set by an error exit: the release then synchronises every stream of the lane
+    bool drained = false;                  // set by a call that has waited for all its device work: the next owner need not wait for, or query, `done`
 };
 
 // One launch of the Fiat-Shamir hash kernel for all the calls that were waiting for one (api_verify.hip hash_round_join)

@@ -77,7 +77,8 @@ def test_compute_blob_kzg_proof(vectors, hash_place):
     assert n_ok == 7
 
 
-def test_verify_kzg_proof(vectors, gpu_ctx):
+def test_verify_kzg_proof(vectors, hash_place):
+    gpu_ctx = hash_place
     n = 0
     for c in vectors.cases("verify_kzg_proof"):
         i = c["input"]
@@ -352,6 +353,80 @@ def test_shared_context_from_threads(gpu_ctx, oracle_ctx):
     for t in ts:
         t.join(timeout=900)
     assert not errors, errors[0]
+
+
+def test_hash_rounds_many_callers(product, oracle_ctx):
+    """Twelve threads verify batches of different sizes on ONE context at once, so that the calls take the throughput shape and share
+    hash launches (api_verify.hip hash_round_join: rounds of several jobs with different n, leaders and followers changing from round to
+    round, two rounds in flight); every third batch carries a wrong proof, a few a non-canonical blob.  Every verdict must be the one the
+    serial, forced-latency-shape call gives.  Reference: verify.go:88-169 (a Context shared by goroutines)."""
+    import random
+    import threading
+    import torch
+    torch.cuda.init()
+    ctx = product.Context()
+    NB = 48
+    blobs = [rand_blob(7000 + i) for i in range(NB)]
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cm = torch.zeros(NB * 48, dtype=torch.uint8, device="cuda")
+    d_pr = torch.zeros(NB * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.ones(NB, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), NB, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
+    assert ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), NB, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0
+    cm, pr = bytes(d_cm.cpu().tolist()), bytes(d_pr.cpu().tolist())
+    for i in (0, 17, 47):
+        assert cm[48 * i:48 * i + 48] == oracle_ctx.blob_to_kzg_commitment(blobs[i])[1]
+    d_pr_bad = d_pr.clone()
+    d_pr_bad[0:48 * (NB - 1)] = d_pr[48:48 * NB]                      # every proof but the last belongs to the next blob
+    d_pr_bad[48 * (NB - 1):] = d_pr[0:48]
+    d_blobs_bad = d_blobs.clone()
+    for i in range(NB):
+        d_blobs_bad[131072 * i + 32 * 5:131072 * i + 32 * 6] = 0xff   # a non-canonical field element in every blob
+    torch.cuda.synchronize()
+    # (first blob, count, kind) -> expected rc: serial calls in the latency shape
+    rng = random.Random(5)
+    jobs = []
+    for k in range(12):
+        mine = []
+        for it in range(8):
+            n = rng.choice([1, 2, 3, 5, 8, 13, 21, 34])
+            lo = rng.randrange(0, NB - n + 1)
+            mine.append((lo, n, (k + it) % 3 if (k + it) % 7 else 3))
+        jobs.append(mine)
+
+    def call(lo, n, kind, stream):
+        b = (d_blobs_bad if kind == 3 else d_blobs).data_ptr() + 131072 * lo
+        p = (d_pr_bad if kind == 1 else d_pr).data_ptr() + 48 * lo
+        return ctx.verify_blob_kzg_proof_batch_device(b, d_cm.data_ptr() + 48 * lo, p, n, stream)
+
+    assert ctx.set_option("verify_shape", 0) == 0
+    want = {j: call(*j, st) for mine in jobs for j in mine}
+    assert set(want.values()) == {0, 1, 3}
+    assert all(want[j] == (1 if j[2] == 1 else 3 if j[2] == 3 else 0) for j in want)
+    assert ctx.set_option("verify_shape", -1) == 0
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(priority=-1 if k % 2 else 0)
+            for j in jobs[k]:
+                got = call(*j, stream.cuda_stream)
+                assert got == want[j], (j, got, want[j])
+        except Exception:      # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+
+    for rep in range(2):
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=600)
+        assert not errors, errors[0]
+    ctx.close()
 
 
 def test_first_calls_race_on_a_fresh_context(product, oracle_ctx):

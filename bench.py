@@ -534,6 +534,40 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
     prof = ctx.profile_read(reset=True)
     out["compute_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "fk20_table_bits": ctx.get_option("fk20_bits_effective"), "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s_per_gpu": round(NB / dt, 1),
                                            "kernels_ms": {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3)}
+    ctx.profile_enable(False)
+    if world == 1:
+        # sustained: four caller threads on the shared context, one call of NB blobs in flight each -- one call's latency-bound network
+        # of 686 scalar multiplications (two thirds of the SIMDs, one wavefront each) runs beside another call's VALU-bound MSM
+        KC, reps = 4, 4
+        bufs = [(torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda"), torch.zeros(NB * 128 * 48, dtype=torch.uint8, device="cuda"),
+                 torch.ones(NB, dtype=torch.int32, device="cuda")) for _ in range(KC)]
+        torch.cuda.synchronize()
+        errs = []
+
+        def cells_caller(k):
+            try:
+                s = torch.cuda.Stream(priority=-1 if k % 2 == 0 else 0)
+                cc, pp, ss = bufs[k]
+                for _ in range(reps):
+                    assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, cc.data_ptr(), pp.data_ptr(), ss.data_ptr(), s.cuda_stream) == 0
+                s.synchronize()
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+
+        for trial in range(2):                           # the first trial primes the lanes' workspaces
+            ts = [threading.Thread(target=cells_caller, args=(k,)) for k in range(KC)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            dtk = time.perf_counter() - t0
+        assert not errs, errs[0]
+        assert all(int(b[2].abs().sum().item()) == 0 and bool((b[1] == d_proofs).all().item()) for b in bufs), "concurrent calls disagree with the serial one"
+        out["compute_cells_and_kzg_proofs"]["sustained"] = {"callers": KC, "calls": KC * reps, "blobs_per_s": round(KC * reps * NB / dtk, 1), "ms_per_call_amortised": round(dtk / (KC * reps) * 1e3, 3)}
+        del bufs
+    ctx.profile_enable(True)
     assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), NB, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
     torch.cuda.synchronize()
     cms = d_cm.cpu().numpy().tobytes()

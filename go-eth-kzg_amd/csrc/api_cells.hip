@@ -218,6 +218,7 @@ int mkzg_compute_cells(mkzg_ctx* c, const uint8_t* blob, int num_threads, uint8_
     HIPCHK(hipMemcpyAsync(&st, L->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipStreamSynchronize(G.s));
+    G.L->drained = true;
     return st;
 }
 
@@ -251,6 +252,7 @@ int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* c, const uint8_t* blob, int num_
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(proofs_out, L->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipStreamSynchronize(G.s));
+    G.L->drained = true;
     return st;
 }
 
@@ -379,6 +381,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     HIPCHK(hipMemcpyAsync(h_sub_q.data(), sub_q, n * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS_C * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    L->drained = true;
     // error precedence of api_eip7594.go:190-213: all commitments, then all proofs, then all cells
     for (size_t i = 0; i < n_rows; i++) {
         if (h_st[i]) return h_st[i];
@@ -598,6 +601,7 @@ int mkzg_recover_cells_and_kzg_proofs(mkzg_ctx* c, const uint64_t* cell_ids, siz
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(proofs_out, L->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipStreamSynchronize(G.s));
+    G.L->drained = true;
     return MKZG_OK;
 }
 // n_blobs independent recoveries in one call (no reference analogue; throughput form of the above, used by sharded recovery jobs).
@@ -630,6 +634,7 @@ int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* c, size_t n_blobs, const u
             b = e;
         }
         HIPCHK(hipStreamSynchronize(G.s));
+        G.L->drained = true;
         const int nthr = m >= 8 ? 8 : 1;
         const size_t per = (m + nthr - 1) / nthr;
         c->pool->parallel(nthr, [&](int q) {
@@ -656,6 +661,7 @@ int mkzg_recover_cells(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, cons
     if (st) return st;
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipStreamSynchronize(G.s));
+    G.L->drained = true;
     return MKZG_OK;
 }
 

@@ -282,6 +282,20 @@ def test_proofs_with_direct_table(product, oracle_ctx):
         assert pr[48 * i:48 * i + 48] == oracle_ctx.compute_blob_kzg_proof(blobs[i], cms[i])[1]
     assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), n, st) == 0
     ctx.close()
+    # the lane shapes of the direct-table kernel for calls of few items (1, 2, 4 scalars per lane) on Fr rows: batches of 20, 40, 70 proofs
+    ctx = product.Context()
+    assert ctx.set_option("commit_direct_bits", 12) == 0
+    for m in (20, 40, 70):
+        d_b = torch.frombuffer(bytearray(b"".join(blobs[i % n] for i in range(m))), dtype=torch.uint8).cuda()
+        d_c = torch.frombuffer(bytearray(b"".join(cms[i % n] for i in range(m))), dtype=torch.uint8).cuda()
+        d_p = torch.zeros(m * 48, dtype=torch.uint8, device="cuda")
+        d_s = torch.ones(m, dtype=torch.int32, device="cuda")
+        assert ctx.compute_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), m, d_p.data_ptr(), d_s.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert d_s.cpu().tolist() == [0] * m
+        got = bytes(d_p.cpu().tolist())
+        assert all(got[48 * i:48 * i + 48] == pr[48 * (i % n):48 * (i % n) + 48] for i in range(m)), m
+    ctx.close()
 
 
 def test_shared_context_from_threads(gpu_ctx, oracle_ctx):

@@ -448,8 +448,11 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_us = 0.0
+    each = []
     for _ in range(args.verify_steps):
+        tc = time.perf_counter()
         assert one_call() == 0
+        each.append(round((time.perf_counter() - tc) * 1e3, 3))
         host_us += ctx.last_host_finish_us()
     torch.cuda.synchronize()
     if world > 1:
@@ -465,7 +468,7 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
     algo = (131072 + 48 + 48) * N          # bytes read per blob
     pm = pmc_profile(dom[0]) if N == 1024 else {}
     out = {"metric": "blobs/sec VerifyBlobKZGProofBatch", "batch_per_gpu": N, "unit": "blobs/s",
-           "single_call": {"blobs_per_s": round(N * world / dt * args.verify_steps, 2), "ms_per_call": round(ms, 3), "host_finish_ms": round(host_us / args.verify_steps / 1e3, 3),
+           "single_call": {"blobs_per_s": round(N * world / dt * args.verify_steps, 2), "ms_per_call": round(ms, 3), "host_finish_ms": round(host_us / args.verify_steps / 1e3, 3), "ms_each_call": each,
                            "parallelism": "one call at a time" if world == 1 else f"one global batch of {N * world} sharded x{world}; RCCL broadcast(r) + all_gather(512 B records)"},
            "compute_blob_kzg_proof_batch_proofs_per_s": round(proofs_per_s, 1),
            "kernels_ms_per_call": kern,

@@ -196,7 +196,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     //    (throughput shape: on the call's own stream, ahead of the hash -- HIP multiplexes all streams of the process onto a few hardware
     //    queues, in order within each, so a side stream's short kernels would wait behind some other call's 3 ms hash kernel and a
     //    context with eight calls in flight had two of them progressing; one stream per call keeps one queue per call)
-    hipStream_t s2 = tp ? s : L->side;
+    hipStream_t s2 = tp ? s : lane_side_stream(L, s);
     HIPCHK(hipEventRecord(L->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(s2, L->ev_fork, 0));
     KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? 3 : 0));
@@ -542,9 +542,10 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         int* st_cm = L->d_q_st + L->q_cap;
         // commitment must be a valid subgroup point (prove.go:56-62)
         HIPCHK(hipEventRecord(L->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(L->side, L->ev_fork, 0));
-        g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, L->side);
-        HIPCHK(hipEventRecord(L->ev_join, L->side));
+        hipStream_t s2 = lane_side_stream(L, s);
+        HIPCHK(hipStreamWaitEvent(s2, L->ev_fork, 0));
+        g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, s2);
+        HIPCHK(hipEventRecord(L->ev_join, s2));
         if (d_z32) scalars_to_fr_device(d_z32 + done * 32, (int)slice, L->d_q_z, L->d_v_st + 3 * L->v_cap, s);
         else KT(KT_SHA256, s, challenge_device(blobs, cms, (int)slice, L->d_q_z, s));
         for (size_t off = 0; off < slice; off += (size_t)c->opt_max_batch) {

@@ -224,6 +224,19 @@ void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s);
 // all lanes at once (option changes, profile read-out, destruction): returns with every lane owned by the caller and the device idle
 void lanes_quiesce(mkzg_ctx* c);
 void lanes_resume(mkzg_ctx* c);
+// A side stream for a call whose main stream is `main` (the lane's own, or the caller's in the device-pointer entry points) that can
+// never share a hardware queue with it: HIP keeps one pool of in-order hardware queues per stream PRIORITY and binds a stream to a queue
+// of its pool when it is created.  With the caller's stream and the lane's side stream in the same pool it was a matter of luck whether the
+// side stream's kernels ran beside the main stream's 2.7 ms hash kernel or queued up behind it (VerifyBlobKZGProofBatch of 1024: 4.35 or
+// 6.05 ms per call, fixed for the life of the process).
+inline hipStream_t lane_side_stream(Lane* L, hipStream_t main) {
+    if (main == L->stream) return L->side;
+    int p = 0, least = 0, greatest = 0;
+    if (hipStreamGetPriority(main, &p) != hipSuccess) { (void)hipGetLastError(); p = 0; }
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    return p == greatest ? L->side : L->stream;          // L->stream has the greatest priority, L->side the middle one
+}
+
 struct LaneGuard {                          // one call = one guard
     mkzg_ctx* c;
     Lane* L;

@@ -25,7 +25,7 @@ def main():
     assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), N, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
     assert ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), N, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
     torch.cuda.synchronize()
-    for i in range(5):
+    for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 5):
         t0 = time.perf_counter()
         rc = ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st)
         print(f"verify {i}: rc={rc} {1e3 * (time.perf_counter() - t0):.3f} ms host_finish {ctx.last_host_finish_us():.0f} us", flush=True)

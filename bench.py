@@ -620,6 +620,35 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
                                           "parallelism": "one call" if world == 1 else f"one global batch sharded x{world}; broadcast(r) + all_gather(512 B records)",
                                           "kernels_ms": {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]},
                                           "note": "host pointers in (16 MiB of cells per 8192 gathered and uploaded inside the call)"}
+    if world == 1:
+        # sustained: six caller threads on the shared context, each also submitting one batch with a wrong proof that must be rejected
+        ctx.profile_enable(False)
+        badp = bytearray(proofs)
+        badp[0:48] = proofs[48:96]
+        badp = bytes(badp)
+        KV, reps = 6, 4
+        errs = []
+
+        def cv_caller(k):
+            try:
+                for _ in range(reps):
+                    assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, proofs, n) == 0
+                assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, badp, n) == 1
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+
+        for trial in range(2):                           # the first trial primes the lanes' workspaces
+            ts = [threading.Thread(target=cv_caller, args=(k,)) for k in range(KV)]
+            t0 = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            dtk = time.perf_counter() - t0
+        assert not errs, errs[0]
+        out["verify_cell_kzg_proof_batch"]["sustained"] = {"callers": KV, "calls": KV * (reps + 1), "cells_per_s": round(KV * (reps + 1) * n / dtk, 1),
+                                                           "ms_per_call_amortised": round(dtk / (KV * (reps + 1)) * 1e3, 3)}
+        ctx.profile_enable(True)
     # recovery: every blob of this rank from its 64 even-indexed cells, one batch call (sharded by blob, no collective)
     ids = list(range(0, 128, 2))
     cell_list = [cells[i * 2048:(i + 1) * 2048] for i in range(n)]

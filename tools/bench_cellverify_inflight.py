@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""VerifyCellKZGProofBatch over 64 x 128 = 8192 cells (host pointers, arguments marshalled once as a cgo caller holds them): sustained
+cells/s against the number of caller threads on one shared context."""
+import ctypes
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import rand_blob, load_product  # noqa: E402
+
+
+def main():
+    import torch
+    torch.cuda.init()
+    kzg = load_product()
+    ctx = kzg.Context(device=0)
+    NB = 64
+    blobs = [rand_blob(s) for s in range(NB)]
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cells = torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.zeros(NB * 128 * 48, dtype=torch.uint8, device="cuda")
+    d_cm = torch.zeros(NB * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(NB, dtype=torch.int32, device="cuda")
+    assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), 0) == 0
+    assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), NB, d_cm.data_ptr(), d_st.data_ptr(), 0) == 0
+    torch.cuda.synchronize()
+    cms, cells, proofs = d_cm.cpu().numpy().tobytes(), d_cells.cpu().numpy().tobytes(), d_proofs.cpu().numpy().tobytes()
+    n = NB * 128
+    keep = [ctypes.create_string_buffer(cells[i * 2048:(i + 1) * 2048], 2048) for i in range(n)]
+    arr = (ctypes.c_char_p * n)(*[ctypes.cast(k, ctypes.c_char_p) for k in keep])
+    idx = (ctypes.c_uint64 * n)(*[i % 128 for i in range(n)])
+    cj = b"".join(cms[48 * (i // 128):48 * (i // 128) + 48] for i in range(n))
+    bad = bytearray(proofs)
+    bad[0:48] = proofs[48:96]
+    bad = bytes(bad)
+    L = kzg.lib()
+    for K in (1, 2, 3, 4, 6, 8):
+        reps = 5
+        errs = []
+
+        def caller(k):
+            try:
+                for _ in range(reps):
+                    assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, proofs, n) == 0
+                assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, bad, n) == 1
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+
+        for trial in range(2):
+            ts = [threading.Thread(target=caller, args=(k,)) for k in range(K)]
+            t0 = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            dt = time.perf_counter() - t0
+        assert not errs, errs[0]
+        print(f"{K} callers: {K * (reps + 1) * n / dt / 1e6:.2f} M cells/s, {1e3 * dt / (K * (reps + 1)):.3f} ms per call amortised", flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

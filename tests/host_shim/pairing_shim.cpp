@@ -103,4 +103,47 @@ int shim_g1_mul(const uint8_t* p48, const uint64_t* k, uint8_t* out_xy96) {
     for (int i = 0; i < 6; i++) for (int j = 0; j < 8; j++) out_xy96[48 + (5 - i) * 8 + j] = (uint8_t)(v[i] >> (56 - 8 * j));
     return 0;
 }
+
+// the ADX form of HostFp::mul against the portable loop on n pseudo-random canonical pairs plus the edge values; returns the number of
+// mismatches, -1 if this CPU has no BMI2 + ADX (nothing to compare)
+int shim_hostfp_mul_adx_check(int n, uint64_t seed) {
+#if defined(__x86_64__) && !defined(MKZG_NO_ADX)
+    if (!HostFp::have_adx()) return -1;
+    auto next = [&]() { seed ^= seed << 13; seed ^= seed >> 7; seed ^= seed << 17; return seed; };
+    std::vector<HostFp::El> v;
+    HostFp::El e;
+    HostFp::set_zero(e); v.push_back(e);
+    e.l[0] = 1; v.push_back(e);
+    HostFp::set_one(e); v.push_back(e);
+    for (int k = 1; k <= 3; k++) {                       // p - k
+        memcpy(e.l, HostFpParams::MOD, 48);
+        e.l[0] -= (uint64_t)k;
+        v.push_back(e);
+    }
+    for (int i = 0; i < 6; i++) e.l[i] = ~0ull;          // (2^384 - 1) mod p: at most nine subtractions
+    while (HostFp::geq_mod(e.l)) HostFp::sub_raw(e.l, e.l, HostFpParams::MOD);
+    v.push_back(e);
+    for (int i = 0; i < n; i++) {
+        for (int q = 0; q < 6; q++) e.l[q] = next();
+        e.l[5] &= 0x0fffffffffffffffull;                  // < 2^380 < p
+        v.push_back(e);
+    }
+    int bad = 0;
+    for (size_t i = 0; i < v.size(); i++)
+        for (size_t j = 0; j < (i < 8 ? v.size() : (size_t)16); j++) {
+            HostFp::El x, y;
+            HostFp::mul_adx(x, v[i], v[j]);
+            HostFp::mul_portable(y, v[i], v[j]);
+            if (!HostFp::limbs_equal(x, y) || HostFp::geq_mod(x.l)) bad++;
+            HostFp::mul_adx(x, v[i], v[i]);              // in-place aliasing as sqr() uses it
+            HostFp::El z = v[i];
+            HostFp::mul_adx(z, z, z);
+            if (!HostFp::limbs_equal(x, z)) bad++;
+        }
+    return bad;
+#else
+    (void)n; (void)seed;
+    return -1;
+#endif
+}
 }

@@ -97,3 +97,13 @@ def test_g1_mul_matches_oracle(shim, setup):
 def test_host_pool(shim):
     """the persistent host threads the verifiers' host steps run on (host_pool.hpp)"""
     assert shim.shim_pool_selftest() == 0
+
+
+def test_hostfp_mul_adx_matches_portable(shim):
+    """HostFp::mul has an x86-64 form with mulx / adcx / adox (host_field.hpp) beside the portable loop: both must give the same canonical
+    limbs on random operands and on the edge values 0, 1, R mod p, p - 1, p - 2, p - 3, 2^384 - 1 mod p, also when the output aliases
+    an input"""
+    bad = shim.shim_hostfp_mul_adx_check(4000, 0x9e3779b97f4a7c15)
+    if bad < 0:
+        pytest.skip("this CPU has no BMI2 + ADX")
+    assert bad == 0

@@ -349,12 +349,16 @@ static int verify_device_all(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const
 // threads hash each transcript right after copying it (the blob is then still in their cache) and the device skips its own hash.
 // A nil blob stands in as the zero blob and is reported with the reference's precedence afterwards.
 // ---------------------------------------------------------------------------------------------
-// auto: the device hash is a latency chain of 2050 compressions per blob -- 2.7 ms whether the call brings 1 blob or 1024 -- while a host
-// core with SHA-NI hashes a blob in ~70 us: up to 8 blobs per pool thread the host is the shorter path (a single VerifyBlobKZGProof or
-// ComputeBlobKZGProof saves 2.6 ms); from there on the device hash of the resident batch beats the 16-CPU box.
+// auto: the device hash is a latency chain of 2050 compressions per blob -- 2.7 ms whether the call brings 1 blob or 1024, and only after
+// the upload -- while a host core with SHA-NI hashes a blob in ~70 us right after gathering it, beside the upload.  Measured on the
+// 16-CPU box (tools/bench_verify_host.py, ms per call device / host hash): one caller 128 blobs 4.6 / 3.4, 256: 5.0 / 4.3, 512: 7.0 / 5.5,
+// 768: 7.4 / 6.9, 1024: 7.6 / 9.8; four callers prefer the host up to ~256 blobs (179 k against 117 k blobs/s) and the device above
+// (221 k against 176 k at 512).  So: blobs per pool thread -- 48 for a lone call, 20 with a few others in flight, 8 beyond that.
 static bool use_host_sha(const mkzg_ctx* c, size_t m) {
     if (c->opt_host_sha >= 0) return c->opt_host_sha != 0;
-    return m <= 8 * (size_t)std::max(1, c->pool->size());
+    const int busy = c->lanes_busy.load(std::memory_order_relaxed);
+    const size_t per_thread = busy <= 1 ? 48 : (busy <= 4 ? 20 : 8);
+    return m <= per_thread * (size_t)std::max(1, c->pool->size());
 }
 static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t m, uint32_t exp_offset,
                            const uint8_t* r_le32, VerifyFold* out, int* rc_nil /* out: MKZG_ERR_NIL_INPUT precedence result, or 0 */) {

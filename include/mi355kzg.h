@@ -84,8 +84,9 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
  *   "host_sha"            host-pointer verifiers: Fiat-Shamir challenges hashed by the host pool while the blobs upload (1),
- *                         on the device after the upload (0), library's choice (-1, default: the host for calls of up to 8 blobs per pool
- *                         thread -- a 70 us hash per blob instead of the device's 2.7 ms chain -- and the device above that);
+ *                         on the device after the upload (0), library's choice (-1, default: the host for calls of up to 48 blobs per pool
+ *                         thread -- a 70 us hash per blob beside the upload instead of the device's 2.7 ms chain after it -- fewer when
+ *                         other calls are in flight, the device above that);
  *                         ComputeBlobKZGProof follows the same switch
  *   "verify_shape"        VerifyBlobKZGProofBatch: 0 = latency shape (inverse NTT of the blobs beside the challenge hash, then a short
  *                         Horner pass; a quad of lanes per point in the subgroup tests), 1 = throughput shape (barycentric evaluation

@@ -32,7 +32,8 @@ def main():
     arr = (ctypes.c_char_p * N)(*[ctypes.cast(k, ctypes.c_char_p) for k in keep])
     cms = b"".join(cm[48 * (i % 32):48 * (i % 32) + 48] for i in range(N))
     prs = b"".join(pr[48 * (i % 32):48 * (i % 32) + 48] for i in range(N))
-    bad = prs[:48 * 700] + prs[48 * 701:48 * 702] + prs[48 * 701:]
+    v = min(700, N - 2)
+    bad = prs[:48 * v] + prs[48 * (v + 1):48 * (v + 2)] + prs[48 * (v + 1):]
     L = kzg.lib()
     out = {}
 

@@ -7,7 +7,8 @@
 // fixed-base scalar multiplication, and the 2-pairing product check with prepared G2 lines
 // (reference internal/kzg/kzg_verify.go:160-199).
 // Every call works in one Lane (ctx.h): calls on a shared context overlap on the GPU, and the host finish of one call runs while
-// the next call's challenge hash does (reference verify.go:152-169 gets that from goroutines).
+// the next call's challenge hash does (reference verify.go:152-169 gets that from goroutines).  A call that finds others in flight takes
+// the throughput shape and shares hash launches with them (hash_round_join below).
 #include <sys/random.h>
 #include <chrono>
 #include <functional>

@@ -5,14 +5,15 @@
 //   k_challenge_sha256   compute_challenge (fiatshamir.go:22-33): SHA-256 of the 131,152-byte transcript of every blob
 //                        (inherently serial per blob; blobs are the parallel axis), digest reduced mod r.  Two
 //                        producer wavefronts (message schedule) + two consumer wavefronts (rounds, a PAIR of
-//                        lanes per blob) per 64 blobs.
+//                        lanes per blob) per 64 blobs; k_challenge_sha256_jobs: the same for the blobs of several calls at once.
 //   k_blob_eval          DeserializeBlob + EvaluateLagrangePolynomial (serialization.go:134-146,
 //                        internal/domain/domain.go:193-235): one workgroup per blob, barycentric
 //                        formula over the bit-reversed 4096-domain, batch inversion per lane.
 //   k_blob_quotient      computeQuotientPoly (kzg_prove.go:53-180), both the off-domain and the
 //                        on-domain branch; output feeds the fixed-base MSM of msm_kernels.hip.
 //   k_g1_validate        gnark's SetBytes for the verifiers' points (serialization.go:108-115): decoding
-//                        (g1_decode.hpp) and the r-torsion test as phi(P) == -[x^2]P (Scott 2021), one lane per point.
+//                        (g1_decode.hpp) and the r-torsion test as phi(P) == -[x^2]P (Scott 2021) without the y coordinate, a QUAD of
+//                        lanes per point (g1_quad.hpp) or one lane per point for calls that share the chip.
 //   k_rlc_scalars        utils.ComputePowers + the scalar folds of kzg_verify.go:141-179.
 //   k_vmsm_window        variable-base Pippenger, one workgroup per (MSM, 8-bit window): LDS
 //                        counting sort of Booth digits, one lane per bucket, wavefront-level

@@ -189,11 +189,16 @@ __device__ __noinline__ void f_mul_wnaf(G1X& r, const G1X& p, const uint32_t* __
     G1D::jac_to_xyzz(r, acc);
 }
 
-// The same product on a QUAD of lanes (g1_quad.hpp) for calls of a few blobs, where the wavefronts of the 686 products have lanes to
-// spare and the caller waits for the length of this chain: doublings 3 multiplications deep instead of 7, additions 5 instead of 13
-// (k_fk20_toom_mul 1.76 -> ~0.9 ms for one blob).  All four lanes hold the same point, table and accumulator.
-__device__ __noinline__ void f_mul_wnaf_quad(G1X& r, const G1X& p, const uint32_t* __restrict__ row, int lane) {
+// The same product on a QUAD or a PAIR of lanes (g1_quad.hpp) for calls of a few blobs, where the wavefronts of the 686 products have
+// lanes to spare and the caller waits for the length of this chain: doublings 3 (4) multiplications deep instead of 7, additions 5 (7)
+// instead of 13 (k_fk20_toom_mul 1.76 -> 0.99 ms up to 16 blobs, -> ~1.1 ms up to 32).  All lanes of a group hold the same point, table
+// and accumulator.
+template <int G>     // lanes per point: 4 (quad) or 2 (pair)
+__device__ __noinline__ void f_mul_wnaf_group(G1X& r, const G1X& p, const uint32_t* __restrict__ row, int lane) {
     const QuadRole qr(lane);
+    const bool isB = (lane & 1) != 0;
+#define gdbl(x) do { if constexpr (G == 4) jdbl_quad(x, qr); else jdbl_pair(x, isB); } while (0)
+#define gadd(x, y) do { if constexpr (G == 4) jadd_quad(x, y, qr); else jadd_pair(x, y, isB); } while (0)
     G1JC tbl[8];                                  // (2j + 1) p
     {
         G1J run, two;
@@ -202,12 +207,12 @@ __device__ __noinline__ void f_mul_wnaf_quad(G1X& r, const G1X& p, const uint32_
         G1D::jac_cache(pc, run);
         tbl[0] = pc;
         two = run;
-        jdbl_quad(two, qr);
+        gdbl(two);
         G1D::jac_cache(twoc, two);
 #pragma unroll 1
         for (int j = 1; j < 8; j++) {
             G1JC c;
-            jadd_quad(run, twoc, qr);
+            gadd(run, twoc);
             G1D::jac_cache(c, run);
             tbl[j] = c;
         }
@@ -219,7 +224,7 @@ __device__ __noinline__ void f_mul_wnaf_quad(G1X& r, const G1X& p, const uint32_
     bool started = false;
 #pragma unroll 1
     for (int i = 130; i >= 0; i--) {
-        if (started) jdbl_quad(acc, qr);
+        if (started) gdbl(acc);
         const uint32_t code = (row[i >> 1] >> (16 * (i & 1))) & 0xffffu;
         if (code == 0) continue;
 #pragma unroll 1
@@ -229,12 +234,14 @@ __device__ __noinline__ void f_mul_wnaf_quad(G1X& r, const G1X& p, const uint32_
                 G1JC q = tbl[((d < 0 ? -d : d) - 1) >> 1];
                 if (half) Fp::mul(q.x, q.x, beta);
                 if ((d < 0) != (half != 0)) Fp::template neg<3>(q.y, q.y);   // 8p - Y (Y < 5.01p)
-                jadd_quad(acc, q, qr);
+                gadd(acc, q);
                 started = true;
             }
         }
     }
     G1D::jac_to_xyzz(r, acc);
+#undef gdbl
+#undef gadd
 }
 
 // ------------------------------------------------------------------------------------------
@@ -341,7 +348,8 @@ __global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restr
 // k_fk20_msm: R[b][k] = sum_i V[b][k][i] * T[k][i] through the direct table of C-bit windows (NWIN = ceil(256 / C) signed Booth
 // digits per scalar).  An MSM-64 is shared by LW x LP lanes: lane (wg, pg) adds the rows of windows WPL wg .. WPL wg + WPL - 1 for the
 // points 64/LP pg .. 64/LP (pg + 1) - 1, so every lane of every configuration walks the same number of additions:
-//   C = 11: <8, 1, 3> batches (8 MSMs per wavefront, 192 additions per lane; one wavefront per SIMD at 64 blobs), <24, 1, 1> few blobs
+//   C = 11: <8, 1, 3> batches (8 MSMs per wavefront, 192 additions per lane; one wavefront per SIMD at 64 blobs), <12, 1, 2> up to 39
+//           blobs (5 MSMs per wavefront, 128 additions per lane), <24, 1, 1> up to 16 (2 per wavefront, 64 additions)
 //   C = 13: <4, 2, 5> batches (160 additions per lane), <10, 2, 2> few blobs (64 additions per lane)
 // k_fk20_msm_reduce adds the lanes of an MSM.
 // ------------------------------------------------------------------------------------------
@@ -570,17 +578,17 @@ __global__ void __launch_bounds__(64) k_fk20_post(const uint32_t* __restrict__ i
     }
 }
 // the 686 products: one WAVEFRONT per fixed scalar (blockIdx.x), one lane per blob -- uniform control flow through the digit string
-// QUAD (calls of up to FK_QUAD_MAX_BATCH blobs): four lanes per blob, see f_mul_wnaf_quad
-template <bool QUAD>
+// G lanes per blob: 4 for calls of up to FK_QUAD_MAX_BATCH blobs, 2 up to FK_PAIR_MAX_BATCH, else 1 -- see f_mul_wnaf_group
+template <int G>
 __global__ void __launch_bounds__(64) k_fk20_toom_mul(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const int* __restrict__ status, int n) {
-    const int glane = (blockIdx.y * 64 + threadIdx.x) >> (QUAD ? 2 : 0);
-    const bool live = glane < n && (!QUAD || (threadIdx.x & 3) == 0);
+    const int glane = (blockIdx.y * 64 + threadIdx.x) / G;
+    const bool live = glane < n && (threadIdx.x & (G - 1)) == 0;
     const int b = glane < n ? glane : glane % n;       // FULL_WAVES: surplus lanes repeat a blob and store nothing
     if (status[b] != 0) return;
     const size_t row = ((size_t)blockIdx.x * n + b) * 64;
     G1X p;
     f_load_xyzz(p, in + row);
-    if (QUAD) f_mul_wnaf_quad(p, p, FK20_TOOM_WNAF[blockIdx.x], threadIdx.x);
+    if (G > 1) f_mul_wnaf_group<G>(p, p, FK20_TOOM_WNAF[blockIdx.x], threadIdx.x);
     else f_mul_wnaf(p, p, FK20_TOOM_WNAF[blockIdx.x]);
     if (live) f_store_xyzz(out + row, p);
 }
@@ -617,12 +625,15 @@ static void launch_fk_msm(const uint32_t* d_scalars, const uint32_t* d_table, in
 }
 void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int cbits, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s) {
     if (n <= 0) return;
-    const bool few = n <= FK_DIRECT_MAX_BATCH;      // latency over occupancy: one or two windows per lane
+    // latency over occupancy: the more lanes an MSM gets the shorter each lane's chain, as long as every wavefront still finds a SIMD
+    // of its own (a block carries 6-48 blobs: 24 lanes x 64 additions up to 16 blobs, 12 x 128 up to 39, 8 x 192 from there on)
+    const bool few = n <= FK_DIRECT_MAX_BATCH;
     if (cbits == 13) {
         if (few) launch_fk_msm<13, 10, 2, 2, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
         else launch_fk_msm<13, 4, 2, 5, 8>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
     } else {
         if (few) launch_fk_msm<11, 24, 1, 1, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+        else if (n <= FK_MID_MAX_BATCH) launch_fk_msm<11, 12, 1, 2, 16>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
         else launch_fk_msm<11, 8, 1, 3, 8>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
     }
 }
@@ -636,10 +647,11 @@ void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_
     hipLaunchKernelGGL((k_fk20_pre<true>), grid(1, 16, 7), dim3(64), 0, s, d_results, bufA, d_status, n, 1, 16);
     hipLaunchKernelGGL((k_fk20_pre<false>), grid(7, 4, 7), dim3(64), 0, s, bufA, bufB, d_status, n, 7, 4);
     hipLaunchKernelGGL((k_fk20_pre<false>), grid(49, 1, 7), dim3(64), 0, s, bufB, bufA, d_status, n, 49, 1);
-    // up to 16 blobs the 686 wavefronts have room for a quad of lanes per blob (one wavefront per product either way); above that
-    // the extra wavefronts would share SIMDs and the shorter chains buy nothing
-    if (n <= FK_QUAD_MAX_BATCH) hipLaunchKernelGGL((k_fk20_toom_mul<true>), dim3(686, (4 * n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
-    else hipLaunchKernelGGL((k_fk20_toom_mul<false>), dim3(686, (n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
+    // up to 16 blobs the 686 wavefronts have room for a quad of lanes per blob, up to 32 for a pair (one wavefront per product either
+    // way); above that the extra wavefronts would share SIMDs and the shorter chains buy nothing
+    if (n <= FK_QUAD_MAX_BATCH) hipLaunchKernelGGL((k_fk20_toom_mul<4>), dim3(686, (4 * n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
+    else if (n <= FK_PAIR_MAX_BATCH) hipLaunchKernelGGL((k_fk20_toom_mul<2>), dim3(686, (2 * n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
+    else hipLaunchKernelGGL((k_fk20_toom_mul<1>), dim3(686, (n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
     hipLaunchKernelGGL((k_fk20_post<false>), grid(49, 1, 4), dim3(64), 0, s, bufB, bufA, nullptr, d_status, n, 49, 1);
     hipLaunchKernelGGL((k_fk20_post<false>), grid(7, 4, 4), dim3(64), 0, s, bufA, bufB, nullptr, d_status, n, 7, 4);
     hipLaunchKernelGGL((k_fk20_post<true>), grid(1, 16, 4), dim3(64), 0, s, bufB, d_tmp, d_results, d_status, n, 1, 16);

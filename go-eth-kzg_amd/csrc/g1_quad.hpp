@@ -7,7 +7,7 @@
 // hold the same coordinates, every level each lane forms ONE product -- operands picked by its role with v_cndmask -- and the
 // results travel with quad_perm DPP moves (full rate, no LDS).  Same values as G1D::jdbl / G1D::jadd (up to the bound of Y3 in
 // the addition, noted there); the exceptional cases are decided on replicated values, so a quad never diverges.
-// Requires all four lanes of a quad to be active together (the kernels run FULL_WAVES).
+// Requires all four lanes of a quad to be active together (the kernels run FULL_WAVES).  A pair-of-lanes form follows the quad one.
 #pragma once
 #include "g1.hpp"
 
@@ -124,6 +124,116 @@ __device__ __forceinline__ void jadd_quad(G1J& a, const G1JC& b_, const QuadRole
         quad_bcast<1>(S2, M5);
         Fp::add(res.y, t, S2);
         quad_bcast<3>(res.z, M3);
+        res.x = X3;
+    }
+    G1D::select(res, b_inf, a, res);
+    G1D::select(res, a_inf, bj, res);
+    a = res;
+}
+
+// ---- the same law on a PAIR of lanes (lanes 2i and 2i + 1): for calls with too many points for a quad each but room for two lanes --
+// 17 to 32 blobs in the 686 products of the FK20 network.  The seven products of a doubling go in four rounds
+//   {X^2 | Y^2}, {2Y Z | (2Y^2)^2}, {(3X^2)^2 | (X + 2Y^2)^2}, {3X^2 (D - X3)}
+// and the thirteen of an addition in seven
+//   {Z1^2 | X1 Z2^2}, {Y1 Z2^3 | Z1 Z2}, {Z1^3 | X2 Z1^2}, {Y2 Z1^3 | H^2}, {H^3 | Z1 Z2 H}, {U1 H^2 | R^2}, {R (U1 H^2 - X3) | -S1 H^3}
+// (lane A | lane B): ~2,200 and ~4,100 instructions against ~3,100 and ~6,400 on one lane.  Same values as jdbl_quad / jadd_quad.
+template <bool FROM_B>
+__device__ __forceinline__ void pair_bcast(fp_t& r, const fp_t& a) {
+#pragma unroll
+    for (int q = 0; q < 14; q++) r.l[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)a.l[q], (int)a.l[q], FROM_B ? 0xF5 : 0xA0, 0xf, 0xf, false);   // quad_perm [1,1,3,3] / [0,0,2,2]
+}
+__device__ __forceinline__ void jdbl_pair(G1J& p, const bool isB) {
+    G1D::opaque(p);
+    fp_t a, b, M1, M2, M3, U, B2, T, E, A, EE, C4, TT, D, X3, Y3, t;
+    Fp::select(a, isB, p.y, p.x);
+    Fp::sqr(M1, a);                           // A: X^2           B: Y^2
+    pair_bcast<true>(t, M1);
+    Fp::dbl(B2, t);                           // 2 Y^2            (< 2.01p)
+    Fp::dbl(U, p.y);
+    Fp::select(a, isB, B2, U);
+    Fp::select(b, isB, B2, p.z);
+    Fp::mul(M2, a, b);                        // A: 2Y Z          B: 4 Y^4
+    Fp::add(T, p.x, B2);                      //                   (< 19.1p)
+    Fp::triple(E, M1);                        // A: 3 X^2
+    Fp::select(a, isB, T, E);
+    Fp::sqr(M3, a);                           // A: E^2           B: (X + 2Y^2)^2
+    pair_bcast<false>(A, M1);
+    pair_bcast<false>(EE, M3);
+    pair_bcast<true>(C4, M2);
+    pair_bcast<true>(TT, M3);
+    pair_bcast<false>(p.z, M2);
+    Fp::template sub_b_c<2>(D, TT, A, C4);    // D = 4 X Y^2 + 4p  (< 5.01p)
+    Fp::triple(E, A);
+    Fp::template sub_2c<4>(X3, EE, D);        // E^2 - 2D + 16p    (< 17.01p)
+    Fp::template sub<5>(t, D, X3);            // D - X3 + 32p      (< 37.1p)
+    Fp::mul(Y3, E, t);
+    Fp::template sub_2c<2>(p.y, Y3, C4);      // E (D - X3) - 8 Y^4 + 4p   (< 5.01p)
+    p.x = X3;
+}
+__device__ __forceinline__ void jadd_pair(G1J& a, const G1JC& b_, const bool isB) {
+    G1JC b = b_;
+    G1D::opaque(a);
+    Fp::opaque(b.x);
+    Fp::opaque(b.y);
+    Fp::opaque(b.z);
+    Fp::opaque(b.zz);
+    Fp::opaque(b.zzz);
+    const bool a_inf = G1D::is_inf(a), b_inf = Fp::limbs_all_zero(b.z);
+    fp_t oa, ob, M1, M2, M3, M4, M5, M6, M7, Z1Z1, U1, U2, S1, S2, H, Rd, HH, HHH, Q, RR, t, X3;
+    G1J res, bj;
+    bj.x = b.x;
+    bj.y = b.y;
+    bj.z = b.z;
+    Fp::select(oa, isB, a.x, a.z);
+    Fp::select(ob, isB, b.zz, a.z);
+    Fp::mul(M1, oa, ob);                      // A: Z1^2          B: U1 = X1 Z2^2
+    Fp::select(oa, isB, a.z, a.y);
+    Fp::select(ob, isB, b.z, b.zzz);
+    Fp::mul(M2, oa, ob);                      // A: S1 = Y1 Z2^3  B: Z1 Z2
+    pair_bcast<false>(Z1Z1, M1);
+    Fp::select(oa, isB, b.x, a.z);
+    Fp::mul(M3, oa, Z1Z1);                    // A: Z1^3          B: U2 = X2 Z1^2
+    pair_bcast<true>(U2, M3);
+    pair_bcast<true>(U1, M1);
+    Fp::template sub<1>(H, U2, U1);
+    Fp::select(oa, isB, H, b.y);
+    Fp::select(ob, isB, H, M3);
+    Fp::mul(M4, oa, ob);                      // A: S2 = Y2 Z1^3  B: H^2
+    pair_bcast<false>(S2, M4);
+    pair_bcast<false>(S1, M2);
+    Fp::template sub<1>(Rd, S2, S1);
+    if (!a_inf && !b_inf && Fp::template is_zero_mod<16>(H)) {
+        if (Fp::template is_zero_mod<16>(Rd)) {
+            res = a;
+            jdbl_pair(res, isB);
+        } else {
+            G1D::set_inf(res);
+        }
+    } else {
+        Fp::opaque(H);
+        Fp::opaque(Rd);
+        Fp::opaque(U1);
+        Fp::opaque(S1);
+        pair_bcast<true>(HH, M4);
+        Fp::select(oa, isB, M2, H);
+        Fp::select(ob, isB, H, HH);
+        Fp::mul(M5, oa, ob);                  // A: H^3           B: Z1 Z2 H
+        Fp::select(oa, isB, Rd, U1);
+        Fp::select(ob, isB, Rd, HH);
+        Fp::mul(M6, oa, ob);                  // A: Q = U1 H^2    B: R^2
+        pair_bcast<false>(HHH, M5);
+        pair_bcast<false>(Q, M6);
+        pair_bcast<true>(RR, M6);
+        Fp::template sub_b_2c<2>(X3, RR, HHH, Q);   // R^2 - H^3 - 2 U1 H^2 + 4p   (< 5.01p)
+        Fp::template sub<3>(t, Q, X3);
+        Fp::template neg<1>(S1, S1);
+        Fp::select(oa, isB, S1, Rd);
+        Fp::select(ob, isB, HHH, t);
+        Fp::mul(M7, oa, ob);                  // A: R (U1 H^2 - X3)   B: -S1 H^3
+        pair_bcast<false>(t, M7);
+        pair_bcast<true>(S2, M7);
+        Fp::add(res.y, t, S2);
+        pair_bcast<true>(res.z, M5);
         res.x = X3;
     }
     G1D::select(res, b_inf, a, res);

@@ -40,11 +40,11 @@ def test_ragged_proof_batches_match_single_calls(gpu_ctx, n):
     assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_bad.data_ptr(), n, st) != 0
 
 
-@pytest.mark.parametrize("n", [9, 16, 17, 40, 65, 100])
+@pytest.mark.parametrize("n", [9, 16, 17, 32, 33, 40, 65, 100])
 def test_ragged_cell_proof_batches_match_single_calls(gpu_ctx, n):
     """ComputeCellsAndKZGProofs for n blobs in one call (the 686 fixed-scalar products of the transform network with one LANE per
-    blob above 16 blobs -- partially filled wavefronts, more than one wavefront of blobs -- and a QUAD of lanes per blob up to 16,
-    the MSM with 8 or 24 lanes per sum) against the per-blob entry point -- different code paths for fk20.go:76-124 that must
+    blob above 32 blobs -- partially filled wavefronts, more than one wavefront of blobs --, a PAIR of lanes per blob up to 32 and a QUAD
+    up to 16; the MSM with 8, 12 or 24 lanes per sum) against the per-blob entry point -- different code paths for fk20.go:76-124 that must
     agree byte for byte; one blob of the batch is invalid."""
     import torch
     ctx = gpu_ctx

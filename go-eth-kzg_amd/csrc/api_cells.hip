@@ -130,7 +130,7 @@ int ensure_fk20_ws(Lane* L, size_t n) {
     L->fk_cap = 0;
     rc = dev_realloc(L->d_fk_scalars, n * 128 * 64 * 32);
     if (!rc) rc = dev_realloc(L->d_fk_results, 2 * n * 128 * 256);
-    if (!rc) rc = dev_realloc(L->d_fk_parts, n * fk20_parts_rows() * 256);
+    if (!rc) rc = dev_realloc(L->d_fk_parts, std::max<size_t>(n, 2 * FK_SPLIT_MAX_BATCH) * fk20_parts_rows() * 256);   // calls of up to FK_SPLIT_MAX_BATCH blobs use twice the rows per blob
     if (!rc) rc = dev_realloc(L->d_fk_proofs, n * 128 * 48);
     if (rc) return rc;
     L->fk_cap = n;

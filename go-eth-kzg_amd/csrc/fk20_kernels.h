@@ -12,6 +12,7 @@ int fk20_nwin(int cbits);
 size_t fk20_table_bytes(int cbits);
 // monomial SRS (4096 affine rows) -> T (8192 affine rows, [k][i]) -> direct table (fk20_table_bytes(cbits))
 void fk20_setup_device(const uint32_t* d_monomial_aff, const uint32_t* d_g1tw_fwd, uint32_t* d_t_aff, uint32_t* d_table, int cbits, hipStream_t s);
+constexpr int FK_SPLIT_MAX_BATCH = 8;    // up to this many blobs 48 lanes per MSM (24 windows x 2 halves of the 64 points): 128 x 48 partial sums per blob
 constexpr int FK_DIRECT_MAX_BATCH = 16;  // up to this many blobs per call the MSM runs one window per lane (latency over occupancy)
 constexpr int FK_MID_MAX_BATCH = 39;     // ... and up to this many two windows per lane (26 wavefronts per blob: 1014 at 39 blobs)
 constexpr int FK_PAIR_MAX_BATCH = 32;    // ... and up to this many on a pair of lanes each

@@ -349,7 +349,8 @@ __global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restr
 // digits per scalar).  An MSM-64 is shared by LW x LP lanes: lane (wg, pg) adds the rows of windows WPL wg .. WPL wg + WPL - 1 for the
 // points 64/LP pg .. 64/LP (pg + 1) - 1, so every lane of every configuration walks the same number of additions:
 //   C = 11: <8, 1, 3> batches (8 MSMs per wavefront, 192 additions per lane; one wavefront per SIMD at 64 blobs), <12, 1, 2> up to 39
-//           blobs (5 MSMs per wavefront, 128 additions per lane), <24, 1, 1> up to 16 (2 per wavefront, 64 additions)
+//           blobs (5 MSMs per wavefront, 128 additions per lane), <24, 1, 1> up to 16 (2 per wavefront, 64 additions), <24, 2, 1> up to
+//           8 (one MSM per wavefront, 32 additions)
 //   C = 13: <4, 2, 5> batches (160 additions per lane), <10, 2, 2> few blobs (64 additions per lane)
 // k_fk20_msm_reduce adds the lanes of an MSM.
 // ------------------------------------------------------------------------------------------
@@ -626,13 +627,15 @@ static void launch_fk_msm(const uint32_t* d_scalars, const uint32_t* d_table, in
 void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int cbits, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s) {
     if (n <= 0) return;
     // latency over occupancy: the more lanes an MSM gets the shorter each lane's chain, as long as every wavefront still finds a SIMD
-    // of its own (a block carries 6-48 blobs: 24 lanes x 64 additions up to 16 blobs, 12 x 128 up to 39, 8 x 192 from there on)
+    // of its own (a block carries 6-48 blobs: 48 lanes x 32 additions up to 8 blobs -- the points of a sum split in two halves as well
+    // as its windows --, 24 x 64 up to 16, 12 x 128 up to 39, 8 x 192 from there on)
     const bool few = n <= FK_DIRECT_MAX_BATCH;
     if (cbits == 13) {
         if (few) launch_fk_msm<13, 10, 2, 2, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
         else launch_fk_msm<13, 4, 2, 5, 8>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
     } else {
-        if (few) launch_fk_msm<11, 24, 1, 1, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+        if (n <= FK_SPLIT_MAX_BATCH) launch_fk_msm<11, 24, 2, 1, 64>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+        else if (few) launch_fk_msm<11, 24, 1, 1, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
         else if (n <= FK_MID_MAX_BATCH) launch_fk_msm<11, 12, 1, 2, 16>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
         else launch_fk_msm<11, 8, 1, 3, 8>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
     }

@@ -491,7 +491,8 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
             except Exception as e:      # noqa: BLE001
                 errs.append(repr(e))
 
-        for trial in range(2):                           # the first trial primes every lane's workspaces
+        dtk = None
+        for trial in range(3):                           # the first trial primes every lane's workspaces; the better of the other two counts
             ts = [threading.Thread(target=caller, args=(k,)) for k in range(K)]
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -499,11 +500,12 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
                 t.start()
             for t in ts:
                 t.join()
-            dtk = time.perf_counter() - t0
+            if trial:
+                dtk = min(dtk or 1e9, time.perf_counter() - t0)
         assert not errs, errs[0]
         out["sustained"] = {"callers": K, "calls": K * (reps + 1), "blobs_per_s": round(K * (reps + 1) * N / dtk, 1), "ms_per_call_amortised": round(dtk / (K * (reps + 1)) * 1e3, 3),
                             "shape": "throughput shape: shared hash rounds, barycentric evaluation, one stream per call (option verify_shape -1)",
-                            "note": "verdicts identical to the serial calls (each caller also submits one corrupted batch, which must be rejected)"}
+                            "note": "verdicts identical to the serial calls (each caller also submits one corrupted batch, which must be rejected); one priming trial, then the better of two timed trials"}
     out["value"] = out.get("sustained", {}).get("blobs_per_s", out["single_call"]["blobs_per_s"])
     return out
 
@@ -539,6 +541,21 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
                                            "kernels_ms": {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3)}
     ctx.profile_enable(False)
     if world == 1:
+        # the sizes a block carries (6 blobs today, up to 48 planned): one synchronous caller, ms per call
+        by_batch = {}
+        for nb in (1, 6, 9, 16, 32, 48):
+            if nb > NB:
+                continue
+            ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), nb, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), nb, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st)
+            torch.cuda.synchronize()
+            by_batch[str(nb)] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        out["compute_cells_and_kzg_proofs"]["ms_per_call_by_blobs"] = by_batch
+        assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st) == 0      # the outputs the later legs compare with
+        torch.cuda.synchronize()
         # sustained: four caller threads on the shared context, one call of NB blobs in flight each -- one call's latency-bound network
         # of 686 scalar multiplications (two thirds of the SIMDs, one wavefront each) runs beside another call's VALU-bound MSM
         KC, reps = 4, 4
@@ -557,7 +574,8 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
             except Exception as e:      # noqa: BLE001
                 errs.append(repr(e))
 
-        for trial in range(2):                           # the first trial primes the lanes' workspaces
+        dtk = None
+        for trial in range(3):                           # the first trial primes the lanes' workspaces; the better of the other two counts
             ts = [threading.Thread(target=cells_caller, args=(k,)) for k in range(KC)]
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -565,7 +583,8 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
                 t.start()
             for t in ts:
                 t.join()
-            dtk = time.perf_counter() - t0
+            if trial:
+                dtk = min(dtk or 1e9, time.perf_counter() - t0)
         assert not errs, errs[0]
         assert all(int(b[2].abs().sum().item()) == 0 and bool((b[1] == d_proofs).all().item()) for b in bufs), "concurrent calls disagree with the serial one"
         out["compute_cells_and_kzg_proofs"]["sustained"] = {"callers": KC, "calls": KC * reps, "blobs_per_s": round(KC * reps * NB / dtk, 1), "ms_per_call_amortised": round(dtk / (KC * reps) * 1e3, 3)}
@@ -637,14 +656,16 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
             except Exception as e:      # noqa: BLE001
                 errs.append(repr(e))
 
-        for trial in range(2):                           # the first trial primes the lanes' workspaces
+        dtk = None
+        for trial in range(3):                           # the first trial primes the lanes' workspaces; the better of the other two counts
             ts = [threading.Thread(target=cv_caller, args=(k,)) for k in range(KV)]
             t0 = time.perf_counter()
             for t in ts:
                 t.start()
             for t in ts:
                 t.join()
-            dtk = time.perf_counter() - t0
+            if trial:
+                dtk = min(dtk or 1e9, time.perf_counter() - t0)
         assert not errs, errs[0]
         out["verify_cell_kzg_proof_batch"]["sustained"] = {"callers": KV, "calls": KV * (reps + 1), "cells_per_s": round(KV * (reps + 1) * n / dtk, 1),
                                                            "ms_per_call_amortised": round(dtk / (KV * (reps + 1)) * 1e3, 3)}

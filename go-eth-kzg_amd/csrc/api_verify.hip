@@ -206,8 +206,13 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions;
         //    the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
         //    (throughput shape: none of that -- the three MSMs go out as ONE launch after the challenge, see below)
-        HIPCHK(hipMemcpyAsync(L->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s2));
-        if (!tp) {
+        //    (challenges hashed on the host: there is no hash to run beside -- the points' chains on the side stream, the NTT and the
+        //    evaluation on the main one, and the three MSMs as one launch after both)
+        const bool host_z = d_z32 != nullptr;
+        HIPCHK(hipMemcpyAsync(L->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, host_z ? s : s2));
+        if (!tp && host_z) {
+            KT(KT_CELLS_NTT, s, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s));
+        } else if (!tp) {
             KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s2));
             KT(KT_RLC, s2, rlc_scalars_device(L->d_v_misc, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
             const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
@@ -236,6 +241,13 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             // throughput shape: every launch is time on the call's hardware queue, which it shares with other calls' streams -- one
             // scalar kernel and ONE launch for the three MSMs of kzg_verify.go:150,225,179 instead of two of each
             KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, s));
+            KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
+            const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
+            const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
+            const int njob[3] = {(int)n, (int)n, (int)n};
+            KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
+        } else if (d_z32) {
+            KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
             KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};

@@ -863,6 +863,60 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
         for (int i = 0; i < 14; i++) { dst[i] = tot.x.l[i]; dst[14 + i] = tot.y.l[i]; dst[28 + i] = tot.zz.l[i]; dst[42 + i] = tot.zzz.l[i]; }
     }
 }
+// Single-pair jobs (VerifyKZGProof, VerifyBlobKZGProof: every job is ONE (scalar, point) pair): the window sum is d_w P, which a lane
+// gets by seven doublings and the additions of d_w's bits -- ~90 multiplications deep where the bucket machinery above spends its 13
+// additions of the suffix / tree network (~190) on 127 empty buckets.  One lane per (job, window); output as k_vmsm_combine's.
+__global__ void __launch_bounds__(64) k_vmsm_single(VmsmJobs jobs, int n_msm, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
+    const int g0 = blockIdx.x * 64 + threadIdx.x, total = n_msm * VNWIN;
+    const bool live = g0 < total;
+    const int g = live ? g0 : g0 % total;                  // FULL_WAVES: surplus lanes shadow another window and store nothing
+    const int m = g / VNWIN, w = g % VNWIN;
+    const uint32_t* s = jobs.j[m].scalars;
+    const int bit = VC * w - 1;
+    uint32_t v;
+    if (bit < 0) {
+        v = (s[0] << 1) & 0x1ffu;
+    } else {
+        const int wi = bit >> 5, off = bit & 31;
+        v = s[wi] >> off;
+        if (off + VC + 1 > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - off);
+        v &= 0x1ffu;
+    }
+    int d = (int)((v + 1) >> 1);                           // Booth digit of window w, as in k_vmsm_window
+    if (v >> VC) d -= (1 << VC);
+    G1Aff p;
+    load_affine_v(p, jobs.j[m].points);
+    G1X tot;
+    g1x_set_inf(tot);
+    const int a = d < 0 ? -d : d;
+    if (a != 0 && !p.inf) {
+        if (d < 0) Fp::template neg<0>(p.y, p.y);
+        bool started = false;
+#pragma unroll 1
+        for (int b = VC; b >= 0; b--) {                    // |d| <= 2^VC
+            if (started) g1x_dbl(tot, tot);
+            if ((a >> b) & 1) {
+                if (started) g1x_madd(tot, p.x, p.y);
+                else g1x_from_affine(tot, p.x, p.y);
+                started = true;
+            }
+        }
+    }
+    if (!live) return;
+    uint32_t* dst = out + (size_t)g * 48;
+    fp_t c;
+    uint32_t ww[12];
+    const fp_t* srcf[4] = {&tot.x, &tot.y, &tot.zz, &tot.zzz};
+    for (int k = 0; k < 4; k++) {
+        if (g1x_is_inf(tot)) {
+            for (int qq = 0; qq < 12; qq++) dst[12 * k + qq] = 0;
+        } else {
+            Fp::to_plain(c, *srcf[k]);
+            Fp::to_words32(ww, c);
+            for (int qq = 0; qq < 12; qq++) dst[12 * k + qq] = ww[qq];
+        }
+    }
+}
 // window sum = sum of its slices; exported as canonical plain coordinates (all-zero = identity) for the host's Horner step
 __global__ void __launch_bounds__(64) k_vmsm_combine(VmsmJobs jobs, int n_msm, const uint32_t* __restrict__ parts, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
     const int g = blockIdx.x * 64 + threadIdx.x;
@@ -995,6 +1049,12 @@ int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const*
         jobs.j[m].n = n_per_job[q];
         jobs.k[m] = std::min(VMSM_KMAX, std::max(1, n_per_job[q] / points_per_slice));   // 2048 points per slice: 8192-point jobs fill the GPU in one round of workgroups
         if (m < n_msm) kmax = std::max(kmax, jobs.k[m]);
+    }
+    bool single = true;
+    for (int m = 0; m < n_msm; m++) single = single && n_per_job[m] == 1;
+    if (single) {                                           // the single-proof verifiers
+        hipLaunchKernelGGL(k_vmsm_single, dim3((n_msm * VNWIN + 63) / 64), dim3(64), 0, s, jobs, n_msm, d_out);
+        return 0;
     }
     hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts);
     hipLaunchKernelGGL(k_vmsm_combine, dim3((n_msm * VNWIN + 63) / 64), dim3(64), 0, s, jobs, n_msm, d_parts, d_out);

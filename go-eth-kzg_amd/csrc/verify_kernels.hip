@@ -739,6 +739,15 @@ __global__ void __launch_bounds__(EV_T) k_rlc_scalars(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------
 constexpr int VC = 8, VNB = 128, VNWIN = 32, VMAXN = 8192;
 
+__device__ __forceinline__ void shfl_xor_xyzz_v(G1X& r, const G1X& a, int m) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.x.l[i] = __shfl_xor(a.x.l[i], m);
+        r.y.l[i] = __shfl_xor(a.y.l[i], m);
+        r.zz.l[i] = __shfl_xor(a.zz.l[i], m);
+        r.zzz.l[i] = __shfl_xor(a.zzz.l[i], m);
+    }
+}
 __device__ __forceinline__ void shfl_down_xyzz_v(G1X& r, const G1X& a, int d) {
 #pragma unroll
     for (int i = 0; i < 14; i++) {
@@ -863,47 +872,59 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
         for (int i = 0; i < 14; i++) { dst[i] = tot.x.l[i]; dst[14 + i] = tot.y.l[i]; dst[28 + i] = tot.zz.l[i]; dst[42 + i] = tot.zzz.l[i]; }
     }
 }
-// Single-pair jobs (VerifyKZGProof, VerifyBlobKZGProof: every job is ONE (scalar, point) pair): the window sum is d_w P, which a lane
-// gets by seven doublings and the additions of d_w's bits -- ~90 multiplications deep where the bucket machinery above spends its 13
-// additions of the suffix / tree network (~190) on 127 empty buckets.  One lane per (job, window); output as k_vmsm_combine's.
-__global__ void __launch_bounds__(64) k_vmsm_single(VmsmJobs jobs, int n_msm, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
-    const int g0 = blockIdx.x * 64 + threadIdx.x, total = n_msm * VNWIN;
-    const bool live = g0 < total;
-    const int g = live ? g0 : g0 % total;                  // FULL_WAVES: surplus lanes shadow another window and store nothing
-    const int m = g / VNWIN, w = g % VNWIN;
-    const uint32_t* s = jobs.j[m].scalars;
-    const int bit = VC * w - 1;
-    uint32_t v;
-    if (bit < 0) {
-        v = (s[0] << 1) & 0x1ffu;
-    } else {
-        const int wi = bit >> 5, off = bit & 31;
-        v = s[wi] >> off;
-        if (off + VC + 1 > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - off);
-        v &= 0x1ffu;
-    }
-    int d = (int)((v + 1) >> 1);                           // Booth digit of window w, as in k_vmsm_window
-    if (v >> VC) d -= (1 << VC);
-    G1Aff p;
-    load_affine_v(p, jobs.j[m].points);
+// Jobs of a few pairs (VerifyKZGProof and VerifyBlobKZGProof: ONE pair per job; the blob verifier on the blobs of a block: 6 today):
+// the window sum is sum_i d_i P_i with |d_i| <= 128, so a lane per (window, pair) gets d_i P_i by seven doublings and the additions of
+// d_i's bits (~90 multiplications deep) and an xor butterfly adds the PN lanes of a window (14 per level) -- 90 + 14 log2(PN) where the
+// bucket machinery above spends the 13 additions of its suffix / tree network (~190) on mostly empty buckets.  PN = pairs per job rounded
+// up to a power of two, 64 / PN windows per wavefront; output as k_vmsm_combine's.
+template <int PN>
+__global__ void __launch_bounds__(64) k_vmsm_small(VmsmJobs jobs, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
+    constexpr int WPW = 64 / PN;                            // windows per wavefront
+    const int m = blockIdx.y, lane = threadIdx.x, i = lane % PN;
+    const int w0 = blockIdx.x * WPW + lane / PN;
+    const bool live = w0 < VNWIN;
+    const int w = live ? w0 : w0 % VNWIN;                   // FULL_WAVES: surplus lanes shadow another window and store nothing
     G1X tot;
     g1x_set_inf(tot);
-    const int a = d < 0 ? -d : d;
-    if (a != 0 && !p.inf) {
-        if (d < 0) Fp::template neg<0>(p.y, p.y);
-        bool started = false;
+    if (i < jobs.j[m].n) {
+        const uint32_t* s = jobs.j[m].scalars + (size_t)i * 8;
+        const int bit = VC * w - 1;
+        uint32_t v;
+        if (bit < 0) {
+            v = (s[0] << 1) & 0x1ffu;
+        } else {
+            const int wi = bit >> 5, off = bit & 31;
+            v = s[wi] >> off;
+            if (off + VC + 1 > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - off);
+            v &= 0x1ffu;
+        }
+        int d = (int)((v + 1) >> 1);                       // Booth digit of window w, as in k_vmsm_window
+        if (v >> VC) d -= (1 << VC);
+        G1Aff p;
+        load_affine_v(p, jobs.j[m].points + (size_t)i * 32);
+        const int a = d < 0 ? -d : d;
+        if (a != 0 && !p.inf) {
+            if (d < 0) Fp::template neg<0>(p.y, p.y);
+            bool started = false;
 #pragma unroll 1
-        for (int b = VC; b >= 0; b--) {                    // |d| <= 2^VC
-            if (started) g1x_dbl(tot, tot);
-            if ((a >> b) & 1) {
-                if (started) g1x_madd(tot, p.x, p.y);
-                else g1x_from_affine(tot, p.x, p.y);
-                started = true;
+            for (int b = VC; b >= 0; b--) {                // |d| <= 2^VC
+                if (started) g1x_dbl(tot, tot);
+                if ((a >> b) & 1) {
+                    if (started) g1x_madd(tot, p.x, p.y);
+                    else g1x_from_affine(tot, p.x, p.y);
+                    started = true;
+                }
             }
         }
     }
-    if (!live) return;
-    uint32_t* dst = out + (size_t)g * 48;
+#pragma unroll 1
+    for (int sh = PN / 2; sh >= 1; sh >>= 1) {
+        G1X o;
+        shfl_xor_xyzz_v(o, tot, sh);
+        g1x_add(tot, tot, o);
+    }
+    if (!live || i != 0) return;
+    uint32_t* dst = out + ((size_t)m * VNWIN + w) * 48;
     fp_t c;
     uint32_t ww[12];
     const fp_t* srcf[4] = {&tot.x, &tot.y, &tot.zz, &tot.zzz};
@@ -1050,10 +1071,18 @@ int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const*
         jobs.k[m] = std::min(VMSM_KMAX, std::max(1, n_per_job[q] / points_per_slice));   // 2048 points per slice: 8192-point jobs fill the GPU in one round of workgroups
         if (m < n_msm) kmax = std::max(kmax, jobs.k[m]);
     }
-    bool single = true;
-    for (int m = 0; m < n_msm; m++) single = single && n_per_job[m] == 1;
-    if (single) {                                           // the single-proof verifiers
-        hipLaunchKernelGGL(k_vmsm_single, dim3((n_msm * VNWIN + 63) / 64), dim3(64), 0, s, jobs, n_msm, d_out);
+    int nmax = 0;
+    for (int m = 0; m < n_msm; m++) nmax = std::max(nmax, n_per_job[m]);
+    if (nmax >= 1 && nmax <= 16) {                           // the single-proof verifiers, the batch verifier on the blobs of a block
+        const int pn = nmax <= 1 ? 1 : (nmax <= 2 ? 2 : (nmax <= 4 ? 4 : (nmax <= 8 ? 8 : 16)));
+        const dim3 grid((VNWIN * pn + 63) / 64, n_msm);
+        switch (pn) {
+            case 1: hipLaunchKernelGGL((k_vmsm_small<1>), grid, dim3(64), 0, s, jobs, d_out); break;
+            case 2: hipLaunchKernelGGL((k_vmsm_small<2>), grid, dim3(64), 0, s, jobs, d_out); break;
+            case 4: hipLaunchKernelGGL((k_vmsm_small<4>), grid, dim3(64), 0, s, jobs, d_out); break;
+            case 8: hipLaunchKernelGGL((k_vmsm_small<8>), grid, dim3(64), 0, s, jobs, d_out); break;
+            default: hipLaunchKernelGGL((k_vmsm_small<16>), grid, dim3(64), 0, s, jobs, d_out); break;
+        }
         return 0;
     }
     hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts);

@@ -504,7 +504,10 @@ __global__ void __launch_bounds__(64) k_fk20_msm_reduce(const uint32_t* __restri
 // holds fewer than ~8200 active lanes the figure grows with the number of resident wavefronts -- 19.6 cycles at one sparse wavefront
 // per SIMD.  A single-blob call ran this stage's 686 one-lane wavefronts at 4.7 ms; with full wavefronts it takes the 1.7 ms of a batch.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void toom_run(G1X& acc, const uint8_t* __restrict__ prog, const uint32_t* const* __restrict__ src) {
+// QUAD: calls of up to FK_QUAD_MAX_BATCH blobs run every item on four lanes (g1_quad.hpp xadd_quad / xdbl_quad: an addition four
+// products deep instead of fourteen) -- the six network launches are chains of ~10 group operations that a single blob's caller waits for
+template <bool QUAD>
+__device__ __forceinline__ void toom_run(G1X& acc, const uint8_t* __restrict__ prog, const uint32_t* const* __restrict__ src, const QuadRole& qr) {
     // src[x]: row of operand x (4 or 7 of them)
 #pragma unroll 1
     for (int i = 0; i < FK20_PROG_LEN; i++) {
@@ -513,25 +516,28 @@ __device__ __forceinline__ void toom_run(G1X& acc, const uint8_t* __restrict__ p
         if (op == 0) {
             f_load_xyzz(acc, src[x]);
         } else if (op == 3) {
-            g1x_dbl(acc, acc);
+            if constexpr (QUAD) xdbl_quad(acc, qr);
+            else g1x_dbl(acc, acc);
         } else if (op == 4) {
             g1x_neg(acc, acc);
         } else {
             G1X t;
             f_load_xyzz(t, src[x]);
             if (op == 2) g1x_neg(t, t);
-            g1x_add(acc, acc, t);
+            if constexpr (QUAD) xadd_quad(acc, t, qr);
+            else g1x_add(acc, acc, t);
         }
     }
 }
 // pre level: out[blk][p][r][q] = sum_j e_r[j] in[blk][p][j][q]   (r = blockIdx.y).  FIRST: in = u' rows [b][128], block blk reads the
 // inputs of the other parity, (p, j, q) = (0, j, q) -> element 16 j + q.
-template <bool FIRST>
+template <bool FIRST, bool QUAD>
 __global__ void __launch_bounds__(64) k_fk20_pre(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const int* __restrict__ status, int n, int npre, int npost) {
     const int r = blockIdx.y;
-    const size_t glane = (size_t)blockIdx.x * 64 + threadIdx.x, total = (size_t)n * 2 * npre * npost;
-    const bool live = glane < total;
-    const size_t lane = live ? glane : glane % total;      // surplus lanes of the last wavefront shadow other lanes (FULL_WAVES below)
+    const QuadRole qr(threadIdx.x);
+    const size_t glane = ((size_t)blockIdx.x * 64 + threadIdx.x) / (QUAD ? 4 : 1), total = (size_t)n * 2 * npre * npost;
+    const bool live = glane < total && (!QUAD || (threadIdx.x & 3) == 0);
+    const size_t lane = glane % total;                      // surplus lanes of the last wavefront shadow other lanes (FULL_WAVES below)
     const int b = (int)(lane % n);
     size_t item = lane / n;
     const int q = (int)(item % npost);
@@ -545,18 +551,19 @@ __global__ void __launch_bounds__(64) k_fk20_pre(const uint32_t* __restrict__ in
         else src[j] = in + (((((size_t)blk * npre + p) * 4 + j) * npost + q) * n + b) * 64;
     }
     G1X acc;
-    toom_run(acc, FK20_PRE_PROG[r], src);
+    toom_run<QUAD>(acc, FK20_PRE_PROG[r], src, qr);
     if (live) f_store_xyzz(out + (((((size_t)blk * npre + p) * 7 + r) * npost + q) * n + b) * 64, acc);
 }
 // post level: out[blk][p][A][q] = sum_r e_r[3 - A] in[blk][p][r][q]   (A = blockIdx.y).  LAST: (p, A, q) = (0, A, q) -> element
 // a = 16 A + q of the block's output; the result plus u' goes to rows [b][128] at index 2 a + blk.
-template <bool LAST>
+template <bool LAST, bool QUAD>
 __global__ void __launch_bounds__(64) k_fk20_post(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ u, const int* __restrict__ status, int n,
                                                   int npre, int npost) {
     const int A = blockIdx.y;
-    const size_t glane = (size_t)blockIdx.x * 64 + threadIdx.x, total = (size_t)n * 2 * npre * npost;
-    const bool live = glane < total;
-    const size_t lane = live ? glane : glane % total;
+    const QuadRole qr(threadIdx.x);
+    const size_t glane = ((size_t)blockIdx.x * 64 + threadIdx.x) / (QUAD ? 4 : 1), total = (size_t)n * 2 * npre * npost;
+    const bool live = glane < total && (!QUAD || (threadIdx.x & 3) == 0);
+    const size_t lane = glane % total;
     const int b = (int)(lane % n);
     size_t item = lane / n;
     const int q = (int)(item % npost);
@@ -567,12 +574,13 @@ __global__ void __launch_bounds__(64) k_fk20_post(const uint32_t* __restrict__ i
 #pragma unroll
     for (int r = 0; r < 7; r++) src[r] = in + (((((size_t)blk * npre + p) * 7 + r) * npost + q) * n + b) * 64;
     G1X acc;
-    toom_run(acc, FK20_POST_PROG[A], src);
+    toom_run<QUAD>(acc, FK20_POST_PROG[A], src, qr);
     if (LAST) {
         const size_t j = (size_t)b * 128 + 2 * (A * npost + q) + blk;
         G1X t;
         f_load_xyzz(t, u + j * 64);
-        g1x_add(acc, acc, t);
+        if constexpr (QUAD) xadd_quad(acc, t, qr);
+        else g1x_add(acc, acc, t);
         if (live) f_store_xyzz(out + j * 64, acc);
     } else if (live) {
         f_store_xyzz(out + (((((size_t)blk * npre + p) * 4 + A) * npost + q) * n + b) * 64, acc);
@@ -646,18 +654,31 @@ void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_
     if (n <= 0) return;
     uint32_t* bufA = d_parts;
     uint32_t* bufB = d_parts + (size_t)686 * n * 64;
-    auto grid = [&](int npre, int npost, int ny) { return dim3((unsigned)(((size_t)n * 2 * npre * npost + 63) / 64), (unsigned)ny); };
-    hipLaunchKernelGGL((k_fk20_pre<true>), grid(1, 16, 7), dim3(64), 0, s, d_results, bufA, d_status, n, 1, 16);
-    hipLaunchKernelGGL((k_fk20_pre<false>), grid(7, 4, 7), dim3(64), 0, s, bufA, bufB, d_status, n, 7, 4);
-    hipLaunchKernelGGL((k_fk20_pre<false>), grid(49, 1, 7), dim3(64), 0, s, bufB, bufA, d_status, n, 49, 1);
+    const bool quad = n <= FK_QUAD_MAX_BATCH;               // the addition networks on a quad of lanes per item, like the products
+    auto grid = [&](int npre, int npost, int ny) { return dim3((unsigned)(((size_t)n * 2 * npre * npost * (quad ? 4 : 1) + 63) / 64), (unsigned)ny); };
+    if (quad) {
+        hipLaunchKernelGGL((k_fk20_pre<true, true>), grid(1, 16, 7), dim3(64), 0, s, d_results, bufA, d_status, n, 1, 16);
+        hipLaunchKernelGGL((k_fk20_pre<false, true>), grid(7, 4, 7), dim3(64), 0, s, bufA, bufB, d_status, n, 7, 4);
+        hipLaunchKernelGGL((k_fk20_pre<false, true>), grid(49, 1, 7), dim3(64), 0, s, bufB, bufA, d_status, n, 49, 1);
+    } else {
+        hipLaunchKernelGGL((k_fk20_pre<true, false>), grid(1, 16, 7), dim3(64), 0, s, d_results, bufA, d_status, n, 1, 16);
+        hipLaunchKernelGGL((k_fk20_pre<false, false>), grid(7, 4, 7), dim3(64), 0, s, bufA, bufB, d_status, n, 7, 4);
+        hipLaunchKernelGGL((k_fk20_pre<false, false>), grid(49, 1, 7), dim3(64), 0, s, bufB, bufA, d_status, n, 49, 1);
+    }
     // up to 16 blobs the 686 wavefronts have room for a quad of lanes per blob, up to 32 for a pair (one wavefront per product either
     // way); above that the extra wavefronts would share SIMDs and the shorter chains buy nothing
     if (n <= FK_QUAD_MAX_BATCH) hipLaunchKernelGGL((k_fk20_toom_mul<4>), dim3(686, (4 * n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
     else if (n <= FK_PAIR_MAX_BATCH) hipLaunchKernelGGL((k_fk20_toom_mul<2>), dim3(686, (2 * n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
     else hipLaunchKernelGGL((k_fk20_toom_mul<1>), dim3(686, (n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
-    hipLaunchKernelGGL((k_fk20_post<false>), grid(49, 1, 4), dim3(64), 0, s, bufB, bufA, nullptr, d_status, n, 49, 1);
-    hipLaunchKernelGGL((k_fk20_post<false>), grid(7, 4, 4), dim3(64), 0, s, bufA, bufB, nullptr, d_status, n, 7, 4);
-    hipLaunchKernelGGL((k_fk20_post<true>), grid(1, 16, 4), dim3(64), 0, s, bufB, d_tmp, d_results, d_status, n, 1, 16);
+    if (quad) {
+        hipLaunchKernelGGL((k_fk20_post<false, true>), grid(49, 1, 4), dim3(64), 0, s, bufB, bufA, nullptr, d_status, n, 49, 1);
+        hipLaunchKernelGGL((k_fk20_post<false, true>), grid(7, 4, 4), dim3(64), 0, s, bufA, bufB, nullptr, d_status, n, 7, 4);
+        hipLaunchKernelGGL((k_fk20_post<true, true>), grid(1, 16, 4), dim3(64), 0, s, bufB, d_tmp, d_results, d_status, n, 1, 16);
+    } else {
+        hipLaunchKernelGGL((k_fk20_post<false, false>), grid(49, 1, 4), dim3(64), 0, s, bufB, bufA, nullptr, d_status, n, 49, 1);
+        hipLaunchKernelGGL((k_fk20_post<false, false>), grid(7, 4, 4), dim3(64), 0, s, bufA, bufB, nullptr, d_status, n, 7, 4);
+        hipLaunchKernelGGL((k_fk20_post<true, false>), grid(1, 16, 4), dim3(64), 0, s, bufB, d_tmp, d_results, d_status, n, 1, 16);
+    }
     hipLaunchKernelGGL(k_fk20_finish, dim3(2, n), dim3(64), 0, s, d_tmp, d_status, d_proofs48);
 }
 

@@ -131,6 +131,94 @@ __device__ __forceinline__ void jadd_quad(G1J& a, const G1JC& b_, const QuadRole
     a = res;
 }
 
+// ---- extended-Jacobian (XYZZ) accumulators on a quad: the addition networks around the FK20 products (fk20_kernels.hip toom_run) are
+// chains of ~10 additions / doublings of whole points.  add-2008-s is 14 products in four levels
+//   {X1 ZZ2, X2 ZZ1, Y1 ZZZ2, Y2 ZZZ1}, {P^2, ZZ1 ZZ2, ZZZ1 ZZZ2, R^2}, {P^3, ZZ1 ZZ2 P^2, U1 P^2}, {R (Q - X3), -S1 P^3, ZZZ1 ZZZ2 P^3}
+// and dbl-2008-s-1 nine in three: {(2Y)^2, X^2}, {U V, X V, (3X^2)^2, V ZZ}, {M (S - X3), -W Y, W ZZZ}.  Same values as G1D::add / G1D::dbl
+// except that Y3 is the sum of two reduced products (< 2.02p instead of < 1.01p; the XYZZ bound is Y < 4p).
+__device__ __forceinline__ void xdbl_quad(G1X& p, const QuadRole& q) {
+    G1D::opaque(p);
+    fp_t U, a, b, M1, M2, M3, V, T, M, W, S, MM, X3, t, nY;
+    Fp::dbl(U, p.y);
+    Fp::select(a, q.r0, U, p.x);
+    Fp::sqr(M1, a);                           // lane 0: V = (2Y)^2       lanes 1..3: X^2
+    quad_bcast<0>(V, M1);
+    quad_bcast<1>(T, M1);
+    Fp::triple(M, T);                         // 3 X^2
+    quad_pick(a, q, U, p.x, M, V);
+    quad_pick(b, q, V, V, M, p.zz);
+    Fp::mul(M2, a, b);                        // W = U V | S = X V | M^2 | ZZ3 = V ZZ   (ZZ = 0 stays all-zero limbs)
+    quad_bcast<0>(W, M2);
+    quad_bcast<1>(S, M2);
+    quad_bcast<2>(MM, M2);
+    Fp::template sub_2c<2>(X3, MM, S);        // M^2 - 2S + 4p        (< 5.01p)
+    Fp::template sub<3>(t, S, X3);            // S - X3 + 8p
+    Fp::template neg<2>(nY, p.y);             // 4p - Y
+    quad_pick(a, q, M, W, W, W);
+    quad_pick(b, q, t, nY, p.zzz, p.zzz);
+    Fp::mul(M3, a, b);                        // M (S - X3) | -W Y | ZZZ3 = W ZZZ | (again)
+    quad_bcast<0>(t, M3);
+    quad_bcast<1>(S, M3);
+    Fp::add(p.y, t, S);
+    quad_bcast<3>(p.zz, M2);
+    quad_bcast<2>(p.zzz, M3);
+    p.x = X3;
+}
+__device__ __forceinline__ void xadd_quad(G1X& a, const G1X& b_, const QuadRole& q) {
+    G1X b = b_;
+    G1D::opaque(a);
+    G1D::opaque(b);
+    const bool a_inf = G1D::is_inf(a), b_inf = G1D::is_inf(b);
+    fp_t oa, ob, M1, M2, M3, M4, U1, U2, S1, S2, Pd, Rd, PP, PPP, Q, RR, X3, t;
+    G1X res;
+    quad_pick(oa, q, a.x, b.x, a.y, b.y);
+    quad_pick(ob, q, b.zz, a.zz, b.zzz, a.zzz);
+    Fp::mul(M1, oa, ob);                      // U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
+    quad_bcast<0>(U1, M1);
+    quad_bcast<1>(U2, M1);
+    quad_bcast<2>(S1, M1);
+    quad_bcast<3>(S2, M1);
+    Fp::template sub<1>(Pd, U2, U1);
+    Fp::template sub<1>(Rd, S2, S1);
+    if (!a_inf && !b_inf && Fp::template is_zero_mod<16>(Pd)) {
+        if (Fp::template is_zero_mod<16>(Rd)) {
+            res = a;
+            xdbl_quad(res, q);
+        } else {
+            G1D::set_inf(res);
+        }
+    } else {
+        Fp::opaque(Pd);
+        Fp::opaque(Rd);
+        Fp::opaque(U1);
+        Fp::opaque(S1);
+        quad_pick(oa, q, Pd, a.zz, a.zzz, Rd);
+        quad_pick(ob, q, Pd, b.zz, b.zzz, Rd);
+        Fp::mul(M2, oa, ob);                  // PP = P^2 | ZZ1 ZZ2 | ZZZ1 ZZZ2 | R^2
+        quad_bcast<0>(PP, M2);
+        quad_pick(oa, q, Pd, M2, U1, U1);
+        Fp::mul(M3, oa, PP);                  // PPP = P^3 | ZZ3 = ZZ1 ZZ2 PP | Q = U1 PP | (Q again)
+        quad_bcast<0>(PPP, M3);
+        quad_bcast<2>(Q, M3);
+        quad_bcast<3>(RR, M2);
+        Fp::template sub_b_2c<2>(X3, RR, PPP, Q);   // R^2 - PPP - 2Q + 4p   (< 5.01p)
+        Fp::template sub<3>(t, Q, X3);
+        Fp::template neg<1>(S1, S1);          // 2p - S1
+        quad_pick(oa, q, Rd, S1, M2, M2);
+        quad_pick(ob, q, t, PPP, PPP, PPP);
+        Fp::mul(M4, oa, ob);                  // R (Q - X3) | -S1 PPP | ZZZ3 = ZZZ1 ZZZ2 PPP | (garbage on lane 3: R^2 PPP, unused)
+        quad_bcast<0>(t, M4);
+        quad_bcast<1>(S2, M4);
+        Fp::add(res.y, t, S2);
+        quad_bcast<1>(res.zz, M3);
+        quad_bcast<2>(res.zzz, M4);
+        res.x = X3;
+    }
+    G1D::select(res, b_inf, a, res);
+    G1D::select(res, a_inf, b, res);
+    a = res;
+}
+
 // ---- the same law on a PAIR of lanes (lanes 2i and 2i + 1): for calls with too many points for a quad each but room for two lanes --
 // 17 to 32 blobs in the 686 products of the FK20 network.  The seven products of a doubling go in four rounds
 //   {X^2 | Y^2}, {2Y Z | (2Y^2)^2}, {(3X^2)^2 | (X + 2Y^2)^2}, {3X^2 (D - X3)}

@@ -237,6 +237,40 @@ def test_cells_and_proofs_async_on_two_streams(gpu_ctx, oracle_ctx):
             assert rc == 0 and cb[i * 262144:(i + 1) * 262144] == oc and pb[i * 6144:(i + 1) * 6144] == op
 
 
+def test_structured_blobs_through_every_lane_shape(gpu_ctx, oracle_ctx):
+    """Blobs whose FK20 intermediates collide -- the zero polynomial (every point the identity), constant polynomials (all but one
+    coefficient zero: the addition networks meet P + P, P - P and identity operands), a blob with one non-zero evaluation, all r - 1, an
+    arithmetic progression -- through ComputeCellsAndKZGProofs alone (quad of lanes per item), in a batch of 6 (quad), of 20 (pair of
+    lanes in the products) and of 40 (one lane): the exceptional cases of g1_quad.hpp must give the oracle's bytes like the plain law."""
+    import torch
+    const7 = (7).to_bytes(32, "big") * 4096
+    const_big = (R - 2).to_bytes(32, "big") * 4096
+    one_hot = bytearray(131072)
+    one_hot[32 * 1234 + 31] = 5
+    ramp = b"".join(((i * 0x1000193 + 11) % R).to_bytes(32, "big") for i in range(4096))
+    special = [bytes(131072), const7, const_big, bytes(one_hot), (R - 1).to_bytes(32, "big") * 4096, ramp]
+    exp = []
+    for b in special:
+        rc, oc, op = oracle_ctx.compute_cells_and_kzg_proofs(b)
+        assert rc == 0
+        exp.append((oc, op))
+        rc, cells, proofs = gpu_ctx.ComputeCellsAndKZGProofs(b)
+        assert rc == 0 and b"".join(cells) == oc and b"".join(proofs) == op
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (6, 20, 40):
+        blobs = [special[i % 6] for i in range(n)]
+        d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+        d_cells = torch.zeros(n * 262144, dtype=torch.uint8, device="cuda")
+        d_proofs = torch.zeros(n * 128 * 48, dtype=torch.uint8, device="cuda")
+        d_st = torch.ones(n, dtype=torch.int32, device="cuda")
+        assert gpu_ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), n, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert d_st.cpu().tolist() == [0] * n
+        cb, pb = d_cells.cpu().numpy().tobytes(), d_proofs.cpu().numpy().tobytes()
+        for i in range(n):
+            assert cb[i * 262144:(i + 1) * 262144] == exp[i % 6][0] and pb[i * 6144:(i + 1) * 6144] == exp[i % 6][1], (n, i)
+
+
 def test_fk20_table_widths_agree(product, oracle_ctx):
     """fk20_bits 11 (default) and 13 (86 GB table, 20 instead of 24 additions per scalar) give the oracle's bytes, for one blob (few-blob
     lane layout) and for a batch (batch lane layout); switching the option rebuilds the table"""

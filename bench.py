@@ -474,6 +474,23 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
            "kernels_ms_per_call": kern,
            "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(algo / (dom[1] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(algo / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": pm.get("traffic_bytes")}}
+    if world == 1:
+        # the reference's own API shape at the sizes a block carries: host pointers in (Go's []*Blob), one synchronous caller
+        hb = d_blobs[: min(N, 48) * BLOB].cpu().numpy().tobytes()
+        hcm, hpr = d_cm.cpu().numpy().tobytes(), d_pr.cpu().numpy().tobytes()
+        small = {}
+        for nb in (1, 6, 16, 48):
+            if nb > N:
+                continue
+            bl = [hb[i * BLOB:(i + 1) * BLOB] for i in range(nb)]
+            cl = [hcm[48 * i:48 * i + 48] for i in range(nb)]
+            pl = [hpr[48 * i:48 * i + 48] for i in range(nb)]
+            assert ctx.VerifyBlobKZGProofBatch(bl, cl, pl) == 0
+            t0 = time.perf_counter()
+            for _ in range(5):
+                assert ctx.VerifyBlobKZGProofBatch(bl, cl, pl) == 0
+            small[str(nb)] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+        out["host_pointer_ms_per_call_by_blobs"] = small
     # sustained rate: K caller threads on one shared context, one call in flight each (reference verify.go:152-169: the Context is
     # shared by goroutines).  Each call works in its own lane; calls that find others in flight take the throughput shape (barycentric
     # evaluation, one stream per call) and share hash launches (api_verify.hip hash_round_join).

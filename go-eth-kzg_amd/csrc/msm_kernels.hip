@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "g1.hpp"
+#include "g1_quad.hpp"
 #include "msm_kernels.h"
 #include "g1_decode.hpp"
 
@@ -580,7 +581,8 @@ __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
 // shift register: static register indices only), prefetching the table row of window j+1 while the row of
 // window j is added.  K = 8 is the throughput shape (256 blobs fill the chip twice over with 136 additions per lane); calls of
 // fewer blobs spread each blob over more lanes (K = 4, 2, 1: 4096 lanes per blob, 17 additions each) and pay for it with the
-// log-depth fold of the partial sums below -- the caller of one blob waits for 17 + 12 dependent additions instead of 136 + 14.  When C divides 255 the signed recoding has no spare top window; scalars with bit 254
+// log-depth fold of the partial sums below -- the caller of one blob waits for 17 + 12 dependent additions instead of 136 + 14, and
+// the 12 run on a quad of lanes each.  When C divides 255 the signed recoding has no spare top window; scalars with bit 254
 // set are replaced by r - s (top digit then <= 2^(C-1)) and every digit sign is flipped.
 template <int C, int INPUT_KIND>     // INPUT_KIND 0: 32-byte big-endian scalars (blobs); 1: 12-word Montgomery Fr rows (quotient polynomials)
 __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, const uint32_t* __restrict__ direct,
@@ -678,22 +680,25 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
     const int anybad = __syncthreads_or(bad);
     if (t == 0) bad_flags[b * DBAD + half] = anybad;
 }
-// Fold (K < 8): one wavefront per accumulate workgroup sums its 64 lane accumulators with an xor butterfly and leaves the sum in
-// the workgroup's first record; the finish kernel then meets 4096 / (64 K) records per blob, 64 apart.
-__global__ void __launch_bounds__(64, 2) k_commit_direct_fold(uint32_t* __restrict__ parts) {
-    const size_t base = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64;
+// Fold (K < 8, calls of few blobs: somebody waits for this chain): 16 records per wavefront, a QUAD of lanes per record (g1_quad.hpp
+// xadd_quad: an addition four products deep instead of fourteen), xor butterfly over the 16 quads, the sum left in the first record.
+// Two launches take a blob's 4096 / K records (stride 1) to 4096 / 16K (stride 16) to 4096 / 256K (stride 256) for the finish kernel.
+__global__ void __launch_bounds__(64, 2) k_commit_direct_fold16(uint32_t* __restrict__ parts, int per_blob /* records of a blob, in units of `stride` */, int stride) {
+    const QuadRole qr(threadIdx.x);
+    const size_t base = (size_t)blockIdx.y * per_blob * stride + (size_t)blockIdx.x * 16 * stride;
     G1X acc, o;
-    load_xyzz(acc, parts + (base + threadIdx.x) * 64);
+    load_xyzz(acc, parts + (base + (size_t)(threadIdx.x >> 2) * stride) * 64);
 #pragma unroll 1
-    for (int m = 32; m >= 1; m >>= 1) {
+    for (int m = 32; m >= 4; m >>= 1) {
         shfl_xor_xyzz(o, acc, m);
-        g1x_add(acc, acc, o);
+        xadd_quad(acc, o, qr);
     }
     if (threadIdx.x == 0) store_xyzz(parts + base * 64, acc);
 }
 // Finish: one wavefront per blob sums the 512 lane accumulators (8 per lane, then an xor butterfly), converts to
 // affine and writes the compressed commitment.  Tiny and latency-bound: it runs beside the next accumulate kernel.
-// folded (K < 8): the blob's nblk records sit 64 apart (k_commit_direct_fold); lanes beyond them start from the identity.
+// folded (K < 8): the blob's nblk / 4 records sit 256 apart (two rounds of k_commit_direct_fold16), a quad of lanes per record;
+// quads beyond them start from the identity.
 __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __restrict__ parts, const int* __restrict__ bad_flags, uint8_t* __restrict__ out48,
                                                           int* __restrict__ status, int nblk, int folded) {
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -706,8 +711,14 @@ __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __r
     G1X acc, o;
     const size_t base = (size_t)b * nblk * 64;
     if (folded) {
+        const QuadRole qr(lane);
         g1x_set_inf(acc);
-        if (lane < nblk) load_xyzz(acc, parts + (base + (size_t)lane * 64) * 64);
+        if ((lane >> 2) < nblk / 4) load_xyzz(acc, parts + (base + (size_t)(lane >> 2) * 256) * 64);
+#pragma unroll 1
+        for (int m = 32; m >= 4; m >>= 1) {
+            shfl_xor_xyzz(o, acc, m);
+            xadd_quad(acc, o, qr);
+        }
     } else {
         load_xyzz(acc, parts + (base + lane) * 64);
 #pragma unroll 1
@@ -717,7 +728,7 @@ __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __r
         }
     }
 #pragma unroll 1
-    for (int m = 32; m >= 1; m >>= 1) {
+    for (int m = folded ? 0 : 32; m >= 1; m >>= 1) {
         shfl_xor_xyzz(o, acc, m);
         g1x_add(acc, acc, o);
     }
@@ -883,7 +894,11 @@ void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot&
     const dim3 grid(4096 / (ws.k * DTA), n);
     if (input_kind == 0) launch_direct_acc<0>(c, grid, s, d_scalars, stride, d_direct, ws);
     else launch_direct_acc<1>(c, grid, s, d_scalars, stride, d_direct, ws);
-    if (ws.k < 8) hipLaunchKernelGGL(k_commit_direct_fold, grid, dim3(64), 0, s, ws.d_parts);
+    if (ws.k < 8) {
+        const int pp = 4096 / ws.k;                       // records per blob: 4096, 2048, 1024 -> / 16 -> / 256
+        hipLaunchKernelGGL(k_commit_direct_fold16, dim3(pp / 16, n), dim3(64), 0, s, ws.d_parts, pp, 1);
+        hipLaunchKernelGGL(k_commit_direct_fold16, dim3(pp / 256, n), dim3(64), 0, s, ws.d_parts, pp / 16, 16);
+    }
     if (kt) kt->end(KT_COMMIT_DIRECT, s);
 }
 void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {

@@ -332,7 +332,7 @@ def source_hash(files):
     return h.hexdigest()[:16]
 
 
-PMC_SOURCES = {"commit": ["msm_kernels.hip", "g1.hpp", "mont29.hpp", "modinv30.hpp"], "verify": ["verify_kernels.hip", "cells_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp"]}
+PMC_SOURCES = {"commit": ["msm_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "modinv30.hpp"], "verify": ["verify_kernels.hip", "cells_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp"]}
 
 
 def pmc_profile(kernel):

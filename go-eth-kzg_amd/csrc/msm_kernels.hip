@@ -315,14 +315,17 @@ __global__ void __launch_bounds__(256) k_bucket_accumulate(const uint32_t* __res
 // partials[b][t] = (S_t, T_t)
 // ------------------------------------------------------------------------------------------
 constexpr int CHUNK = 16;
-template <int C>
+// QUAD (calls of a few blobs, where somebody waits for this 32- to 48-addition chain): four lanes per chunk, g1_quad.hpp xadd_quad
+template <int C, bool QUAD>
 __global__ void __launch_bounds__(64, 2) k_bucket_reduce1(const uint32_t* __restrict__ parts, const uint32_t* __restrict__ task_off, const int* __restrict__ status,
                                                        uint32_t* __restrict__ partials) {
     using RC = Recode<C>;
     using TG = TaskGeom<C>;
     constexpr int NCHUNK = RC::NBUCKET / CHUNK;
+    static_assert(NCHUNK % 64 == 0, "whole wavefronts of chunks (the quad form needs all four lanes of a quad)");
+    const QuadRole qr(threadIdx.x);
     const int b = blockIdx.y;
-    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int t = (blockIdx.x * 64 + threadIdx.x) / (QUAD ? 4 : 1);
     if (t >= NCHUNK || status[b] != 0) return;
     const uint32_t* off = task_off + (size_t)b * (RC::NBUCKET + 1) + t * CHUNK;
     const uint32_t* src = parts + (size_t)b * TG::MAXT * 64;
@@ -333,10 +336,13 @@ __global__ void __launch_bounds__(64, 2) k_bucket_reduce1(const uint32_t* __rest
         const uint32_t p0 = off[q], p1 = off[q + 1];
         for (uint32_t p = p0; p < p1; p++) {
             load_xyzz(bk, src + (size_t)p * 64);
-            g1x_add_ni(run, run, bk);
+            if constexpr (QUAD) xadd_quad(run, bk, qr);
+            else g1x_add_ni(run, run, bk);
         }
-        g1x_add_ni(sum, sum, run);
+        if constexpr (QUAD) xadd_quad(sum, run, qr);
+        else g1x_add_ni(sum, sum, run);
     }
+    if (QUAD && (threadIdx.x & 3) != 0) return;
     uint32_t* dst = partials + ((size_t)b * NCHUNK + t) * 128;
     store_xyzz(dst, run);
     store_xyzz(dst + 64, sum);
@@ -423,6 +429,92 @@ __global__ void __launch_bounds__(64, 2) k_bucket_reduce2(const uint32_t* __rest
 #pragma unroll
             for (int i = 0; i < 12; i++) o32[i] = __builtin_bswap32(w[i]);
         }
+    }
+}
+// The same reduction for calls of a few blobs on QUADS of lanes (g1_quad.hpp): FOUR wavefronts, 64 groups of four lanes with
+// NCHUNK / 64 chunks each as above; the ~45 group operations of the chain (loop, suffix scan, trees, doublings) are four or three
+// products deep instead of fourteen or nine, and the scan and the trees cross the wavefronts through LDS (one record per wavefront).
+template <int C>
+__global__ void __launch_bounds__(256) k_bucket_reduce2_quad(const uint32_t* __restrict__ partials, const int* __restrict__ status, uint8_t* __restrict__ out48) {
+    using RC = Recode<C>;
+    constexpr int NCHUNK = RC::NBUCKET / CHUNK;
+    constexpr int M = NCHUNK / 64;
+    static_assert(M >= 1 && (M & (M - 1)) == 0, "bucket count must give a power-of-two number of chunks per group");
+    __shared__ uint32_t xw[3][4][56];                        // per wavefront: its SS total, its P partial, its X partial
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, gl = lane >> 2, g = tid >> 2;
+    const QuadRole qr(tid);
+    if (status[b] != 0) return;
+    auto put = [&](int k, const G1X& v) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) { xw[k][wave][i] = v.x.l[i]; xw[k][wave][14 + i] = v.y.l[i]; xw[k][wave][28 + i] = v.zz.l[i]; xw[k][wave][42 + i] = v.zzz.l[i]; }
+    };
+    auto get = [&](G1X& v, int k, int w) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) { v.x.l[i] = xw[k][w][i]; v.y.l[i] = xw[k][w][14 + i]; v.zz.l[i] = xw[k][w][28 + i]; v.zzz.l[i] = xw[k][w][42 + i]; }
+    };
+    const uint32_t* src = partials + ((size_t)b * NCHUNK + (size_t)g * M) * 128;
+    G1X U, run, wsum, t;
+    g1x_set_inf(U);
+    g1x_set_inf(run);
+    g1x_set_inf(wsum);
+#pragma unroll 1
+    for (int i = M - 1; i >= 0; i--) {
+        load_xyzz(t, src + i * 128 + 64);
+        xadd_quad(U, t, qr);
+        load_xyzz(t, src + i * 128);
+        xadd_quad(run, t, qr);
+        if (i > 0) xadd_quad(wsum, run, qr);
+    }
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) xdbl_quad(wsum, qr);
+    G1X X = U;
+    xadd_quad(X, wsum, qr);                                  // X = U + 16 Wt
+    G1X P = run, o;
+#pragma unroll 1
+    for (int d = 1; d < 16; d <<= 1) {                       // suffix scan of SS over the 16 groups of this wavefront
+        shfl_down_xyzz(o, P, 4 * d);
+        if (gl + d < 16) xadd_quad(P, o, qr);
+    }
+    if (lane == 0) put(0, P);                                // group 0 of the wavefront now holds the wavefront's total
+    __syncthreads();
+#pragma unroll 1
+    for (int w = wave + 1; w < 4; w++) {                     // ... plus the totals of the wavefronts after this one
+        get(o, 0, w);
+        xadd_quad(P, o, qr);
+    }
+    if (g == 0) g1x_set_inf(P);
+#pragma unroll 1
+    for (int d = 8; d >= 1; d >>= 1) {                       // sum_g g SS_g and sum_g X_g, first inside the wavefront
+        shfl_down_xyzz(o, P, 4 * d);
+        if (gl < d) xadd_quad(P, o, qr);
+        shfl_down_xyzz(o, X, 4 * d);
+        if (gl < d) xadd_quad(X, o, qr);
+    }
+    if (lane == 0) { put(1, P); put(2, X); }
+    __syncthreads();
+    if (wave != 0) return;
+    get(P, 1, 0);                                            // every lane of wavefront 0 adds the four partials (replicated: full wavefront)
+    get(X, 2, 0);
+#pragma unroll 1
+    for (int w = 1; w < 4; w++) {
+        get(o, 1, w);
+        xadd_quad(P, o, qr);
+        get(o, 2, w);
+        xadd_quad(X, o, qr);
+    }
+    int sh = 4;
+    for (int m = M; m > 1; m >>= 1) sh++;
+#pragma unroll 1
+    for (int q = 0; q < sh; q++) xdbl_quad(P, qr);
+    xadd_quad(X, P, qr);
+    G1Aff a;
+    g1x_to_affine(a, X);
+    uint32_t w[12];
+    g1_compress_words(w, a);
+    if (lane == 0) {
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(out48 + (size_t)b * 48);
+#pragma unroll
+        for (int i = 0; i < 12; i++) o32[i] = __builtin_bswap32(w[i]);
     }
 }
 
@@ -806,10 +898,12 @@ static void launch_commit(const CommitPlan& pl, const uint8_t* d_scalars, size_t
     if (kt) kt->end(KT_BUCKET_ACC, s);
     constexpr int NCHUNK = RC::NBUCKET / CHUNK;
     if (kt) kt->begin(KT_REDUCE1, s);
-    hipLaunchKernelGGL((k_bucket_reduce1<C>), dim3((NCHUNK + 63) / 64, n), dim3(64), 0, s, pl.d_parts, pl.d_task_off, d_status, pl.d_partials);
+    if (n <= 16) hipLaunchKernelGGL((k_bucket_reduce1<C, true>), dim3((4 * NCHUNK + 63) / 64, n), dim3(64), 0, s, pl.d_parts, pl.d_task_off, d_status, pl.d_partials);
+    else hipLaunchKernelGGL((k_bucket_reduce1<C, false>), dim3((NCHUNK + 63) / 64, n), dim3(64), 0, s, pl.d_parts, pl.d_task_off, d_status, pl.d_partials);
     if (kt) kt->end(KT_REDUCE1, s);
     if (kt) kt->begin(KT_REDUCE2, s);
-    hipLaunchKernelGGL((k_bucket_reduce2<C>), dim3(n), dim3(64), 0, s, pl.d_partials, d_status, d_out48);
+    if (n <= 16) hipLaunchKernelGGL((k_bucket_reduce2_quad<C>), dim3(n), dim3(256), 0, s, pl.d_partials, d_status, d_out48);
+    else hipLaunchKernelGGL((k_bucket_reduce2<C>), dim3(n), dim3(64), 0, s, pl.d_partials, d_status, d_out48);
     if (kt) kt->end(KT_REDUCE2, s);
 }
 

@@ -219,6 +219,52 @@ __device__ __forceinline__ void xadd_quad(G1X& a, const G1X& b_, const QuadRole&
     a = res;
 }
 
+// acc += (x2, y2), affine and not the identity: G1D::madd (madd-2008-s, 10 products) in four levels
+//   {X2 ZZ1, Y2 ZZZ1}, {P^2, R^2}, {P^3, X1 P^2, ZZ1 P^2}, {R (Q - X3), -Y1 P^3, ZZZ1 P^3}
+__device__ __forceinline__ void xmadd_quad(G1X& acc, const fp_t& x2_, const fp_t& y2_, const QuadRole& q) {
+    fp_t x2 = x2_, y2 = y2_;
+    if (G1D::is_inf(acc)) { G1D::from_affine(acc, x2, y2); return; }
+    G1D::opaque(acc);
+    Fp::opaque(x2);
+    Fp::opaque(y2);
+    fp_t oa, ob, M1, M2, M3, M4, U2, S2, Pd, Rd, PP, RR, PPP, Q, X3, t, nY;
+    Fp::select(oa, q.r0, x2, y2);
+    Fp::select(ob, q.r0, acc.zz, acc.zzz);
+    Fp::mul(M1, oa, ob);                      // lane 0: U2 = X2 ZZ1      lanes 1..3: S2 = Y2 ZZZ1
+    quad_bcast<0>(U2, M1);
+    quad_bcast<1>(S2, M1);
+    Fp::template sub<3>(Pd, U2, acc.x);       // U2 - X1 + 8p
+    Fp::template sub<2>(Rd, S2, acc.y);       // S2 - Y1 + 4p
+    if (Fp::template is_zero_mod<16>(Pd)) {
+        if (Fp::template is_zero_mod<16>(Rd)) G1D::dbl_affine(acc, x2, y2);
+        else G1D::set_inf(acc);
+        return;
+    }
+    G1D::opaque(acc);
+    Fp::opaque(Pd);
+    Fp::opaque(Rd);
+    Fp::select(oa, q.r0, Pd, Rd);
+    Fp::sqr(M2, oa);                          // lane 0: PP = P^2         lanes 1..3: R^2
+    quad_bcast<0>(PP, M2);
+    quad_bcast<1>(RR, M2);
+    quad_pick(oa, q, Pd, acc.x, acc.zz, acc.zz);
+    Fp::mul(M3, oa, PP);                      // PPP | Q = X1 PP | ZZ3 = ZZ1 PP | (again)
+    quad_bcast<0>(PPP, M3);
+    quad_bcast<1>(Q, M3);
+    Fp::template sub_b_2c<2>(X3, RR, PPP, Q); // R^2 - PPP - 2Q + 4p   (< 5.01p)
+    Fp::template sub<3>(t, Q, X3);            // Q - X3 + 8p
+    Fp::template neg<2>(nY, acc.y);           // 4p - Y1
+    quad_pick(oa, q, Rd, nY, acc.zzz, acc.zzz);
+    quad_pick(ob, q, t, PPP, PPP, PPP);
+    Fp::mul(M4, oa, ob);                      // R (Q - X3) | -Y1 PPP | ZZZ3 = ZZZ1 PPP | (again)
+    quad_bcast<0>(t, M4);
+    quad_bcast<1>(S2, M4);
+    Fp::add(acc.y, t, S2);
+    quad_bcast<2>(acc.zz, M3);
+    quad_bcast<2>(acc.zzz, M4);
+    acc.x = X3;
+}
+
 // ---- the same law on a PAIR of lanes (lanes 2i and 2i + 1): for calls with too many points for a quad each but room for two lanes --
 // 17 to 32 blobs in the 686 products of the FK20 network.  The seven products of a doubling go in four rounds
 //   {X^2 | Y^2}, {2Y Z | (2Y^2)^2}, {(3X^2)^2 | (X + 2Y^2)^2}, {3X^2 (D - X3)}

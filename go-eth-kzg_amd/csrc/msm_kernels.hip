@@ -280,12 +280,14 @@ __global__ void __launch_bounds__(1024) k_digits_sort(const uint8_t* __restrict_
 // kernel B: one lane per task: mixed additions of table rows into an XYZZ accumulator.  The
 // next table row is fetched while the current addition runs.
 // ------------------------------------------------------------------------------------------
-template <int C>
+// QUAD (calls of up to 4 blobs): a quad of lanes per task, g1_quad.hpp xmadd_quad -- the lanes walk runs of up to 64 entries
+template <int C, bool QUAD>
 __global__ void __launch_bounds__(256) k_bucket_accumulate(const uint32_t* __restrict__ table, const uint32_t* __restrict__ entries, const uint2* __restrict__ tasks,
                                                            const uint32_t* __restrict__ ntasks, uint32_t* __restrict__ parts) {
     using TG = TaskGeom<C>;
+    const QuadRole qr(threadIdx.x);
     const int b = blockIdx.y;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = (blockIdx.x * 256 + threadIdx.x) / (QUAD ? 4 : 1);
     if (i >= ntasks[b]) return;
     const uint2 d = tasks[(size_t)b * TG::MAXT + i];
     const uint32_t len = d.y & 0xffu, tid = d.y >> 8;
@@ -301,11 +303,13 @@ __global__ void __launch_bounds__(256) k_bucket_accumulate(const uint32_t* __res
         load_affine(pn, table + (size_t)(vn & 0x7fffffffu) * 32);
         if (!p.inf) {
             if (v >> 31) Fp::template neg<0>(p.y, p.y);     // p - y  (table rows are canonical)
-            g1x_madd(acc, p.x, p.y);
+            if constexpr (QUAD) xmadd_quad(acc, p.x, p.y, qr);
+            else g1x_madd(acc, p.x, p.y);
         }
         p = pn;
         v = vn;
     }
+    if (QUAD && (threadIdx.x & 3) != 0) return;
     store_xyzz(parts + ((size_t)b * TG::MAXT + tid) * 64, acc);
 }
 
@@ -894,7 +898,8 @@ static void launch_commit(const CommitPlan& pl, const uint8_t* d_scalars, size_t
     else hipLaunchKernelGGL((k_digits_sort<C, 1>), dim3(n), dim3(1024), 0, s, d_scalars, stride, pl.d_entries, pl.d_task_off, tasks, pl.d_ntasks, d_status);
     if (kt) kt->end(KT_DIGITS_SORT, s);
     if (kt) kt->begin(KT_BUCKET_ACC, s);
-    hipLaunchKernelGGL((k_bucket_accumulate<C>), dim3(TG::MAXT / 256, n), dim3(256), 0, s, pl.d_table, pl.d_entries, tasks, pl.d_ntasks, pl.d_parts);
+    if (n <= 4) hipLaunchKernelGGL((k_bucket_accumulate<C, true>), dim3(4 * TG::MAXT / 256, n), dim3(256), 0, s, pl.d_table, pl.d_entries, tasks, pl.d_ntasks, pl.d_parts);
+    else hipLaunchKernelGGL((k_bucket_accumulate<C, false>), dim3(TG::MAXT / 256, n), dim3(256), 0, s, pl.d_table, pl.d_entries, tasks, pl.d_ntasks, pl.d_parts);
     if (kt) kt->end(KT_BUCKET_ACC, s);
     constexpr int NCHUNK = RC::NBUCKET / CHUNK;
     if (kt) kt->begin(KT_REDUCE1, s);

@@ -496,7 +496,7 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
     # evaluation, one stream per call) and share hash launches (api_verify.hip hash_round_join).
     K = args.verify_inflight
     if world == 1 and K > 1:
-        reps = max(2, args.verify_steps)
+        reps = max(12, args.verify_steps)                # long enough to leave the ramp-up of the first hash rounds behind
         errs = []
 
         def caller(k):

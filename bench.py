@@ -15,6 +15,9 @@ verifiers are the part of the path with an exchange step: one global batch shard
 of r, all_gather of one 512-byte record per rank (go-eth-kzg_amd/distributed.py).
 
 The JSON line also carries
+  repeats      : the timed region run five times in all (the first one is `value`): min / median / max of ms per step;
+  multi_gpu    : (N > 1) ranks, the PCI bus ids of the GPUs they run on, the cost of the verifiers' exchange step alone, and a
+                 STRONG-scaling figure for both batch verifiers (one fixed global batch of 8192 blobs / 65,536 cells cut over the ranks);
   roofline     : dominant kernel (k_commit_direct_acc; k_bucket_accumulate with --direct-bits 0) -- algorithmic bytes per launch
                  (131,120 B per blob) / its average duration measured with
                  hipEvents on the launch stream inside the timed region, against 8 TB/s HBM;
@@ -23,6 +26,8 @@ The JSON line also carries
   drop_in      : what a caller of the reference API gets -- host pointers in, host bytes out (PCIe inclusive; never `value`);
   verify_blob_kzg_proof_batch : configs[2], single-call latency and sustained rate with several calls in flight;
   eip7594      : configs[3] and configs[4] (cells + proofs, cell batch verification, recovery);
+                 every leg carries its own `roofline` (dominant kernel of the leg, algorithmic bytes of SURVEY.md 8d) and `valu`
+                 (wave-instructions per second of each kernel against the hardware issue limit) objects;
   cpu_baseline : the plain-C oracle (oracle/, "port") timed on the host cores this process may use, bounded sample.
 torch is used for device memory, streams and torch.distributed only.
 """
@@ -90,8 +95,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="blobs per GPU per step (configs[1]: 256)")
     ap.add_argument("--window", type=int, default=0, help="MSM window bits override (11..13)")
-    ap.add_argument("--direct-bits", type=int, default=15,
-                    help="commit_direct_bits option: 0 = bucket method (0.5 GB table), 12..15 = direct window table (15: 146 GB of the 288 GB HBM)")
+    ap.add_argument("--direct-bits", type=int, default=-1,
+                    help="commit_direct_bits option: -1 = the library's default (widest direct window table that leaves 40 GB of free HBM: 15 bits = 146 GB on an empty MI355X), "
+                         "0 = bucket method (10.5 MB table), 12..15 = that width")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the first is `value`, all are reported (min / median / max)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling legs of the two batch verifiers (8192 blobs / 65,536 cells in all)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate over (1 = strictly serial steps)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents (roofline section is then empty)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,7 +120,7 @@ def spawn_ranks(args):
     s.close()
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out, _ = procs[0].communicate()
@@ -132,25 +140,35 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # test aids for a 1-GPU box (never set by the driver): run the N > 1 code path with all ranks on GPU 0 over gloo
+    # test aids for a 1-GPU box (never set by the driver): run the N > 1 code path with all ranks on GPU 0 over gloo (BENCH_SHARE_GPU,
+    # BENCH_DIST_BACKEND); run the exchange steps on real RCCL with ONE rank (BENCH_FORCE_DIST: the process group is created although
+    # the world is 1, and the batch verifiers take the sharded route -- broadcast and all_gather on device tensors over "nccl")
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    if os.environ.get("BENCH_SHARE_GPU"):
+    shared_gpu = bool(os.environ.get("BENCH_SHARE_GPU"))
+    if shared_gpu:
         local_rank = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))        # the library sizes its host pool by the ranks that share the node
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), world_size=world, rank=rank)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, world_size=world, rank=rank)
+    dist_dev = (torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")) if dist_on else None
 
     kzg = load_product()
     ctx = kzg.Context(device=local_rank)
     if args.window:
         assert ctx.set_option("msm_window", args.window) == 0
     assert ctx.set_option("max_batch", args.batch) == 0
+    if shared_gpu and world > 2:
+        # test aid only: eight ranks' tables do not fit ONE GPU's HBM -- bucket method and the smallest FK20 table for every rank
+        args.direct_bits, args.fk20_bits = 0, 8
     B = args.batch
 
     # synthetic inputs of the reference benches, distinct seeds per rank, resident in HBM
@@ -162,22 +180,25 @@ def main():
     drop_in = {}
     d_ref = None
     if args.direct_bits:
-        # untimed cross-check material: the same batch through the bucket method (the two methods share no kernel) -- and, while the
-        # context still runs with the library's default options, what a host-pointer caller gets from those
+        # untimed cross-check material: the same batch through the bucket method (the two methods share no kernel) -- and what a
+        # host-pointer caller gets from it
+        assert ctx.set_option("commit_direct_bits", 0) == 0
         d_ref = torch.zeros(B * 48, dtype=torch.uint8, device="cuda")
         d_ref_st = torch.zeros(B, dtype=torch.int32, device="cuda")
         assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), B, d_ref.data_ptr(), d_ref_st.data_ptr(), 0) == 0
         torch.cuda.synchronize()
         if rank == 0 and not args.no_drop_in:
-            drop_in["default_options_bucket_method"] = bench_drop_in(ctx, kzg, host_blobs, d_ref)
-        assert ctx.set_option("commit_direct_bits", args.direct_bits) == 0
+            drop_in["bucket_method"] = bench_drop_in(ctx, kzg, host_blobs, d_ref)
+    assert ctx.set_option("commit_direct_bits", args.direct_bits) == 0
+    requested_bits = args.direct_bits
+    if args.direct_bits:
         probe = torch.zeros(48, dtype=torch.uint8, device="cuda")
         probe_st = torch.zeros(1, dtype=torch.int32, device="cuda")
         rc = ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), 1, probe.data_ptr(), probe_st.data_ptr(), 0)      # builds the table (or degrades)
         torch.cuda.synchronize()
         assert rc == 0, rc
         eff = ctx.get_option("commit_direct_bits_effective")
-        if eff != args.direct_bits:
+        if args.direct_bits > 0 and eff != args.direct_bits:
             print(f"bench.py: direct table with {args.direct_bits} bits unavailable on this box, the library degraded to {eff or 'the bucket method'}", file=sys.stderr)
         args.direct_bits = eff
     # consecutive steps alternate between two HIP streams (each with its own output buffers): every call works in its own lane of the
@@ -197,6 +218,27 @@ def main():
         if rc:
             raise RuntimeError(f"mkzg_blob_to_kzg_commitment_batch_device rc={rc}")
 
+    def timed_region():
+        """EXACTLY --steps steps between barrier + synchronize on both sides; the MAX over ranks"""
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist_on:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            if backend != "nccl":
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     # priming (always, untimed, not counted as warmup): calls with the profiler on, so that lazily built workspaces of every lane,
     # events and first-launch costs never land in the timed region even with --warmup 0
     ctx.profile_enable(not args.no_profile)
@@ -208,22 +250,10 @@ def main():
         step()
     torch.cuda.synchronize()
     ctx.profile_read(reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_region()                                  # THE timed region: `value` comes from this one
     prof = ctx.profile_read(reset=True)
+    region_s = [elapsed] + [timed_region() for _ in range(max(0, args.repeats - 1))]
+    ctx.profile_read(reset=True)
     ctx.profile_enable(False)
     assert all(int(t.abs().sum().item()) == 0 for t in d_stats), "some blobs were rejected"
     if NS > 1 and args.steps + args.warmup >= 2:
@@ -244,16 +274,19 @@ def main():
         ctx.profile_enable(False)
         calib = ctx.valu_calibrate()
     if rank == 0 and not args.no_drop_in:
-        key = f"direct_table_c{args.direct_bits}" if args.direct_bits else "bucket_method"
-        if key != "bucket_method" or not drop_in:
+        key = ("default_options" if requested_bits < 0 else "direct_table") + (f"_c{args.direct_bits}" if args.direct_bits else "_bucket_method")
+        if args.direct_bits or not drop_in:
             drop_in[key] = bench_drop_in(ctx, kzg, host_blobs, d_outs[0])
 
+    props = torch.cuda.get_device_properties(local_rank)
+    hw = hw_limits(props)
+    multi = multi_gpu_info(torch, dist, dist_on, world, rank, local_rank, backend, dist_dev, props, ctx) if dist_on else None
     verify = None
     if args.verify_batch > 0:
-        verify = bench_verify(ctx, torch, dist, world, rank, args, d_blobs, B)
+        verify = bench_verify(ctx, torch, dist, dist_on, dist_dev, world, rank, args, d_blobs, B, hw)
     eip7594 = None
     if args.cell_blobs > 0:
-        eip7594 = bench_eip7594(ctx, kzg, torch, dist, world, rank, args)
+        eip7594 = bench_eip7594(ctx, kzg, torch, dist, dist_on, dist_dev, world, rank, args, hw)
 
     if rank == 0:
         total_blobs = B * world * args.steps
@@ -287,28 +320,34 @@ def main():
                     scale *= -(-255 // args.direct_bits) / 17.0
                 insts = pmc["valu_wave_insts"] * scale
                 iso_ms = iso[0] / iso[1]
-                props = torch.cuda.get_device_properties(local_rank)
-                clk_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
-                peak_hw = props.multi_processor_count * 4 * clk_hz / 4.0
+                peak_hw = hw["valu_peak"]
                 rate_iso = insts / (iso_ms * 1e-3)
                 rate_timed = insts / (elapsed / args.steps)
                 valu = {"kernel": dom, "wave_insts_per_launch": insts, "unit": "G wave-instr/s",
                         "isolated_kernel_ms": round(iso_ms, 4), "achieved_isolated": round(rate_iso / 1e9, 2),
                         "achieved_timed_region": round(rate_timed / 1e9, 2),
-                        "peak_hw": round(peak_hw / 1e9, 1), "peak_hw_note": f"{props.multi_processor_count} CUs x 4 SIMDs x {clk_hz / 1e9:.2f} GHz / 4 cycles per wave64 instruction",
+                        "peak_hw": round(peak_hw / 1e9, 1), "peak_hw_note": hw["note"],
                         "frac_hw_isolated": round(rate_iso / peak_hw, 4), "frac_hw_timed_region": round(rate_timed / peak_hw, 4),
                         "calibrated_mad_rate": round(calib / 1e9, 2) if calib else None,
                         "calibration_note": "v_mad_u64_u32 only, 2 wavefronts per SIMD, measured in this run: what this GPU's clock under load allows for the slowest-issuing instruction of the mix; not a ceiling",
                         "pmc_source": pmc.get("source_file")}
+        ms_steps = sorted(r / args.steps * 1e3 for r in region_s)
         out = {
             "metric": "blobs/sec BlobToKZGCommitment (batch=256 per GPU)", "value": round(value, 2), "unit": "blobs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "dtype_note": "381-bit Montgomery field elements as 14 x 29-bit limbs in u32, 64-bit column accumulators (v_mad_u64_u32)",
             "data": "synthetic (GetRandBlob seeds, reference bench_test.go:17-46)",
             "config": {"workload": "configs[1]: BlobToKZGCommitment batch=256 blobs x 4096 scalars per GPU, fixed-base G1 MSM",
-                       "batch_per_gpu": B, "msm": (f"direct window table c={args.direct_bits}" if args.direct_bits else f"bucket method c={args.window or 13}"), "parallelism": f"blob-sharded x{world}, no collective", "streams": NS},
+                       "batch_per_gpu": B, "msm": (f"direct window table c={args.direct_bits}" + (" (library default: auto-sized)" if requested_bits < 0 else "") if args.direct_bits else f"bucket method c={args.window or 13}"),
+                       "parallelism": f"blob-sharded x{world}, no collective", "streams": NS},
+            "repeats": {"regions": len(region_s), "steps_each": args.steps, "ms_per_step_each": [round(r / args.steps * 1e3, 3) for r in region_s],
+                        "ms_per_step_min": round(ms_steps[0], 3), "ms_per_step_median": round(ms_steps[len(ms_steps) // 2], 3), "ms_per_step_max": round(ms_steps[-1], 3),
+                        "blobs_per_s_median": round(B * world / (ms_steps[len(ms_steps) // 2] * 1e-3), 1),
+                        "note": "`value` is the first region (the contract's K steps); the others repeat it back to back"},
             "roofline": roofline, "valu": valu,
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if drop_in:
             out["drop_in"] = drop_in
         if verify is not None:
@@ -318,10 +357,89 @@ def main():
         if not args.no_cpu_baseline and world == 1:        # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def hw_limits(props):
+    """the hardware's VALU issue limit: one wave64 instruction per SIMD per 4 cycles at the device's maximum clock"""
+    clk_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+    return {"valu_peak": props.multi_processor_count * 4 * clk_hz / 4.0,
+            "note": f"{props.multi_processor_count} CUs x 4 SIMDs x {clk_hz / 1e9:.2f} GHz / 4 cycles per wave64 instruction"}
+
+
+# profile kinds of mkzg_profile_read that bracket several kernels -> the kernels (x launches per call) whose PMC figures add up to them
+KIND_KERNELS = {
+    "k_fk20_ffts": {"k_fk20_pre": 3, "k_fk20_toom_mul": 1, "k_fk20_post": 3, "k_fk20_finish": 1},
+    "k_fk20_msm": {"k_fk20_msm": 1, "k_fk20_msm_reduce": 1},
+    "k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_combine": 1},
+    "k_cell_verify_scalars": {"k_cell_rpowers": 1, "k_cell_weights": 1, "k_cell_interp": 1, "k_cell_interp_reduce": 1},
+    "k_recover_*": {"k_recover_vanishing": 1, "k_recover_stage_a": 1, "k_recover_stage_b1": 1, "k_recover_stage_c": 1, "k_recover_stage_d": 1},
+}
+
+
+def leg_roofline(kern_ms, algo_bytes, hw, pmc_valid_for_size=True):
+    """`roofline` + `valu` objects of one leg.  kern_ms: {profile kind: ms per call}; algo_bytes: SURVEY.md 8(d)'s algorithmic bytes of
+    one call.  The dominant kernel is the kind with the largest duration.  PMC figures (HBM-side traffic, VALU wave-instructions per
+    launch) come from the committed rocprofv3 passes and are used only while the kernel sources they were collected on are unchanged
+    and the leg runs at the size they were collected at."""
+    if not kern_ms:
+        return None, None
+    dom, dom_ms = max(kern_ms.items(), key=lambda kv: kv[1])
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+            "traffic": None, "avg_kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_call": algo_bytes}
+    valu = {"unit": "G wave-instr/s", "peak_hw": round(hw["valu_peak"] / 1e9, 1), "peak_hw_note": hw["note"], "kernels": {}}
+    stale = None
+    for kind, ms in kern_ms.items():
+        parts = KIND_KERNELS.get(kind, {kind: 1})
+        insts, traffic, src, ok = 0.0, 0.0, None, pmc_valid_for_size
+        for kname, mult in parts.items():
+            pm = pmc_profile(kname)
+            if pm.get("stale"):
+                stale = pm["stale"]
+            if not pm.get("valu_wave_insts"):
+                ok = False
+                break
+            insts += pm["valu_wave_insts"] * mult
+            traffic += pm.get("traffic_bytes", 0.0) * mult
+            src = pm.get("source_file")
+        if not ok or ms <= 0:
+            continue
+        rate = insts / (ms * 1e-3)
+        valu["kernels"][kind] = {"wave_insts_per_call": round(insts), "ms": round(ms, 4), "achieved": round(rate / 1e9, 2), "frac_hw": round(rate / hw["valu_peak"], 4),
+                                 "traffic_bytes": round(traffic), "pmc_source": src}
+        if kind == dom:
+            roof["traffic"] = round(traffic)
+            roof["traffic_over_algorithmic"] = round(traffic / algo_bytes, 2)
+    if not valu["kernels"]:
+        valu["note"] = stale or ("no committed PMC pass covers this leg at this size" if not pmc_valid_for_size else "no committed PMC pass covers these kernels")
+        roof["traffic_note"] = valu["note"]
+    return roof, valu
+
+
+def multi_gpu_info(torch, dist, dist_on, world, rank, local_rank, backend, dev, props, ctx):
+    """who the ranks are (proof of N distinct GPUs), what the library's host pools add up to, and what the batch verifiers' exchange
+    step costs on its own: all_gather of the shard sizes, broadcast of r, all_gather of one 512-byte record per rank
+    (go-eth-kzg_amd/distributed.py) -- timed alone, between barriers, over 20 repetitions"""
+    D = load_distributed()
+    bus = getattr(props, "pci_bus_id", None)
+    ident = {"rank": rank, "local_rank": local_rank, "device": props.name,
+             "pci": (f"{getattr(props, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(props, 'pci_device_id', 0):02x}" if bus is not None else None),
+             "uuid": str(getattr(props, "uuid", "")) or None, "host_threads": ctx.get_option("host_threads")}
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    ex = D.measure_exchange(dist, dev, reps=20)
+    t = torch.tensor([ex["exchange_us"], ex["broadcast_us"], ex["all_gather_sizes_us"], ex["all_gather_records_us"]], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    pcis = [i["pci"] or i["uuid"] for i in idents]
+    return {"ranks": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend), "rank_gpus": idents, "distinct_gpus": len(set(pcis)),
+            "host_threads_total": sum(i["host_threads"] or 0 for i in idents), "usable_cpus": usable_cpus(),
+            "exchange_us": round(float(t[0]), 1), "exchange_breakdown_us": {"broadcast_r_32B": round(float(t[1]), 1), "all_gather_shard_sizes": round(float(t[2]), 1),
+                                                                           "all_gather_records_512B": round(float(t[3]), 1)},
+            "exchange_note": "max over ranks of the mean of 20 repetitions, tensors on " + ("the GPUs over RCCL" if backend == "nccl" else "the host over " + backend)}
 
 
 def source_hash(files):
@@ -397,7 +515,7 @@ def bench_drop_in(ctx, kzg, host_blobs, d_expect):
             "note": "PCIe inclusive: pageable host blobs in (gathered into pinned staging chunk by chunk), host bytes out"}
 
 
-def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
+def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, B, hw):
     """configs[2]: VerifyBlobKZGProofBatch on N synthetic (blob, commitment, proof) triples per GPU.
     Commitments and proofs are produced on the device by the product itself; one corrupted run
     must be rejected."""
@@ -426,12 +544,18 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
     d_bad = d_pr.clone()
     d_bad[0:48] = d_pr[48:96]
     assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_bad.data_ptr(), N, st) == 1, "corrupted batch accepted"
-    D = load_distributed() if world > 1 else None
-    eng = D.ProductEngine(ctx) if world > 1 else None
-    dev = (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")) if world > 1 else None
+    D = load_distributed() if dist_on else None
+    eng = D.ProductEngine(ctx) if dist_on else None
+
+    def maxed(dt):
+        if not dist_on:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def one_call():
-        if world > 1:
+        if dist_on:
             # one global batch of N * world proofs, sharded: broadcast r, fold locally, all-gather 512-byte records
             # over RCCL, finish with one pairing (go-eth-kzg_amd/distributed.py)
             return D.verify_blob_kzg_proof_batch_sharded(eng, (d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st), N * world, dist, dev)
@@ -443,7 +567,7 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
     assert one_call() == 0
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -455,26 +579,51 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
         each.append(round((time.perf_counter() - tc) * 1e3, 3))
         host_us += ctx.last_host_finish_us()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = maxed(time.perf_counter() - t0)
     ms = dt / args.verify_steps * 1e3
     kern = {k: round(v[0], 4) for k, v in prof.items() if v[1]}
-    dom = max(kern.items(), key=lambda kv: kv[1])
     algo = (131072 + 48 + 48) * N          # bytes read per blob
-    pm = pmc_profile(dom[0]) if N == 1024 else {}
+    roof, valu = leg_roofline(kern, algo, hw, pmc_valid_for_size=(N == 1024))
     out = {"metric": "blobs/sec VerifyBlobKZGProofBatch", "batch_per_gpu": N, "unit": "blobs/s",
            "single_call": {"blobs_per_s": round(N * world / dt * args.verify_steps, 2), "ms_per_call": round(ms, 3), "host_finish_ms": round(host_us / args.verify_steps / 1e3, 3), "ms_each_call": each,
-                           "parallelism": "one call at a time" if world == 1 else f"one global batch of {N * world} sharded x{world}; RCCL broadcast(r) + all_gather(512 B records)"},
+                           "parallelism": "one call at a time" if not dist_on else f"one global batch of {N * world} sharded x{world}; RCCL broadcast(r) + all_gather(512 B records)"},
            "compute_blob_kzg_proof_batch_proofs_per_s": round(proofs_per_s, 1),
            "kernels_ms_per_call": kern,
-           "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": round(algo / (dom[1] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(algo / (dom[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": pm.get("traffic_bytes")}}
-    if world == 1:
+           "roofline": roof, "valu": valu}
+    if dist_on and not args.no_strong:
+        # STRONG scaling: one fixed global batch of 8192 proofs whatever the number of ranks -- rank r folds 8192 / world of them (its own
+        # N distinct triples, repeated to fill its shard), one exchange, one pairing.  The driver sets the per-N values side by side.
+        G = 8192
+        lo, hi = D.shard_bounds(G, world, rank)
+        m = hi - lo
+        reps_t = -(-m // N)
+        sb = d_blobs.view(N, BLOB).repeat(reps_t, 1)[:m].contiguous()
+        sc = d_cm.view(N, 48).repeat(reps_t, 1)[:m].contiguous()
+        sp = d_pr.view(N, 48).repeat(reps_t, 1)[:m].contiguous()
+        spb = sp.clone()
+        if rank == world - 1:
+            spb[m - 1] = sc[m - 1]                       # the last proof of the batch replaced by a valid point that is not the proof
+        torch.cuda.synchronize()
+
+        def strong_call(proofs):
+            return D.verify_blob_kzg_proof_batch_sharded(eng, (sb.data_ptr(), sc.data_ptr(), proofs.data_ptr(), m, st), G, dist, dev)
+
+        assert strong_call(sp) == 0
+        assert strong_call(spb) == 1, "a wrong proof in the last shard went unnoticed"
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.verify_steps):
+            assert strong_call(sp) == 0
+        dist.barrier()
+        dts = maxed(time.perf_counter() - t0) / args.verify_steps
+        out["strong_scaling"] = {"global_batch": G, "per_rank": m, "ranks": world, "ms_per_call": round(dts * 1e3, 3), "blobs_per_s": round(G / dts, 1),
+                                 "note": f"one global batch of {G} proofs cut over {world} rank(s) ({N} distinct triples per rank, repeated to fill its shard); "
+                                         "broadcast(r) + all_gather(sizes) + all_gather(512 B records), one pairing on every rank"}
+        del sb, sc, sp, spb
+    if world == 1 and not dist_on:
         # the reference's own API shape at the sizes a block carries: host pointers in (Go's []*Blob), one synchronous caller
         hb = d_blobs[: min(N, 48) * BLOB].cpu().numpy().tobytes()
         hcm, hpr = d_cm.cpu().numpy().tobytes(), d_pr.cpu().numpy().tobytes()
@@ -495,7 +644,7 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
     # shared by goroutines).  Each call works in its own lane; calls that find others in flight take the throughput shape (barycentric
     # evaluation, one stream per call) and share hash launches (api_verify.hip hash_round_join).
     K = args.verify_inflight
-    if world == 1 and K > 1:
+    if world == 1 and not dist_on and K > 1:
         reps = max(12, args.verify_steps)                # long enough to leave the ramp-up of the first hash rounds behind
         errs = []
 
@@ -527,12 +676,22 @@ def bench_verify(ctx, torch, dist, world, rank, args, d_blobs256, B):
     return out
 
 
-def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
+def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
     """configs[3] (ComputeCellsAndKZGProofs, FK20) and configs[4] (VerifyCellKZGProofBatch over NB x 128 cells per GPU -- one global batch
     sharded over the ranks with one exchange step -- and RecoverCellsAndComputeKZGProofs of NB blobs per GPU from their even cells,
     sharded by blob with no collective).  SURVEY.md 8d: seeds 0..63, blob-major tuples, even-indexed cells."""
     NB = args.cell_blobs
+    solo = world == 1 and not dist_on
+    full_size = NB == 64                    # the committed PMC passes were collected at 64 blobs / 8192 cells
     assert ctx.set_option("fk20_bits", args.fk20_bits) == 0
+
+    def maxed(dt):
+        if not dist_on:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     blobs = [rand_blob(rank * NB + s) for s in range(NB)]
     d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
     d_cells = torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda")
@@ -554,10 +713,12 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile_read(reset=True)
+    kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
+    roof, valu = leg_roofline(kern, 399360 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 11)
     out["compute_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "fk20_table_bits": ctx.get_option("fk20_bits_effective"), "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s_per_gpu": round(NB / dt, 1),
-                                           "kernels_ms": {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3)}
+                                           "kernels_ms": kern, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3), "roofline": roof, "valu": valu}
     ctx.profile_enable(False)
-    if world == 1:
+    if solo:
         # the sizes a block carries (6 blobs today, up to 48 planned): one synchronous caller, ms per call
         by_batch = {}
         for nb in (1, 6, 9, 16, 32, 48):
@@ -619,44 +780,72 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
     idx = (ctypes.c_uint64 * n)(*[i % 128 for i in range(n)])
     cj = b"".join(cms[48 * (i // 128):48 * (i // 128) + 48] for i in range(n))
     L = kzg.lib()
-    if world > 1:
-        D = load_distributed()
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    D = load_distributed() if dist_on else None
 
-        class RawCellEngine:
-            def cell_partial(self, shard, offset, r32):
-                rec = ctypes.create_string_buffer(512)
-                rc = L.mkzg_verify_cell_kzg_proof_batch_partial(ctx._h, cj, n, idx, n, arr, n, proofs, n, offset, bytes(r32), rec)
-                return rc, rec.raw
+    class RawCellEngine:
+        """C-ABI calls on pre-marshalled arguments; `shard` = (commitments, indices, cell pointer array, proofs, count)"""
 
-            def cell_finish(self, records):
-                return L.mkzg_verify_cell_kzg_proof_batch_finish(ctx._h, b"".join(records), len(records))
+        def cell_partial(self, shard, offset, r32):
+            c_, i_, a_, p_, m_ = shard
+            rec = ctypes.create_string_buffer(512)
+            rc = L.mkzg_verify_cell_kzg_proof_batch_partial(ctx._h, c_, m_, i_, m_, a_, m_, p_, m_, offset, bytes(r32), rec)
+            return rc, rec.raw
 
+        def cell_finish(self, records):
+            return L.mkzg_verify_cell_kzg_proof_batch_finish(ctx._h, b"".join(records), len(records))
+
+    if dist_on:
         def verify_once():
-            return D.verify_cell_kzg_proof_batch_sharded(RawCellEngine(), None, n * world, dist, dev, n_local=n)
+            return D.verify_cell_kzg_proof_batch_sharded(RawCellEngine(), (cj, idx, arr, proofs, n), n * world, dist, dev, n_local=n)
     else:
         def verify_once():
             return L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, proofs, n)
     assert verify_once() == 0
     ctx.profile_read(reset=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         assert verify_once() == 0
-    if world > 1:
+    if dist_on:
         dist.barrier()
-    dt = (time.perf_counter() - t0) / steps
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = maxed((time.perf_counter() - t0) / steps)
     prof = ctx.profile_read(reset=True)
+    kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
+    roof, valu = leg_roofline(kern, 2152 * n, hw, pmc_valid_for_size=full_size)
     out["verify_cell_kzg_proof_batch"] = {"cells_per_gpu": n, "cells_total": n * world, "ms_per_call": round(dt * 1e3, 3), "cells_per_s": round(n * world / dt, 1),
-                                          "parallelism": "one call" if world == 1 else f"one global batch sharded x{world}; broadcast(r) + all_gather(512 B records)",
-                                          "kernels_ms": {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]},
+                                          "parallelism": "one call" if not dist_on else f"one global batch sharded x{world}; broadcast(r) + all_gather(512 B records)",
+                                          "kernels_ms": kern, "roofline": roof, "valu": valu,
                                           "note": "host pointers in (16 MiB of cells per 8192 gathered and uploaded inside the call)"}
-    if world == 1:
+    if dist_on and not args.no_strong:
+        # STRONG scaling: one fixed global batch of 65,536 cells (512 blobs' worth) whatever the number of ranks; a rank's shard is its
+        # own NB x 128 tuples repeated to fill 65,536 / world (pointers into the same host cells: nothing is copied)
+        G = 65536
+        lo, hi = D.shard_bounds(G, world, rank)
+        m = hi - lo
+        reps_t = -(-m // n)
+        arr_s = (ctypes.c_char_p * m)(*([ctypes.cast(k, ctypes.c_char_p) for k in keep] * reps_t)[:m])
+        idx_s = (ctypes.c_uint64 * m)(*([i % 128 for i in range(n)] * reps_t)[:m])
+        cj_s = (cj * reps_t)[:48 * m]
+        pr_s = (proofs * reps_t)[:48 * m]
+        pr_bad = pr_s[:48 * (m - 1)] + cj_s[48 * (m - 1):48 * m] if rank == world - 1 else pr_s      # last proof := a valid point that is not the proof
+
+        def strong_call(pr):
+            return D.verify_cell_kzg_proof_batch_sharded(RawCellEngine(), (cj_s, idx_s, arr_s, pr, m), G, dist, dev, n_local=m)
+
+        assert strong_call(pr_s) == 0
+        assert strong_call(pr_bad) == 1, "a wrong proof in the last shard went unnoticed"
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            assert strong_call(pr_s) == 0
+        dist.barrier()
+        dts = maxed((time.perf_counter() - t0) / steps)
+        out["verify_cell_kzg_proof_batch"]["strong_scaling"] = {
+            "global_batch": G, "per_rank": m, "ranks": world, "ms_per_call": round(dts * 1e3, 3), "cells_per_s": round(G / dts, 1),
+            "note": f"one global batch of {G} cells cut over {world} rank(s) ({n} distinct tuples per rank, repeated to fill its shard); broadcast(r) + all_gather(sizes) + all_gather(512 B records)"}
+        ctx.profile_read(reset=True)
+    if solo:
         # sustained: six caller threads on the shared context, each also submitting one batch with a wrong proof that must be rejected
         ctx.profile_enable(False)
         badp = bytearray(proofs)
@@ -687,30 +876,39 @@ def bench_eip7594(ctx, kzg, torch, dist, world, rank, args):
         out["verify_cell_kzg_proof_batch"]["sustained"] = {"callers": KV, "calls": KV * (reps + 1), "cells_per_s": round(KV * (reps + 1) * n / dtk, 1),
                                                            "ms_per_call_amortised": round(dtk / (KV * (reps + 1)) * 1e3, 3)}
         ctx.profile_enable(True)
-    # recovery: every blob of this rank from its 64 even-indexed cells, one batch call (sharded by blob, no collective)
+    # recovery: every blob of this rank from its 64 even-indexed cells, one batch call (sharded by blob, no collective) at the C ABI
+    # with the arguments marshalled ONCE, as a cgo caller holds them (api_eip7594.go:144: []uint64 + []*Cell per blob)
     ids = list(range(0, 128, 2))
-    cell_list = [cells[i * 2048:(i + 1) * 2048] for i in range(n)]
-    jobs = [(ids, [cell_list[b * 128 + i] for i in ids]) for b in range(NB)]
-    rc, res = ctx.RecoverCellsAndComputeKZGProofsBatch(jobs)
-    assert rc == 0 and all(s == 0 for s, _, _ in res)
-    assert b"".join(res[NB - 1][1]) == cells[(NB - 1) * 262144:NB * 262144] and b"".join(res[0][2]) == proofs[:6144]
+    id_arr = (ctypes.c_uint64 * 64)(*ids)
+    cell_arrs = [(ctypes.c_char_p * 64)(*[ctypes.cast(keep[b * 128 + i], ctypes.c_char_p) for i in ids]) for b in range(NB)]
+    pid = (ctypes.POINTER(ctypes.c_uint64) * NB)(*[ctypes.cast(id_arr, ctypes.POINTER(ctypes.c_uint64)) for _ in range(NB)])
+    pcl = (ctypes.POINTER(ctypes.c_char_p) * NB)(*[ctypes.cast(a, ctypes.POINTER(ctypes.c_char_p)) for a in cell_arrs])
+    nid = (ctypes.c_size_t * NB)(*[64] * NB)
+    oc = ctypes.create_string_buffer(NB * 262144)
+    op = ctypes.create_string_buffer(NB * 6144)
+    rst = (ctypes.c_int32 * NB)()
+
+    def recover_once():
+        return L.mkzg_recover_cells_and_kzg_proofs_batch(ctx._h, NB, pid, nid, pcl, nid, oc, op, rst)
+
+    assert recover_once() == 0 and not any(rst)
+    assert oc.raw == cells and op.raw == proofs, "recovered cells / proofs differ from the encoder's"
     ctx.profile_read(reset=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        ctx.RecoverCellsAndComputeKZGProofsBatch(jobs)
-    if world > 1:
+        assert recover_once() == 0
+    if dist_on:
         dist.barrier()
-    dt = (time.perf_counter() - t0) / steps
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = maxed((time.perf_counter() - t0) / steps)
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
-    out["recover_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "ms_per_batch_incl_python_marshalling": round(dt * 1e3, 3), "blobs_per_s": round(NB * world / dt, 1),
-                                           "parallelism": f"blob-sharded x{world}, no collective", "kernels_ms": {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}}
+    kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
+    roof, valu = leg_roofline(kern, 399872 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 11)
+    out["recover_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s": round(NB * world / dt, 1),
+                                           "parallelism": f"blob-sharded x{world}, no collective", "kernels_ms": kern, "roofline": roof, "valu": valu,
+                                           "note": "C ABI, arguments marshalled once: 64 scattered host cells in per blob, 128 cells + 128 proofs out to host memory (PCIe inclusive)"}
     return out
 
 

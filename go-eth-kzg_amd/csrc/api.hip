@@ -134,7 +134,7 @@ Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
             Lane* idle = nullptr;
             Lane* warm = nullptr;
             Lane* cold = nullptr;
-            for (int i = 0; i < mkzg_ctx::NLANE; i++) {
+            for (int i = 0; i < c->opt_lanes; i++) {
                 Lane* q = &c->lanes[i];
                 if (q->busy) continue;
                 if (!q->warm) { if (!cold) cold = q; continue; }
@@ -151,7 +151,6 @@ Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
         L->warm = true;
         c->lanes_busy.fetch_add(1, std::memory_order_relaxed);
     }
-    (void)hipSetDevice(c->device);
     L->failed = false;
     L->drained = false;
     tl_hip_error = false;
@@ -193,7 +192,7 @@ void lanes_quiesce(mkzg_ctx* c) {
             c->lanes[i].busy = true;
         }
     }
-    (void)hipSetDevice(c->device);
+    DeviceScope dev(c->device);
     (void)hipDeviceSynchronize();
 }
 void lanes_resume(mkzg_ctx* c) {
@@ -218,6 +217,7 @@ int pointer_device(const void* p) {
 int ensure_commit_table(mkzg_ctx* c) {
     std::lock_guard<std::mutex> g(c->init_mu);
     if (c->d_commit_table && c->commit_table_c == c->opt_c) return MKZG_OK;
+    DeviceScope dev(c->device);
     CommitPlanSizes sz;
     commit_plan_sizes(c->opt_c, 1, &sz);
     c->commit_table_c = 0;
@@ -237,6 +237,7 @@ int ensure_direct(mkzg_ctx* c) {
     std::lock_guard<std::mutex> g(c->init_mu);
     if (c->opt_direct_bits == 0 || c->direct_failed) return MKZG_OK;
     if (c->d_direct && c->direct_bits_built) return MKZG_OK;
+    DeviceScope dev(c->device);
     int want = c->opt_direct_bits;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
@@ -400,25 +401,25 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
     // gather tasks: TPC per chunk, queued in chunk order
     const int TPC = n >= 8 ? 4 : 1;
     const int ntask = (int)plan.size() * TPC;
-    std::vector<std::atomic<int>> left(plan.size());
-    for (auto& a : left) a.store(TPC, std::memory_order_relaxed);
-    std::atomic<int> all_left(ntask);
+    std::vector<Countdown> left(plan.size());
+    for (auto& a : left) a.set(TPC);
+    Countdown all_left(ntask);
     const std::function<void(int)> gather = [&](int t) {
         const Chunk& ch = plan[(size_t)(t / TPC)];
         const int q = t % TPC;
         const size_t per = (ch.m + TPC - 1) / TPC;
         for (size_t i = ch.lo + (size_t)q * per; i < std::min(ch.lo + ch.m, ch.lo + (size_t)(q + 1) * per); i++) memcpy(L->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB);
-        left[(size_t)(t / TPC)].fetch_sub(1, std::memory_order_release);
+        left[(size_t)(t / TPC)].arrive();
     };
     c->pool->run_async(ntask, gather, &all_left);
     // every exit path below must wait for the gather tasks: they reference this frame
-    auto drain = [&] { while (all_left.load(std::memory_order_acquire) != 0) std::this_thread::yield(); };
+    auto drain = [&] { c->pool->wait(all_left); };
     rc = [&]() -> int {
         HIPCHK(hipEventRecord(L->ev_fork, L->stream));
         if (!zc) HIPCHK(hipStreamWaitEvent(copy, L->ev_fork, 0));           // every stream of the call inherits the lane hand-over
         for (size_t k = 0; k < plan.size(); k++) {
             const size_t lo = plan[k].lo, m = plan[k].m;
-            while (left[k].load(std::memory_order_acquire) != 0) std::this_thread::yield();
+            c->pool->wait(left[k]);              // runs queued gather tasks itself while there are any
             if (!zc) HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, m * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, copy));
             if (direct) {
                 const int q = (int)(k & 3);
@@ -471,8 +472,8 @@ int mkzg_valu_calibrate(mkzg_ctx* c, double* wave_instr_per_s) {
 
 static void ctx_destroy_one(mkzg_ctx* c) {
     if (!c) return;
+    DeviceScope dev(c->device);
     if (c->init_stream) lanes_quiesce(c);           // calls still in flight on other threads finish first
-    (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < mkzg_ctx::NLANE; i++) lane_destroy(&c->lanes[i]);
     dev_free(c->d_lagrange_aff); dev_free(c->d_commit_table); dev_free(c->d_direct);
@@ -512,9 +513,23 @@ static unsigned usable_cpus() {
     }
     return n;
 }
-static int ctx_create_one(const char* js, size_t len, int device, mkzg_ctx** out) {
+// Worker threads of one context's host pool: its SHARE of the CPUs the cgroup grants, minus the calling thread.  A node runs one rank
+// per GPU (LOCAL_WORLD_SIZE, set by torch.distributed.run and by bench.py's own launcher) or one context over several devices
+// (`sharers`): eight ranks on a 16-CPU quota get one worker each -- 16 runnable threads in all, where min(15, cpus - 1) per context
+// was 120 workers plus eight spinning callers.  MKZG_HOST_THREADS (callers included) overrides.
+static int pool_workers_for(int sharers) {
+    if (const char* e = getenv("MKZG_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1) return std::min(v, 64) - 1;
+    }
+    int ranks = 1;
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+    const unsigned share = std::max(2u, usable_cpus() / (unsigned)std::max(ranks, std::max(1, sharers)));
+    return (int)std::min(15u, share - 1);
+}
+static int ctx_create_one(const char* js, size_t len, int device, int sharers, mkzg_ctx** out) {
     mkzg_ctx* c = new mkzg_ctx();
-    c->pool = new kzg::HostPool((int)std::min(15u, std::max(3u, usable_cpus() - 1)));
+    c->pool = new kzg::HostPool(pool_workers_for(sharers));
     c->device = device;
     // reference api.go:93-95 (ErrMinSRSSize) and the fixed-size arrays of trusted_setup.go:23-27
     if (!parse_hex_array(js, len, "g1_monomial", 48, c->g1_monomial) || !parse_hex_array(js, len, "g1_lagrange", 48, c->g1_lagrange) ||
@@ -524,8 +539,8 @@ static int ctx_create_one(const char* js, size_t len, int device, mkzg_ctx** out
         delete c;
         return MKZG_ERR_BAD_TRUSTED_SETUP;
     }
+    DeviceScope dev(c->device);                  // the caller's current device is restored on return
     int rc = [&]() -> int {
-        HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipStreamCreateWithFlags(&c->init_stream, hipStreamNonBlocking));
         for (int i = 0; i < mkzg_ctx::NLANE; i++) {
             int r = lane_create(&c->lanes[i], i);
@@ -589,7 +604,7 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
         int dev = 0;
         if (n_dev == 1) dev = device_ids[0];
         else (void)hipGetDevice(&dev);
-        return ctx_create_one(js, len, dev, out);
+        return ctx_create_one(js, len, dev, 1, out);
     }
     // several devices: a front object that owns one full context per listed device and shards batches over them (api_multi.hip)
     mkzg_ctx* front = new mkzg_ctx();
@@ -597,7 +612,7 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
     front->pool = new kzg::HostPool(n_dev - 1);
     for (int i = 0; i < n_dev; i++) {
         mkzg_ctx* p = nullptr;
-        int rc = ctx_create_one(js, len, device_ids[i], &p);
+        int rc = ctx_create_one(js, len, device_ids[i], n_dev, &p);
         if (rc) { mkzg_ctx_free(front); return rc; }
         front->peers.push_back(p);
     }
@@ -606,6 +621,7 @@ int mkzg_ctx_new(const char* js, size_t len, const int* device_ids, int n_dev, m
 }
 
 static int set_option_one(mkzg_ctx* c, const char* key, long value) {
+    DeviceScope dev(c->device);
     if (!strcmp(key, "msm_window")) {
         if (value < 11 || value > 13) return MKZG_ERR_BAD_ARGS;
         lanes_quiesce(c);
@@ -633,7 +649,7 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         return MKZG_OK;
     }
     if (!strcmp(key, "fk20_bits")) {
-        if (value != 11 && value != 13) return MKZG_ERR_BAD_ARGS;
+        if (value != 8 && value != 11 && value != 13) return MKZG_ERR_BAD_ARGS;
         lanes_quiesce(c);
         if (c->opt_fk20_bits != (int)value) {
             c->opt_fk20_bits = (int)value;
@@ -644,6 +660,20 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
                 c->fk_ready.store(false);
             }
         }
+        lanes_resume(c);
+        return MKZG_OK;
+    }
+    if (!strcmp(key, "lanes")) {                 // calls in flight at once; lanes beyond the limit give their memory back
+        if (value < 1 || value > mkzg_ctx::NLANE) return MKZG_ERR_BAD_ARGS;
+        lanes_quiesce(c);
+        c->opt_lanes = (int)value;
+        for (int i = c->opt_lanes; i < mkzg_ctx::NLANE; i++) { free_lane(&c->lanes[i]); c->lanes[i].warm = false; }
+        lanes_resume(c);
+        return MKZG_OK;
+    }
+    if (!strcmp(key, "trim")) {                  // every lane's workspaces and pinned staging back to the system (they are rebuilt on demand)
+        lanes_quiesce(c);
+        for (int i = 0; i < mkzg_ctx::NLANE; i++) { free_lane(&c->lanes[i]); c->lanes[i].warm = false; }
         lanes_resume(c);
         return MKZG_OK;
     }
@@ -692,7 +722,18 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
     else if (!strcmp(key, "devices")) *value = c->peers.empty() ? 1 : (long)c->peers.size();
-    else if (!strcmp(key, "lanes")) *value = mkzg_ctx::NLANE;
+    else if (!strcmp(key, "tables_on_own_device")) {
+        // diagnostic: 1 when every shared table built so far lives on the device of the (per-device) context that owns it
+        *value = 1;
+        const std::vector<mkzg_ctx*> all = c->peers.empty() ? std::vector<mkzg_ctx*>{c} : c->peers;
+        for (const mkzg_ctx* p : all) {
+            const void* tabs[] = {p->d_lagrange_aff, p->d_commit_table, p->d_direct, p->d_roots_brp, p->d_inv_roots_brp, p->d_tw_fwd, p->d_tw_inv, p->d_g1tw_fwd,
+                                  p->d_g1tw_inv, p->d_monomial_aff, p->d_pow7, p->d_ipow7, p->d_fk_t_aff, p->d_fk_table};
+            for (const void* t : tabs) if (t && pointer_device(t) != p->device) *value = 0;
+        }
+    }
+    else if (!strcmp(key, "lanes")) *value = q->opt_lanes;
+    else if (!strcmp(key, "host_threads")) *value = q->pool->size() + 1;                         // workers of one device's pool + the calling thread
     else return MKZG_ERR_BAD_ARGS;
     return MKZG_OK;
 }
@@ -763,6 +804,7 @@ int mkzg_profile_read(mkzg_ctx* c, mkzg_kernel_time* out, int cap, int reset) {
     for (int i = 0; i < KT_COUNT && i < cap; i++) { out[i].name = kKernelNames[i]; out[i].total_ms = 0; out[i].launches = 0; }
     std::vector<mkzg_ctx*> all = c->peers.empty() ? std::vector<mkzg_ctx*>{c} : c->peers;
     for (mkzg_ctx* q : all) {
+        DeviceScope dev(q->device);
         lanes_quiesce(q);
         for (int l = 0; l < mkzg_ctx::NLANE; l++) {
             KernelTimer& t = q->lanes[l].timer;

@@ -23,6 +23,7 @@ int ensure_twiddles(mkzg_ctx* c) {
     if (c->twiddles_ready.load(std::memory_order_acquire)) return MKZG_OK;
     std::lock_guard<std::mutex> g(c->init_mu);
     if (c->twiddles_ready.load(std::memory_order_relaxed)) return MKZG_OK;
+    DeviceScope dev(c->device);                  // shared tables live on the context's device whatever device the calling thread is on
     int rc = dev_realloc(c->d_tw_fwd, 4096 * 48);
     if (!rc) rc = dev_realloc(c->d_tw_inv, 4096 * 48);
     if (!rc) rc = dev_realloc(c->d_g1tw_fwd, 64 * 32);
@@ -39,6 +40,7 @@ int ensure_monomial(mkzg_ctx* c) {
     if (c->monomial_ready.load(std::memory_order_acquire)) return MKZG_OK;
     std::lock_guard<std::mutex> g(c->init_mu);
     if (c->monomial_ready.load(std::memory_order_relaxed)) return MKZG_OK;
+    DeviceScope dev(c->device);
     uint8_t* d_raw = nullptr;
     int* d_st = nullptr;
     int rc = dev_realloc(d_raw, 4096 * 48);
@@ -61,7 +63,12 @@ int ensure_monomial(mkzg_ctx* c) {
     c->monomial_ready.store(true, std::memory_order_release);
     return MKZG_OK;
 }
-// fk20.NewFK20 (reference fk20.go:23-52, called from api.go:137): done lazily on first use
+// fk20.NewFK20 (reference fk20.go:23-52, called from api.go:137): done lazily on first use.
+// The direct window table is sized for an otherwise empty 288 GB part; like the commitment table it DEGRADES instead of failing when
+// another tenant holds the HBM (the reference's ComputeCellsAndKZGProofs / recovery never fail for resource reasons,
+// api_eip7594.go:28-52,144-161): 13-bit windows (86 GB) if asked for, else 11-bit (25.8 GB), else 8-bit (4.3 GB: 32 instead of 24
+// additions per scalar) -- same bytes out at every width; "fk20_bits_effective" reports what is in use.  Only when not even the
+// 4.3 GB table fits does the call fail (MKZG_ERR_HIP).
 int ensure_fk20_tables(mkzg_ctx* c) {
     if (c->fk_ready.load(std::memory_order_acquire)) return MKZG_OK;
     int rc = ensure_twiddles(c);
@@ -69,30 +76,35 @@ int ensure_fk20_tables(mkzg_ctx* c) {
     if (rc) return rc;
     std::lock_guard<std::mutex> g(c->init_mu);
     if (c->fk_ready.load(std::memory_order_relaxed)) return MKZG_OK;
+    DeviceScope dev(c->device);
     rc = dev_realloc(c->d_fk_t_aff, 8192 * 128);
     if (rc) return rc;
-    // 13-bit windows (86 GB) if asked for and available, else 11-bit ones (25.8 GB): same bytes out either way
-    int bits = c->opt_fk20_bits == 13 ? 13 : 11;
-    if (bits == 13) {
+    dev_free(c->d_fk_table);                                   // a block left behind by an attempt that failed after its allocation
+    c->fk20_bits_built = 0;
+    static const int widths[3] = {13, 11, 8};
+    for (int bits : widths) {
+        if (bits > c->opt_fk20_bits) continue;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        if ((free_b && fk20_table_bytes(13) + ((size_t)8 << 30) > free_b) || hipMalloc(&c->d_fk_table, fk20_table_bytes(13)) != hipSuccess) {
+        // headroom: the lanes' workspaces (0.1-0.6 GB per busy lane) must still fit beside the table; the 86 GB table is a luxury and keeps 8 GB free
+        const size_t headroom = bits == 13 ? (size_t)8 << 30 : (size_t)1 << 30;
+        if (free_b && fk20_table_bytes(bits) + headroom > free_b) continue;
+        if (hipMalloc(&c->d_fk_table, fk20_table_bytes(bits)) != hipSuccess) { (void)hipGetLastError(); c->d_fk_table = nullptr; continue; }
+        fk20_setup_device(c->d_monomial_aff, c->d_g1tw_fwd, c->d_fk_t_aff, c->d_fk_table, bits, c->init_stream);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->init_stream) != hipSuccess) {
             (void)hipGetLastError();
-            c->d_fk_table = nullptr;
-            fprintf(stderr, "[mi355kzg] FK20 table with 13-bit windows (86 GB) does not fit in free HBM: using 11-bit windows\n");
-            bits = 11;
+            dev_free(c->d_fk_table);
+            tl_hip_error = true;
+            return MKZG_ERR_HIP;
         }
+        if (bits != c->opt_fk20_bits)
+            fprintf(stderr, "[mi355kzg] FK20 window table: %d bits requested, %d bits (%.1f GB) fit in free HBM\n", c->opt_fk20_bits, bits, (double)fk20_table_bytes(bits) / 1e9);
+        c->fk20_bits_built = bits;
+        c->fk_ready.store(true, std::memory_order_release);
+        return MKZG_OK;
     }
-    if (bits == 11) {
-        rc = dev_realloc(c->d_fk_table, fk20_table_bytes(11));
-        if (rc) return rc;
-    }
-    c->fk20_bits_built = bits;
-    fk20_setup_device(c->d_monomial_aff, c->d_g1tw_fwd, c->d_fk_t_aff, c->d_fk_table, bits, c->init_stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->init_stream));
-    c->fk_ready.store(true, std::memory_order_release);
-    return MKZG_OK;
+    fprintf(stderr, "[mi355kzg] no FK20 window table fits in free HBM (the smallest is %.1f GB)\n", (double)fk20_table_bytes(8) / 1e9);
+    return MKZG_ERR_HIP;
 }
 int ensure_rec_tables(mkzg_ctx* c) {
     if (c->rec_ready.load(std::memory_order_acquire)) return MKZG_OK;
@@ -100,6 +112,7 @@ int ensure_rec_tables(mkzg_ctx* c) {
     if (rc) return rc;
     std::lock_guard<std::mutex> g(c->init_mu);
     if (c->rec_ready.load(std::memory_order_relaxed)) return MKZG_OK;
+    DeviceScope dev(c->device);
     rc = dev_realloc(c->d_pow7, 8192 * 48);
     if (!rc) rc = dev_realloc(c->d_ipow7, 4096 * 48);
     if (rc) return rc;
@@ -333,27 +346,27 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
         const size_t CH = 2048;
         const size_t nch = (n + CH - 1) / CH;
         const int TPC = n >= 256 ? 4 : 1;
-        std::vector<std::atomic<int>> left(nch);
-        for (auto& a : left) a.store(TPC, std::memory_order_relaxed);
-        std::atomic<int> all_left((int)nch * TPC);
+        std::vector<Countdown> left(nch);
+        for (auto& a : left) a.set(TPC);
+        Countdown all_left((int)nch * TPC);
         const std::function<void(int)> gather = [&](int t) {
             const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(n, lo + CH), per = (hi - lo + TPC - 1) / TPC, q = (size_t)(t % TPC);
             for (size_t i = lo + q * per; i < std::min(hi, lo + (q + 1) * per); i++) {
                 if (cells[i]) memcpy(L->h_stage + i * 2048, cells[i], 2048);
                 else memset(L->h_stage + i * 2048, 0, 2048);           // stands in for nil entries (reported after the device work)
             }
-            left[k].fetch_sub(1, std::memory_order_release);
+            left[k].arrive();
         };
         c->pool->run_async((int)nch * TPC, gather, &all_left);
         int urc = [&]() -> int {
             for (size_t k = 0; k < nch; k++) {
                 const size_t lo = k * CH, hi = std::min(n, lo + CH);
-                while (left[k].load(std::memory_order_acquire) != 0) std::this_thread::yield();
+                c->pool->wait(left[k]);
                 HIPCHK(hipMemcpyAsync(L->d_cv_cells + lo * 2048, L->h_stage + lo * 2048, (hi - lo) * 2048, hipMemcpyHostToDevice, s));
             }
             return MKZG_OK;
         }();
-        while (all_left.load(std::memory_order_acquire) != 0) std::this_thread::yield();          // the tasks reference this frame
+        c->pool->wait(all_left);                  // the tasks reference this frame
         if (urc) return urc;
         HIPCHK(hipMemcpyAsync(L->d_cv_cell_idx, h_cidx, n * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(L->d_cv_row_idx, h_ridx, n * 4, hipMemcpyHostToDevice, s));

@@ -394,9 +394,9 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
     const size_t CH = 128;
     const size_t nch = (m + CH - 1) / CH;
     const int TPC = hsha ? (int)std::min<size_t>(std::min(m, CH), (size_t)std::max(1, c->pool->size())) : (m >= 16 ? 4 : 1);
-    std::vector<std::atomic<int>> left(nch);
-    for (auto& a : left) a.store(TPC, std::memory_order_relaxed);
-    std::atomic<int> all_left((int)nch * TPC);
+    std::vector<Countdown> left(nch);
+    for (auto& a : left) a.set(TPC);
+    Countdown all_left((int)nch * TPC);
     const std::function<void(int)> gather = [&](int t) {
         const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(m, lo + CH), per = (hi - lo + TPC - 1) / TPC;
         const size_t q = (size_t)(t % TPC);
@@ -406,18 +406,18 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
             else memset(dst, 0, MKZG_BYTES_PER_BLOB);
             if (hsha) host_compute_challenge(h_z + i * 32, dst, commitments48n + i * 48);
         }
-        left[k].fetch_sub(1, std::memory_order_release);
+        left[k].arrive();
     };
     c->pool->run_async((int)nch * TPC, gather, &all_left);
     rc = [&]() -> int {
         for (size_t k = 0; k < nch; k++) {
             const size_t lo = k * CH, hi = std::min(m, lo + CH);
-            while (left[k].load(std::memory_order_acquire) != 0) std::this_thread::yield();
+            c->pool->wait(left[k]);
             HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, (hi - lo) * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, s));
         }
         return MKZG_OK;
     }();
-    while (all_left.load(std::memory_order_acquire) != 0) std::this_thread::yield();          // the tasks reference this frame
+    c->pool->wait(all_left);                      // the tasks reference this frame
     if (rc) return rc;
     if (hsha) HIPCHK(hipMemcpyAsync(d_z, h_z, m * 32, hipMemcpyHostToDevice, s));
     rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out);

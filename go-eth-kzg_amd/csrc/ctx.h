@@ -62,6 +62,21 @@ static inline void dev_free(T*& p) {
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
+// The calling thread's current HIP device is the caller's business (a PyTorch or HIP program keeps allocating and launching on it
+// after our call returns): every entry point switches to the context's device for the duration of the call and switches BACK.
+// Also taken by everything that allocates or launches outside a lane (the lazily built shared tables, construction, destruction):
+// a pool worker or a caller thread may sit on any device.
+struct DeviceScope {
+    int prev = -1, dev;
+    explicit DeviceScope(int device) : dev(device) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceScope() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 struct mkzg_ctx;
 
 // Per-call mutable state.  Owned by one call at a time (lane_acquire / lane_release in api.hip).
@@ -175,12 +190,13 @@ struct mkzg_ctx {
     kzg::HostPool* pool = nullptr;         // persistent host threads for the host steps (host_pool.hpp), shared by the lanes
     // ---- options (mkzg_ctx_set_option; changed only while no call is in flight)
     int opt_c = 13;
-    int opt_direct_bits = 0;               // 0: bucket method; 12..15: direct-table commitment (HBM-hungry, see msm_kernels.hip)
+    int opt_direct_bits = -1;              // -1: the widest direct table that leaves 40 GB of the free HBM alone (default); 0: bucket method; 12..15: that width
     int opt_max_batch = 256;
-    int opt_fk20_bits = 11;                // window width of the FK20 direct table: 11 (25.8 GB) or 13 (86 GB, 17 % fewer additions per MSM)
+    int opt_fk20_bits = 11;                // widest FK20 direct table to try: 13 (86 GB), 11 (25.8 GB), 8 (4.3 GB); narrower ones are the fallback
     int opt_host_chunk = 128;              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
     int opt_host_zero_copy = 1;            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
     int opt_verify_shape = -1;             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
+    int opt_lanes = NLANE;                 // lanes calls may occupy at once (each keeps its workspaces and pinned staging until trimmed or destroyed)
     int opt_host_sha = -1;                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
     std::atomic<bool> profiling{false};
     // ---- SRS
@@ -238,11 +254,12 @@ inline hipStream_t lane_side_stream(Lane* L, hipStream_t main) {
 }
 
 struct LaneGuard {                          // one call = one guard
+    DeviceScope dev;                        // first member: the device is current before the lane is taken and until after it is handed back
     mkzg_ctx* c;
     Lane* L;
     hipStream_t s;                          // the call's main stream
-    explicit LaneGuard(mkzg_ctx* c_) : c(c_), L(lane_acquire(c_, false, nullptr)), s(L->stream) {}                     // host-pointer entry points
-    LaneGuard(mkzg_ctx* c_, hipStream_t user_stream) : c(c_), L(lane_acquire(c_, true, user_stream)), s(user_stream) {}   // device-pointer entry points
+    explicit LaneGuard(mkzg_ctx* c_) : dev(c_->device), c(c_), L(lane_acquire(c_, false, nullptr)), s(L->stream) {}                     // host-pointer entry points
+    LaneGuard(mkzg_ctx* c_, hipStream_t user_stream) : dev(c_->device), c(c_), L(lane_acquire(c_, true, user_stream)), s(user_stream) {}   // device-pointer entry points
     ~LaneGuard() { if (L) lane_release(c, L, s); }
     LaneGuard(const LaneGuard&) = delete;
     LaneGuard& operator=(const LaneGuard&) = delete;

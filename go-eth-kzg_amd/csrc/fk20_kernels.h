@@ -7,7 +7,8 @@
 
 namespace kzg {
 
-// window width of the FK20 direct table: 11 bits (24 windows, 25.8 GB) or 13 bits (20 windows, 86 GB: 17 % fewer additions per MSM)
+// window width of the FK20 direct table: 11 bits (24 windows, 25.8 GB), 13 bits (20 windows, 86 GB: 17 % fewer additions per MSM)
+// or 8 bits (32 windows, 4.3 GB: the width a context degrades to when the HBM is short)
 int fk20_nwin(int cbits);
 size_t fk20_table_bytes(int cbits);
 // monomial SRS (4096 affine rows) -> T (8192 affine rows, [k][i]) -> direct table (fk20_table_bytes(cbits))

@@ -34,10 +34,11 @@ def shard_bounds(n_total, world, rank):
 def _exchange_setup(n_local, n_total, dist, device):
     """-> (world, rank, offset of this rank's shard, r32).  One all_gather of the shard sizes, one broadcast of r."""
     import torch
-    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-    rank = dist.get_rank() if world > 1 else 0
+    live = dist is not None and dist.is_initialized()          # a process group of ONE rank still runs its collectives (RCCL smoke test)
+    world = dist.get_world_size() if live else 1
+    rank = dist.get_rank() if live else 0
     dev = device if device is not None else torch.device("cpu")
-    if world > 1:
+    if live:
         mine = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
         sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(sizes, mine)
@@ -51,19 +52,55 @@ def _exchange_setup(n_local, n_total, dist, device):
     r = torch.zeros(32, dtype=torch.uint8, device=dev)
     if rank == 0:
         r = torch.frombuffer(bytearray(os.urandom(32)), dtype=torch.uint8).to(dev)
-    if world > 1:
+    if live:
         dist.broadcast(r, src=0)
     return world, rank, offset, bytes(r.cpu().tolist()), dev
 
 
 def _gather_records(rec, world, dist, dev):
     import torch
-    if world == 1:
+    if dist is None or not dist.is_initialized():
         return [rec]
     mine = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
     allr = [torch.zeros(512, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(allr, mine)
     return [bytes(t.cpu().tolist()) for t in allr]
+
+
+def measure_exchange(dist, device=None, reps=20):
+    """What the batch verifiers' exchange step costs on its own, in microseconds per verification: the three collectives of one
+    sharded call -- all_gather of the shard sizes, broadcast of the 32-byte scalar, all_gather of the 512-byte records -- timed
+    between barriers, nothing else in flight.  Collective call (every rank); returns the means over `reps` repetitions."""
+    import time
+    import torch
+    dev = device if device is not None else torch.device("cpu")
+    world = dist.get_world_size()
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    mine = torch.tensor([1], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    r = torch.zeros(32, dtype=torch.uint8, device=dev)
+    rec = torch.zeros(512, dtype=torch.uint8, device=dev)
+    recs = [torch.zeros(512, dtype=torch.uint8, device=dev) for _ in range(world)]
+    acc = [0.0, 0.0, 0.0]
+    for it in range(reps + 3):                     # three untimed rounds: communicators, buffers
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        dist.all_gather(sizes, mine)
+        _ = [int(t.item()) for t in sizes]         # the call reads them on the host (prefix sum of the offsets)
+        t1 = time.perf_counter()
+        dist.broadcast(r, src=0)
+        _ = bytes(r.cpu().tolist())
+        t2 = time.perf_counter()
+        dist.all_gather(recs, rec)
+        _ = [bytes(t.cpu().tolist()) for t in recs]
+        t3 = time.perf_counter()
+        if it >= 3:
+            acc[0] += t1 - t0
+            acc[1] += t2 - t1
+            acc[2] += t3 - t2
+    us = [a / reps * 1e6 for a in acc]
+    return {"all_gather_sizes_us": us[0], "broadcast_us": us[1], "all_gather_records_us": us[2], "exchange_us": sum(us)}
 
 
 def _shard_len(shard, n_local):

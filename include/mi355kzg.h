@@ -15,7 +15,11 @@
  *     reference error sentinel; MKZG_ERR_HIP for a runtime failure.  Never aborts.
  *   - a context is immutable after construction and may be shared by threads, like the reference's Context
  *     (api.go:17-28, examples_test.go:11): every call works in one of the context's lanes (own streams, workspaces
- *     and pinned staging), so up to four calls per device run concurrently on the GPU; further callers wait for a lane.
+ *     and pinned staging), so up to sixteen calls per device run concurrently on the GPU ("lanes" option); further callers wait
+ *     for a lane.  A lane keeps its workspaces (0.1-0.6 GB of HBM and up to 0.3 GB of pinned host memory, by the calls it has run)
+ *     until the context is destroyed, the "lanes" limit is lowered below it, or "trim" is set.
+ *   - the calling thread's current HIP device is left as it was found: every entry point switches to the context's device for the
+ *     duration of the call and back.
  *   - batch entry points take any batch size (pieces are cut internally; the batch verifiers fold all pieces with ONE
  *     random scalar and finish with one pairing check).
  *   - there is NO CPU fallback: without a HIP device mkzg_ctx_new fails with MKZG_ERR_HIP.
@@ -72,14 +76,20 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
 /* Tuning knobs.  Changing one waits for the calls in flight on the context.
  *   "msm_window"          11..13: window width of the bucket method
  *   "max_batch"           blobs per launch of the commitment kernels (workspace size)
- *   "commit_direct_bits"  0 = bucket method (library default: 10.5 MB table); 12..15 = direct window table for
- *                         BlobToKZGCommitment / the proof MSM (21 GB .. 146 GB of HBM, fewer group additions); -1 = the widest
- *                         table that leaves 40 GB of the device's free memory untouched.  If the table cannot be allocated the
- *                         next narrower one is tried and finally the bucket method is used: the call still succeeds with the
- *                         same bytes; "commit_direct_bits_effective" (get) reports what is in use.
- *   "fk20_bits"           window width of the FK20 fixed-base table: 11 (default, 25.8 GB) or 13 (86 GB: 20 instead of 24 group additions
- *                         per scalar in the 128 MSMs of ComputeCellsAndKZGProofs / recovery, but its gathers over 86 GB are TLB-bound: measured
- *                         no faster on MI355X); falls back to 11 when the HBM is short ("fk20_bits_effective" reports what is in use)
+ *   "commit_direct_bits"  -1 (library default) = the widest direct window table that leaves 40 GB of the device's free memory
+ *                         untouched; 12..15 = that width (24 GB .. 146 GB of HBM; fewer group additions the wider); 0 = bucket method
+ *                         (10.5 MB table + 0.5 GB workspace per lane).  The table is built by the first commitment / proof call.  If
+ *                         it cannot be allocated the next narrower one is tried and finally the bucket method is used: the call
+ *                         still succeeds with the same bytes; "commit_direct_bits_effective" (get) reports what is in use.
+ *                         Measured on one MI355X, 256 blobs per call: 95 k blobs/s device-resident and 71 k from host pointers
+ *                         with the 15-bit table, 62 k and 37 k with the bucket method -- hence the default.
+ *   "fk20_bits"           widest window of the FK20 fixed-base table to try: 11 (default, 25.8 GB), 13 (86 GB: 20 instead of 24 group
+ *                         additions per scalar in the 128 MSMs of ComputeCellsAndKZGProofs / recovery, but its gathers over 86 GB are
+ *                         TLB-bound: measured no faster on MI355X) or 8 (4.3 GB, 32 additions per scalar).  When the HBM is short the
+ *                         next narrower table is built instead (13 -> 11 -> 8: same bytes out, "fk20_bits_effective" reports what is
+ *                         in use); only when not even 4.3 GB are free does the call fail with MKZG_ERR_HIP
+ *   "lanes"               1..16 (default 16): calls that may be in flight on the context at once; lanes above the limit free their memory
+ *   "trim"                (set only, any value) frees every lane's workspaces and pinned staging; they are rebuilt on demand
  *   "host_chunk"          blobs per chunk of the host-pointer commitment pipeline (gather / upload / kernels overlap per chunk; 128)
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
@@ -93,7 +103,9 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         straight from the blobs, one lane per point: half the instructions, longer dependent chains), -1 (default)
  *                         = throughput shape when at least two other calls are in flight on the context.  Same results either way. */
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
-/* reads an option back; also "commit_direct_bits_effective", "fk20_bits_effective", "devices", "lanes" */
+/* reads an option back; also "commit_direct_bits_effective", "fk20_bits_effective", "devices", "host_threads" (threads of one device's
+ * host pool including the caller: the CPUs the cgroup grants divided by LOCAL_WORLD_SIZE or the context's devices; the environment
+ * variable MKZG_HOST_THREADS overrides) */
 int mkzg_ctx_get_option(mkzg_ctx* ctx, const char* key, long* value);
 
 /* ---- EIP-4844 ------------------------------------------------------------------------------ */
@@ -151,7 +163,7 @@ int mkzg_compute_cells(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint
 int mkzg_compute_cells_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n, void* d_cells, int* d_status, void* stream);
 
 /* Context.ComputeCellsAndKZGProofs (reference api_eip7594.go:28-52): cells 128 x 2048 B, proofs 128 x 48 B.
- * The first call builds the FK20 tables (fk20.NewFK20, reference fk20.go:23-52; 25.8 GB of HBM, 0.3 s). */
+ * The first call builds the FK20 tables (fk20.NewFK20, reference fk20.go:23-52; 25.8 GB of HBM, 0.3 s; see "fk20_bits"). */
 int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint8_t* cells_out, uint8_t* proofs_out);
 int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n, void* d_cells, void* d_proofs, int* d_status, void* stream);
 

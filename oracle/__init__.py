@@ -13,7 +13,11 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkzg_oracle.so")
+# KZG_ORACLE_SANITIZE=1: the AddressSanitizer + UBSan build (oracle/Makefile; the process must preload the sanitizer runtime --
+# tests/test_host_sanitizers.py runs the vector tests that way in a child process)
+_SAN = os.environ.get("KZG_ORACLE_SANITIZE") == "1"
+LIB_NAME = "libkzg_oracle_asan.so" if _SAN else "libkzg_oracle.so"
+LIB_PATH = os.path.join(HERE, LIB_NAME)
 DEFAULT_SETUP = os.path.join(os.path.dirname(HERE), "go-eth-kzg_amd", "trusted_setup.json")
 
 BLOB_BYTES = 131072
@@ -30,7 +34,8 @@ def build(force=False):
         m = os.path.getmtime(LIB_PATH)
         if all(os.path.getmtime(os.path.join(HERE, s)) <= m for s in srcs):
             return LIB_PATH
-    subprocess.check_call(["make", "-C", HERE, "libkzg_oracle.so"], stdout=subprocess.DEVNULL)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+    subprocess.check_call(["make", "-C", HERE, LIB_NAME], stdout=subprocess.DEVNULL, env=env)
     return LIB_PATH
 
 

@@ -68,6 +68,25 @@ def load_product():
     return mod
 
 
+def build_host_shim(name, headers, extra_flags=()):
+    """g++ build of tests/host_shim/<name>_shim.cpp -- the product's HOST code (go-eth-kzg_amd/csrc/host_*.hpp and the field / group
+    templates the kernels instantiate) behind a C interface for CPU unit tests.  With MKZG_SHIM_SANITIZE=1 the shim is built with
+    AddressSanitizer + UndefinedBehaviorSanitizer (tests/test_host_sanitizers.py runs the host test files that way in a child
+    process with the sanitizer runtime preloaded).  Returns the path of the .so."""
+    import subprocess
+    shim_dir = os.path.join(ROOT, "tests", "host_shim")
+    san = os.environ.get("MKZG_SHIM_SANITIZE") == "1"
+    so = os.path.join(shim_dir, f"lib{name}_shim{'_asan' if san else ''}.so")
+    src = os.path.join(shim_dir, f"{name}_shim.cpp")
+    deps = [src] + [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in headers]
+    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in deps):
+        # -O2 and no frame pointer also under the sanitizers: HostFp::mul_adx is one asm block that needs fourteen general registers
+        flags = ["-O2", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"] if san else ["-O2"]
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}          # the compiler itself runs without the preloaded runtime
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-shared", "-fPIC", "-pthread"] + list(extra_flags) + ["-o", so, src], env=env)
+    return so
+
+
 @pytest.fixture(scope="session")
 def product():
     return load_product()
@@ -82,6 +101,10 @@ def gpu_ctx(product):
     if torch.cuda.is_available():
         torch.cuda.init()
     ctx = product.Context()
+    # The shared context of the vector / oracle tests runs the BUCKET method, explicitly: the library's default is the direct window
+    # table sized from free HBM (146 GB on an empty MI355X), which tests/test_gpu_defaults.py covers on a context of its own -- holding
+    # that table here for the whole session would starve the tests that build their own contexts with their own table widths.
+    assert ctx.set_option("commit_direct_bits", 0) == 0
     yield ctx
     ctx.close()
 

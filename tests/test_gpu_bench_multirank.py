@@ -1,7 +1,10 @@
 """The N > 1 path of bench.py on a box with ONE GPU: `python bench.py --gpus 2` (no launcher: bench.py starts its own ranks, the parent
 never touches the GPU) with both ranks on GPU 0 talking over gloo (bench.py's BENCH_SHARE_GPU / BENCH_DIST_BACKEND test aids).  Checked:
 the run completes, rank 0 prints ONE JSON line with n_gpus = 2 and every section -- weak-scaled commitments, the sharded blob batch
-verifier, the sharded cell batch verifier (one global batch, broadcast + all_gather) and the blob-sharded recovery."""
+verifier, the sharded cell batch verifier (one global batch, broadcast + all_gather), the blob-sharded recovery, who the ranks are, what
+the exchange step costs and the strong-scaling legs.  Also: EIGHT ranks on the one GPU (the shape of the driver's 8-GPU run: the host
+pools must add up to the CPUs the box grants, not to eight times them), and ONE rank over the "nccl" backend, so that the broadcast /
+all_gather calls of go-eth-kzg_amd/distributed.py run on device tensors over real RCCL at least once before an 8-GPU node sees them."""
 import json
 import os
 import subprocess
@@ -13,10 +16,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env, launcher):
+def _run(extra_env, launcher, gpus=2, sizes=("32", "32", "3")):
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    env.pop("WORLD_SIZE", None)
-    args = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32", "--direct-bits", "12", "--verify-batch", "32", "--verify-steps", "1", "--cell-blobs", "3"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    if env.get("BENCH_DIST_BACKEND") == "":
+        del env["BENCH_DIST_BACKEND"]
+    if env.get("BENCH_SHARE_GPU") == "":
+        del env["BENCH_SHARE_GPU"]
+    args = ["--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", sizes[0], "--direct-bits", "12", "--verify-batch", sizes[1], "--verify-steps", "1",
+            "--cell-blobs", sizes[2], "--no-cpu-baseline"]
     cmd = launcher + [os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -25,16 +34,23 @@ def _run(extra_env, launcher):
     return json.loads(lines[0])
 
 
-def _check(d):
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+def _check(d, n=2, cell_blobs=3):
+    assert d["n_gpus"] == n and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["repeats"]["regions"] == 2 and d["repeats"]["ms_per_step_min"] <= d["repeats"]["ms_per_step_max"]
+    m = d["multi_gpu"]
+    assert m["ranks"] == n and len(m["rank_gpus"]) == n and sorted(g["rank"] for g in m["rank_gpus"]) == list(range(n))
+    assert m["exchange_us"] > 0 and set(m["exchange_breakdown_us"]) == {"broadcast_r_32B", "all_gather_shard_sizes", "all_gather_records_512B"}
     v = d["verify_blob_kzg_proof_batch"]
-    assert v["value"] > 0 and "sharded x2" in v["single_call"]["parallelism"]
+    assert v["value"] > 0 and f"sharded x{n}" in v["single_call"]["parallelism"]
+    assert v["strong_scaling"]["global_batch"] == 8192 and v["strong_scaling"]["per_rank"] == 8192 // n and v["strong_scaling"]["blobs_per_s"] > 0
     e = d["eip7594"]
     assert e["compute_cells_and_kzg_proofs"]["blobs_per_s_per_gpu"] > 0
     cv = e["verify_cell_kzg_proof_batch"]
-    assert cv["cells_total"] == 2 * 3 * 128 and cv["cells_per_s"] > 0 and "sharded x2" in cv["parallelism"]
-    assert e["recover_cells_and_kzg_proofs"]["blobs_per_s"] > 0 and "x2" in e["recover_cells_and_kzg_proofs"]["parallelism"]
+    assert cv["cells_total"] == n * cell_blobs * 128 and cv["cells_per_s"] > 0 and f"sharded x{n}" in cv["parallelism"]
+    assert cv["strong_scaling"]["global_batch"] == 65536 and cv["strong_scaling"]["cells_per_s"] > 0
+    assert e["recover_cells_and_kzg_proofs"]["blobs_per_s"] > 0 and f"x{n}" in e["recover_cells_and_kzg_proofs"]["parallelism"]
     assert "cpu_baseline" not in d                      # reported at N = 1 only
+    return d
 
 
 def test_bench_starts_its_own_ranks():
@@ -48,3 +64,25 @@ def test_bench_under_torch_distributed_run():
     port = s.getsockname()[1]
     s.close()
     _check(_run({}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]))
+
+
+def test_eight_ranks_share_the_cpus():
+    """`bench.py --gpus 8` as the driver runs it on an 8-GPU node, here with all eight ranks on the one GPU over gloo: completes, and the
+    ranks' host pools together hold no more threads than the CPUs the box grants (two per rank at least: caller + one worker)"""
+    d = _check(_run({}, [sys.executable], gpus=8, sizes=("16", "16", "2")), n=8, cell_blobs=2)
+    m = d["multi_gpu"]
+    assert m["distinct_gpus"] == 1                                      # they do share one GPU here, and the line says so
+    assert m["host_threads_total"] <= max(16, m["usable_cpus"]), m
+    assert all(g["host_threads"] >= 2 for g in m["rank_gpus"])
+
+
+def test_exchange_on_rccl_with_one_rank():
+    """BENCH_FORCE_DIST: world size 1, process group on the "nccl" backend (= RCCL): the sharded verifiers' broadcast / all_gather run on
+    device tensors through RCCL"""
+    d = _run({"BENCH_DIST_BACKEND": "", "BENCH_SHARE_GPU": "", "BENCH_FORCE_DIST": "1"}, [sys.executable], gpus=1)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    m = d["multi_gpu"]
+    assert m["backend"].startswith("nccl") and m["ranks"] == 1 and m["distinct_gpus"] == 1 and m["exchange_us"] > 0
+    v = d["verify_blob_kzg_proof_batch"]
+    assert "sharded x1" in v["single_call"]["parallelism"] and v["strong_scaling"]["per_rank"] == 8192
+    assert d["eip7594"]["verify_cell_kzg_proof_batch"]["strong_scaling"]["per_rank"] == 65536

@@ -94,6 +94,7 @@ def test_windows_agree(product, oracle_ctx):
     exp = oracle_ctx.blob_to_kzg_commitment(blob)[1]
     for c in (11, 12, 13):
         ctx = product.Context()
+        assert ctx.set_option("commit_direct_bits", 0) == 0       # the window width is the bucket method's
         assert ctx.set_option("msm_window", c) == 0
         assert ctx.set_option("max_batch", 4) == 0
         rc, out = ctx.BlobToKZGCommitment(blob)
@@ -174,13 +175,21 @@ def test_options_and_calibration(product, oracle_ctx):
         assert ctx.set_option("max_batch", batch) == 0 and ctx.get_option("max_batch") == batch
         assert ctx.set_option("host_chunk", chunk) == 0 and ctx.get_option("host_chunk") == chunk
         assert ctx.set_option("host_zero_copy", zc) == 0 and ctx.get_option("host_zero_copy") == zc
-        if chunk == 3:
-            assert ctx.set_option("commit_direct_bits", 12) == 0     # the chunked accumulate launches exist in direct-table mode only
+        assert ctx.get_option("commit_direct_bits") == -1            # library default: auto-sized direct table
+        assert ctx.set_option("commit_direct_bits", 12 if chunk == 3 else 0) == 0     # the chunked accumulate launches exist in direct-table mode only
         assert ctx.set_option("host_chunk", 0) == 17                 # MKZG_ERR_BAD_ARGS
         assert ctx.set_option("no_such_option", 1) == 17 and ctx.get_option("no_such_option") is None
         rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
         assert rc == 0 and outs == exp and st == [0] * 7
-        assert ctx.get_option("commit_direct_bits_effective") == (12 if chunk == 3 else 0) and ctx.get_option("devices") == 1 and ctx.get_option("lanes") >= 4
+        assert ctx.get_option("commit_direct_bits_effective") == (12 if chunk == 3 else 0) and ctx.get_option("devices") == 1 and ctx.get_option("lanes") == 16
+        # lanes / trim: the memory the lanes hold goes back to the device and is rebuilt by the next call (same bytes)
+        free0 = torch.cuda.mem_get_info()[0]
+        assert ctx.set_option("trim", 1) == 0
+        assert torch.cuda.mem_get_info()[0] > free0
+        assert ctx.set_option("lanes", 0) == 17 and ctx.set_option("lanes", 17) == 17 and ctx.set_option("lanes", 2) == 0 and ctx.get_option("lanes") == 2
+        rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
+        assert rc == 0 and outs == exp and st == [0] * 7
+        assert 2 <= ctx.get_option("host_threads") <= 16 and ctx.get_option("tables_on_own_device") == 1
         ctx.close()
     ctx = product.Context()
     rate = ctx.valu_calibrate()

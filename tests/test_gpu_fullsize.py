@@ -198,6 +198,7 @@ def test_commitment_batch_256_direct_table_c15(product, oracle_ctx):
     ctx = product.Context()
     try:
         assert ctx.set_option("max_batch", B) == 0
+        assert ctx.set_option("commit_direct_bits", 0) == 0
         d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
         d_ref = torch.zeros(B * 48, dtype=torch.uint8, device="cuda")
         d_st = torch.ones(B, dtype=torch.int32, device="cuda")
@@ -307,6 +308,7 @@ def test_multi_device_context_on_one_gpu(product, oracle_ctx):
     ctx = product.Context(devices=[0, 0])
     try:
         assert ctx.get_option("devices") == 2
+        assert ctx.set_option("commit_direct_bits", 12) == 0           # two full per-device contexts share this one GPU's HBM
         blobs = _blobs(7, 500)
         exp_cm = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
         rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)

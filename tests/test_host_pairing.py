@@ -4,7 +4,6 @@
 import ctypes as C
 import json
 import os
-import subprocess
 import time
 
 import pytest
@@ -18,12 +17,8 @@ X = -0xD201000000010000
 
 @pytest.fixture(scope="module")
 def shim():
-    so = os.path.join(SHIM_DIR, "libpairing_shim.so")
-    src = os.path.join(SHIM_DIR, "pairing_shim.cpp")
-    hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("host_pairing.hpp", "host_field.hpp", "host_g1.hpp", "host_pool.hpp", "g1.hpp", "mont29.hpp", "constants29.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", so, src])
-    return C.CDLL(so)
+    from conftest import build_host_shim
+    return C.CDLL(build_host_shim("pairing", ("host_pairing.hpp", "host_field.hpp", "host_g1.hpp", "host_pool.hpp", "g1.hpp", "mont29.hpp", "constants29.h")))
 
 
 @pytest.fixture(scope="module")

@@ -4,7 +4,6 @@ restatement of fiatshamir.go:22-33 with hashlib, and against the oracle."""
 import ctypes as C
 import hashlib
 import os
-import subprocess
 
 import pytest
 
@@ -15,12 +14,8 @@ R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 @pytest.fixture(scope="module")
 def shim():
-    so = os.path.join(SHIM_DIR, "libsha_shim.so")
-    src = os.path.join(SHIM_DIR, "sha_shim.cpp")
-    hdr = os.path.join(ROOT, "go-eth-kzg_amd", "csrc", "host_sha256.hpp")
-    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
-    L = C.CDLL(so)
+    from conftest import build_host_shim
+    L = C.CDLL(build_host_shim("sha", ("host_sha256.hpp",)))
     L.shim_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
     L.shim_sha256_c.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
     L.shim_challenge.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]

@@ -8,7 +8,6 @@ the CPU oracle (compressed encodings are canonical, so any correct implementatio
 import ctypes as C
 import os
 import random
-import subprocess
 
 import pytest
 
@@ -24,12 +23,8 @@ G1Y = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744
 
 @pytest.fixture(scope="module")
 def shim():
-    so = os.path.join(SHIM_DIR, "libmont29_shim.so")
-    src = os.path.join(SHIM_DIR, "mont29_shim.cpp")
-    hdrs = [os.path.join(ROOT, "go-eth-kzg_amd", "csrc", h) for h in ("mont29.hpp", "g1.hpp", "constants29.h", "modinv30.hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in [src] + hdrs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
-    return C.CDLL(so)
+    from conftest import build_host_shim
+    return C.CDLL(build_host_shim("mont29", ("mont29.hpp", "g1.hpp", "constants29.h", "modinv30.hpp")))
 
 
 def limbs(v, n=14):

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(extra_env, launcher, gpus=2, sizes=("32", "32", "3")):
-    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
         env.pop(k, None)
     if env.get("BENCH_DIST_BACKEND") == "":

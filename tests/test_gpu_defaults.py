@@ -259,8 +259,14 @@ def test_fk20_table_degrades_instead_of_failing(product, oracle_ctx):
     try:
         rc, cells = ctx.ComputeCells(blob)
         assert rc == 0
-        free = torch.cuda.mem_get_info()[0]
-        hog = torch.empty(free - 2 * GB, dtype=torch.uint8, device="cuda")
+        hog = []
+        for _ in range(8):                                           # the driver gives large blocks back lazily: take what turns up until 2 GB are left
+            free = torch.cuda.mem_get_info()[0]
+            if free <= 3 * GB:
+                break
+            hog.append(torch.empty(free - 2 * GB, dtype=torch.uint8, device="cuda"))
+            torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] <= 3 * GB
         rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blob)
         assert rc == 100 and cells is None                          # MKZG_ERR_HIP
         del hog

@@ -302,7 +302,7 @@ static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t s
     KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
     if (c->direct_bits_built) {
         DirectSlot slot = L->dslot;
-        slot.k = ws_off ? 8 : direct_pick_k(n, L->dslot_batch);          // a call of few blobs spreads each over more lanes
+        if (!ws_off) direct_pick_shape(n, L->dslot_batch, &slot);        // a call of few blobs spreads each over more lanes
         const DirectSlot ws = direct_slot_offset(slot, ws_off);
         commit_direct_device(c->direct_bits_built, c->d_direct, ws, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt);
     } else {
@@ -317,7 +317,7 @@ static int commit_prepare(mkzg_ctx* c, Lane* L) {
         if (rc) return rc;
     }
     if (c->direct_bits_built) return ensure_lane_direct(c, L);
-    if (!c->d_commit_table || c->commit_table_c != c->opt_c) {
+    if (c->commit_table_c.load(std::memory_order_acquire) != c->opt_c) {      // published after the table is complete; 0 until then
         int rc = ensure_commit_table(c);
         if (rc) return rc;
     }
@@ -384,9 +384,12 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
     if (rc) return rc;
     const bool direct = c->direct_bits_built != 0, zc = direct && c->opt_host_zero_copy != 0;
     DirectSlot dslot = L->dslot;
-    if (direct) dslot.k = direct_pick_k((int)n, L->dslot_batch);
+    if (direct) {
+        direct_pick_shape((int)n, L->dslot_batch, &dslot);
+        if (dslot.serial) dslot.k = 8;                                  // the chunks' launches fill the chip together: eight scalars per lane
+    }
     KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
-    const size_t CH = (size_t)std::max(1, c->opt_host_chunk);
+    const size_t CH = (size_t)std::max(1, c->opt_host_chunk.load(std::memory_order_relaxed));
     hipStream_t copy = L->side, cs[4] = {L->stream, L->side2, L->aux[0], L->aux[1]};
     bool cs_used[4] = {true, false, false, false};
     // chunk plan
@@ -399,7 +402,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
         lo += m;
     }
     // gather tasks: TPC per chunk, queued in chunk order
-    const int TPC = n >= 8 ? 4 : 1;
+    const int TPC = n >= 8 ? std::max(1, c->opt_host_gather_tasks.load(std::memory_order_relaxed)) : 1;
     const int ntask = (int)plan.size() * TPC;
     std::vector<Countdown> left(plan.size());
     for (auto& a : left) a.set(TPC);
@@ -666,7 +669,10 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
     if (!strcmp(key, "lanes")) {                 // calls in flight at once; lanes beyond the limit give their memory back
         if (value < 1 || value > mkzg_ctx::NLANE) return MKZG_ERR_BAD_ARGS;
         lanes_quiesce(c);
-        c->opt_lanes = (int)value;
+        {
+            std::lock_guard<std::mutex> g(c->mu);          // lane_acquire reads it under the hand-over mutex
+            c->opt_lanes = (int)value;
+        }
         for (int i = c->opt_lanes; i < mkzg_ctx::NLANE; i++) { free_lane(&c->lanes[i]); c->lanes[i].warm = false; }
         lanes_resume(c);
         return MKZG_OK;
@@ -677,9 +683,21 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         lanes_resume(c);
         return MKZG_OK;
     }
+    if (!strcmp(key, "cells_chunk")) {
+        if (value < 1 || value > 512) return MKZG_ERR_BAD_ARGS;
+        lanes_quiesce(c);
+        c->opt_cells_chunk = (int)value;
+        lanes_resume(c);
+        return MKZG_OK;
+    }
     if (!strcmp(key, "host_chunk")) {
         if (value < 1 || value > 4096) return MKZG_ERR_BAD_ARGS;
         c->opt_host_chunk = (int)value;
+        return MKZG_OK;
+    }
+    if (!strcmp(key, "host_gather_tasks")) {
+        if (value < 1 || value > 64) return MKZG_ERR_BAD_ARGS;
+        c->opt_host_gather_tasks = (int)value;
         return MKZG_OK;
     }
     if (!strcmp(key, "host_zero_copy")) {
@@ -710,7 +728,7 @@ int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
 }
 int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     if (!c || !key || !value) return MKZG_ERR_BAD_ARGS;
-    const mkzg_ctx* q = c->peers.empty() ? c : c->peers[0];
+    mkzg_ctx* q = c->peers.empty() ? c : c->peers[0];
     if (!strcmp(key, "msm_window")) *value = q->opt_c;
     else if (!strcmp(key, "commit_direct_bits")) *value = q->opt_direct_bits;
     else if (!strcmp(key, "commit_direct_bits_effective")) *value = q->direct_bits_built;      // 0 until the first commitment builds the table, or after degrading to buckets
@@ -718,6 +736,7 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "fk20_bits")) *value = q->opt_fk20_bits;
     else if (!strcmp(key, "fk20_bits_effective")) *value = q->fk20_bits_built;                   // 0 until the first call that needs the table
     else if (!strcmp(key, "host_chunk")) *value = q->opt_host_chunk;
+    else if (!strcmp(key, "cells_chunk")) *value = q->opt_cells_chunk;
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
     else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
@@ -726,7 +745,8 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
         // diagnostic: 1 when every shared table built so far lives on the device of the (per-device) context that owns it
         *value = 1;
         const std::vector<mkzg_ctx*> all = c->peers.empty() ? std::vector<mkzg_ctx*>{c} : c->peers;
-        for (const mkzg_ctx* p : all) {
+        for (mkzg_ctx* p : all) {
+            std::lock_guard<std::mutex> g(p->init_mu);     // tables are built under it
             const void* tabs[] = {p->d_lagrange_aff, p->d_commit_table, p->d_direct, p->d_roots_brp, p->d_inv_roots_brp, p->d_tw_fwd, p->d_tw_inv, p->d_g1tw_fwd,
                                   p->d_g1tw_inv, p->d_monomial_aff, p->d_pow7, p->d_ipow7, p->d_fk_t_aff, p->d_fk_table};
             for (const void* t : tabs) if (t && pointer_device(t) != p->device) *value = 0;

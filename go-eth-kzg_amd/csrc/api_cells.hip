@@ -177,13 +177,16 @@ static int ensure_rec_ws(Lane* L, size_t n_blobs) {
 
 // cells + proofs of n device-resident blobs in pieces of the lane's FK20 workspace; asynchronous on s
 static int cells_and_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, size_t n, uint8_t* d_cells, uint8_t* d_proofs, int* d_status, hipStream_t s) {
-    const size_t chunk_max = 64;
+    // Pieces of at most cells_chunk blobs, cut evenly.  The MSM is VALU-bound at any size from 64 blobs on, but the transform stage is a
+    // latency-bound round of 686 wavefronts whatever the piece holds up to 64 blobs per wavefront row: 2.3 ms for 64 blobs, 5.9 ms for
+    // 256 (measured, tools/sweep_cells.py: 256 blobs in 14.6 ms as one piece against 18.5 ms as four).
+    const size_t chunk_max = (size_t)c->opt_cells_chunk, pieces = (n + chunk_max - 1) / chunk_max, even = (n + pieces - 1) / pieces;
     int rc = ensure_fk20_tables(c);
-    if (!rc) rc = ensure_fk20_ws(L, std::min(n, chunk_max));
+    if (!rc) rc = ensure_fk20_ws(L, even);
     if (rc) return rc;
     size_t done = 0;
     while (done < n) {
-        const size_t chunk = std::min(n - done, L->fk_cap);
+        const size_t chunk = std::min(n - done, even);
         const uint8_t* blobs = d_blobs + done * MKZG_BYTES_PER_BLOB;
         KT(KT_CELLS_NTT, s, cells_from_blobs_device(blobs, (int)chunk, c->d_tw_fwd, c->d_tw_inv, L->d_coeffs, d_cells + done * 262144, d_status + done, s));
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(L->d_coeffs, (int)chunk, c->d_tw_fwd, d_status + done, L->d_fk_scalars, s));
@@ -628,8 +631,9 @@ int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* c, size_t n_blobs, const u
     LaneGuard G(c);
     Lane* L = G.L;
     int first = MKZG_OK;
-    for (size_t done = 0; done < n_blobs; done += 64) {                 // pieces of 64 blobs bound the workspaces
-        const size_t m = std::min<size_t>(64, n_blobs - done);
+    const size_t chunk_max = (size_t)c->opt_cells_chunk, pieces = (n_blobs + chunk_max - 1) / chunk_max, even = (n_blobs + pieces - 1) / pieces;
+    for (size_t done = 0; done < n_blobs; done += even) {               // even pieces of at most cells_chunk blobs bound the workspaces
+        const size_t m = std::min<size_t>(even, n_blobs - done);
         int rc = recover_front(c, L, m, cell_ids + done, n_ids + done, cells + done, n_cells + done, true, status + done);
         if (rc) return G.fail(rc);
         // good blobs leave through the lane's pinned staging area (a device-to-pageable copy is staged by the runtime at a fraction of

@@ -188,16 +188,19 @@ struct mkzg_ctx {
     std::mutex init_mu;                    // lazy construction of the shared tables below
     hipStream_t init_stream = nullptr;
     kzg::HostPool* pool = nullptr;         // persistent host threads for the host steps (host_pool.hpp), shared by the lanes
-    // ---- options (mkzg_ctx_set_option; changed only while no call is in flight)
+    // ---- options (mkzg_ctx_set_option).  Plain ints change only while no call is in flight (the setter holds every lane); the atomic
+    // ones are read by calls in flight and may change under them (each call reads them once per decision)
     int opt_c = 13;
     int opt_direct_bits = -1;              // -1: the widest direct table that leaves 40 GB of the free HBM alone (default); 0: bucket method; 12..15: that width
     int opt_max_batch = 256;
     int opt_fk20_bits = 11;                // widest FK20 direct table to try: 13 (86 GB), 11 (25.8 GB), 8 (4.3 GB); narrower ones are the fallback
-    int opt_host_chunk = 128;              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
-    int opt_host_zero_copy = 1;            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
-    int opt_verify_shape = -1;             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
+    std::atomic<int> opt_host_chunk{128};              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
+    std::atomic<int> opt_host_gather_tasks{4};         // gather tasks per chunk of the host-pointer commitment pipeline
+    std::atomic<int> opt_host_zero_copy{1};            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
+    std::atomic<int> opt_verify_shape{-1};             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
+    int opt_cells_chunk = 256;             // most blobs per launch set of a ComputeCellsAndKZGProofs batch (a lane's FK20 workspace grows to the pieces it has seen: 1.6 MB per blob)
     int opt_lanes = NLANE;                 // lanes calls may occupy at once (each keeps its workspaces and pinned staging until trimmed or destroyed)
-    int opt_host_sha = -1;                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
+    std::atomic<int> opt_host_sha{-1};                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
     std::atomic<bool> profiling{false};
     // ---- SRS
     std::vector<uint8_t> g1_monomial, g1_lagrange, g2_monomial;   // raw compressed bytes

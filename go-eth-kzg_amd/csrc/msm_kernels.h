@@ -72,13 +72,14 @@ void build_table_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int
 size_t direct_table_bytes(int c);
 void build_table_any_device(int c, const uint32_t* d_src_aff, uint32_t* d_table, int n, int bitrev_bits, hipStream_t s);
 void build_direct_device(int c, const uint32_t* d_table, uint32_t* d_direct, hipStream_t s);
-// per-call workspace of the direct mode: 512 lane accumulators per blob + one rejection flag per accumulate workgroup
+// per-call workspace of the direct mode: up to 4096 lane accumulators per blob + one rejection flag per accumulate workgroup
 struct DirectSlot {
     uint32_t* d_parts = nullptr;
     int* d_bad = nullptr;
-    int k = 8;                 // scalars per lane of the accumulate kernel (8, 4, 2, 1): 4096 / k partial sums per blob; see direct_pick_k
+    int k = 8;                 // scalars per lane of the accumulate kernel (8, 4, 2, 1): 4096 / k partial sums per blob; see direct_pick_shape
+    int serial = 1;            // 1: the finish kernel sums the 4096 / (64 k) records of a lane serially; 0: two butterfly folds first (calls of few blobs)
 };
-int direct_pick_k(int n, int max_batch);
+void direct_pick_shape(int n, int max_batch, DirectSlot* slot);
 size_t direct_parts_bytes(int max_batch);
 size_t direct_bad_bytes(int max_batch);
 DirectSlot direct_slot_offset(const DirectSlot& ws, int off);

@@ -20,6 +20,7 @@
 // Integer modular arithmetic only -- no MFMA.  Field representation: mont29.hpp.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "g1.hpp"
 #include "g1_quad.hpp"
 #include "msm_kernels.h"
@@ -661,7 +662,7 @@ __global__ void __launch_bounds__(64, 2) k_build_direct_level(uint32_t* __restri
 #define MKZG_DTA 64
 #endif
 constexpr int DTA = MKZG_DTA; // threads per accumulate workgroup, 8 points per lane (64: single-wave workgroups, any free wave slot takes one)
-constexpr int DPARTS = 512;   // lane accumulators per blob (64-word XYZZ records) at 8 scalars per lane: what the workspace is sized for
+constexpr int DPARTS = 4096;  // lane accumulators per blob (64-word XYZZ records) the workspace is sized for: one scalar per lane at any batch size (1 MB per blob)
 constexpr int DBAD = 4096 / DTA;   // stride of a blob's bad-scalar flags (one per accumulate workgroup, at most 4096 / DTA of them)
 static_assert(DTA == 64, "the partial-sum layout below (64 parts per accumulate workgroup, folded by one wavefront) assumes single-wave workgroups");
 __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
@@ -791,21 +792,37 @@ __global__ void __launch_bounds__(64, 2) k_commit_direct_fold16(uint32_t* __rest
     }
     if (threadIdx.x == 0) store_xyzz(parts + base * 64, acc);
 }
+// Serial pre-sum for the shapes with more than eight 64-record blocks per blob (129 .. DIRECT_MID_MAX blobs): wavefront w of a blob adds
+// blocks w, w + W, ..., w + 7 W lane by lane into block w (its own first input: no other wavefront reads or writes it), W = blocks / 8,
+// so that the finish kernel's chain is W + 6 additions instead of 8 W + 6.
+__global__ void __launch_bounds__(64, 2) k_commit_direct_sum8(uint32_t* __restrict__ parts, int blob_blocks) {
+    const int W = blob_blocks / 8, w = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    uint32_t* base = parts + ((size_t)b * blob_blocks * 64 + lane) * 64;
+    G1X acc, o;
+    load_xyzz(acc, base + (size_t)w * 64 * 64);
+#pragma unroll 1
+    for (int j = 1; j < 8; j++) {
+        load_xyzz(o, base + (size_t)(w + j * W) * 64 * 64);
+        g1x_add(acc, acc, o);
+    }
+    store_xyzz(base + (size_t)w * 64 * 64, acc);
+}
 // Finish: one wavefront per blob sums the 512 lane accumulators (8 per lane, then an xor butterfly), converts to
 // affine and writes the compressed commitment.  Tiny and latency-bound: it runs beside the next accumulate kernel.
 // folded (K < 8): the blob's nblk / 4 records sit 256 apart (two rounds of k_commit_direct_fold16), a quad of lanes per record;
 // quads beyond them start from the identity.
 __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __restrict__ parts, const int* __restrict__ bad_flags, uint8_t* __restrict__ out48,
-                                                          int* __restrict__ status, int nblk, int folded) {
+                                                          int* __restrict__ status, int blob_blocks /* 64-record blocks per blob = accumulate workgroups */,
+                                                          int nblk /* blocks to sum (the first ones) */, int folded) {
     const int b = blockIdx.x, lane = threadIdx.x;
     int anybad = 0;
-    for (int q = 0; q < nblk; q++) anybad |= bad_flags[b * DBAD + q];
+    for (int q = 0; q < blob_blocks; q++) anybad |= bad_flags[b * DBAD + q];
     if (anybad) {
         if (lane == 0) status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
         return;
     }
     G1X acc, o;
-    const size_t base = (size_t)b * nblk * 64;
+    const size_t base = (size_t)b * blob_blocks * 64;
     if (folded) {
         const QuadRole qr(lane);
         g1x_set_inf(acc);
@@ -956,12 +973,22 @@ DirectSlot direct_slot_offset(const DirectSlot& ws, int off) {
     o.d_bad = ws.d_bad + (size_t)off * DBAD;
     return o;
 }
-// scalars per lane for a call of n blobs through a workspace sized for max_batch: the fewest (most lanes per blob, shortest chain)
-// whose partial sums fit the workspace and whose wavefronts still find a free slot each (two per SIMD)
-int direct_pick_k(int n, int max_batch) {
+// The shape of a call of n blobs through a workspace sized for max_batch.
+//   up to 128 blobs : the fewest scalars per lane (most lanes per blob, shortest chain) whose wavefronts still find a free slot each
+//                     (two per SIMD), the partial sums folded by butterflies on quads of lanes -- somebody waits for this chain;
+//   129 .. 255      : ONE scalar per lane, the 64 blocks of partial sums of a blob added up serially (k_commit_direct_sum8, then the
+//                     finish kernel).  Eight scalars per lane is the shape of exactly 256 blobs (2048 wavefronts = two per SIMD): with
+//                     fewer blobs some SIMDs hold two of those 136-addition wavefronts and some one, and the launch lasts as long as
+//                     the full one (2.78 ms from 129 to 256 blobs).  With 17-addition wavefronts, eight times as many, the dispatcher
+//                     keeps every SIMD busy until the end: 1.77 ms at 129 blobs, 2.20 at 192, 2.65 at 240 (tools/sweep_sizes.py; two
+//                     or four scalars per lane were measured too: steps at 160 / 176 / 208 blobs where a round of wavefronts fills);
+//   from 256 on     : eight scalars per lane.
+void direct_pick_shape(int n, int max_batch, DirectSlot* slot) {
+    slot->k = 8;
+    slot->serial = 1;
     for (int k = 1; k < 8; k *= 2)
-        if ((size_t)n * (4096 / k) <= (size_t)max_batch * DPARTS && n * (4096 / k) / 64 <= 2048) return k;
-    return 8;
+        if ((size_t)n * (4096 / k) <= (size_t)max_batch * DPARTS && n * (4096 / k) / 64 <= 2048) { slot->k = k; slot->serial = 0; return; }
+    if (n > 128 && n < 256 && (size_t)n * 4096 <= (size_t)max_batch * DPARTS) slot->k = 1;
 }
 CommitPlan commit_plan_offset(const CommitPlan& pl, int off) {
     CommitPlanSizes sz;
@@ -993,7 +1020,7 @@ void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot&
     const dim3 grid(4096 / (ws.k * DTA), n);
     if (input_kind == 0) launch_direct_acc<0>(c, grid, s, d_scalars, stride, d_direct, ws);
     else launch_direct_acc<1>(c, grid, s, d_scalars, stride, d_direct, ws);
-    if (ws.k < 8) {
+    if (!ws.serial) {
         const int pp = 4096 / ws.k;                       // records per blob: 4096, 2048, 1024 -> / 16 -> / 256
         hipLaunchKernelGGL(k_commit_direct_fold16, dim3(pp / 16, n), dim3(64), 0, s, ws.d_parts, pp, 1);
         hipLaunchKernelGGL(k_commit_direct_fold16, dim3(pp / 256, n), dim3(64), 0, s, ws.d_parts, pp / 16, 16);
@@ -1003,7 +1030,13 @@ void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot&
 void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
     if (n <= 0) return;
     if (kt) kt->begin(KT_COMMIT_DIRECT_FIN, s);
-    hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, 4096 / (ws.k * DTA), ws.k < 8 ? 1 : 0);
+    const int blocks = 4096 / (ws.k * DTA);
+    int nblk = blocks;
+    if (ws.serial && blocks > 8) {
+        hipLaunchKernelGGL(k_commit_direct_sum8, dim3(blocks / 8, n), dim3(64), 0, s, ws.d_parts, blocks);
+        nblk = blocks / 8;
+    }
+    hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, blocks, nblk, ws.serial ? 0 : 1);
     if (kt) kt->end(KT_COMMIT_DIRECT_FIN, s);
 }
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status,

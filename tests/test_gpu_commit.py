@@ -127,7 +127,8 @@ def test_direct_table_mode(product, oracle_ctx, bits):
 
 def test_direct_table_lane_shapes(product, oracle_ctx):
     """The direct-table commitment spreads a blob over 512 lanes (8 scalars each) in a full batch and over 1024, 2048 or 4096 lanes
-    in calls of fewer blobs (msm_kernels.hip direct_pick_k: 1..32 blobs -> 1 scalar per lane, ..64 -> 2, ..128 -> 4), with a fold of
+    in calls of fewer blobs (msm_kernels.hip direct_pick_shape: 1..32 blobs -> 1 scalar per lane, ..64 -> 2, ..128 -> 4; 129..255 -> 1 with a
+    serial sum instead of the butterflies), with a fold of
     the partial sums in between: every shape gives the oracle's bytes, an invalid blob is reported at its index."""
     import torch
     torch.cuda.init()
@@ -135,7 +136,7 @@ def test_direct_table_lane_shapes(product, oracle_ctx):
     exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in distinct]
     ctx = product.Context()
     assert ctx.set_option("commit_direct_bits", 12) == 0
-    for n in (1, 2, 20, 32, 33, 64, 65, 128, 129):
+    for n in (1, 2, 20, 32, 33, 64, 65, 128, 129, 200, 255):
         blobs = [distinct[i % 6] for i in range(n)]
         bad_at = n // 2 if n > 2 else None
         if bad_at is not None:

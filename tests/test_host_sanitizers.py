@@ -5,6 +5,10 @@ available on the pool).
   * the host unit tests (pairing, tower arithmetic, ADX Montgomery multiplication, SHA-NI / portable SHA-256, the 29-bit-limb field and
     group templates the kernels instantiate) re-run in a child process against shims built with -fsanitize=address,undefined;
   * the host pool (parked workers, callers that help, futex countdowns) under -fsanitize=thread, driven the way the C ABI drives it;
+  * the whole HOST LAYER of the product -- go-eth-kzg_amd/csrc/api*.hip compiled as plain C++: lanes and their hand-over, lazily built
+    shared tables, hash rounds, option changes under load, the multi-device front -- under -fsanitize=thread on an inert HIP runtime made
+    of host memory (tests/host_shim/stub_hip.cpp) with do-nothing kernel wrappers generated from the kernel headers
+    (tests/host_shim/gen_stub_device.py), driven through the public C ABI by tests/host_shim/stub_device_driver.cpp;
   * the oracle's ASan/UBSan build (oracle/Makefile) over the consensus vectors once.
 """
 import os
@@ -47,6 +51,27 @@ def test_host_pool_under_tsan():
     r = subprocess.run([exe], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_host_layer_on_stub_device_under_tsan():
+    """ten caller threads on one context (one of them changing options and reading the profile all the while), four on a context of the
+    device they are NOT on, six on a two-device context: no runtime error, tables on their own device, the callers' current device
+    restored by every entry point, every "device" allocation returned -- and no data race"""
+    if not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("HIP headers not installed")
+    csrc = os.path.join(ROOT, "go-eth-kzg_amd", "csrc")
+    gen = os.path.join(SHIM_DIR, "stub_device_gen.cpp")
+    subprocess.check_call([sys.executable, os.path.join(SHIM_DIR, "gen_stub_device.py"), gen], stdout=subprocess.DEVNULL)
+    exe = os.path.join(SHIM_DIR, "stub_device_tsan")
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-Wno-unused-result", "-w", "-x", "c++"]
+    cmd += [os.path.join(csrc, f) for f in ("api.hip", "api_verify.hip", "api_cells.hip", "api_multi.hip")]
+    cmd += ["-x", "none", os.path.join(SHIM_DIR, "stub_hip.cpp"), gen, os.path.join(SHIM_DIR, "stub_device_driver.cpp"), "-o", exe]
+    subprocess.check_call(cmd)
+    for rep in range(2):
+        r = subprocess.run([exe, os.path.join(ROOT, "go-eth-kzg_amd", "trusted_setup.json")], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1"),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "0 failed checks" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
 
 
 def test_oracle_vectors_under_asan_ubsan():

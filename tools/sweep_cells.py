@@ -15,7 +15,9 @@ def main():
     torch.cuda.init()
     kzg = load_product()
     ctx = kzg.Context(device=0)
-    NB = 128
+    NB = int(os.environ.get("SWEEP_NB", "128"))
+    if os.environ.get("CELLS_CHUNK"):
+        assert ctx.set_option("cells_chunk", int(os.environ["CELLS_CHUNK"])) == 0
     blobs = [rand_blob(s % 8) for s in range(NB)]
     d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
     d_cells = torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda")
@@ -28,7 +30,8 @@ def main():
 
     call(64)
     torch.cuda.synchronize()
-    for n in (1, 3, 6, 8, 9, 12, 16, 17, 21, 24, 32, 42, 48, 64, 96, 128):
+    sizes = [int(x) for x in os.environ["SWEEP_SIZES"].split(",")] if os.environ.get("SWEEP_SIZES") else (1, 3, 6, 8, 9, 12, 16, 17, 21, 24, 32, 42, 48, 64, 96, 128)
+    for n in sizes:
         call(n)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

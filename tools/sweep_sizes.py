@@ -39,9 +39,13 @@ def main():
 
     d_out = torch.zeros(NMAX * 48, dtype=torch.uint8, device="cuda")
     print("commit (direct table c=15)")
-    for n in (1, 2, 8, 32, 33, 64, 65, 128, 129, 192, 256, 257, 512, 1024):
+    sizes = [int(x) for x in os.environ["SWEEP_SIZES"].split(",")] if os.environ.get("SWEEP_SIZES") else (1, 2, 8, 32, 33, 64, 65, 128, 129, 160, 192, 224, 240, 255, 256, 257, 512, 1024)
+    for n in sizes:
         dt = timeit(lambda: ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), n, d_out.data_ptr(), d_st.data_ptr(), st))
         print(f"  n={n:5d}  {dt * 1e3:8.3f} ms  {n / dt:10.0f} blobs/s", flush=True)
+    if os.environ.get("SWEEP_COMMIT_ONLY"):
+        ctx.close()
+        return
     print("verify (device-resident)")
     for n in (1, 8, 32, 48, 64, 96, 128, 256, 512, 1024, 2048, 4096):
         dt = timeit(lambda: ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), n, st), 4)

@@ -385,7 +385,8 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     const uint32_t* pts[4] = {aff_q, aff_rows, c->d_monomial_aff, aff_q};
     const int njob[4] = {(int)n, (int)n_rows, 64, (int)n};
     int vrc = 0;
-    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 4, L->d_v_misc + V_MISC_WORDS_C, L->d_v_misc + 16, s));
+    // (a quad of lanes per bucket when the launch leaves the chip mostly empty: one blob's 128 cells, not a block's 8192)
+    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 4, L->d_v_misc + V_MISC_WORDS_C, L->d_v_misc + 16, s, 2048, 1));
     if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     int* h_st = (int*)L->h_v;

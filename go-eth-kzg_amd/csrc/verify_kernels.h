@@ -36,7 +36,8 @@ void gnark_to_vmsm_device(const uint32_t* d_scalars_mont, const uint32_t* d_poin
 constexpr int VMSM_KMAX = 8;                                        // slices of the point range per (job, window)
 constexpr size_t VMSM_PART_WORDS = (size_t)4 * 32 * VMSM_KMAX * 64;   // scratch of vmsm_windows_device (XYZZ rows)
 int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_parts, uint32_t* d_out, hipStream_t s,
-                        int points_per_slice = 2048 /* 2048: 8192-point jobs fill the GPU in one round of workgroups */);
+                        int points_per_slice = 2048 /* 2048: 8192-point jobs fill the GPU in one round of workgroups */,
+                        int latency = 0 /* 1: a caller waits for this launch alone -- a quad of lanes per bucket when the grid leaves the chip mostly empty */);
 void build_roots_device(uint32_t* d_roots_brp, uint32_t* d_inv_roots_brp, int log_n, hipStream_t s);
 void scalars_to_fr_device(const uint8_t* d_in32, int n, uint32_t* d_out12, int* d_status, hipStream_t s);
 void fr_to_scalars_device(const uint32_t* d_in12, int n, uint8_t* d_out32, hipStream_t s);

@@ -872,6 +872,109 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
         for (int i = 0; i < 14; i++) { dst[i] = tot.x.l[i]; dst[14 + i] = tot.y.l[i]; dst[28 + i] = tot.zz.l[i]; dst[42 + i] = tot.zzz.l[i]; }
     }
 }
+// The same, a QUAD of lanes per bucket (g1_quad.hpp): for the MSM a lone caller WAITS for -- sum r^i z_i Q_i of the blob batch verifier
+// can only start when the challenge hash has finished, and what it costs is the length of its dependent chain: the bucket walk and then
+// the 13-addition suffix / tree network, ~14.5 us per addition on one lane.  On a quad an addition is four products deep instead of
+// fourteen (xadd_quad / xmadd_quad), the points travel between buckets through LDS instead of wavefront shuffles (128 buckets x 4 lanes
+// = 8 wavefronts), and the network is the same suffix scan (7 rounds over 128 buckets) + tree (7 rounds).  2.1x the instructions, a
+// third of the latency: used when the launch leaves most of the chip empty anyway (vmsm_windows_device).  Slices of at most VQ_MAXN points.
+constexpr int VQT = 4 * VNB, VQ_MAXN = 2048;
+__global__ void __launch_bounds__(VQT) k_vmsm_window_quad(VmsmJobs jobs, uint32_t* __restrict__ parts /* [msm][VNWIN][VMSM_KMAX][64] XYZZ */) {
+    __shared__ uint32_t ent[VQ_MAXN];
+    __shared__ uint32_t hist[VNB + 1];
+    __shared__ uint32_t cursor[VNB];
+    __shared__ uint32_t pbuf[VNB * 56];
+    const int w = blockIdx.x, m = blockIdx.y, t = threadIdx.x, z = blockIdx.z;
+    if (z >= jobs.k[m]) return;
+    const int n_all = jobs.j[m].n, lo = (int)((long long)n_all * z / jobs.k[m]), hi = (int)((long long)n_all * (z + 1) / jobs.k[m]);
+    const uint32_t* sc = jobs.j[m].scalars + (size_t)lo * 8;
+    const uint32_t* pts = jobs.j[m].points + (size_t)lo * 32;
+    const int n = hi - lo;
+    if (t <= VNB) hist[t] = 0;
+    __syncthreads();
+    auto digit = [&](int i) -> int {                       // Booth digit of window w, as in k_vmsm_window
+        const uint32_t* s = sc + (size_t)i * 8;
+        const int bit = VC * w - 1;
+        uint32_t v;
+        if (bit < 0) {
+            v = (s[0] << 1) & 0x1ffu;
+        } else {
+            const int wi = bit >> 5, off = bit & 31;
+            v = s[wi] >> off;
+            if (off + VC + 1 > 32 && wi + 1 < 8) v |= s[wi + 1] << (32 - off);
+            v &= 0x1ffu;
+        }
+        int d = (int)((v + 1) >> 1);
+        if (v >> VC) d -= (1 << VC);
+        return d;
+    };
+    for (int i = t; i < n; i += VQT) {
+        const int d = digit(i);
+        if (d != 0) atomicAdd(&hist[(d < 0 ? -d : d) - 1], 1u);
+    }
+    __syncthreads();
+    if (t < 64) {                                           // exclusive prefix sum of the 128 counts on one wavefront (two per lane)
+        const uint32_t c0 = hist[2 * t], c1 = hist[2 * t + 1];
+        uint32_t run = c0 + c1;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t up = __shfl_up(run, sft);
+            if (t >= sft) run += up;
+        }
+        const uint32_t before = run - (c0 + c1);
+        hist[2 * t] = before;
+        cursor[2 * t] = before;
+        hist[2 * t + 1] = before + c0;
+        cursor[2 * t + 1] = before + c0;
+        if (t == 63) hist[VNB] = run;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += VQT) {
+        const int d = digit(i);
+        if (d != 0) {
+            const uint32_t slot = atomicAdd(&cursor[(d < 0 ? -d : d) - 1], 1u);
+            ent[slot] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+    __syncthreads();
+    const QuadRole qr(t);
+    const int b = t >> 2, role = t & 3;
+    // (measured: ONE rolled loop with one general addition for both phases spills as much as the two copies below -- a G1X is 56
+    // registers and the law needs three of them plus its temporaries -- and its walk is slower: 0.41 ms against 0.32 for this launch)
+    G1X Pf, o;
+    g1x_set_inf(Pf);
+    for (uint32_t e = hist[b]; e < hist[b + 1]; e++) {      // the order within a bucket varies from run to run (atomics): the sum does not
+        const uint32_t v = ent[e];
+        G1Aff p;
+        load_affine_v(p, pts + (size_t)(v & 0x7fffffffu) * 32);
+        if (p.inf) continue;
+        if (v >> 31) Fp::template neg<0>(p.y, p.y);
+        xmadd_quad(Pf, p.x, p.y, qr);
+    }
+    // window sum = sum of the 128 suffix sums (see k_vmsm_window): 7 rounds of suffix scan, 7 rounds of tree, through LDS
+#pragma unroll 1
+    for (int round = 0; round < 14; round++) {
+        const int d = round < 7 ? (1 << round) : (64 >> (round - 7));
+        const bool take = round < 7 ? (b + d < VNB) : (b < d);
+        fp_t mine;
+        quad_pick(mine, qr, Pf.x, Pf.y, Pf.zz, Pf.zzz);     // each lane of the quad publishes one coordinate
+#pragma unroll
+        for (int i = 0; i < 14; i++) pbuf[b * 56 + role * 14 + i] = mine.l[i];
+        __syncthreads();
+        if (take) {
+            const uint32_t* src = pbuf + (b + d) * 56;
+#pragma unroll
+            for (int i = 0; i < 14; i++) { o.x.l[i] = src[i]; o.y.l[i] = src[14 + i]; o.zz.l[i] = src[28 + i]; o.zzz.l[i] = src[42 + i]; }
+        }
+        __syncthreads();                                    // everybody has read before the next round overwrites
+        if (take) xadd_quad(Pf, o, qr);
+    }
+    if (t == 0) {
+        uint32_t* dst = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + z) * 64;
+#pragma unroll
+        for (int i = 0; i < 14; i++) { dst[i] = Pf.x.l[i]; dst[14 + i] = Pf.y.l[i]; dst[28 + i] = Pf.zz.l[i]; dst[42 + i] = Pf.zzz.l[i]; }
+    }
+}
 // Jobs of a few pairs (VerifyKZGProof and VerifyBlobKZGProof: ONE pair per job; the blob verifier on the blobs of a block: 6 today):
 // the window sum is sum_i d_i P_i with |d_i| <= 128, so a lane per (window, pair) gets d_i P_i by seven doublings and the additions of
 // d_i's bits (~90 multiplications deep) and an xor butterfly adds the PN lanes of a window (14 per level) -- 90 + 14 log2(PN) where the
@@ -1058,7 +1161,7 @@ void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_
     hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, exp_offset, d_s1, d_s3, d_e, mode);
 }
 int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_parts, uint32_t* d_out, hipStream_t s,
-                        int points_per_slice) {
+                        int points_per_slice, int latency) {
     if (n_msm < 1 || n_msm > 4) return -1;
     VmsmJobs jobs;
     int kmax = 1;
@@ -1085,7 +1188,10 @@ int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const*
         }
         return 0;
     }
-    hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts);
+    bool quad = latency != 0 && VNWIN * n_msm * kmax <= 256;                      // somebody waits for this launch and it leaves the chip mostly empty: a quad per bucket
+    for (int m = 0; m < n_msm; m++) quad = quad && (n_per_job[m] + jobs.k[m] - 1) / jobs.k[m] <= VQ_MAXN;
+    if (quad) hipLaunchKernelGGL(k_vmsm_window_quad, dim3(VNWIN, n_msm, kmax), dim3(VQT), 0, s, jobs, d_parts);
+    else hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts);
     hipLaunchKernelGGL(k_vmsm_combine, dim3((n_msm * VNWIN + 63) / 64), dim3(64), 0, s, jobs, n_msm, d_parts, d_out);
     return 0;
 }

@@ -380,7 +380,7 @@ KIND_KERNELS = {
 }
 
 
-def leg_roofline(kern_ms, algo_bytes, hw, pmc_valid_for_size=True):
+def leg_roofline(kern_ms, algo_bytes, hw, pmc_valid_for_size=True, leg="verify", kinds=None):
     """`roofline` + `valu` objects of one leg.  kern_ms: {profile kind: ms per call}; algo_bytes: SURVEY.md 8(d)'s algorithmic bytes of
     one call.  The dominant kernel is the kind with the largest duration.  PMC figures (HBM-side traffic, VALU wave-instructions per
     launch) come from the committed rocprofv3 passes and are used only while the kernel sources they were collected on are unchanged
@@ -391,13 +391,15 @@ def leg_roofline(kern_ms, algo_bytes, hw, pmc_valid_for_size=True):
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "traffic": None, "avg_kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_call": algo_bytes}
-    valu = {"unit": "G wave-instr/s", "peak_hw": round(hw["valu_peak"] / 1e9, 1), "peak_hw_note": hw["note"], "kernels": {}}
+    valu = {"unit": "G wave-instr/s", "peak_hw": round(hw["valu_peak"] / 1e9, 1), "peak_hw_note": hw["note"], "kernels": {},
+            "note": "ms: hipEvent brackets of this run; wave-instructions and traffic: committed rocprofv3 PMC passes (per kernel the mean over its largest launches; "
+                    "a kind that brackets several kernels sums them), used only while the kernel sources they were collected on are unchanged"}
     stale = None
     for kind, ms in kern_ms.items():
-        parts = KIND_KERNELS.get(kind, {kind: 1})
+        parts = (kinds or {}).get(kind) or KIND_KERNELS.get(kind, {kind: 1})
         insts, traffic, src, ok = 0.0, 0.0, None, pmc_valid_for_size
         for kname, mult in parts.items():
-            pm = pmc_profile(kname)
+            pm = pmc_profile(kname, leg)
             if pm.get("stale"):
                 stale = pm["stale"]
             if not pm.get("valu_wave_insts"):
@@ -453,10 +455,11 @@ def source_hash(files):
 PMC_SOURCES = {"commit": ["msm_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "modinv30.hpp"], "verify": ["verify_kernels.hip", "cells_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp"]}
 
 
-def pmc_profile(kernel):
+def pmc_profile(kernel, leg="commit"):
     """Per-launch PMC figures of `kernel` from the committed rocprofv3 passes (profiles/*_traffic.json: HBM-side bytes,
-    VALU wave-instructions; the counters cannot be read from inside the process).  A profile is only used for the kernel sources it
-    was collected on (it records their hash); {} if no valid profile covers the kernel."""
+    VALU wave-instructions; the counters cannot be read from inside the process), as collected for `leg` ("commit", "verify",
+    "eip7594": one bench.py configuration each, so that a kernel's largest launches are that leg's).  A profile is only used for the
+    kernel sources it was collected on (it records their hash); {} if no valid profile covers the kernel."""
     import glob
     fam = "commit" if ("commit" in kernel or "bucket" in kernel or "digits" in kernel) else "verify"
     stale = None
@@ -464,7 +467,7 @@ def pmc_profile(kernel):
         try:
             with open(f) as fh:
                 j = json.load(fh)
-            k = j["kernels"].get(kernel)
+            k = (j.get("legs", {}).get(leg) or j.get("kernels") or {}).get(kernel)
             if not k:
                 continue
             want = (j.get("sources") or {}).get(fam)
@@ -585,7 +588,9 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
     ms = dt / args.verify_steps * 1e3
     kern = {k: round(v[0], 4) for k, v in prof.items() if v[1]}
     algo = (131072 + 48 + 48) * N          # bytes read per blob
-    roof, valu = leg_roofline(kern, algo, hw, pmc_valid_for_size=(N == 1024))
+    # the latency shape brackets two launches under k_vmsm_window (two jobs beside the hash, the late one on quads of lanes) and two under k_rlc_scalars
+    kinds = None if dist_on else {"k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_window_quad": 1, "k_vmsm_combine": 2}, "k_rlc_scalars": {"k_rlc_scalars": 2}}
+    roof, valu = leg_roofline(kern, algo, hw, pmc_valid_for_size=(N == 1024), leg="verify", kinds=kinds)
     out = {"metric": "blobs/sec VerifyBlobKZGProofBatch", "batch_per_gpu": N, "unit": "blobs/s",
            "single_call": {"blobs_per_s": round(N * world / dt * args.verify_steps, 2), "ms_per_call": round(ms, 3), "host_finish_ms": round(host_us / args.verify_steps / 1e3, 3), "ms_each_call": each,
                            "parallelism": "one call at a time" if not dist_on else f"one global batch of {N * world} sharded x{world}; RCCL broadcast(r) + all_gather(512 B records)"},
@@ -714,7 +719,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile_read(reset=True)
     kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
-    roof, valu = leg_roofline(kern, 399360 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 11)
+    roof, valu = leg_roofline(kern, 399360 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 11, leg="eip7594")
     out["compute_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "fk20_table_bits": ctx.get_option("fk20_bits_effective"), "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s_per_gpu": round(NB / dt, 1),
                                            "kernels_ms": kern, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3), "roofline": roof, "valu": valu}
     ctx.profile_enable(False)
@@ -812,7 +817,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
     dt = maxed((time.perf_counter() - t0) / steps)
     prof = ctx.profile_read(reset=True)
     kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
-    roof, valu = leg_roofline(kern, 2152 * n, hw, pmc_valid_for_size=full_size)
+    roof, valu = leg_roofline(kern, 2152 * n, hw, pmc_valid_for_size=full_size, leg="eip7594")
     out["verify_cell_kzg_proof_batch"] = {"cells_per_gpu": n, "cells_total": n * world, "ms_per_call": round(dt * 1e3, 3), "cells_per_s": round(n * world / dt, 1),
                                           "parallelism": "one call" if not dist_on else f"one global batch sharded x{world}; broadcast(r) + all_gather(512 B records)",
                                           "kernels_ms": kern, "roofline": roof, "valu": valu,
@@ -905,7 +910,8 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
     kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
-    roof, valu = leg_roofline(kern, 399872 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 11)
+    roof, valu = leg_roofline(kern, 399872 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 11, leg="eip7594",
+                              kinds={"k_cells_ntt": {"k_cells_first_half": 1, "k_cells_ntt": 1}})
     out["recover_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s": round(NB * world / dt, 1),
                                            "parallelism": f"blob-sharded x{world}, no collective", "kernels_ms": kern, "roofline": roof, "valu": valu,
                                            "note": "C ABI, arguments marshalled once: 64 scattered host cells in per blob, 128 cells + 128 proofs out to host memory (PCIe inclusive)"}

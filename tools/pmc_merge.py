@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""tools/pmc_merge.py OUT.json commit=A_traffic.json verify=B_traffic.json eip7594=C_traffic.json -- fold the per-leg PMC summaries
+(tools/pmc_collect.sh + pmc_summarize.py, one bench.py configuration per leg so that "the largest launches of a kernel" are that leg's)
+into the one file bench.py reads: {"sources": hashes of the kernel sources, "legs": {leg: {kernel: figures}}}."""
+import json
+import sys
+
+out = {"legs": {}}
+for arg in sys.argv[2:]:
+    leg, path = arg.split("=")
+    j = json.load(open(path))
+    out.setdefault("sources", j["sources"])
+    assert out["sources"] == j["sources"], "the passes were collected on different kernel sources"
+    out.setdefault("correction", j["correction"])
+    out["legs"][leg] = {k: v for k, v in j["kernels"].items() if k.startswith("k_")}
+out["source"] = ("rocprofv3 --pmc passes (tools/pmc_collect.sh; one counter group per pass, never combined with tracing) over short bench.py runs, one per leg: "
+                 "commit = batch 256 with the library's defaults (15-bit direct table) + the bucket-method cross-check; verify = --verify-batch 1024 alone; "
+                 "eip7594 = --cell-blobs 64 alone.  Per kernel: mean over its launches with the largest grid")
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print({leg: len(k) for leg, k in out["legs"].items()})

@@ -356,11 +356,22 @@ def main():
             out["eip7594"] = eip7594
         if not args.no_cpu_baseline and world == 1:        # reported baseline: rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if line is not None:
+        # the JSON line is the LAST thing on stdout: RCCL and gloo write banners to the C-level stdout (RCCL's version block sits in the
+        # stdio buffer until the process exits), so that buffer goes out first
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:      # noqa: BLE001
+            pass
+        print(line, flush=True)
 
 
 def hw_limits(props):

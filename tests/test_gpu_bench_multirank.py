@@ -32,6 +32,7 @@ def _run(extra_env, launcher, gpus=2, sizes=("32", "32", "3")):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == lines[0], "the JSON line must be the last line on stdout (RCCL / gloo print banners there too)"
     return json.loads(lines[0])
 
 

@@ -71,6 +71,8 @@ def _worker(rank, world, port, q):
         nc[4] = b"\xff" * 131072
         out["noncanonical"] = D.verify_blob_kzg_proof_batch_sharded(OracleEngine(), (nc[lo:hi], cms[lo:hi], prs[lo:hi]), n_total, dist)
         out["bounds"] = (lo, hi)
+        ex = D.measure_exchange(dist, None, reps=3)          # the exchange step alone (bench.py reports it as multi_gpu.exchange_us)
+        out["exchange"] = (ex["exchange_us"] > 0 and abs(ex["exchange_us"] - ex["broadcast_us"] - ex["all_gather_sizes_us"] - ex["all_gather_records_us"]) < 1e-6)
         out["single"] = octx.verify_blob_kzg_proof_batch(blobs, cms, prs)
 
         # --- sharded VerifyCellKZGProofBatch: 2 blobs x 6 cells, cut 6 / 6 across the two ranks (rows repeat inside a shard)
@@ -131,6 +133,7 @@ def test_sharded_verify_gloo_world2():
         assert res[r]["corrupt"] == 1
         assert res[r]["noncanonical"] == 3
         assert res[r]["uneven"] == 0 and res[r]["uneven_corrupt"] == 1 and res[r]["mismatch"] == "refused"
+        assert res[r]["exchange"] is True
         assert res[r]["cells_valid"] == 0 and res[r]["cells_single"] == 0
         assert res[r]["cells_corrupt"] == 1
         assert res[r]["cells_noncanonical"] == 3

@@ -710,6 +710,10 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         c->opt_host_sha = (int)value;
         return MKZG_OK;
     }
+    if (!strcmp(key, "debug_serial")) {
+        c->opt_debug_serial = value != 0;
+        return MKZG_OK;
+    }
     if (!strcmp(key, "verify_shape")) {
         if (value < -1 || value > 1) return MKZG_ERR_BAD_ARGS;
         c->opt_verify_shape = (int)value;

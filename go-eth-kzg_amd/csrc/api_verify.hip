@@ -234,6 +234,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             if (round && round->done) HIPCHK(hipEventSynchronize(round->done));
             if (rc) return rc;
         } else {
+            if (c->opt_debug_serial.load(std::memory_order_relaxed)) HIPCHK(hipStreamSynchronize(s2));
             KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, L->d_v_z, s));
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));

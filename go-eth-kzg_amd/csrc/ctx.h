@@ -200,6 +200,7 @@ struct mkzg_ctx {
     std::atomic<int> opt_verify_shape{-1};             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
     int opt_cells_chunk = 256;             // most blobs per launch set of a ComputeCellsAndKZGProofs batch (a lane's FK20 workspace grows to the pieces it has seen: 1.6 MB per blob)
     int opt_lanes = NLANE;                 // lanes calls may occupy at once (each keeps its workspaces and pinned staging until trimmed or destroyed)
+    std::atomic<int> opt_debug_serial{0};  // measurement aid: the blob verifier waits for its side stream before it launches the challenge hash (the hash kernel alone on the chip)
     std::atomic<int> opt_host_sha{-1};                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
     std::atomic<bool> profiling{false};
     // ---- SRS

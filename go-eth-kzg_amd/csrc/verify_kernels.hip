@@ -156,6 +156,19 @@ constexpr int SHA_NBLOCKS = 2050;
 #define SHA_DPP_A " row_mask:0xf bank_mask:0xc\n\t"
 #define SHA_DPP_ALL " row_mask:0xf bank_mask:0xf\n\t"
 #define SHA_ID " quad_perm:[0,1,2,3]"
+#ifndef SHA_EXP
+#define SHA_EXP 0
+#endif
+#if SHA_EXP == 1      /* diagnostic (tools/ubench_sha.py): one instruction fewer, wrong digests */
+#define SHA_X1(R2, HN, WN) ""
+#else
+#define SHA_X1(R2, HN, WN) "v_xad_u32 %[" HN "], %[" R2 "], %[ma], %[" WN "]\n\t"
+#endif
+#if SHA_EXP == 2      /* diagnostic: one independent instruction more */
+#define SHA_X2 "v_mov_b32 %[tb], %[tc]\n\t"
+#else
+#define SHA_X2 ""
+#endif
 #define SHA_STEP(R0, R1, R2, T, HC, HN, WN)                                              \
     "v_alignbit_b32 %[ta], %[" R0 "], %[" R0 "], %[s1]\n\t"                              \
     "v_alignbit_b32 %[tb], %[" R0 "], %[" R0 "], %[s2]\n\t"                              \
@@ -163,7 +176,7 @@ constexpr int SHA_NBLOCKS = 2050;
     "v_bitop3_b32 %[tx], %[" R0 "], %[" R2 "], %[ma] bitop3:0x78\n\t"                    \
     "v_bitop3_b32 %[ta], %[ta], %[tb], %[tc] bitop3:0x96\n\t"                            \
     "v_bitop3_b32 %[tx], %[tx], %[" R1 "], %[" R2 "] bitop3:0xca\n\t"                    \
-    "v_xad_u32 %[" HN "], %[" R2 "], %[ma], %[" WN "]\n\t"                               \
+    SHA_X1(R2, HN, WN) SHA_X2                                                            \
     "v_add3_u32 %[" T "], %[tx], %[" HC "], %[ta]\n\t"                                   \
     "v_add_u32_dpp %[" HN "], %[" R0 "], %[" HN "] row_mirror" SHA_DPP_ALL
 // after step 0 of a block (next addend in hY): E: its d of round 1 is the A lane's a + old H2; A: the E lane's e was fed forward
@@ -266,15 +279,15 @@ __device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ 
 #pragma unroll 1
     for (int j = 0; j <= SHA_NBLOCKS / 2; j++) {
         if (j >= 1) {
-#pragma unroll 1
-            for (int k = 2 * j - 2; k < 2 * j; k++) {
+            auto load_wk = [&](uint32_t (&wkr)[64], int k) {            // the block's 64 W + K words (A lane: ones)
                 const uint4* src = a_side ? &wk[4][0][0] : &wk[k & 3][0][col];
-                uint32_t wkr[64];                                     // the block's 64 W + K words (A lane: ones), read up front
 #pragma unroll
                 for (int q = 0; q < 16; q++) {
                     const uint4 v = src[q * 64];
                     wkr[4 * q] = v.x; wkr[4 * q + 1] = v.y; wkr[4 * q + 2] = v.z; wkr[4 * q + 3] = v.w;
                 }
+            };
+            auto rounds = [&](const uint32_t (&wkr)[64]) {
                 asm volatile(SHA_INIT_E
                              SHA_STEP("p0", "p1", "p2", "p3", "hX", "hY", "w1")
                              SHA_CORR0
@@ -296,6 +309,15 @@ __device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ 
                                  : SHA_CONST_OPS, [w1] "v"(wkr[4 * g + 1]), [w2] "v"(wkr[4 * g + 2]), [w3] "v"(wkr[4 * g + 3]), [w4] "v"(wkr[(4 * g + 4) & 63]));
                 }
                 asm volatile(SHA_END_BODY : SHA_STATE_OPS, SHA_HS_OPS :);
+            };
+            // both blocks' operands are read up front: one LDS wait per step instead of two (measured with tools/ubench_sha.py: 2.82 ->
+            // 2.71 ms per 1024 transcripts beside the call's other kernels, 2.63 -> 2.60 alone on the chip)
+            {
+                uint32_t wa[64], wb[64];
+                load_wk(wa, 2 * j - 2);
+                load_wk(wb, 2 * j - 1);
+                rounds(wa);
+                rounds(wb);
             }
         }
         __syncthreads();

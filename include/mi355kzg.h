@@ -88,6 +88,7 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         TLB-bound: measured no faster on MI355X) or 8 (4.3 GB, 32 additions per scalar).  When the HBM is short the
  *                         next narrower table is built instead (13 -> 11 -> 8: same bytes out, "fk20_bits_effective" reports what is
  *                         in use); only when not even 4.3 GB are free does the call fail with MKZG_ERR_HIP
+ *   "debug_serial"        measurement aid: 1 = the blob verifier's challenge hash runs alone on the chip (the call waits for its side stream first)
  *   "lanes"               1..16 (default 16): calls that may be in flight on the context at once; lanes above the limit free their memory
  *   "trim"                (set only, any value) frees every lane's workspaces and pinned staging; they are rebuilt on demand
  *   "host_chunk"          blobs per chunk of the host-pointer commitment pipeline (gather / upload / kernels overlap per chunk; 128)

@@ -282,10 +282,11 @@ def test_proofs_with_direct_table(product, oracle_ctx):
         assert pr[48 * i:48 * i + 48] == oracle_ctx.compute_blob_kzg_proof(blobs[i], cms[i])[1]
     assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), n, st) == 0
     ctx.close()
-    # the lane shapes of the direct-table kernel for calls of few items (1, 2, 4 scalars per lane) on Fr rows: batches of 20, 40, 70 proofs
+    # the lane shapes of the direct-table kernel on Fr rows: calls of few items (1, 2, 4 scalars per lane: 20, 40, 70 proofs) and the
+    # one-scalar-per-lane shape with the serial pre-sum of 129..255 items (150 proofs)
     ctx = product.Context()
     assert ctx.set_option("commit_direct_bits", 12) == 0
-    for m in (20, 40, 70):
+    for m in (20, 40, 70, 150):
         d_b = torch.frombuffer(bytearray(b"".join(blobs[i % n] for i in range(m))), dtype=torch.uint8).cuda()
         d_c = torch.frombuffer(bytearray(b"".join(cms[i % n] for i in range(m))), dtype=torch.uint8).cuda()
         d_p = torch.zeros(m * 48, dtype=torch.uint8, device="cuda")

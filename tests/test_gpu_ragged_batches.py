@@ -7,10 +7,22 @@ from test_gpu_commit import rand_blob
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n", [1, 31, 33, 63, 65, 130])
-def test_ragged_proof_batches_match_single_calls(gpu_ctx, n):
+@pytest.fixture(scope="module")
+def table_ctx(product):
+    """a second context whose proof MSMs go through the direct window table (12 bits: 24 GB), closed with the module"""
     import torch
-    ctx = gpu_ctx
+    torch.cuda.init()
+    ctx = product.Context()
+    assert ctx.set_option("commit_direct_bits", 12) == 0
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("method", ["buckets", "table"])
+@pytest.mark.parametrize("n", [1, 31, 33, 63, 65, 130, 200, 300])
+def test_ragged_proof_batches_match_single_calls(gpu_ctx, table_ctx, n, method):
+    import torch
+    ctx = gpu_ctx if method == "buckets" else table_ctx          # 130, 200: the one-scalar-per-lane shape of 129..255 items; 300: 256 + 44
     blobs = [rand_blob(2000 + (i % 5)) for i in range(n)]           # five distinct blobs, repeated
     singles = {}
     for i in range(5):
@@ -40,11 +52,11 @@ def test_ragged_proof_batches_match_single_calls(gpu_ctx, n):
     assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_bad.data_ptr(), n, st) != 0
 
 
-@pytest.mark.parametrize("n", [9, 16, 17, 32, 33, 40, 65, 100])
+@pytest.mark.parametrize("n", [9, 16, 17, 32, 33, 40, 65, 100, 130, 300])
 def test_ragged_cell_proof_batches_match_single_calls(gpu_ctx, n):
     """ComputeCellsAndKZGProofs for n blobs in one call (the 686 fixed-scalar products of the transform network with one LANE per
     blob above 32 blobs -- partially filled wavefronts, more than one wavefront of blobs --, a PAIR of lanes per blob up to 32 and a QUAD
-    up to 16; the MSM with 8, 12 or 24 lanes per sum) against the per-blob entry point -- different code paths for fk20.go:76-124 that must
+    up to 16; the MSM with 8, 12 or 24 lanes per sum; 130 blobs as one piece, 300 as two of 150) against the per-blob entry point -- different code paths for fk20.go:76-124 that must
     agree byte for byte; one blob of the batch is invalid."""
     import torch
     ctx = gpu_ctx

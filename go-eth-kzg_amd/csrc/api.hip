@@ -134,16 +134,18 @@ Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
             Lane* idle = nullptr;
             Lane* warm = nullptr;
             Lane* cold = nullptr;
+            int active = 0;
             for (int i = 0; i < c->opt_lanes; i++) {
                 Lane* q = &c->lanes[i];
-                if (q->busy) continue;
+                if (q->busy) { active++; continue; }
                 if (!q->warm) { if (!cold) cold = q; continue; }
                 if (!warm || q->released_at < warm->released_at) warm = q;
                 const bool finished = !q->used || hipEventQuery(q->done) == hipSuccess;
+                if (!finished) active++;
                 if (finished && (!idle || q->released_at > idle->released_at)) idle = q;
             }
             L = idle ? idle : (cold && user_stream ? cold : (warm ? warm : cold));
-            if (L) break;
+            if (L) { L->others_active = active; break; }
             c->cv.wait(lk);
         }
         (void)hipGetLastError();           // hipEventQuery reports hipErrorNotReady through the sticky error too
@@ -303,6 +305,7 @@ static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t s
     if (c->direct_bits_built) {
         DirectSlot slot = L->dslot;
         if (!ws_off) direct_pick_shape(n, L->dslot_batch, &slot);        // a call of few blobs spreads each over more lanes
+        slot.fin_quad = L->others_active == 0;                          // nobody else on the GPU: the short finish; else the cheap one (it hides behind the next call)
         const DirectSlot ws = direct_slot_offset(slot, ws_off);
         commit_direct_device(c->direct_bits_built, c->d_direct, ws, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt);
     } else {
@@ -387,6 +390,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
     if (direct) {
         direct_pick_shape((int)n, L->dslot_batch, &dslot);
         if (dslot.serial) dslot.k = 8;                                  // the chunks' launches fill the chip together: eight scalars per lane
+        dslot.fin_quad = L->others_active == 0;
     }
     KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
     const size_t CH = (size_t)std::max(1, c->opt_host_chunk.load(std::memory_order_relaxed));

@@ -92,6 +92,7 @@ struct Lane {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_decoded = nullptr;
     hipEvent_t done = nullptr;             // recorded on the call's main stream at release: the next owner's stream waits for it (no host sync)
     bool used = false;
+    int others_active = 0;                 // at hand-over: lanes held by other calls or whose last call is still running on the GPU (latency vs throughput choices)
     bool warm = false;                     // has run a call before (workspaces allocated)
     // ---- commitment MSM workspaces
     CommitPlan plan;                       // bucket method: per-lane arrays; plan.d_table points at the context's shared table

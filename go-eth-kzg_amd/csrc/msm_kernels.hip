@@ -1057,6 +1057,12 @@ void direct_pick_shape(int n, int max_batch, DirectSlot* slot) {
     for (int k = 1; k < 8; k *= 2)
         if ((size_t)n * (4096 / k) <= (size_t)max_batch * DPARTS && n * (4096 / k) / 64 <= 2048) { slot->k = k; slot->serial = 0; return; }
     if (n > 128 && n < 256 && (size_t)n * 4096 <= (size_t)max_batch * DPARTS) slot->k = 1;
+    // pieces above 256 blobs (max_batch raised by the caller): eight scalars per lane cost whole rounds of 2048 wavefronts (2.75 ms each),
+    // one scalar per lane costs 10.8 us per blob + 0.3 ms -- e.g. 300 blobs: two rounds = 5.5 ms against 3.5 ms
+    if (n > 256 && (size_t)n * 4096 <= (size_t)max_batch * DPARTS) {
+        const int rounds = (8 * n + 2047) / 2048;
+        if (rounds * 2.75 > 0.0108 * n + 0.3) slot->k = 1;
+    }
 }
 CommitPlan commit_plan_offset(const CommitPlan& pl, int off) {
     CommitPlanSizes sz;

@@ -136,7 +136,9 @@ def test_direct_table_lane_shapes(product, oracle_ctx):
     exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in distinct]
     ctx = product.Context()
     assert ctx.set_option("commit_direct_bits", 12) == 0
-    for n in (1, 2, 20, 32, 33, 64, 65, 128, 129, 200, 255):
+    for n in (1, 2, 20, 32, 33, 64, 65, 128, 129, 200, 255, 300):
+        if n == 300:
+            assert ctx.set_option("max_batch", 320) == 0          # one piece above 256 blobs: one scalar per lane again (a full round + 352 wavefronts otherwise)
         blobs = [distinct[i % 6] for i in range(n)]
         bad_at = n // 2 if n > 2 else None
         if bad_at is not None:

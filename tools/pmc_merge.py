@@ -5,12 +5,12 @@ into the one file bench.py reads: {"sources": hashes of the kernel sources, "leg
 import json
 import sys
 
-out = {"legs": {}}
+out = {"legs": {}, "sources": {}}
 for arg in sys.argv[2:]:
     leg, path = arg.split("=")
     j = json.load(open(path))
-    out.setdefault("sources", j["sources"])
-    assert out["sources"] == j["sources"], "the passes were collected on different kernel sources"
+    fam = "commit" if leg == "commit" else "verify"          # the source family whose hash guards this leg's figures in bench.py
+    assert out["sources"].setdefault(fam, j["sources"][fam]) == j["sources"][fam], "legs of one family were collected on different kernel sources"
     out.setdefault("correction", j["correction"])
     out["legs"][leg] = {k: v for k, v in j["kernels"].items() if k.startswith("k_")}
 out["source"] = ("rocprofv3 --pmc passes (tools/pmc_collect.sh; one counter group per pass, never combined with tracing) over short bench.py runs, one per leg: "

@@ -84,6 +84,7 @@ static void free_lane_plan(Lane* L) {
 static void free_lane_direct(Lane* L) {
     dev_free(L->dslot.d_parts); dev_free(L->dslot.d_bad);
     L->dslot_batch = 0;
+    L->dslot_records = 0;
 }
 void free_lane(Lane* L) {
     free_lane_plan(L);
@@ -286,12 +287,18 @@ static int ensure_lane_plan(mkzg_ctx* c, Lane* L) {
     L->plan_batch = c->opt_max_batch;
     return MKZG_OK;
 }
-static int ensure_lane_direct(mkzg_ctx* c, Lane* L) {
-    if (L->dslot_batch >= c->opt_max_batch && L->dslot.d_parts) return MKZG_OK;
+// The lane accumulators of the direct mode: 512 records per blob of max_batch to begin with (eight scalars per lane at a full batch, and
+// every few-blob shape); a call whose shape needs more -- one scalar per lane from 129 blobs on: 4096 records per blob -- grows the
+// buffer once (hipFree waits for the lane's earlier, possibly still running, calls).
+static int ensure_lane_direct(mkzg_ctx* c, Lane* L, size_t need_records = 0) {
+    const size_t base = (size_t)c->opt_max_batch * 512;
+    if (L->dslot_batch >= c->opt_max_batch && L->dslot.d_parts && L->dslot_records >= std::max(base, need_records)) return MKZG_OK;
+    const size_t records = std::max(std::max(base, need_records), L->dslot_batch >= c->opt_max_batch ? L->dslot_records : (size_t)0);
     free_lane_direct(L);
-    HIPCHK(hipMalloc(&L->dslot.d_parts, direct_parts_bytes(c->opt_max_batch)));
+    HIPCHK(hipMalloc(&L->dslot.d_parts, records * 256));
     HIPCHK(hipMalloc(&L->dslot.d_bad, direct_bad_bytes(c->opt_max_batch)));
     L->dslot_batch = c->opt_max_batch;
+    L->dslot_records = records;
     return MKZG_OK;
 }
 
@@ -305,6 +312,12 @@ static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t s
     if (c->direct_bits_built) {
         DirectSlot slot = L->dslot;
         if (!ws_off) direct_pick_shape(n, L->dslot_batch, &slot);        // a call of few blobs spreads each over more lanes
+        if ((size_t)(n + ws_off) * (4096 / slot.k) > L->dslot_records) {
+            int rc = ensure_lane_direct(c, L, (size_t)L->dslot_batch * 4096);
+            if (rc) return rc;
+            slot.d_parts = L->dslot.d_parts;
+            slot.d_bad = L->dslot.d_bad;
+        }
         slot.fin_quad = L->others_active == 0;                          // nobody else on the GPU: the short finish; else the cheap one (it hides behind the next call)
         const DirectSlot ws = direct_slot_offset(slot, ws_off);
         commit_direct_device(c->direct_bits_built, c->d_direct, ws, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt);
@@ -332,7 +345,8 @@ int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t
     size_t done = 0;
     while (done < n) {
         const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
-        commit_piece(c, L, d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, 0, d_out48n + done * 48, d_status + done, s);
+        rc = commit_piece(c, L, d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, 0, d_out48n + done * 48, d_status + done, s);
+        if (rc) return rc;
         done += chunk;
     }
     HIPCHK(hipGetLastError());
@@ -451,7 +465,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
             HIPCHK(hipStreamWaitEvent(L->stream, L->ev_cs[0], 0));
         }
         if (direct) commit_direct_fin_device(dslot, (int)n, L->d_out, L->d_status, L->stream, kt);
-        else commit_piece(c, L, L->d_blobs, MKZG_BYTES_PER_BLOB, 0, (int)n, 0, L->d_out, L->d_status, L->stream);
+        else (void)commit_piece(c, L, L->d_blobs, MKZG_BYTES_PER_BLOB, 0, (int)n, 0, L->d_out, L->d_status, L->stream);      // bucket method: no buffer to grow
         HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, n * 48, hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipMemcpyAsync(L->h_out + L->h_out_items * 48, L->d_status, n * sizeof(int), hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipGetLastError());

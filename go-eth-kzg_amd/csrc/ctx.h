@@ -99,6 +99,7 @@ struct Lane {
     int plan_c = 0, plan_batch = 0;
     DirectSlot dslot;                      // direct-table method: lane accumulators
     int dslot_batch = 0;
+    size_t dslot_records = 0;              // capacity of dslot.d_parts in 256-byte XYZZ records (512 per blob of max_batch at first; 4096 once a one-scalar-per-lane shape asked for it)
     // ---- staging of host-pointer entry points
     uint8_t* h_stage = nullptr;            // pinned
     size_t h_stage_bytes = 0;

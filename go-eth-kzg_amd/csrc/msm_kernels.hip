@@ -662,7 +662,7 @@ __global__ void __launch_bounds__(64, 2) k_build_direct_level(uint32_t* __restri
 #define MKZG_DTA 64
 #endif
 constexpr int DTA = MKZG_DTA; // threads per accumulate workgroup, 8 points per lane (64: single-wave workgroups, any free wave slot takes one)
-constexpr int DPARTS = 4096;  // lane accumulators per blob (64-word XYZZ records) the workspace is sized for: one scalar per lane at any batch size (1 MB per blob)
+constexpr int DPARTS = 4096;  // lane accumulators per blob (64-word XYZZ records) of the one-scalar-per-lane shapes: 1 MB per blob (a lane's buffer grows to it on demand, api.hip ensure_lane_direct)
 constexpr int DBAD = 4096 / DTA;   // stride of a blob's bad-scalar flags (one per accumulate workgroup, at most 4096 / DTA of them)
 static_assert(DTA == 64, "the partial-sum layout below (64 parts per accumulate workgroup, folded by one wavefront) assumes single-wave workgroups");
 __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
@@ -1054,8 +1054,8 @@ DirectSlot direct_slot_offset(const DirectSlot& ws, int off) {
 void direct_pick_shape(int n, int max_batch, DirectSlot* slot) {
     slot->k = 8;
     slot->serial = 1;
-    for (int k = 1; k < 8; k *= 2)
-        if ((size_t)n * (4096 / k) <= (size_t)max_batch * DPARTS && n * (4096 / k) / 64 <= 2048) { slot->k = k; slot->serial = 0; return; }
+    for (int k = 1; k < 8; k *= 2)      // within the 512 records per blob of max_batch that every lane's buffer starts with
+        if ((size_t)n * (4096 / k) <= (size_t)max_batch * 512 && n * (4096 / k) / 64 <= 2048) { slot->k = k; slot->serial = 0; return; }
     if (n > 128 && n < 256 && (size_t)n * 4096 <= (size_t)max_batch * DPARTS) slot->k = 1;
     // pieces above 256 blobs (max_batch raised by the caller): eight scalars per lane cost whole rounds of 2048 wavefronts (2.75 ms each),
     // one scalar per lane costs 10.8 us per blob + 0.3 ms -- e.g. 300 blobs: two rounds = 5.5 ms against 3.5 ms

@@ -457,9 +457,13 @@ __global__ void __launch_bounds__(EVB_T) k_blob_eval(const uint8_t* __restrict__
     fr_inv_n(inv, acc);   // 1 / prod d_i over this lane's non-zero d_i
 
     if (MODE == 0 || fidx < 0) {
-        // sum_i f_i w_i / (z - w_i)
-        fr_t part;
-        Fr::set_zero(part);
+        // sum_i f_i w_i / (z - w_i) = z sum_i f_i / (z - w_i) - sum_i f_i   (w_i / (z - w_i) = z / (z - w_i) - 1): no product with the
+        // roots, and the blob's words never have to be brought into Montgomery form -- the Montgomery product of the PLAIN f_i with
+        // the Montgomery form of 1 / (z - w_i) is the plain f_i / (z - w_i).  Four multiplications per element (three of them the
+        // batch inversion) instead of six; both sums are plain residues and meet Montgomery form once per lane.
+        fr_t s1, s2;
+        Fr::set_zero(s1);
+        Fr::set_zero(s2);
 #pragma unroll 4
         for (int k = EVB_PER - 1; k >= 0; k--) {
             const int i = t + EVB_T * k;
@@ -470,12 +474,19 @@ __global__ void __launch_bounds__(EVB_T) k_blob_eval(const uint8_t* __restrict__
             FrC::mul(inv, inv, d);
             uint32_t w[8];
             load_be32_words(w, blob + (size_t)i * 32);
-            fr_from_words(f, w);
-            FrC::mul(term, f, wi);
-            FrC::mul(term, term, di);
-            FrC::add(part, part, term);
+            Fr::from_words32(f, w);                  // plain, canonical (checked in pass 1)
+            FrC::mul(term, f, di);                   // plain f_i / (z - w_i)
+            FrC::add(s1, s1, term);
+            FrC::add(s2, s2, f);
             if (MODE == 1) pre[k] = di;   // keep 1/(z - w_i) for the quotient
         }
+        fr_t part, s1m, s2m;
+        Fr::from_plain(s1m, s1);
+        Fr::reduce_once(s1m, s1m);
+        Fr::from_plain(s2m, s2);
+        Fr::reduce_once(s2m, s2m);
+        FrC::mul(part, s1m, z);
+        FrC::sub(part, part, s2m);
         block_sum_fr<EVB_T>(part, sh);
         // y = (z^4096 - 1)/4096 * sum
         fr_t y;

@@ -106,7 +106,7 @@ def parse_args():
     ap.add_argument("--no-drop-in", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=1024, help="configs[2]: proofs per VerifyBlobKZGProofBatch call per GPU (0 = skip)")
     ap.add_argument("--verify-steps", type=int, default=3)
-    ap.add_argument("--verify-inflight", type=int, default=16, help="caller threads of the sustained-rate leg (one call in flight each; a context has 16 lanes)")
+    ap.add_argument("--verify-inflight", type=int, default=32, help="caller threads of the sustained-rate leg (one call in flight each; a context has 32 lanes)")
     ap.add_argument("--fk20-bits", type=int, default=11, help="window width of the FK20 fixed-base table: 11 (25.8 GB, default) or 13 (86 GB: 17% fewer additions but TLB-bound gathers, measured no faster; falls back to 11 if HBM is short)")
     ap.add_argument("--cell-blobs", type=int, default=64, help="configs[3]/[4]: blobs per GPU for the EIP-7594 legs (64 x 128 = 8192 cells; 0 = skip)")
     return ap.parse_args()

@@ -72,6 +72,7 @@ static int lane_create(Lane* L, int id) {
     HIPCHK(hipEventCreateWithFlags(&L->ev_join, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L->ev_decoded, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&L->ev_block, hipEventDisableTiming | hipEventBlockingSync));
     for (auto& e : L->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return MKZG_OK;
 }
@@ -117,7 +118,7 @@ static void lane_destroy(Lane* L) {
     if (L->side2) (void)hipStreamDestroy(L->side2);
     for (auto& a : L->aux) if (a) (void)hipStreamDestroy(a);
     for (auto& e : L->ev_cs) if (e) (void)hipEventDestroy(e);
-    hipEvent_t evs[] = {L->ev_fork, L->ev_join, L->ev_decoded, L->done};
+    hipEvent_t evs[] = {L->ev_fork, L->ev_join, L->ev_decoded, L->done, L->ev_block};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
     for (auto& e : L->ev_chunk) if (e) (void)hipEventDestroy(e);
 }

@@ -90,6 +90,7 @@ struct Lane {
     hipStream_t aux[2] = {nullptr, nullptr};   // with stream and side2: the four compute streams of the host-pointer commit pipeline
     hipEvent_t ev_cs[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_decoded = nullptr;
+    hipEvent_t ev_block = nullptr;         // hipEventBlockingSync: a caller that shares the host with many others sleeps on it instead of polling the stream
     hipEvent_t done = nullptr;             // recorded on the call's main stream at release: the next owner's stream waits for it (no host sync)
     bool used = false;
     int others_active = 0;                 // at hand-over: lanes held by other calls or whose last call is still running on the GPU (latency vs throughput choices)
@@ -175,7 +176,10 @@ struct mkzg_ctx {
     std::vector<mkzg_ctx*> peers;          // further devices of a multi-device context (owned by this, the primary)
     std::atomic<unsigned> rr{0};           // round-robin cursor of single-item calls over the devices
     // ---- lanes
-    static constexpr int NLANE = 16;
+#ifndef MKZG_NLANE
+#define MKZG_NLANE 32            // measured (tools/trace.py verify_inflight): VerifyBlobKZGProofBatch(1024) 1.34 M blobs/s from 16 callers, 1.47 M from 24, 1.55-1.60 M from 32
+#endif
+    static constexpr int NLANE = MKZG_NLANE;
     Lane lanes[NLANE];
     std::atomic<int> lanes_busy{0};        // calls in flight on this context right now
     // ---- hash rounds (throughput shape of the blob verifier)

@@ -9,7 +9,10 @@ namespace kzg {
 // Fr rows are 12 words (9 limbs + padding), affine G1 rows 32 words, as in msm_kernels.hip.
 void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s);
 // the same for up to SHA_MAX_JOBS (blobs, commitments, n, z) jobs -- one per call in flight -- in ONE launch; every n > 0
-constexpr int SHA_MAX_JOBS = 16;
+#ifndef MKZG_NLANE
+#define MKZG_NLANE 32
+#endif
+constexpr int SHA_MAX_JOBS = MKZG_NLANE;        // one job per lane at most
 struct ShaJobs {
     const uint8_t* blobs[SHA_MAX_JOBS];
     const uint8_t* commitments[SHA_MAX_JOBS];

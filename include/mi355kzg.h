@@ -15,7 +15,7 @@
  *     reference error sentinel; MKZG_ERR_HIP for a runtime failure.  Never aborts.
  *   - a context is immutable after construction and may be shared by threads, like the reference's Context
  *     (api.go:17-28, examples_test.go:11): every call works in one of the context's lanes (own streams, workspaces
- *     and pinned staging), so up to sixteen calls per device run concurrently on the GPU ("lanes" option); further callers wait
+ *     and pinned staging), so up to 32 calls per device run concurrently on the GPU ("lanes" option); further callers wait
  *     for a lane.  A lane keeps its workspaces (0.1-0.6 GB of HBM and up to 0.3 GB of pinned host memory, by the calls it has run)
  *     until the context is destroyed, the "lanes" limit is lowered below it, or "trim" is set.
  *   - the calling thread's current HIP device is left as it was found: every entry point switches to the context's device for the
@@ -89,7 +89,7 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         next narrower table is built instead (13 -> 11 -> 8: same bytes out, "fk20_bits_effective" reports what is
  *                         in use); only when not even 4.3 GB are free does the call fail with MKZG_ERR_HIP
  *   "debug_serial"        measurement aid: 1 = the blob verifier's challenge hash runs alone on the chip (the call waits for its side stream first)
- *   "lanes"               1..16 (default 16): calls that may be in flight on the context at once; lanes above the limit free their memory
+ *   "lanes"               1..32 (default 32): calls that may be in flight on the context at once; lanes above the limit free their memory
  *   "trim"                (set only, any value) frees every lane's workspaces and pinned staging; they are rebuilt on demand
  *   "host_chunk"          blobs per chunk of the host-pointer commitment pipeline (gather / upload / kernels overlap per chunk; 128)
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe

@@ -184,12 +184,12 @@ def test_options_and_calibration(product, oracle_ctx):
         assert ctx.set_option("no_such_option", 1) == 17 and ctx.get_option("no_such_option") is None
         rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
         assert rc == 0 and outs == exp and st == [0] * 7
-        assert ctx.get_option("commit_direct_bits_effective") == (12 if chunk == 3 else 0) and ctx.get_option("devices") == 1 and ctx.get_option("lanes") == 16
+        assert ctx.get_option("commit_direct_bits_effective") == (12 if chunk == 3 else 0) and ctx.get_option("devices") == 1 and ctx.get_option("lanes") == 32
         # lanes / trim: the memory the lanes hold goes back to the device and is rebuilt by the next call (same bytes)
         free0 = torch.cuda.mem_get_info()[0]
         assert ctx.set_option("trim", 1) == 0
         assert torch.cuda.mem_get_info()[0] > free0
-        assert ctx.set_option("lanes", 0) == 17 and ctx.set_option("lanes", 17) == 17 and ctx.set_option("lanes", 2) == 0 and ctx.get_option("lanes") == 2
+        assert ctx.set_option("lanes", 0) == 17 and ctx.set_option("lanes", 33) == 17 and ctx.set_option("lanes", 2) == 0 and ctx.get_option("lanes") == 2
         rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)
         assert rc == 0 and outs == exp and st == [0] * 7
         assert 2 <= ctx.get_option("host_threads") <= 16 and ctx.get_option("tables_on_own_device") == 1

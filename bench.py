@@ -107,7 +107,7 @@ def parse_args():
     ap.add_argument("--verify-batch", type=int, default=1024, help="configs[2]: proofs per VerifyBlobKZGProofBatch call per GPU (0 = skip)")
     ap.add_argument("--verify-steps", type=int, default=3)
     ap.add_argument("--verify-inflight", type=int, default=32, help="caller threads of the sustained-rate leg (one call in flight each; a context has 32 lanes)")
-    ap.add_argument("--fk20-bits", type=int, default=11, help="window width of the FK20 fixed-base table: 11 (25.8 GB, default) or 13 (86 GB: 17% fewer additions but TLB-bound gathers, measured no faster; falls back to 11 if HBM is short)")
+    ap.add_argument("--fk20-bits", type=int, default=12, help="window width of the FK20 fixed-base table: 12 (47 GB, the library default), 11 (25.8 GB), 8 (4.3 GB) or 13 (86 GB: fewer additions but TLB-bound gathers, measured no faster); narrower ones are the fallback when HBM is short")
     ap.add_argument("--cell-blobs", type=int, default=64, help="configs[3]/[4]: blobs per GPU for the EIP-7594 legs (64 x 128 = 8192 cells; 0 = skip)")
     return ap.parse_args()
 
@@ -730,7 +730,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
     dt = (time.perf_counter() - t0) / steps
     prof = ctx.profile_read(reset=True)
     kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
-    roof, valu = leg_roofline(kern, 399360 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 11, leg="eip7594")
+    roof, valu = leg_roofline(kern, 399360 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 12, leg="eip7594")
     out["compute_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "fk20_table_bits": ctx.get_option("fk20_bits_effective"), "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s_per_gpu": round(NB / dt, 1),
                                            "kernels_ms": kern, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3), "roofline": roof, "valu": valu}
     ctx.profile_enable(False)
@@ -921,7 +921,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
     kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
-    roof, valu = leg_roofline(kern, 399872 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 11, leg="eip7594",
+    roof, valu = leg_roofline(kern, 399872 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 12, leg="eip7594",
                               kinds={"k_cells_ntt": {"k_cells_first_half": 1, "k_cells_ntt": 1}})
     out["recover_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s": round(NB * world / dt, 1),
                                            "parallelism": f"blob-sharded x{world}, no collective", "kernels_ms": kern, "roofline": roof, "valu": valu,

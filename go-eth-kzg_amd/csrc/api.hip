@@ -671,7 +671,7 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         return MKZG_OK;
     }
     if (!strcmp(key, "fk20_bits")) {
-        if (value != 8 && value != 11 && value != 13) return MKZG_ERR_BAD_ARGS;
+        if (value != 8 && value != 11 && value != 12 && value != 13) return MKZG_ERR_BAD_ARGS;
         lanes_quiesce(c);
         if (c->opt_fk20_bits != (int)value) {
             c->opt_fk20_bits = (int)value;

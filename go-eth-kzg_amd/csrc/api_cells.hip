@@ -81,7 +81,7 @@ int ensure_fk20_tables(mkzg_ctx* c) {
     if (rc) return rc;
     dev_free(c->d_fk_table);                                   // a block left behind by an attempt that failed after its allocation
     c->fk20_bits_built = 0;
-    static const int widths[3] = {13, 11, 8};
+    static const int widths[4] = {13, 12, 11, 8};
     for (int bits : widths) {
         if (bits > c->opt_fk20_bits) continue;
         size_t free_b = 0, total_b = 0;

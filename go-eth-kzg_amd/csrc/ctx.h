@@ -199,7 +199,7 @@ struct mkzg_ctx {
     int opt_c = 13;
     int opt_direct_bits = -1;              // -1: the widest direct table that leaves 40 GB of the free HBM alone (default); 0: bucket method; 12..15: that width
     int opt_max_batch = 256;
-    int opt_fk20_bits = 11;                // widest FK20 direct table to try: 13 (86 GB), 11 (25.8 GB), 8 (4.3 GB); narrower ones are the fallback
+    int opt_fk20_bits = 12;                // widest FK20 direct table to try: 13 (86 GB), 12 (47 GB), 11 (25.8 GB), 8 (4.3 GB); narrower ones are the fallback
     std::atomic<int> opt_host_chunk{128};              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
     std::atomic<int> opt_host_gather_tasks{4};         // gather tasks per chunk of the host-pointer commitment pipeline
     std::atomic<int> opt_host_zero_copy{1};            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)

@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(64) k_fk20_setup_table(const uint32_t* __restr
 //           blobs (5 MSMs per wavefront, 128 additions per lane), <24, 1, 1> up to 16 (2 per wavefront, 64 additions), <24, 2, 1> up to
 //           8 (one MSM per wavefront, 32 additions)
 //   C = 13: <4, 2, 5> batches (160 additions per lane), <10, 2, 2> few blobs (64 additions per lane)
+//   C = 12: <2, 4, 11> batches (176 additions per lane), <11, 1, 2> / <22, 1, 1> / <22, 2, 1> for fewer blobs
 //   C = 8 : <8, 1, 4> batches (256 additions per lane), <16, 1, 2> up to 39 blobs (128 additions per lane)
 // k_fk20_msm_reduce adds the lanes of an MSM.
 // ------------------------------------------------------------------------------------------
@@ -642,6 +643,14 @@ void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int cbi
     if (cbits == 13) {
         if (few) launch_fk_msm<13, 10, 2, 2, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
         else launch_fk_msm<13, 4, 2, 5, 8>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+    } else if (cbits == 12) {
+        // 22 windows (47 GB): batches with 2 lanes of 11 windows x 4 point groups of 16 per MSM -- 176 additions per lane against the
+        // 192 of the 11-bit table (measured: 1.90 against 2.01 ms per 64 blobs, 18.7 k against 18.0 k blobs/s from eight callers);
+        // the few-blob shapes mirror the 11-bit ones with 22 lanes where those have 24
+        if (n <= FK_SPLIT_MAX_BATCH) launch_fk_msm<12, 22, 2, 1, 64>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+        else if (few) launch_fk_msm<12, 22, 1, 1, 32>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+        else if (n <= FK_MID_MAX_BATCH) launch_fk_msm<12, 11, 1, 2, 16>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
+        else launch_fk_msm<12, 2, 4, 11, 8>(d_scalars, d_table, n, d_status, d_parts, d_results, s);
     } else if (cbits == 8) {
         // the 4.3 GB table the context degrades to when the HBM is short (api_cells.hip ensure_fk20_tables): 32 windows per scalar
         if (n <= FK_MID_MAX_BATCH) launch_fk_msm<8, 16, 1, 2, 16>(d_scalars, d_table, n, d_status, d_parts, d_results, s);

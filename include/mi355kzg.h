@@ -83,10 +83,11 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         still succeeds with the same bytes; "commit_direct_bits_effective" (get) reports what is in use.
  *                         Measured on one MI355X, 256 blobs per call: 95 k blobs/s device-resident and 71 k from host pointers
  *                         with the 15-bit table, 62 k and 37 k with the bucket method -- hence the default.
- *   "fk20_bits"           widest window of the FK20 fixed-base table to try: 11 (default, 25.8 GB), 13 (86 GB: 20 instead of 24 group
+ *   "fk20_bits"           widest window of the FK20 fixed-base table to try: 12 (default, 47 GB: 22 group additions per scalar), 11 (25.8 GB: 24
+ *                         additions, 3 % fewer blobs/s on batches of 64 and more), 13 (86 GB: 20 instead of 24 group
  *                         additions per scalar in the 128 MSMs of ComputeCellsAndKZGProofs / recovery, but its gathers over 86 GB are
  *                         TLB-bound: measured no faster on MI355X) or 8 (4.3 GB, 32 additions per scalar).  When the HBM is short the
- *                         next narrower table is built instead (13 -> 11 -> 8: same bytes out, "fk20_bits_effective" reports what is
+ *                         next narrower table is built instead (13 -> 12 -> 11 -> 8: same bytes out, "fk20_bits_effective" reports what is
  *                         in use); only when not even 4.3 GB are free does the call fail with MKZG_ERR_HIP
  *   "debug_serial"        measurement aid: 1 = the blob verifier's challenge hash runs alone on the chip (the call waits for its side stream first)
  *   "lanes"               1..32 (default 32): calls that may be in flight on the context at once; lanes above the limit free their memory
@@ -164,7 +165,7 @@ int mkzg_compute_cells(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint
 int mkzg_compute_cells_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n, void* d_cells, int* d_status, void* stream);
 
 /* Context.ComputeCellsAndKZGProofs (reference api_eip7594.go:28-52): cells 128 x 2048 B, proofs 128 x 48 B.
- * The first call builds the FK20 tables (fk20.NewFK20, reference fk20.go:23-52; 25.8 GB of HBM, 0.3 s; see "fk20_bits"). */
+ * The first call builds the FK20 tables (fk20.NewFK20, reference fk20.go:23-52; 47 GB of HBM, 0.5 s; see "fk20_bits"). */
 int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* ctx, const uint8_t* blob, int num_threads, uint8_t* cells_out, uint8_t* proofs_out);
 int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* ctx, const void* d_blobs, size_t n, void* d_cells, void* d_proofs, int* d_status, void* stream);
 

@@ -219,7 +219,7 @@ def test_bad_trusted_setup_is_refused_without_leaks(product):
 
 def test_fk20_table_degrades_instead_of_failing(product, oracle_ctx):
     """ComputeCellsAndKZGProofs / recovery never fail for resource reasons in the reference (api_eip7594.go:28-52,144-161): with the HBM
-    taken by another tenant the FK20 window table steps down 11 -> 8 bits (25.8 -> 4.3 GB) and the bytes stay the oracle's; only when
+    taken by another tenant the FK20 window table steps down 12 -> 11 -> 8 bits (47 -> 25.8 -> 4.3 GB) and the bytes stay the oracle's; only when
     not even that fits does the call report MKZG_ERR_HIP -- and succeeds again once memory is back"""
     import torch
     torch.cuda.init()
@@ -238,7 +238,7 @@ def test_fk20_table_degrades_instead_of_failing(product, oracle_ctx):
         hog = torch.empty(free - keep, dtype=torch.uint8, device="cuda")
         rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blob)
         assert rc == 0 and b"".join(cells) == oc and b"".join(proofs) == op
-        assert ctx.get_option("fk20_bits") == 11 and ctx.get_option("fk20_bits_effective") == 8
+        assert ctx.get_option("fk20_bits") == 12 and ctx.get_option("fk20_bits_effective") == 8
         ids = list(range(0, 128, 2))
         rc, c2, p2 = ctx.RecoverCellsAndComputeKZGProofs(ids, [cells[i] for i in ids])
         assert rc == 0 and c2 == cells and p2 == proofs
@@ -246,9 +246,9 @@ def test_fk20_table_degrades_instead_of_failing(product, oracle_ctx):
         hog = None
         torch.cuda.empty_cache()
         # asking again rebuilds the table at the width that now fits
-        assert ctx.set_option("fk20_bits", 13) == 0 and ctx.set_option("fk20_bits", 11) == 0
+        assert ctx.set_option("fk20_bits", 13) == 0 and ctx.set_option("fk20_bits", 12) == 0
         rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blob)
-        assert rc == 0 and b"".join(proofs) == op and ctx.get_option("fk20_bits_effective") == 11
+        assert rc == 0 and b"".join(proofs) == op and ctx.get_option("fk20_bits_effective") == 12
     finally:
         del hog
         ctx.close()

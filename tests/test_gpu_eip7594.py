@@ -272,7 +272,7 @@ def test_structured_blobs_through_every_lane_shape(gpu_ctx, oracle_ctx):
 
 
 def test_fk20_table_widths_agree(product, oracle_ctx):
-    """fk20_bits 11 (default), 13 (86 GB table, 20 instead of 24 additions per scalar) and 8 (4.3 GB, 32 additions: the width a context
+    """fk20_bits 12 (default, 47 GB), 11, 13 (86 GB table, 20 instead of 24 additions per scalar) and 8 (4.3 GB, 32 additions: the width a context
     degrades to when the HBM is short) give the oracle's bytes, for one blob (few-blob lane layout) and for a batch (batch lane layout);
     switching the option rebuilds the table"""
     import torch
@@ -284,9 +284,9 @@ def test_fk20_table_widths_agree(product, oracle_ctx):
     outs = {}
     ctx = product.Context()
     try:
-        for bits in (13, 11, 8, 13):
+        for bits in (13, 12, 11, 8, 13):
             assert ctx.set_option("fk20_bits", bits) == 0
-            assert ctx.set_option("fk20_bits", 12) == 17
+            assert ctx.set_option("fk20_bits", 10) == 17
             rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blobs[0])
             assert rc == 0 and ctx.get_option("fk20_bits_effective") == bits
             assert b"".join(cells) == exp[0][1] and b"".join(proofs) == exp[0][2]
@@ -300,6 +300,6 @@ def test_fk20_table_widths_agree(product, oracle_ctx):
             for j, b in enumerate([0, 1, n - 2, n - 1]):
                 assert pr[b * 6144:(b + 1) * 6144] == exp[j][2], (bits, b)
             outs[bits] = pr
-        assert outs[11] == outs[13] == outs[8]
+        assert outs[11] == outs[13] == outs[8] == outs[12]
     finally:
         ctx.close()

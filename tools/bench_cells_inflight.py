@@ -16,10 +16,12 @@ def main():
     torch.cuda.init()
     kzg = load_product()
     ctx = kzg.Context(device=0)
+    if os.environ.get("FK20_BITS"):
+        assert ctx.set_option("fk20_bits", int(os.environ["FK20_BITS"])) == 0
     NB = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     blobs = [rand_blob(s) for s in range(min(NB, 16))]
     d_blobs = torch.frombuffer(bytearray(b"".join(blobs[i % len(blobs)] for i in range(NB))), dtype=torch.uint8).cuda()
-    for K in (1, 2, 3, 4):
+    for K in ([int(x) for x in os.environ["CI_CALLERS"].split(",")] if os.environ.get("CI_CALLERS") else (1, 2, 3, 4, 6, 8)):
         bufs = [(torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda"), torch.zeros(NB * 128 * 48, dtype=torch.uint8, device="cuda"),
                  torch.ones(NB, dtype=torch.int32, device="cuda")) for _ in range(K)]
         torch.cuda.synchronize()

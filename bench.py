@@ -463,7 +463,9 @@ def source_hash(files):
     return h.hexdigest()[:16]
 
 
-PMC_SOURCES = {"commit": ["msm_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "modinv30.hpp"], "verify": ["verify_kernels.hip", "cells_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp"]}
+PMC_SOURCES = {"commit": ["msm_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "modinv30.hpp"],
+               "verify": ["verify_kernels.hip", "cells_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp"],
+               "eip7594": ["fk20_kernels.hip", "recover_kernels.hip", "cells_kernels.hip", "verify_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp"]}
 
 
 def pmc_profile(kernel, leg="commit"):
@@ -472,7 +474,7 @@ def pmc_profile(kernel, leg="commit"):
     "eip7594": one bench.py configuration each, so that a kernel's largest launches are that leg's).  A profile is only used for the
     kernel sources it was collected on (it records their hash); {} if no valid profile covers the kernel."""
     import glob
-    fam = "commit" if ("commit" in kernel or "bucket" in kernel or "digits" in kernel) else "verify"
+    fam = leg if leg in PMC_SOURCES else "verify"               # the source family whose hash guards the leg's figures
     stale = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         try:

@@ -9,7 +9,7 @@ out = {"legs": {}, "sources": {}}
 for arg in sys.argv[2:]:
     leg, path = arg.split("=")
     j = json.load(open(path))
-    fam = "commit" if leg == "commit" else "verify"          # the source family whose hash guards this leg's figures in bench.py
+    fam = leg if leg in j["sources"] else "verify"           # the source family whose hash guards this leg's figures in bench.py
     assert out["sources"].setdefault(fam, j["sources"][fam]) == j["sources"][fam], "legs of one family were collected on different kernel sources"
     out.setdefault("correction", j["correction"])
     out["legs"][leg] = {k: v for k, v in j["kernels"].items() if k.startswith("k_")}

@@ -106,6 +106,27 @@ int shim_g1_mul(const uint8_t* p48, const uint64_t* k, uint8_t* out_xy96) {
 
 // the ADX form of HostFp::mul against the portable loop on n pseudo-random canonical pairs plus the edge values; returns the number of
 // mismatches, -1 if this CPU has no BMI2 + ADX (nothing to compare)
+// HostFp::inv (divsteps through the 29-bit-limb field) against a^(p-2), and a * a^-1 == 1; returns the number of mismatches
+int shim_hostfp_inv_check(int n, uint64_t seed) {
+    int bad = 0;
+    HostFp::El a, i1, i2, one, t;
+    HostFp::set_one(one);
+    uint64_t s = seed;
+    auto next = [&] { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (int k = 0; k < n; k++) {
+        uint64_t w[6];
+        for (int q = 0; q < 6; q++) w[q] = next();
+        w[5] &= 0x0fffffffffffffffull;                       // < 2^380 < p
+        if (k == 0) memset(w, 0, 48);                          // 0 -> 0 in both forms
+        if (k == 1) { memset(w, 0, 48); w[0] = 1; }
+        HostFp::from_plain(a, w);
+        HostFp::inv(i1, a);
+        HostFp::inv_fermat(i2, a);
+        if (!HostFp::limbs_equal(i1, i2)) bad++;
+        if (k > 0) { HostFp::mul(t, a, i1); if (!HostFp::limbs_equal(t, one)) bad++; }
+    }
+    return bad;
+}
 int shim_hostfp_mul_adx_check(int n, uint64_t seed) {
 #if defined(__x86_64__) && !defined(MKZG_NO_ADX)
     if (!HostFp::have_adx()) return -1;

@@ -94,6 +94,13 @@ def test_host_pool(shim):
     assert shim.shim_pool_selftest() == 0
 
 
+def test_hostfp_inv_divsteps_matches_fermat(shim):
+    """HostFp::inv goes through the divsteps inversion of the 29-bit-limb field (modinv30.hpp, the one the kernels use): same
+    values as a^(p-2) on random elements, on 0 and on 1, and a * a^-1 == 1"""
+    shim.shim_hostfp_inv_check.argtypes = [C.c_int, C.c_uint64]
+    assert shim.shim_hostfp_inv_check(3000, 0x243f6a8885a308d3) == 0
+
+
 def test_hostfp_mul_adx_matches_portable(shim):
     """HostFp::mul has an x86-64 form with mulx / adcx / adox (host_field.hpp) beside the portable loop: both must give the same canonical
     limbs on random operands and on the edge values 0, 1, R mod p, p - 1, p - 2, p - 3, 2^384 - 1 mod p, also when the output aliases

@@ -27,6 +27,9 @@ int main() {
     volatile uint64_t sink = 0;
     printf("Fp mul            %8.1f ns\n", 1e3 * time_us(2000000, [&] { HostFp::mul(r, a, b); a = r; }));
     sink += a.l[0];
+    printf("Fp inv (divsteps) %8.2f us\n", time_us(20000, [&] { HostFp::inv(r, a); a = r; }));
+    printf("Fp inv (Fermat)   %8.2f us\n", time_us(2000, [&] { HostFp::inv_fermat(r, a); a = r; }));
+    sink += a.l[0];
     Fp12 f, g;
     miller_loop_prepared(f, P, prep);
     printf("Miller loop       %8.1f us\n", time_us(200, [&] { miller_loop_prepared(g, P, prep); }));

@@ -22,7 +22,7 @@ ctx = t("Context() (JSON, 8192 G1 + 65 G2 decodes, roots)", lambda: kzg.Context(
 rc, cm = t("first BlobToKZGCommitment (bucket plan + table)", lambda: ctx.BlobToKZGCommitment(blob))
 rc, pr = t("first ComputeBlobKZGProof", lambda: ctx.ComputeBlobKZGProof(blob, cm))
 t("first VerifyBlobKZGProof (verify ws, G1 fixed base)", lambda: ctx.VerifyBlobKZGProof(blob, cm, pr))
-rc, cells, proofs = t("first ComputeCellsAndKZGProofs (FK20 25.8 GB table)", lambda: ctx.ComputeCellsAndKZGProofs(blob))
+rc, cells, proofs = t("first ComputeCellsAndKZGProofs (FK20 47 GB table)", lambda: ctx.ComputeCellsAndKZGProofs(blob))
 t("first VerifyCellKZGProofBatch", lambda: ctx.VerifyCellKZGProofBatch([cm] * 128, list(range(128)), cells, proofs))
 ids = list(range(0, 128, 2))
 t("first RecoverCellsAndComputeKZGProofs", lambda: ctx.RecoverCellsAndComputeKZGProofs(ids, [cells[i] for i in ids]))

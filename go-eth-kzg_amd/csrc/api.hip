@@ -74,7 +74,6 @@ static int lane_create(Lane* L, int id) {
     HIPCHK(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&L->ev_block, hipEventDisableTiming | hipEventBlockingSync));
     for (auto& e : L->ev_chunk) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    L->created = true;
     return MKZG_OK;
 }
 static void free_lane_plan(Lane* L) {
@@ -131,7 +130,6 @@ static void lane_destroy(Lane* L) {
 // every warm lane is taken.
 Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
     Lane* L = nullptr;
-  again:
     {
         std::unique_lock<std::mutex> lk(c->mu);
         for (;;) {
@@ -141,7 +139,6 @@ Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
             int active = 0;
             for (int i = 0; i < c->opt_lanes; i++) {
                 Lane* q = &c->lanes[i];
-                if (q->dead) continue;
                 if (q->busy) { active++; continue; }
                 if (!q->warm) { if (!cold) cold = q; continue; }
                 if (!warm || q->released_at < warm->released_at) warm = q;
@@ -157,21 +154,6 @@ Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
         L->busy = true;
         L->warm = true;
         c->lanes_busy.fetch_add(1, std::memory_order_relaxed);
-    }
-    if (!L->created && lane_create(L, L->id) != MKZG_OK) {
-        // a lane's five streams and twenty events are made when it is first handed out (32 lanes at construction cost 0.2 s); one
-        // that cannot be made is retired, and the caller takes another (lane 0 exists from construction)
-        (void)hipGetLastError();
-        tl_hip_error = false;
-        {
-            std::lock_guard<std::mutex> g(c->mu);
-            L->dead = true;
-            L->busy = false;
-            L->warm = false;
-            c->lanes_busy.fetch_sub(1, std::memory_order_relaxed);
-        }
-        c->cv.notify_all();
-        goto again;
     }
     L->failed = false;
     L->drained = false;
@@ -582,9 +564,8 @@ static int ctx_create_one(const char* js, size_t len, int device, int sharers, m
     DeviceScope dev(c->device);                  // the caller's current device is restored on return
     int rc = [&]() -> int {
         HIPCHK(hipStreamCreateWithFlags(&c->init_stream, hipStreamNonBlocking));
-        for (int i = 0; i < mkzg_ctx::NLANE; i++) c->lanes[i].id = i;
-        {
-            int r = lane_create(&c->lanes[0], 0);       // the others on their first hand-over (lane_acquire)
+        for (int i = 0; i < mkzg_ctx::NLANE; i++) {
+            int r = lane_create(&c->lanes[i], i);
             if (r) return r;
         }
         // decode the Lagrange SRS on the device (no subgroup check: trusted_setup.go:104-117)

@@ -93,8 +93,6 @@ struct Lane {
     hipEvent_t ev_block = nullptr;         // hipEventBlockingSync: a caller that shares the host with many others sleeps on it instead of polling the stream
     hipEvent_t done = nullptr;             // recorded on the call's main stream at release: the next owner's stream waits for it (no host sync)
     bool used = false;
-    bool created = false;                  // streams and events exist (lane 0 from construction, the others from their first hand-over)
-    bool dead = false;                     // their creation failed: never handed out
     int others_active = 0;                 // at hand-over: lanes held by other calls or whose last call is still running on the GPU (latency vs throughput choices)
     bool warm = false;                     // has run a call before (workspaces allocated)
     // ---- commitment MSM workspaces

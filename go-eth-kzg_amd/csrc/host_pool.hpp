@@ -12,6 +12,7 @@
 //   * with nothing left to run it spins on yield() for SPIN_US, then parks on a futex until the last task signs off.
 #pragma once
 #include <linux/futex.h>
+#include <pthread.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <atomic>
@@ -132,6 +133,7 @@ class HostPool {
 
    private:
     void loop() {
+        (void)pthread_setname_np(pthread_self(), "mkzg-pool");          // visible in /proc/<pid>/task/*/comm, top -H, perf
         for (;;) {
             std::function<void()> job;
             {

@@ -12,6 +12,8 @@ Workloads (run under the profiler on the GPU box; the program itself goes after 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/t -- python3 tools/trace.py msm_paths
         ComputeCellsAndKZGProofs and the recovery batch alternated in one process (IDS=even|first|all picks the supplied cells): the
         same FK20 launches behind different predecessors (the sparse-wavefront finding of DESIGN.md section 7)
+    rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/t -- python3 tools/trace.py cells_batch [N=128] [R=3]
+        R device-resident ComputeCellsAndKZGProofs calls of N blobs, one caller: the launches of one piece and the gaps between them
 Readers (anywhere):
     python3 tools/trace.py timeline DIR [t_from_ms t_to_ms]   kernel + copy records merged into one time-ordered listing
     python3 tools/trace.py busy DIR [gap_ms]                  last burst of kernels: wall time, time with a kernel running, kernels in flight
@@ -126,16 +128,48 @@ def wl_verify_inflight(args):
         for _ in range(reps):
             assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, s.cuda_stream) == 0
 
+    def task_cpu():
+        """CPU seconds of every thread of the process so far, by thread id: (name, user + system)"""
+        out = {}
+        tick = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                with open(f"/proc/self/task/{tid}/stat") as fh:
+                    st = fh.read()
+                name = st[st.index("(") + 1:st.rindex(")")]
+                f = st[st.rindex(")") + 2:].split()
+                out[tid] = (name, (int(f[11]) + int(f[12])) / tick)
+            except OSError:
+                pass
+        return out
+
     for trial, reps in enumerate((2, R)):
-        ts = [threading.Thread(target=caller, args=(k, reps)) for k in range(K)]
+        ts = [threading.Thread(target=caller, args=(k, reps), name=f"caller{k}") for k in range(K)]
         torch.cuda.synchronize()
         time.sleep(0.05)
         t0, c0 = time.perf_counter(), time.process_time()
+        before = task_cpu()
         for t in ts:
             t.start()
+        mid = None
+        if os.environ.get("TRACE_THREAD_CPU") and trial == 1:
+            time.sleep(0.15)
+            m0, mt0 = task_cpu(), time.perf_counter()
+            time.sleep(0.25)
+            m1, mt1 = task_cpu(), time.perf_counter()
+            mid = (m0, m1, mt1 - mt0)
         for t in ts:
             t.join()
         dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+        if mid:
+            m0, m1, span = mid
+            groups = defaultdict(lambda: [0, 0.0])
+            for tid, (name, v) in m1.items():
+                d = v - m0.get(tid, (name, 0.0))[1]
+                key = "python caller" if name.startswith("caller") or name.startswith("python") else name
+                groups[key][0] += 1
+                groups[key][1] += d
+            print(f"  thread CPU over {1e3 * span:.0f} ms mid-run: " + "; ".join(f"{k} x{n}: {c / span:.2f} cores" for k, (n, c) in sorted(groups.items(), key=lambda kv: -kv[1][1]) if c > 0), flush=True)
         print(f"trial {trial}: {K} callers x {reps} calls: {K * reps * N / dt:.0f} blobs/s, {1e3 * dt / (K * reps):.3f} ms per call amortised; host CPUs busy {cpu / dt:.1f}", flush=True)
     ctx.close()
 
@@ -184,6 +218,29 @@ def wl_msm_paths(args):
         recover()
     for _ in range(2):
         compute()
+    ctx.close()
+
+
+def wl_cells_batch(args):
+    BLOB, load_product, rand_blob = _product()
+    import torch
+    torch.cuda.init()
+    kzg = load_product()
+    n = int(args[0]) if args else 128
+    reps = int(args[1]) if len(args) > 1 else 3
+    ctx = kzg.Context()
+    d_blobs = torch.frombuffer(bytearray(b"".join(rand_blob(s % 8) for s in range(n))), dtype=torch.uint8).cuda()
+    d_cells = torch.zeros(n * 262144, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.zeros(n * 128 * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for i in range(reps + 2):
+        t0 = time.perf_counter()
+        assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), n, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st) == 0
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        print(f"call {i}: returned after {1e3 * (t1 - t0):.3f} ms, finished after {1e3 * (time.perf_counter() - t0):.3f} ms", flush=True)
+        time.sleep(0.02)
     ctx.close()
 
 
@@ -260,7 +317,7 @@ def rd_summary(args):
         print(f"  grid {grid} queue {q}: n={len(ds)} mean={sum(ds) / len(ds):.3f} min={min(ds):.3f} max={max(ds):.3f}   [{' '.join(f'{d:.2f}' for d in ds)}]")
 
 
-COMMANDS = {"single": wl_single, "verify_host": wl_verify_host, "verify_inflight": wl_verify_inflight, "msm_paths": wl_msm_paths,
+COMMANDS = {"single": wl_single, "verify_host": wl_verify_host, "verify_inflight": wl_verify_inflight, "msm_paths": wl_msm_paths, "cells_batch": wl_cells_batch,
             "busy": rd_busy, "timeline": rd_timeline, "summary": rd_summary}
 
 if __name__ == "__main__":

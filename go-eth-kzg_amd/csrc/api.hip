@@ -9,6 +9,8 @@
 //   multiexp.MultiExpG1       internal/multiexp/multiexp.go:20-50
 #include <functional>
 #include <thread>
+#include <sys/prctl.h>
+#include <time.h>
 #include "ctx.h"
 #include "api_multi.h"
 
@@ -187,6 +189,35 @@ void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s) {
         c->lanes_busy.fetch_sub(1, std::memory_order_relaxed);
     }
     c->cv.notify_all();
+}
+bool wait_sleeping(const mkzg_ctx* c) {
+    const int o = c->opt_host_wait.load(std::memory_order_relaxed);
+    if (o >= 0) return o == 1;
+    return c->lanes_busy.load(std::memory_order_relaxed) > std::max(1, c->cpu_share / 2);
+}
+int wait_event_sleeping(hipEvent_t ev) {
+    // the default timer slack (50 us) would more than double every step; the caller's value is put back before returning
+    const int slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+    if (slack > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+    int rc = MKZG_OK;
+    for (int i = 0;; i++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();               // hipErrorNotReady is reported through the sticky error too
+        if (e != hipErrorNotReady) { rc = MKZG_ERR_HIP; tl_hip_error = true; break; }
+        timespec ts{0, i < 8 ? 20000 : 60000};
+        nanosleep(&ts, nullptr);
+    }
+    if (slack > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
+    return rc;
+}
+int lane_sync(mkzg_ctx* c, Lane* L, hipStream_t s) {
+    if (wait_sleeping(c)) {
+        HIPCHK(hipEventRecord(L->ev_block, s));
+        return wait_event_sleeping(L->ev_block);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return MKZG_OK;
 }
 void lanes_quiesce(mkzg_ctx* c) {
     {
@@ -470,7 +501,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
         HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, n * 48, hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipMemcpyAsync(L->h_out + L->h_out_items * 48, L->d_status, n * sizeof(int), hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(L->stream));
+        LANE_SYNC(c, L, L->stream);
         L->drained = true;                  // every stream of the call was joined into L->stream above
         return MKZG_OK;
     }();
@@ -539,19 +570,22 @@ static unsigned usable_cpus() {
 // per GPU (LOCAL_WORLD_SIZE, set by torch.distributed.run and by bench.py's own launcher) or one context over several devices
 // (`sharers`): eight ranks on a 16-CPU quota get one worker each -- 16 runnable threads in all, where min(15, cpus - 1) per context
 // was 120 workers plus eight spinning callers.  MKZG_HOST_THREADS (callers included) overrides.
+static unsigned cpu_share_for(int sharers) {
+    int ranks = 1;
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+    return std::max(2u, usable_cpus() / (unsigned)std::max(ranks, std::max(1, sharers)));
+}
 static int pool_workers_for(int sharers) {
     if (const char* e = getenv("MKZG_HOST_THREADS")) {
         const int v = atoi(e);
         if (v >= 1) return std::min(v, 64) - 1;
     }
-    int ranks = 1;
-    if (const char* e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
-    const unsigned share = std::max(2u, usable_cpus() / (unsigned)std::max(ranks, std::max(1, sharers)));
-    return (int)std::min(15u, share - 1);
+    return (int)std::min(15u, cpu_share_for(sharers) - 1);
 }
 static int ctx_create_one(const char* js, size_t len, int device, int sharers, mkzg_ctx** out) {
     mkzg_ctx* c = new mkzg_ctx();
     c->pool = new kzg::HostPool(pool_workers_for(sharers));
+    c->cpu_share = (int)cpu_share_for(sharers);
     c->device = device;
     // reference api.go:93-95 (ErrMinSRSSize) and the fixed-size arrays of trusted_setup.go:23-27
     if (!parse_hex_array(js, len, "g1_monomial", 48, c->g1_monomial) || !parse_hex_array(js, len, "g1_lagrange", 48, c->g1_lagrange) ||
@@ -731,6 +765,9 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
     }
     if (!strcmp(key, "debug_serial")) {
         c->opt_debug_serial = value != 0;
+    } else if (!strcmp(key, "host_wait")) {
+        if (value < -1 || value > 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_host_wait = (int)value;
         return MKZG_OK;
     }
     if (!strcmp(key, "verify_shape")) {
@@ -762,6 +799,8 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "cells_chunk")) *value = q->opt_cells_chunk;
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
     else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
+    else if (!strcmp(key, "host_wait")) *value = q->opt_host_wait;
+    else if (!strcmp(key, "cpu_share")) *value = q->cpu_share;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
     else if (!strcmp(key, "devices")) *value = c->peers.empty() ? 1 : (long)c->peers.size();
     else if (!strcmp(key, "tables_on_own_device")) {

@@ -233,7 +233,7 @@ int mkzg_compute_cells(mkzg_ctx* c, const uint8_t* blob, int num_threads, uint8_
     int st = 0;
     HIPCHK(hipMemcpyAsync(&st, L->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
-    HIPCHK(hipStreamSynchronize(G.s));
+    LANE_SYNC(c, G.L, G.s);
     G.L->drained = true;
     return st;
 }
@@ -267,7 +267,7 @@ int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* c, const uint8_t* blob, int num_
     HIPCHK(hipMemcpyAsync(&st, L->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(proofs_out, L->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, G.s));
-    HIPCHK(hipStreamSynchronize(G.s));
+    LANE_SYNC(c, G.L, G.s);
     G.L->drained = true;
     return st;
 }
@@ -397,7 +397,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     HIPCHK(hipMemcpyAsync(h_sub_rows.data(), sub_rows, n_rows * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_sub_q.data(), sub_q, n * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS_C * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    LANE_SYNC(c, L, s);
     L->drained = true;
     // error precedence of api_eip7594.go:190-213: all commitments, then all proofs, then all cells
     for (size_t i = 0; i < n_rows; i++) {
@@ -537,7 +537,7 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
     // device-side statuses (non-canonical field elements in the cells) join the host-side ones
     std::vector<int> dst(n_blobs);
     HIPCHK(hipMemcpyAsync(dst.data(), L->d_cell_st, n_blobs * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    LANE_SYNC(c, L, s);
     for (size_t b = 0; b < n_blobs; b++) if (!status[b]) status[b] = dst[b];
     return MKZG_OK;
 }
@@ -617,7 +617,7 @@ int mkzg_recover_cells_and_kzg_proofs(mkzg_ctx* c, const uint64_t* cell_ids, siz
     if (st) return st;
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(proofs_out, L->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, G.s));
-    HIPCHK(hipStreamSynchronize(G.s));
+    LANE_SYNC(c, G.L, G.s);
     G.L->drained = true;
     return MKZG_OK;
 }
@@ -651,7 +651,7 @@ int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* c, size_t n_blobs, const u
             HIPCHK(hipMemcpyAsync(h_proofs + b * 128 * 48, L->d_fk_proofs + b * 128 * 48, (e - b) * 128 * 48, hipMemcpyDeviceToHost, G.s));
             b = e;
         }
-        HIPCHK(hipStreamSynchronize(G.s));
+        LANE_SYNC(c, G.L, G.s);
         G.L->drained = true;
         const int nthr = m >= 8 ? 8 : 1;
         const size_t per = (m + nthr - 1) / nthr;
@@ -678,7 +678,7 @@ int mkzg_recover_cells(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, cons
     if (rc) return G.fail(rc);
     if (st) return st;
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
-    HIPCHK(hipStreamSynchronize(G.s));
+    LANE_SYNC(c, G.L, G.s);
     G.L->drained = true;
     return MKZG_OK;
 }

@@ -161,12 +161,37 @@ static bool throughput_shape(const mkzg_ctx* c) {
     if (c->opt_verify_shape >= 0) return c->opt_verify_shape == 1;
     return c->lanes_busy.load(std::memory_order_relaxed) >= 3;
 }
+#ifdef MKZG_CPU_PROF
+// diagnostic build (tools: build_variant.sh cpuprof "-DMKZG_CPU_PROF" api_verify.hip): thread CPU time of the caller by section of a verifier call
+#include <time.h>
+static std::atomic<long long> g_cpu_ns[8];
+static std::atomic<long long> g_wall_ns[8];
+static std::atomic<long long> g_cpu_calls{0};
+struct CpuMark {
+    long long c, w;
+    static long long now(clockid_t id) { timespec t; clock_gettime(id, &t); return t.tv_sec * 1000000000ll + t.tv_nsec; }
+    CpuMark() : c(now(CLOCK_THREAD_CPUTIME_ID)), w(now(CLOCK_MONOTONIC)) {}
+    void lap(int k) { long long c2 = now(CLOCK_THREAD_CPUTIME_ID), w2 = now(CLOCK_MONOTONIC); g_cpu_ns[k] += c2 - c; g_wall_ns[k] += w2 - w; c = c2; w = w2; }
+};
+struct CpuProfPrinter { ~CpuProfPrinter() {
+    long long n = g_cpu_calls.load(); if (!n) return;
+    static const char* nm[8] = {"launch1", "hash_join", "round_wait", "launch2", "final_wait", "status+horner", "finish", "-"};
+    for (int k = 0; k < 7; k++) fprintf(stderr, "cpuprof %-14s cpu %8.1f us  wall %8.1f us per call\n", nm[k], g_cpu_ns[k] / 1e3 / n, g_wall_ns[k] / 1e3 / n);
+} } g_cpu_prof_printer;
+#define CPU_LAP(k) cpu_mark.lap(k)
+#else
+#define CPU_LAP(k) ((void)0)
+#endif
 static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
                        uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out) {
     if (n == 0 || n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
     int rc = ensure_verify_ws(L, n);
     if (rc) return rc;
     const bool tp = throughput_shape(c);
+#ifdef MKZG_CPU_PROF
+    CpuMark cpu_mark;
+    g_cpu_calls++;
+#endif
     if (d_blobs && !tp) {
         // coefficient rows of the blobs (inverse NTT beside the challenge hash) and the NTT twiddles they need
         rc = ensure_twiddles(c);
@@ -230,8 +255,14 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             scalars_to_fr_device(d_z32, (int)n, L->d_v_z, st_x, s);          // challenges hashed on the host (canonical by construction)
         } else if (tp) {
             std::shared_ptr<HashRound> round;                                // the hash of this call and of whoever else is waiting for one
+            CPU_LAP(0);
             rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->ev_fork, &round);   // ev_fork: recorded on s before any of this call's kernels
-            if (round && round->done) HIPCHK(hipEventSynchronize(round->done));
+            CPU_LAP(1);
+            if (round && round->done) {                                      // on the host: a device-side wait would hold the call's queue
+                if (wait_sleeping(c)) { const int wr = wait_event_sleeping(round->done); if (wr) return wr; }
+                else HIPCHK(hipEventSynchronize(round->done));
+            }
+            CPU_LAP(2);
             if (rc) return rc;
         } else {
             if (c->opt_debug_serial.load(std::memory_order_relaxed)) HIPCHK(hipStreamSynchronize(s2));
@@ -272,7 +303,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         {
             std::vector<int> sty(n);
             HIPCHK(hipMemcpyAsync(sty.data(), st_x, n * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            LANE_SYNC(c, L, s);
             for (int v : sty) if (v) y_bad = v;
         }
         HIPCHK(hipMemcpyAsync(L->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
@@ -289,14 +320,9 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     int* h_st = (int*)L->h_v;
     HIPCHK(hipMemcpyAsync(h_st, L->d_v_st, 3 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS * 4, hipMemcpyDeviceToHost, s));
-    if (tp) {
-        // many calls in flight: hipStreamSynchronize POLLS, and dozens of polling callers take the cores that the host finish of the
-        // other calls needs (measured with 32 callers: 14.7 of 16 CPUs busy for 1 ms of host work per call); sleep on an event instead
-        HIPCHK(hipEventRecord(L->ev_block, s));
-        HIPCHK(hipEventSynchronize(L->ev_block));
-    } else {
-        HIPCHK(hipStreamSynchronize(s));
-    }
+    CPU_LAP(3);
+    LANE_SYNC(c, L, s);                     // polls for a lone caller, asks and sleeps when the context is crowded (ctx.h)
+    CPU_LAP(4);
     L->drained = true;                      // the side stream was joined into s above; nothing of this call is left on the device
     if (d_blobs) {
         for (size_t i = 0; i < n; i++) {                           // verify.go:102-123 order: commitment, proof, blob
@@ -323,6 +349,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     }
     memcpy(out->e, h_misc + 8, 32);
     L->last_host_finish_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
+    CPU_LAP(5);
     return MKZG_OK;
 }
 // kzg_verify.go:160-199: F = Cc - [e]G + D ; e(F, G2) e(-A, [alpha]G2) == 1
@@ -587,11 +614,11 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         std::vector<int> stb(slice), stc(slice);
         HIPCHK(hipMemcpyAsync(stb.data(), st_blob, slice * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipMemcpyAsync(stc.data(), st_cm, slice * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        LANE_SYNC(c, L, s);
         bool any = false;
         for (size_t i = 0; i < slice; i++) { stb[i] = stb[i] ? stb[i] : stc[i]; any = any || stb[i]; }
         if (any) HIPCHK(hipMemcpyAsync(d_status + done, stb.data(), slice * sizeof(int), hipMemcpyHostToDevice, s));
-        if (any) HIPCHK(hipStreamSynchronize(s));
+        if (any) LANE_SYNC(c, L, s);
         done += slice;
     }
     return MKZG_OK;
@@ -622,7 +649,7 @@ int mkzg_compute_blob_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t 
     if (rc) return G.fail(rc);
     HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, 48, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(L->h_out + 48, L->d_status, sizeof(int), hipMemcpyDeviceToHost, G.s));
-    HIPCHK(hipStreamSynchronize(G.s));
+    LANE_SYNC(c, G.L, G.s);
     L->drained = true;
     int st = 0;
     memcpy(&st, L->h_out + 48, sizeof(int));
@@ -657,7 +684,7 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     HIPCHK(hipMemcpyAsync(L->h_out + 48, L->d_blobs + MKZG_BYTES_PER_BLOB + 64, 32, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(L->h_out + 80, L->d_q_st, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(L->h_out + 84, st_z, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    LANE_SYNC(c, L, s);
     L->drained = true;
     int stb = 0, stz = 0;
     memcpy(&stb, L->h_out + 80, sizeof(int));
@@ -696,7 +723,7 @@ int mkzg_msm_g1(mkzg_ctx* c, const uint64_t* scalars_mont4, const uint64_t* poin
         HIPCHK(hipGetLastError());
         uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * L->v_cap * sizeof(int));
         HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, (16 + VMSM_WINDOWS * 48) * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        LANE_SYNC(c, L, s);
         G1HX part;
         g1h_horner_words(part, h_misc + 16, VMSM_WINDOWS, VMSM_WINDOW_BITS);
         G1H::add(total, total, part);

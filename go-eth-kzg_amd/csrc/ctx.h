@@ -206,6 +206,8 @@ struct mkzg_ctx {
     std::atomic<int> opt_verify_shape{-1};             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
     int opt_cells_chunk = 256;             // most blobs per launch set of a ComputeCellsAndKZGProofs batch (a lane's FK20 workspace grows to the pieces it has seen: 1.6 MB per blob)
     int opt_lanes = NLANE;                 // lanes calls may occupy at once (each keeps its workspaces and pinned staging until trimmed or destroyed)
+    std::atomic<int> opt_host_wait{-1};    // how a call waits for the GPU: 0 the runtime's own wait (polls), 1 query + sleep, -1 by the calls in flight and the CPUs of the context's share; lane_sync (api.hip)
+    int cpu_share = 1;                     // CPUs this context may count on: the cgroup's, divided by the ranks on the node / the devices of the context
     std::atomic<int> opt_debug_serial{0};  // measurement aid: the blob verifier waits for its side stream before it launches the challenge hash (the hash kernel alone on the chip)
     std::atomic<int> opt_host_sha{-1};                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)
     std::atomic<bool> profiling{false};
@@ -275,6 +277,15 @@ struct LaneGuard {                          // one call = one guard
     LaneGuard& operator=(const LaneGuard&) = delete;
     int fail(int rc) { if (L && rc != MKZG_OK) L->failed = true; return rc; }    // error exit after device work was enqueued
 };
+// Waiting for the GPU (api.hip).  hipStreamSynchronize polls, and on this runtime hipEventSynchronize does too, even for an event made with
+// hipEventBlockingSync: *measured* (thread CPU clock around the calls, 32 callers of the blob verifier on one context) 7.7 ms of CPU per
+// call, 6.1 of them in the last wait, 13 of the 16 granted CPUs busy.  A call that shares the context with more calls than half the CPUs
+// of the context's share records an event and asks + sleeps instead (20 us steps, then 60; the thread's timer slack lowered meanwhile):
+// 3.8 CPUs busy, 1.49-1.50 M blobs/s against 1.55-1.62 M.  A lone caller keeps the polling wait: it is the lowest latency.
+bool wait_sleeping(const mkzg_ctx* c);
+int wait_event_sleeping(hipEvent_t ev);
+int lane_sync(mkzg_ctx* c, Lane* L, hipStream_t s);
+#define LANE_SYNC(c, L, s) do { const int ls__ = lane_sync(c, L, s); if (ls__) return ls__; } while (0)
 #define KT(kind, s, call)                                         \
     do {                                                          \
         const bool kt_on__ = c->profiling.load(std::memory_order_relaxed); \

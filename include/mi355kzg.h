@@ -89,6 +89,12 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         TLB-bound: measured no faster on MI355X) or 8 (4.3 GB, 32 additions per scalar).  When the HBM is short the
  *                         next narrower table is built instead (13 -> 12 -> 11 -> 8: same bytes out, "fk20_bits_effective" reports what is
  *                         in use); only when not even 4.3 GB are free does the call fail with MKZG_ERR_HIP
+ *   "host_wait"           how a call waits for its device work: 0 = the HIP runtime's own wait, which POLLS (a busy CPU per waiting caller:
+ *                         lowest latency), 1 = ask and sleep (an event query every 20-60 us: ~0.1 ms more latency, next to no CPU),
+ *                         -1 (default) = sleep when more calls are in flight on the context than half the CPUs of its share ("cpu_share",
+ *                         get only: the cgroup's CPUs divided by LOCAL_WORLD_SIZE / the context's devices), else poll.  Measured, 32
+ *                         callers of VerifyBlobKZGProofBatch(1024) on 16 CPUs: 14.6 CPUs busy and 1.55-1.62 M blobs/s polling, 3.8 CPUs
+ *                         busy and 1.49-1.50 M sleeping
  *   "debug_serial"        measurement aid: 1 = the blob verifier's challenge hash runs alone on the chip (the call waits for its side stream first)
  *   "lanes"               1..32 (default 32): calls that may be in flight on the context at once; lanes above the limit free their memory
  *   "trim"                (set only, any value) frees every lane's workspaces and pinned staging; they are rebuilt on demand

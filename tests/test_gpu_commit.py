@@ -180,6 +180,8 @@ def test_options_and_calibration(product, oracle_ctx):
         assert ctx.set_option("host_zero_copy", zc) == 0 and ctx.get_option("host_zero_copy") == zc
         assert ctx.get_option("commit_direct_bits") == -1            # library default: auto-sized direct table
         assert ctx.set_option("commit_direct_bits", 12 if chunk == 3 else 0) == 0     # the chunked accumulate launches exist in direct-table mode only
+        assert ctx.get_option("host_wait") == -1 and ctx.set_option("host_wait", 2) == 17 and ctx.set_option("host_wait", chunk & 1) == 0 and ctx.get_option("host_wait") == (chunk & 1)
+        assert ctx.get_option("cpu_share") >= 2
         assert ctx.set_option("host_chunk", 0) == 17                 # MKZG_ERR_BAD_ARGS
         assert ctx.set_option("no_such_option", 1) == 17 and ctx.get_option("no_such_option") is None
         rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)

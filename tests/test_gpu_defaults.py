@@ -326,3 +326,44 @@ def test_multi_device_context_on_two_gpus(product, oracle_ctx):
     t.join(timeout=900)
     ctx.close()
     assert not errors, errors[0]
+
+
+def test_sleeping_waits_give_the_same_results(product):
+    """option host_wait: every entry point that waits for the device does so by the runtime's polling wait (0) or by event queries and
+    sleeps (1, what a crowded context does by itself) -- same bytes and verdicts either way (api.go / api_eip7594.go entry points)"""
+    import torch
+    torch.cuda.init()
+    blobs = [rand_blob(900 + i) for i in range(3)]
+    results = []
+    for mode in (0, 1):
+        ctx = product.Context()
+        assert ctx.set_option("host_wait", mode) == 0
+        out = []
+        rc, cms, st = ctx.BlobToKZGCommitmentBatch(blobs)
+        assert rc == 0 and st == [0] * 3
+        out.append(cms)
+        prs = []
+        for b, cm in zip(blobs, cms):
+            rc, pr = ctx.ComputeBlobKZGProof(b, cm)
+            assert rc == 0
+            prs.append(pr)
+        out.append(prs)
+        z = (12345).to_bytes(32, "big")
+        rc, pz, y = ctx.ComputeKZGProof(blobs[0], z)
+        assert rc == 0
+        out.append((pz, y))
+        assert ctx.VerifyKZGProof(cms[0], z, y, pz) == 0
+        assert ctx.VerifyBlobKZGProof(blobs[0], cms[0], prs[0]) == 0
+        assert ctx.VerifyBlobKZGProofBatch(blobs, cms, prs) == 0
+        assert ctx.VerifyBlobKZGProofBatch(blobs, cms, prs[::-1]) != 0
+        rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blobs[1])
+        assert rc == 0
+        out.append((cells, proofs))
+        assert ctx.VerifyCellKZGProofBatch([cms[1]] * 128, list(range(128)), cells, proofs) == 0
+        assert ctx.VerifyCellKZGProofBatch([cms[0]] * 128, list(range(128)), cells, proofs) != 0
+        ids = list(range(1, 128, 2))
+        rc, rcells, rproofs = ctx.RecoverCellsAndComputeKZGProofs(ids, [cells[i] for i in ids])
+        assert rc == 0 and rcells == cells and rproofs == proofs
+        results.append(out)
+        ctx.close()
+    assert results[0] == results[1]

@@ -151,25 +151,20 @@ def wl_verify_inflight(args):
         before = task_cpu()
         for t in ts:
             t.start()
-        mid = None
-        if os.environ.get("TRACE_THREAD_CPU") and trial == 1:
-            time.sleep(0.15)
-            m0, mt0 = task_cpu(), time.perf_counter()
-            time.sleep(0.25)
-            m1, mt1 = task_cpu(), time.perf_counter()
-            mid = (m0, m1, mt1 - mt0)
+        tids = {}
+        while any(t.is_alive() for t in ts):          # thread ids die with their threads: keep the last reading of each
+            tids.update(task_cpu())
+            time.sleep(0.02)
         for t in ts:
             t.join()
         dt, cpu = time.perf_counter() - t0, time.process_time() - c0
-        if mid:
-            m0, m1, span = mid
+        if os.environ.get("TRACE_THREAD_CPU"):
             groups = defaultdict(lambda: [0, 0.0])
-            for tid, (name, v) in m1.items():
-                d = v - m0.get(tid, (name, 0.0))[1]
-                key = "python caller" if name.startswith("caller") or name.startswith("python") else name
-                groups[key][0] += 1
-                groups[key][1] += d
-            print(f"  thread CPU over {1e3 * span:.0f} ms mid-run: " + "; ".join(f"{k} x{n}: {c / span:.2f} cores" for k, (n, c) in sorted(groups.items(), key=lambda kv: -kv[1][1]) if c > 0), flush=True)
+            for tid, (name, v) in tids.items():
+                d = v - before.get(tid, (name, 0.0))[1]
+                groups[name][0] += 1
+                groups[name][1] += d
+            print("  thread CPU: " + "; ".join(f"{k} x{n}: {c / dt:.2f} cores" for k, (n, c) in sorted(groups.items(), key=lambda kv: -kv[1][1]) if c > 0), flush=True)
         print(f"trial {trial}: {K} callers x {reps} calls: {K * reps * N / dt:.0f} blobs/s, {1e3 * dt / (K * reps):.3f} ms per call amortised; host CPUs busy {cpu / dt:.1f}", flush=True)
     ctx.close()
 

@@ -500,3 +500,41 @@ def test_first_calls_race_on_a_fresh_context(product, oracle_ctx):
         t.join(timeout=900)
     ctx.close()
     assert not errors, errors[0]
+
+
+def test_throughput_shape_respects_stream_order(product, oracle_ctx):
+    """Device-pointer entry points are stream-ordered: work the caller enqueued on its stream before the call (here: a long sleep
+    kernel, then the copies that PRODUCE the blobs, commitments and proofs) is finished before the library reads them -- also in the
+    throughput shape, whose shared hash launch runs on the context's own stream and skips the wait for the caller's stream only when
+    that stream was idle at the call (api_verify.hip).  A hash over the stale (zero) buffers would reject the batch."""
+    import torch
+    torch.cuda.init()
+    ctx = product.Context()
+    NB = 8
+    blobs = [rand_blob(700 + i) for i in range(NB)]
+    h_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).pin_memory()
+    d_src = h_blobs.cuda()
+    d_cm = torch.zeros(NB * 48, dtype=torch.uint8, device="cuda")
+    d_pr = torch.zeros(NB * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(NB, dtype=torch.int32, device="cuda")
+    assert ctx.blob_to_kzg_commitment_batch_device(d_src.data_ptr(), NB, d_cm.data_ptr(), d_st.data_ptr(), 0) == 0
+    assert ctx.compute_blob_kzg_proof_batch_device(d_src.data_ptr(), d_cm.data_ptr(), NB, d_pr.data_ptr(), d_st.data_ptr(), 0) == 0
+    torch.cuda.synchronize()
+    h_cm, h_pr = d_cm.cpu().pin_memory(), d_pr.cpu().pin_memory()
+    assert ctx.set_option("verify_shape", 1) == 0
+    for rep in range(3):
+        stream = torch.cuda.Stream()
+        d_b = torch.zeros_like(d_src)
+        d_c = torch.zeros_like(d_cm)
+        d_p = torch.zeros_like(d_pr)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            torch.cuda._sleep(20_000_000)                       # 10-200 ms of GPU time (clock dependent) ahead of the producers
+            d_b.copy_(h_blobs, non_blocking=True)
+            d_c.copy_(h_cm, non_blocking=True)
+            d_p.copy_(h_pr, non_blocking=True)
+        assert ctx.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), NB, stream.cuda_stream) == 0
+        # and an idle stream (the other path)
+        stream.synchronize()
+        assert ctx.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), NB, stream.cuda_stream) == 0
+    ctx.close()

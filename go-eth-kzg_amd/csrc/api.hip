@@ -190,6 +190,14 @@ void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s) {
     }
     c->cv.notify_all();
 }
+bool lane_fork(Lane* L, hipStream_t s, hipStream_t side_a, hipStream_t side_b) {
+    if (hipStreamQuery(s) == hipSuccess) return true;
+    (void)hipGetLastError();                   // hipErrorNotReady is reported through the sticky error too
+    if (hipEventRecord(L->ev_fork, s) != hipSuccess) { tl_hip_error = true; return false; }
+    if (side_a && side_a != s && hipStreamWaitEvent(side_a, L->ev_fork, 0) != hipSuccess) tl_hip_error = true;
+    if (side_b && side_b != s && hipStreamWaitEvent(side_b, L->ev_fork, 0) != hipSuccess) tl_hip_error = true;
+    return false;
+}
 bool wait_sleeping(const mkzg_ctx* c) {
     const int o = c->opt_host_wait.load(std::memory_order_relaxed);
     if (o >= 0) return o == 1;
@@ -468,8 +476,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
     // every exit path below must wait for the gather tasks: they reference this frame
     auto drain = [&] { c->pool->wait(all_left); };
     rc = [&]() -> int {
-        HIPCHK(hipEventRecord(L->ev_fork, L->stream));
-        if (!zc) HIPCHK(hipStreamWaitEvent(copy, L->ev_fork, 0));           // every stream of the call inherits the lane hand-over
+        const bool idle = lane_fork(L, L->stream, zc ? nullptr : copy);      // every stream of the call inherits the lane hand-over
         for (size_t k = 0; k < plan.size(); k++) {
             const size_t lo = plan[k].lo, m = plan[k].m;
             c->pool->wait(left[k]);              // runs queued gather tasks itself while there are any
@@ -477,7 +484,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
             if (direct) {
                 const int q = (int)(k & 3);
                 hipStream_t s = cs[q];
-                if (!cs_used[q]) { HIPCHK(hipStreamWaitEvent(s, L->ev_fork, 0)); cs_used[q] = true; }
+                if (!cs_used[q]) { if (!idle) HIPCHK(hipStreamWaitEvent(s, L->ev_fork, 0)); cs_used[q] = true; }
                 if (!zc) {
                     HIPCHK(hipEventRecord(L->ev_chunk[k & 7], copy));
                     HIPCHK(hipStreamWaitEvent(s, L->ev_chunk[k & 7], 0));

@@ -335,9 +335,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     hipStream_t s2 = L->side, s3 = L->side2;
     int* sub_rows = L->d_cv_st + L->cv_cap;
     int* sub_q = L->d_cv_st + 2 * L->cv_cap;
-    HIPCHK(hipEventRecord(L->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(s2, L->ev_fork, 0));
-    HIPCHK(hipStreamWaitEvent(s3, L->ev_fork, 0));
+    lane_fork(L, s, s2, s3);
     KT(KT_DECOMPRESS, s2, g1_validate2_device(L->d_v_raw, (int)n_rows, aff_rows, st_rows, L->d_v_raw + cap * 48, (int)n, aff_q, st_q, s2, 1));
     HIPCHK(hipEventRecord(L->ev_decoded, s2));
     KT(KT_SUBGROUP, s3, g1_validate2_device(L->d_v_raw, (int)n_rows, nullptr, sub_rows, L->d_v_raw + cap * 48, (int)n, nullptr, sub_q, s3, 2));

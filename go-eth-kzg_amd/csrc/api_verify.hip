@@ -195,12 +195,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     // Was the caller's stream idle when the call arrived?  Then nothing that produces this call's inputs can still be pending on it, and
     // the hash round need not wait for this call's marker -- which sits in a hardware queue the stream SHARES with other calls' streams,
     // behind their kernels: *measured* with 32 callers the round's launch-to-finish time was 8.5 ms for a 2.6-4.7 ms kernel.
-#ifndef MKZG_NO_IDLE_CHECK
-    const bool s_idle = tp && hipStreamQuery(s) == hipSuccess;
-#else
-    const bool s_idle = false;
-#endif
-    (void)hipGetLastError();
+    // (decided below, where the side stream is known: lane_fork)
 #ifdef MKZG_CPU_PROF
     CpuMark cpu_mark;
     g_cpu_calls++;
@@ -236,8 +231,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     //    queues, in order within each, so a side stream's short kernels would wait behind some other call's 3 ms hash kernel and a
     //    context with eight calls in flight had two of them progressing; one stream per call keeps one queue per call)
     hipStream_t s2 = tp ? s : lane_side_stream(L, s);
-    HIPCHK(hipEventRecord(L->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(s2, L->ev_fork, 0));
+    const bool s_idle = lane_fork(L, s, s2);
     KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? 3 : 0));
     if (d_blobs) {
         //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
@@ -607,9 +601,8 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         int* st_blob = L->d_q_st;
         int* st_cm = L->d_q_st + L->q_cap;
         // commitment must be a valid subgroup point (prove.go:56-62)
-        HIPCHK(hipEventRecord(L->ev_fork, s));
         hipStream_t s2 = lane_side_stream(L, s);
-        HIPCHK(hipStreamWaitEvent(s2, L->ev_fork, 0));
+        lane_fork(L, s, s2);
         g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, s2);
         HIPCHK(hipEventRecord(L->ev_join, s2));
         if (d_z32) scalars_to_fr_device(d_z32 + done * 32, (int)slice, L->d_q_z, L->d_v_st + 3 * L->v_cap, s);

@@ -282,6 +282,10 @@ struct LaneGuard {                          // one call = one guard
 // call, 6.1 of them in the last wait, 13 of the 16 granted CPUs busy.  A call that shares the context with more calls than half the CPUs
 // of the context's share records an event and asks + sleeps instead (20 us steps, then 60; the thread's timer slack lowered meanwhile):
 // 3.8 CPUs busy, 1.49-1.50 M blobs/s against 1.55-1.62 M.  A lone caller keeps the polling wait: it is the lowest latency.
+// Side streams of a call inherit what is pending on its main stream (the entry points are stream-ordered) through an event recorded on
+// the main stream -- a marker that waits its turn in a hardware queue the stream shares with other calls' streams.  A main stream with
+// nothing pending (hipStreamQuery) has nothing to hand on: no marker, the side streams start at once.  Returns whether s was idle.
+bool lane_fork(Lane* L, hipStream_t s, hipStream_t side_a = nullptr, hipStream_t side_b = nullptr);
 bool wait_sleeping(const mkzg_ctx* c);
 int wait_event_sleeping(hipEvent_t ev);
 int lane_sync(mkzg_ctx* c, Lane* L, hipStream_t s);

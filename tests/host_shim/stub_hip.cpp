@@ -71,5 +71,6 @@ hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t) new int(0); return 
 hipError_t hipEventDestroy(hipEvent_t e) { delete (int*)e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }

@@ -110,7 +110,8 @@ void free_lane(Lane* L) {
     L->cv_cap = 0;
     dev_free(L->d_rec_scratch); dev_free(L->d_rec_pos);
     L->rec_cap = 0;
-    dev_free(L->d_fk_scalars); dev_free(L->d_fk_results); dev_free(L->d_fk_parts); dev_free(L->d_fk_proofs);
+    dev_free(L->d_fk_scalars); dev_free(L->d_fk_results); dev_free(L->d_fk_parts); dev_free(L->d_fk_proofs); dev_free(L->d_fk_seg);
+    L->fk_seg_bytes = 0;
     L->fk_cap = 0;
 }
 static void lane_destroy(Lane* L) {

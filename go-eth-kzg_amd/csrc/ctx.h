@@ -152,6 +152,8 @@ struct Lane {
     size_t fk_cap = 0;
     uint32_t* d_fk_scalars = nullptr;      // fk_cap x 128 x 64 x 8 words
     uint32_t* d_fk_results = nullptr;      // 2 x fk_cap x 128 XYZZ rows (MSM results + second buffer of the transform stage)
+    void* d_fk_seg = nullptr;              // accumulators and tables of the segmented products (fk20_kernels.hip k_fk20_toom_seg): calls of 65..192 blobs, 159 KB per product and 64 blobs
+    size_t fk_seg_bytes = 0;
     uint32_t* d_fk_parts = nullptr;        // fk_cap x 128 x 24 XYZZ rows: per-lane partial sums of the FK20 MSMs, then the transform stage's terms
     uint8_t* d_fk_proofs = nullptr;        // fk_cap x 128 x 48 B
     // ---- profiling (hipEvent brackets on the streams this lane's kernels are launched on)

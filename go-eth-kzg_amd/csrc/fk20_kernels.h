@@ -23,6 +23,9 @@ size_t fk20_parts_rows();        // XYZZ rows of scratch per blob shared by the 
 // scalars [n][128][64][8 words] -> parts [n][128][16] XYZZ rows (scratch) -> results [n][128] XYZZ rows
 void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int cbits, int n, const int* d_status, uint32_t* d_parts, uint32_t* d_results, hipStream_t s);
 // results [n][128] XYZZ rows + tmp of the same size -> proofs [n][128][48 B]; d_parts: fk20_parts_rows() x n XYZZ rows of scratch
-void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_status, uint8_t* d_proofs48, uint32_t* d_parts, hipStream_t s);
+// d_seg: fk20_seg_bytes(n) bytes when fk20_seg_count(n) != 0 (the products of calls of 65..192 blobs run in segments), else unused / nullptr
+void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_status, uint8_t* d_proofs48, uint32_t* d_parts, void* d_seg, hipStream_t s);
+int fk20_seg_count(int n);
+size_t fk20_seg_bytes(int n);
 
 }  // namespace kzg

@@ -603,6 +603,138 @@ __global__ void __launch_bounds__(64) k_fk20_toom_mul(const uint32_t* __restrict
     else f_mul_wnaf(p, p, FK20_TOOM_WNAF[blockIdx.x]);
     if (live) f_store_xyzz(out + row, p);
 }
+// The same products in SEGMENTS, for calls of 65 to 192 blobs.  A product is a 1.76 ms chain that saturates its SIMD (the field
+// multiplications give one wavefront all the independent work the SIMD can issue), so ceil(n / 64) x 686 wavefronts on 1024 SIMDs take
+// 1.76 ms times the LARGEST number of wavefronts any SIMD was dealt: 1372 wavefronts (128 blobs) took 3.5 ms, as 2058 (192) and 2744
+// (256) took 5.3.  Cut into K segments of equal cost -- the table in segment 0, the digit positions dealt out by the cost of their
+// doubling and additions -- the K x units pieces go out as launches of at most 1024 single-wavefront workgroups (one per SIMD),
+// segment-major: piece (unit, s) lies units >= 1024 places after (unit, s - 1), hence in a later launch, and the launch boundary is
+// the only synchronisation.  The accumulator and the table of a unit live in global memory between launches (fk20_seg_bytes).
+constexpr int FK_SEG_ENTRY_Q = 18;                        // uint4 per table entry and lane (70 words)
+constexpr int FK_SEG_ACC_Q = 11;                          // uint4 per accumulator and lane (42 words)
+constexpr int FK_SEG_UNIT_Q = 8 * FK_SEG_ENTRY_Q + FK_SEG_ACC_Q;
+size_t fk20_seg_bytes(int n) { return (size_t)686 * ((n + 63) / 64) * FK_SEG_UNIT_Q * 64 * sizeof(uint4); }
+__device__ __forceinline__ void seg_store_jc(uint4* unit, int entry, int lane, const G1JC& e) {
+    uint32_t w[72];
+#pragma unroll
+    for (int i = 0; i < 14; i++) { w[i] = e.x.l[i]; w[14 + i] = e.y.l[i]; w[28 + i] = e.z.l[i]; w[42 + i] = e.zz.l[i]; w[56 + i] = e.zzz.l[i]; }
+    w[70] = 0; w[71] = 0;
+#pragma unroll
+    for (int q = 0; q < FK_SEG_ENTRY_Q; q++) unit[(size_t)(entry * FK_SEG_ENTRY_Q + q) * 64 + lane] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+__device__ __forceinline__ void seg_load_jc(G1JC& e, const uint4* unit, int entry, int lane) {
+    uint32_t w[72];
+#pragma unroll
+    for (int q = 0; q < FK_SEG_ENTRY_Q; q++) {
+        const uint4 v = unit[(size_t)(entry * FK_SEG_ENTRY_Q + q) * 64 + lane];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) { e.x.l[i] = w[i]; e.y.l[i] = w[14 + i]; e.z.l[i] = w[28 + i]; e.zz.l[i] = w[42 + i]; e.zzz.l[i] = w[56 + i]; }
+}
+__device__ __forceinline__ void seg_store_acc(uint4* unit, int lane, const G1J& a) {
+    uint32_t w[44];
+#pragma unroll
+    for (int i = 0; i < 14; i++) { w[i] = a.x.l[i]; w[14 + i] = a.y.l[i]; w[28 + i] = a.z.l[i]; }
+    w[42] = 0; w[43] = 0;
+#pragma unroll
+    for (int q = 0; q < FK_SEG_ACC_Q; q++) unit[(size_t)(8 * FK_SEG_ENTRY_Q + q) * 64 + lane] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+__device__ __forceinline__ void seg_load_acc(G1J& a, const uint4* unit, int lane) {
+    uint32_t w[44];
+#pragma unroll
+    for (int q = 0; q < FK_SEG_ACC_Q; q++) {
+        const uint4 v = unit[(size_t)(8 * FK_SEG_ENTRY_Q + q) * 64 + lane];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; i++) { a.x.l[i] = w[i]; a.y.l[i] = w[14 + i]; a.z.l[i] = w[28 + i]; }
+}
+// costs in field multiplications: a doubling 7, an addition 16, the table (one doubling, seven additions, eight caches) 135
+constexpr int FK_SEG_COST_DBL = 7, FK_SEG_COST_ADD = 16, FK_SEG_COST_TABLE = 135;
+__global__ void __launch_bounds__(64) k_fk20_toom_seg(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const int* __restrict__ status, int n, int units, int K,
+                                                       int base, uint4* __restrict__ seg) {
+    const int idx = base + (int)blockIdx.x;
+    const int sg = idx / units, u = idx - sg * units;
+    const int t = u % 686, y = u / 686;
+    const int lane = threadIdx.x;
+    const int glane = y * 64 + lane;
+    const bool live = glane < n;
+    const int b = live ? glane : glane % n;                // FULL_WAVES: surplus lanes repeat a blob and store nothing
+    if (status[b] != 0) return;
+    const uint32_t* __restrict__ row = FK20_TOOM_WNAF[t];
+    uint4* unit = seg + (size_t)u * FK_SEG_UNIT_Q * 64;
+    const size_t prow = ((size_t)t * n + b) * 64;
+    // the scalar's total cost (uniform: it depends on the digit string only)
+    int total = FK_SEG_COST_TABLE;
+    {
+        bool st = false;
+        for (int i = 130; i >= 0; i--) {
+            const uint32_t code = (row[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            if (st) total += FK_SEG_COST_DBL;
+            if (code & 0xffu) { total += FK_SEG_COST_ADD; st = true; }
+            if (code >> 8) { total += FK_SEG_COST_ADD; st = true; }
+        }
+    }
+    G1J acc;
+    if (sg == 0) {
+        G1X p;
+        f_load_xyzz(p, in + prow);
+        G1J run, two;
+        G1JC c, twoc;
+        G1D::jac_from_xyzz(run, p);
+        G1D::jac_cache(c, run);
+        seg_store_jc(unit, 0, lane, c);
+        G1D::jdbl(two, run);
+        G1D::jac_cache(twoc, two);
+#pragma unroll 1
+        for (int j = 1; j < 8; j++) {
+            G1D::jadd(run, run, twoc);
+            G1D::jac_cache(c, run);
+            seg_store_jc(unit, j, lane, c);
+        }
+        G1D::set_inf(acc);
+    } else {
+        seg_load_acc(acc, unit, lane);
+    }
+    fp_t beta;
+    Fp::set(beta, FP_BETA);
+    bool started = false;
+    int cum = FK_SEG_COST_TABLE;
+#pragma unroll 1
+    for (int i = 130; i >= 0; i--) {
+        const uint32_t code = (row[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+        const int mine = min(K - 1, cum * K / total) - sg;        // < 0: an earlier segment's position, > 0: a later one's
+        if (mine > 0) break;
+        if (started) cum += FK_SEG_COST_DBL;
+        if (started && mine == 0) G1D::jdbl(acc, acc);
+        if (code == 0) continue;
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            const int d = (int)(int8_t)(half ? code >> 8 : code & 0xffu);
+            if (d) {
+                cum += FK_SEG_COST_ADD;
+                started = true;
+                if (mine == 0) {
+                    G1JC q;
+                    seg_load_jc(q, unit, ((d < 0 ? -d : d) - 1) >> 1, lane);
+                    // second half: -phi(.) = (beta X, -Y); a negative digit flips the sign once more
+                    if (half) Fp::mul(q.x, q.x, beta);
+                    if ((d < 0) != (half != 0)) Fp::template neg<3>(q.y, q.y);   // 8p - Y (Y < 5.01p)
+                    G1D::jadd(acc, acc, q);
+                }
+            }
+        }
+    }
+    if (sg == K - 1) {
+        G1X r;
+        G1D::jac_to_xyzz(r, acc);
+        if (live) f_store_xyzz(out + prow, r);
+    } else {
+        seg_store_acc(unit, lane, acc);
+    }
+}
+
 // proofs[i] = X[brev7(i)] (fk20.go:90), affine, compressed
 __global__ void __launch_bounds__(64) k_fk20_finish(const uint32_t* __restrict__ x, const int* __restrict__ status, uint8_t* __restrict__ proofs48) {
     const int b = blockIdx.y, i = blockIdx.x * 64 + threadIdx.x;
@@ -664,7 +796,17 @@ void fk20_msm_device(const uint32_t* d_scalars, const uint32_t* d_table, int cbi
 }
 // MSM results u' [n][128] XYZZ rows in d_results -> proofs [n][128][48 B].  d_tmp: n x 128 rows (the transformed points before
 // compression); d_parts: the two buffers of the network, 2 x 686 x n rows (fk20_parts_rows() per blob).
-void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_status, uint8_t* d_proofs48, uint32_t* d_parts, hipStream_t s) {
+int fk20_seg_count(int n) {                 // segments per product for a call of n blobs; 0: one launch of whole products
+#ifdef FK_SEG_OFF
+    return 0;
+#endif
+    const int g = (n + 63) / 64;
+    // 65..128 blobs: 2744 pieces -> 3 launches of 915; 129..192: 8232 -> 9 of 915.  *Measured* (tools/sweep_cells.py, whole call):
+    // 96 blobs 8.4 -> 7.5 ms, 128: 8.6 -> 7.7, 160: 11.9 -> 10.9, 192: 12.3 -> 11.0; 256 blobs (10976 pieces, 11 launches) 13.9 -> 13.9:
+    // eleven launches each as long as its slowest piece give back what the balance gains, so 193 blobs and more run whole products
+    return g == 2 ? 2 : g == 3 ? 4 : 0;
+}
+void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_status, uint8_t* d_proofs48, uint32_t* d_parts, void* d_seg, hipStream_t s) {
     if (n <= 0) return;
     uint32_t* bufA = d_parts;
     uint32_t* bufB = d_parts + (size_t)686 * n * 64;
@@ -683,7 +825,12 @@ void fk20_ffts_device(uint32_t* d_results, uint32_t* d_tmp, int n, const int* d_
     // way); above that the extra wavefronts would share SIMDs and the shorter chains buy nothing
     if (n <= FK_QUAD_MAX_BATCH) hipLaunchKernelGGL((k_fk20_toom_mul<4>), dim3(686, (4 * n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
     else if (n <= FK_PAIR_MAX_BATCH) hipLaunchKernelGGL((k_fk20_toom_mul<2>), dim3(686, (2 * n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
-    else hipLaunchKernelGGL((k_fk20_toom_mul<1>), dim3(686, (n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
+    else if (d_seg && fk20_seg_count(n)) {
+        const int K = fk20_seg_count(n), units = 686 * ((n + 63) / 64), total = units * K;
+        const int rounds = (total + 1023) / 1024, per = (total + rounds - 1) / rounds;       // per <= 1024 <= units: a piece's predecessor is in an earlier launch
+        for (int r = 0; r < rounds; r++)
+            hipLaunchKernelGGL(k_fk20_toom_seg, dim3((unsigned)std::min(per, total - r * per)), dim3(64), 0, s, bufA, bufB, d_status, n, units, K, r * per, (uint4*)d_seg);
+    } else hipLaunchKernelGGL((k_fk20_toom_mul<1>), dim3(686, (n + 63) / 64), dim3(64), 0, s, bufA, bufB, d_status, n);
     if (quad) {
         hipLaunchKernelGGL((k_fk20_post<false, true>), grid(49, 1, 4), dim3(64), 0, s, bufB, bufA, nullptr, d_status, n, 49, 1);
         hipLaunchKernelGGL((k_fk20_post<false, true>), grid(7, 4, 4), dim3(64), 0, s, bufA, bufB, nullptr, d_status, n, 7, 4);

@@ -704,7 +704,10 @@ __global__ void __launch_bounds__(64) k_fk20_toom_seg(const uint32_t* __restrict
 #pragma unroll 1
     for (int i = 130; i >= 0; i--) {
         const uint32_t code = (row[i >> 1] >> (16 * (i & 1))) & 0xffffu;
-        const int mine = min(K - 1, cum * K / total) - sg;        // < 0: an earlier segment's position, > 0: a later one's
+        // a position belongs to the segment its MIDDLE falls into (the heaviest segment of any scalar: 1.05 x the mean for K = 4, 1.09 x
+        // when dealt by the position's start; tests/test_fk20_segments.py restates the rule for all 686 scalars)
+        const int pc = (started ? FK_SEG_COST_DBL : 0) + FK_SEG_COST_ADD * (((code & 0xffu) != 0) + ((code >> 8) != 0));
+        const int mine = min(K - 1, (cum + pc / 2) * K / total) - sg;        // < 0: an earlier segment's position, > 0: a later one's
         if (mine > 0) break;
         if (started) cum += FK_SEG_COST_DBL;
         if (started && mine == 0) G1D::jdbl(acc, acc);

@@ -106,6 +106,7 @@ def parse_args():
     ap.add_argument("--no-drop-in", action="store_true")
     ap.add_argument("--verify-batch", type=int, default=1024, help="configs[2]: proofs per VerifyBlobKZGProofBatch call per GPU (0 = skip)")
     ap.add_argument("--verify-steps", type=int, default=3)
+    ap.add_argument("--no-big-cells", action="store_true", help="skip the ComputeCellsAndKZGProofs calls of 128 / 192 / 256 blobs (PMC passes: a kernel's largest launches must be the 64-blob leg's)")
     ap.add_argument("--verify-inflight", type=int, default=32, help="caller threads of the sustained-rate leg (one call in flight each; a context has 32 lanes)")
     ap.add_argument("--fk20-bits", type=int, default=12, help="window width of the FK20 fixed-base table: 12 (47 GB, the library default), 11 (25.8 GB), 8 (4.3 GB) or 13 (86 GB: fewer additions but TLB-bound gathers, measured no faster); narrower ones are the fallback when HBM is short")
     ap.add_argument("--cell-blobs", type=int, default=64, help="configs[3]/[4]: blobs per GPU for the EIP-7594 legs (64 x 128 = 8192 cells; 0 = skip)")
@@ -132,6 +133,9 @@ def spawn_ranks(args):
 
 def main():
     args = parse_args()
+    if os.environ.get("BENCH_WATCHDOG"):               # diagnosis aid: every thread's Python stack after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG"]), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     import torch
@@ -764,7 +768,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
             by_batch[str(nb)] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
         assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st) == 0      # the outputs the later legs compare with
         torch.cuda.synchronize()
-        if NB == 64:
+        if NB == 64 and not args.no_big_cells:
             # calls of more blobs than a block carries (a node catching up; pieces of up to 256 blobs, the products of 65..192 in segments):
             # the first NB blobs' proofs must equal the NB-blob call's
             big = 256

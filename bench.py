@@ -782,10 +782,14 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
                 torch.cuda.synchronize()
                 assert int(d_s4[:nb].abs().sum().item()) == 0 and torch.equal(d_p4[:NB * 6144], d_proofs) and torch.equal(d_p4[(nb - NB) * 6144:nb * 6144], d_proofs)
                 t0 = time.perf_counter()
+                marks = []
                 for _ in range(3):
                     ctx.compute_cells_and_kzg_proofs_batch_device(d_b4.data_ptr(), nb, d_c4.data_ptr(), d_p4.data_ptr(), d_s4.data_ptr(), st)
+                    marks.append(round((time.perf_counter() - t0) * 1e3, 2))
                 torch.cuda.synchronize()
                 by_batch[str(nb)] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+                if os.environ.get("BENCH_DEBUG"):
+                    print(f"[debug] cells nb={nb}: calls returned at {marks} ms, all done at {by_batch[str(nb)] * 3:.2f} ms, free HBM {torch.cuda.mem_get_info()[0] / 2**30:.1f} GiB", file=sys.stderr, flush=True)
             out["compute_cells_and_kzg_proofs"]["blobs_per_s_256_per_call"] = round(256 / (by_batch["256"] * 1e-3), 1)
             del d_b4, d_c4, d_p4, d_s4
         out["compute_cells_and_kzg_proofs"]["ms_per_call_by_blobs"] = by_batch

@@ -126,7 +126,10 @@ static void lane_destroy(Lane* L) {
     for (auto& e : L->ev_chunk) if (e) (void)hipEventDestroy(e);
 }
 
-// Which free lane: (1) the most recently used one whose previous call has finished on the GPU -- its workspaces are allocated and
+// Which free lane: (0) for a device-pointer call, the lane whose last call ran on the SAME stream (stream order serialises the two
+// calls anyway; *measured* with three ComputeCellsAndKZGProofs calls of 128-256 blobs issued back to back on one stream: the second
+// and third used to take fresh lanes, grow their workspaces -- hipFree waits for the device -- and return after 16-28 ms, and
+// sometimes cost 5 ms per call; now they return after 0.1 ms each and hold one set of workspaces); (1) the most recently used one whose previous call has finished on the GPU -- its workspaces are allocated and
 // warm, so a lone synchronous caller keeps to one lane; (2) else a lane that has been used before, the one released longest ago (its
 // work ends soonest: asynchronous callers issuing faster than the GPU retires alternate between lanes and overlap, as the
 // two-workspace scheme of the commitment path always did); (3) a lane never used -- cold: its first call allocates -- only when
@@ -139,17 +142,22 @@ Lane* lane_acquire(mkzg_ctx* c, bool user_stream, hipStream_t s) {
             Lane* idle = nullptr;
             Lane* warm = nullptr;
             Lane* cold = nullptr;
+            Lane* same = nullptr;              // free, and its last call ran on this caller's stream
             int active = 0;
             for (int i = 0; i < c->opt_lanes; i++) {
                 Lane* q = &c->lanes[i];
                 if (q->busy) { active++; continue; }
                 if (!q->warm) { if (!cold) cold = q; continue; }
                 if (!warm || q->released_at < warm->released_at) warm = q;
+                if (user_stream && q->last_stream == s && (!same || q->released_at > same->released_at)) same = q;
                 const bool finished = !q->used || hipEventQuery(q->done) == hipSuccess;
                 if (!finished) active++;
                 if (finished && (!idle || q->released_at > idle->released_at)) idle = q;
             }
-            L = idle ? idle : (cold && user_stream ? cold : (warm ? warm : cold));
+            // (0) asynchronous calls issued back to back on ONE stream run one after the other whatever lane they take: the lane of the
+            // previous call on that stream has the workspaces already, and stream order makes its reuse safe -- a fresh lane per call in
+            // flight would allocate its own (and hipFree of an outgrown block waits for the whole device)
+            L = same ? same : idle ? idle : (cold && user_stream ? cold : (warm ? warm : cold));
             if (L) { L->others_active = active; break; }
             c->cv.wait(lk);
         }
@@ -177,6 +185,7 @@ void lane_release(mkzg_ctx* c, Lane* L, hipStream_t s) {
     // a call that has waited for its last device work on the host hands on an idle lane: no event, and the next acquire does not have to
     // guess from hipEventQuery (an event recorded microseconds ago reads "not ready", and the caller would be sent to a cold lane --
     // a synchronous caller looping over one context walked through all the lanes that way, allocating workspaces in each)
+    L->last_stream = s;
     if (L->drained) {
         L->used = false;
     } else {

@@ -92,6 +92,7 @@ struct Lane {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_decoded = nullptr;
     hipEvent_t ev_block = nullptr;         // hipEventBlockingSync: a caller that shares the host with many others sleeps on it instead of polling the stream
     hipEvent_t done = nullptr;             // recorded on the call's main stream at release: the next owner's stream waits for it (no host sync)
+    hipStream_t last_stream = nullptr;     // the stream of the lane's last call: a caller that pipelines calls on ONE stream keeps one lane (lane_acquire)
     bool used = false;
     int others_active = 0;                 // at hand-over: lanes held by other calls or whose last call is still running on the GPU (latency vs throughput choices)
     bool warm = false;                     // has run a call before (workspaces allocated)

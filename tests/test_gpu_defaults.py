@@ -367,3 +367,41 @@ def test_sleeping_waits_give_the_same_results(product):
         results.append(out)
         ctx.close()
     assert results[0] == results[1]
+
+
+def test_pipelined_calls_on_one_stream_keep_one_lane(product):
+    """Asynchronous device-pointer calls issued back to back on ONE stream are serialised by the stream anyway: they must reuse the lane
+    (and the workspaces) of the previous call on that stream instead of taking a fresh lane each -- no new device memory, every call
+    returns at once, same bytes (api.hip lane_acquire, rule 0)."""
+    import time
+    import torch
+    torch.cuda.init()
+    ctx = product.Context()
+    n = 24
+    blobs = [rand_blob(1200 + i) for i in range(n)]
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    outs = [(torch.zeros(n * 262144, dtype=torch.uint8, device="cuda"), torch.zeros(n * 6144, dtype=torch.uint8, device="cuda"),
+             torch.ones(n, dtype=torch.int32, device="cuda")) for _ in range(5)]
+    stream = torch.cuda.Stream()
+    st = stream.cuda_stream
+
+    def call(k):
+        c, p, s = outs[k]
+        assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), n, c.data_ptr(), p.data_ptr(), s.data_ptr(), st) == 0
+
+    call(0)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    returned = []
+    t0 = time.perf_counter()
+    for k in range(1, 5):
+        call(k)
+        returned.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    assert free0 - torch.cuda.mem_get_info()[0] < (64 << 20), "back-to-back calls on one stream allocated new lane workspaces"
+    assert returned[-1] < 0.5 * total, (returned, total)          # the calls were enqueued, not waited for
+    for k in range(1, 5):
+        assert int(outs[k][2].abs().sum().item()) == 0
+        assert torch.equal(outs[k][0], outs[0][0]) and torch.equal(outs[k][1], outs[0][1])
+    ctx.close()

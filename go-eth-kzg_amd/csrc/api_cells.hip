@@ -380,11 +380,9 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
         if (urc) return urc;
         HIPCHK(hipMemcpyAsync(L->d_cv_cell_idx, h_cidx, n * 8, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(L->d_cv_row_idx, h_ridx, n * 4, hipMemcpyHostToDevice, s));
-        memcpy(h_misc, r_words, 32);
-        HIPCHK(hipMemcpyAsync(L->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
     }
     // scalars
-    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(L->d_v_misc, exp_offset, L->d_cv_cell_idx, L->d_cv_row_idx, L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,
+    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, L->d_cv_cell_idx, L->d_cv_row_idx, L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,
                                                        L->d_v_s1, L->d_v_s3, L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s));
     HIPCHK(hipStreamWaitEvent(s, L->ev_decoded, 0));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k

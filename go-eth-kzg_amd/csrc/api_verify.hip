@@ -223,7 +223,8 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     int* st_x = L->d_v_st + 3 * cap;        // scratch: status of a second scalar array
     // 0. everything that needs r but not the challenges runs beside the challenge hash
     uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * cap * sizeof(int));
-    memcpy(h_misc, r_le32, 32);
+    uint32_t r_words[8];                        // r travels in the kernel arguments (rwords.h), not through a 32-byte upload
+    memcpy(r_words, r_le32, 32);
     uint32_t* d_parts = L->d_v_misc + V_MISC_WORDS;
     uint32_t* d_wsum = L->d_v_misc + 16;
     const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
@@ -244,12 +245,11 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         //    (challenges hashed on the host: there is no hash to run beside -- the points' chains on the side stream, the NTT and the
         //    evaluation on the main one, and the three MSMs as one launch after both)
         const bool host_z = d_z32 != nullptr;
-        HIPCHK(hipMemcpyAsync(L->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, host_z ? s : s2));
         if (!tp && host_z) {
             KT(KT_CELLS_NTT, s, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s));
         } else if (!tp) {
             KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s2));
-            KT(KT_RLC, s2, rlc_scalars_device(L->d_v_misc, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
+            KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
             const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
             const uint32_t* pts[2] = {aff_q, aff_c};
             const int njob[2] = {(int)n, (int)n};
@@ -283,14 +283,14 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             // throughput shape: every launch is time on the call's hardware queue, which it shares with other calls' streams -- one
             // scalar kernel and ONE launch for the three MSMs of kzg_verify.go:150,225,179 instead of two of each
             KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, s));
-            KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
+            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
             const int njob[3] = {(int)n, (int)n, (int)n};
             KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
         } else if (d_z32) {
             KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
-            KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
+            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
             const int njob[3] = {(int)n, (int)n, (int)n};
@@ -298,7 +298,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         } else {
             KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
             // 3. what depends on the challenges: r^i z_i, sum r^i y_i, and the MSM sum r^i z_i Q_i (kzg_verify.go:179)
-            KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
+            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
             const uint32_t* scal[1] = {L->d_v_s3};
             const uint32_t* pts[1] = {aff_q};
             const int njob[1] = {(int)n};
@@ -316,8 +316,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             LANE_SYNC(c, L, s);
             for (int v : sty) if (v) y_bad = v;
         }
-        HIPCHK(hipMemcpyAsync(L->d_v_misc, h_misc, 32, hipMemcpyHostToDevice, s));
-        KT(KT_RLC, s, rlc_scalars_device(L->d_v_misc, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
+        KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
         // the three MSMs of kzg_verify.go:150,225,179: sum r^i Q_i, sum r^i C_i, sum r^i z_i Q_i
         const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
         const uint32_t* pts[3] = {aff_q, aff_c, aff_q};

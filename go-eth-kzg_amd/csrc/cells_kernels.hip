@@ -366,13 +366,13 @@ __device__ __forceinline__ void fr_store_plain8(uint32_t* dst, const fr_t& m) {
     for (int q = 0; q < 8; q++) dst[q] = w[q];
 }
 // r^k rows, s1_k = r^k, s4_k = r^k * h_{cell_k}^64   (kzg_verify.go:28, 73-79; srs.go:75-78)
-__global__ void __launch_bounds__(256) k_cell_rpowers(const uint32_t* __restrict__ r_words8, uint32_t exp_offset, const uint64_t* __restrict__ cell_idx, int n, const uint32_t* __restrict__ tw_fwd,
+__global__ void __launch_bounds__(256) k_cell_rpowers(const RWords r_words8, uint32_t exp_offset, const uint64_t* __restrict__ cell_idx, int n, const uint32_t* __restrict__ tw_fwd,
                                                       uint32_t* __restrict__ rp_rows, uint32_t* __restrict__ s1, uint32_t* __restrict__ s4) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     uint32_t rw[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) rw[i] = r_words8[i];
+    for (int i = 0; i < 8; i++) rw[i] = r_words8.w[i];
     fr_reduce_words(rw);
     fr_t r, pl;
     Fr::from_words32(pl, rw);
@@ -542,11 +542,13 @@ void fk20_scalars_device(const uint32_t* d_coeffs, int n, const uint32_t* d_tw_f
     if (n > 0) hipLaunchKernelGGL(k_fk20_scalars, dim3(n), dim3(NT), 9 * 4096 * 4, s, d_coeffs, d_tw_fwd, d_status, d_scalars);
 }
 
-void cell_verify_scalars_device(const uint32_t* d_r8, uint32_t exp_offset, const uint64_t* d_cell_idx, const uint32_t* d_row_idx, const uint8_t* d_cells, int n, int n_rows,
+void cell_verify_scalars_device(const uint32_t* h_r8, uint32_t exp_offset, const uint64_t* d_cell_idx, const uint32_t* d_row_idx, const uint8_t* d_cells, int n, int n_rows,
                                 const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint32_t* d_rp_rows, uint32_t* d_s1, uint32_t* d_s4, uint32_t* d_weights8,
                                 uint32_t* d_partials, uint32_t* d_interp8, int* d_cell_status, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_cell_rpowers, dim3((n + 255) / 256), dim3(256), 0, s, d_r8, exp_offset, d_cell_idx, n, d_tw_fwd, d_rp_rows, d_s1, d_s4);
+    RWords r;                                  // by value: see rlc_scalars_device
+    for (int i = 0; i < 8; i++) r.w[i] = h_r8[i];
+    hipLaunchKernelGGL(k_cell_rpowers, dim3((n + 255) / 256), dim3(256), 0, s, r, exp_offset, d_cell_idx, n, d_tw_fwd, d_rp_rows, d_s1, d_s4);
     hipLaunchKernelGGL(k_cell_weights, dim3(n_rows), dim3(256), 0, s, d_rp_rows, d_row_idx, n, n_rows, d_weights8);
     const int nb = n < CELL_INTERP_BLOCKS ? n : CELL_INTERP_BLOCKS;
     hipLaunchKernelGGL(k_cell_interp, dim3(nb), dim3(64), 0, s, d_cells, d_cell_idx, d_rp_rows, n, d_tw_inv, d_partials, d_cell_status);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "rwords.h"
 #include "../../include/mi355kzg.h"
 
 namespace kzg {
@@ -31,7 +32,8 @@ void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
                          int mode = 0 /* 0: decode + subgroup test (a lane quad per point); 1: decode only; 2: subgroup test only, verdicts to d_st_*; 3: as 0, one lane per point */);
 // r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)
-void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
+// h_r8: HOST pointer to the eight words of r
+void rlc_scalars_device(const uint32_t* h_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         int mode /* 0 all, 1 s1 only, 2 s3 and e only */, hipStream_t s);
 // n_msm <= 4 jobs of n_per_job[m] <= 8192 (scalar, point) pairs; d_out[msm][32 windows][48 words]
 // gnark-crypto Montgomery layouts (fr.Element 4 x u64, G1Affine 12 x u64) -> plain 8-word scalars + radix-2^29 affine rows

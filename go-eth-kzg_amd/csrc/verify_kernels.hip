@@ -705,13 +705,13 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
 // outputs as plain little-endian 8-word scalars
 // ------------------------------------------------------------------------------------------
 // mode 0: everything; mode 1: s1 only (does not need z, y: issued before the challenges exist); mode 2: s3 and e only
-__global__ void __launch_bounds__(EV_T) k_rlc_scalars(const uint32_t* __restrict__ r_words8, const uint32_t* __restrict__ z_in, const uint32_t* __restrict__ y_in, int n,
+__global__ void __launch_bounds__(EV_T) k_rlc_scalars(const RWords r_words8, const uint32_t* __restrict__ z_in, const uint32_t* __restrict__ y_in, int n,
                                                       uint32_t exp_offset, uint32_t* __restrict__ s1, uint32_t* __restrict__ s3, uint32_t* __restrict__ e_out, int mode) {
     __shared__ uint32_t sh[EV_T * 9];
     const int t = threadIdx.x;
     uint32_t rw[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) rw[i] = r_words8[i];
+    for (int i = 0; i < 8; i++) rw[i] = r_words8.w[i];
     for (int rep = 0; rep < 2; rep++) {
         if (Fr::words32_geq_mod(rw)) {
             uint64_t br = 0;
@@ -1189,9 +1189,11 @@ void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, in
     if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + per_block - 1) / per_block), dim3((mode == 0 || mode == 3) ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b,
                                   d_st_b, mode);
 }
-void rlc_scalars_device(const uint32_t* d_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
+void rlc_scalars_device(const uint32_t* h_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         int mode, hipStream_t s) {
-    hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, d_r8, d_z, d_y, n, exp_offset, d_s1, d_s3, d_e, mode);
+    RWords r;                                  // by value in the kernel arguments: a 32-byte upload is a copy KERNEL that reads host memory, and its
+    for (int i = 0; i < 8; i++) r.w[i] = h_r8[i];   // system-scope acquire waited for whatever else was running (cell verifier: 0.2 ms per call in the trace)
+    hipLaunchKernelGGL(k_rlc_scalars, dim3(1), dim3(EV_T), 0, s, r, d_z, d_y, n, exp_offset, d_s1, d_s3, d_e, mode);
 }
 int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const* d_points, const int* n_per_job, int n_msm, uint32_t* d_parts, uint32_t* d_out, hipStream_t s,
                         int points_per_slice, int latency) {

@@ -2,6 +2,12 @@
 # tools/pmc_collect.sh ROUND_TAG [bench args...]  -- run on the GPU box (gpurun).
 # Separate rocprofv3 --pmc passes (never combined with tracing) over a short bench.py run, then
 # tools/pmc_summarize.py folds them into gpurun_out/<tag>_pmc_summary.csv and gpurun_out/<tag>_traffic.json.
+# The three legs of profiles/r03_traffic.json (each leg's kernels must see that leg's launches as their largest, so the sustained and
+# big-batch sections stay out):
+#   bash tools/pmc_collect.sh r03c                                                          (commit: batch 256, defaults + bucket-method cross-check)
+#   bash tools/pmc_collect.sh r03v --verify-batch 1024 --verify-inflight 1 --no-strong     (verify: single calls only)
+#   bash tools/pmc_collect.sh r03e --cell-blobs 64                                          (eip7594; --no-big-cells is always passed)
+# then, on the build host: python3 tools/pmc_merge.py profiles/r03_traffic.json commit=gpurun_out/r03c_traffic.json verify=... eip7594=...
 set -u
 TAG=${1:-r01}; shift || true
 OUT=gpurun_out/pmc_$TAG

@@ -782,7 +782,13 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
     }
     if (!strcmp(key, "debug_serial")) {
         c->opt_debug_serial = value != 0;
-    } else if (!strcmp(key, "host_wait")) {
+        return MKZG_OK;
+    }
+    if (!strcmp(key, "fk20_segments")) {
+        c->opt_fk20_segments = value != 0;
+        return MKZG_OK;
+    }
+    if (!strcmp(key, "host_wait")) {
         if (value < -1 || value > 1) return MKZG_ERR_BAD_ARGS;
         c->opt_host_wait = (int)value;
         return MKZG_OK;
@@ -817,6 +823,7 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
     else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
     else if (!strcmp(key, "host_wait")) *value = q->opt_host_wait;
+    else if (!strcmp(key, "fk20_segments")) *value = q->opt_fk20_segments;
     else if (!strcmp(key, "cpu_share")) *value = q->cpu_share;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
     else if (!strcmp(key, "devices")) *value = c->peers.empty() ? 1 : (long)c->peers.size();

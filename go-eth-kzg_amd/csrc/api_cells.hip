@@ -200,7 +200,7 @@ static int cells_and_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs,
         KT(KT_CELLS_NTT, s, cells_from_blobs_device(blobs, (int)chunk, c->d_tw_fwd, c->d_tw_inv, L->d_coeffs, d_cells + done * 262144, d_status + done, s));
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(L->d_coeffs, (int)chunk, c->d_tw_fwd, d_status + done, L->d_fk_scalars, s));
         KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, c->fk20_bits_built, (int)chunk, d_status + done, L->d_fk_parts, L->d_fk_results, s));
-        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)chunk, d_status + done, d_proofs + done * 128 * 48, L->d_fk_parts, fk20_seg_bytes((int)chunk) <= L->fk_seg_bytes ? L->d_fk_seg : nullptr, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)chunk, d_status + done, d_proofs + done * 128 * 48, L->d_fk_parts, c->opt_fk20_segments.load(std::memory_order_relaxed) && fk20_seg_bytes((int)chunk) <= L->fk_seg_bytes ? L->d_fk_seg : nullptr, s));
         done += chunk;
     }
     HIPCHK(hipGetLastError());
@@ -536,7 +536,7 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
     if (with_proofs) {
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(L->d_coeffs, (int)n_blobs, c->d_tw_fwd, L->d_cell_st, L->d_fk_scalars, s));
         KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, c->fk20_bits_built, (int)n_blobs, L->d_cell_st, L->d_fk_parts, L->d_fk_results, s));
-        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)n_blobs, L->d_cell_st, L->d_fk_proofs, L->d_fk_parts, fk20_seg_bytes((int)n_blobs) <= L->fk_seg_bytes ? L->d_fk_seg : nullptr, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)n_blobs, L->d_cell_st, L->d_fk_proofs, L->d_fk_parts, c->opt_fk20_segments.load(std::memory_order_relaxed) && fk20_seg_bytes((int)n_blobs) <= L->fk_seg_bytes ? L->d_fk_seg : nullptr, s));
     }
     HIPCHK(hipGetLastError());
     // device-side statuses (non-canonical field elements in the cells) join the host-side ones

@@ -95,6 +95,8 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         get only: the cgroup's CPUs divided by LOCAL_WORLD_SIZE / the context's devices), else poll.  Measured, 32
  *                         callers of VerifyBlobKZGProofBatch(1024) on 16 CPUs: 14.6 CPUs busy and 1.55-1.62 M blobs/s polling, 3.8 CPUs
  *                         busy and 1.49-1.50 M sleeping
+ *   "fk20_segments"       1 (default): the 686 fixed-scalar products of ComputeCellsAndKZGProofs / recovery calls of 65..192 blobs run as
+ *                         cost-equal segments dealt one wavefront per SIMD (128 blobs: 8.6 -> 7.5 ms); 0: whole products.  Same bytes.
  *   "debug_serial"        measurement aid: 1 = the blob verifier's challenge hash runs alone on the chip (the call waits for its side stream first)
  *   "lanes"               1..32 (default 32): calls that may be in flight on the context at once; lanes above the limit free their memory
  *   "trim"                (set only, any value) frees every lane's workspaces and pinned staging; they are rebuilt on demand

@@ -182,6 +182,10 @@ def test_options_and_calibration(product, oracle_ctx):
         assert ctx.set_option("commit_direct_bits", 12 if chunk == 3 else 0) == 0     # the chunked accumulate launches exist in direct-table mode only
         assert ctx.get_option("host_wait") == -1 and ctx.set_option("host_wait", 2) == 17 and ctx.set_option("host_wait", chunk & 1) == 0 and ctx.get_option("host_wait") == (chunk & 1)
         assert ctx.get_option("cpu_share") >= 2
+        assert ctx.set_option("debug_serial", 1) == 0 and ctx.set_option("debug_serial", 0) == 0
+        assert ctx.set_option("fk20_segments", 0) == 0 and ctx.get_option("fk20_segments") == 0 and ctx.set_option("fk20_segments", 1) == 0
+        for key in ("verify_shape", "host_sha"):
+            assert ctx.set_option(key, 2) == 17 and ctx.set_option(key, 1) == 0 and ctx.get_option(key) == 1 and ctx.set_option(key, -1) == 0
         assert ctx.set_option("host_chunk", 0) == 17                 # MKZG_ERR_BAD_ARGS
         assert ctx.set_option("no_such_option", 1) == 17 and ctx.get_option("no_such_option") is None
         rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)

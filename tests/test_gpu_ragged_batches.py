@@ -88,3 +88,37 @@ def test_ragged_cell_proof_batches_match_single_calls(gpu_ctx, n):
         assert status[i] == 0, i
         assert cells[i * 262144:(i + 1) * 262144] == singles[i % 4][0], (n, i)
         assert proofs[i * 6144:(i + 1) * 6144] == singles[i % 4][1], (n, i)
+
+
+@pytest.mark.parametrize("n", [100, 150])
+def test_segmented_and_whole_fk20_products_agree(gpu_ctx, n):
+    """Calls of 65..192 blobs run the 686 fixed-scalar products of the FK20 transform stage in cost-equal segments over several launches
+    (fk20_kernels.hip k_fk20_toom_seg: K = 2 at 100 blobs, K = 4 at 150); option fk20_segments 0 runs them whole, as calls of other
+    sizes do.  Same proofs byte for byte (fk20.go:76-124), including a blob the batch rejects."""
+    import torch
+    ctx = gpu_ctx
+    blobs = [rand_blob(4000 + (i % 7)) for i in range(n)]
+    bad = bytearray(blobs[n - 3])
+    bad[32 * 9:32 * 10] = b"\xff" * 32
+    blobs[n - 3] = bytes(bad)
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    results = []
+    for seg in (1, 0):
+        assert ctx.set_option("fk20_segments", seg) == 0 and ctx.get_option("fk20_segments") == seg
+        d_cells = torch.zeros(n * 262144, dtype=torch.uint8, device="cuda")
+        d_proofs = torch.zeros(n * 6144, dtype=torch.uint8, device="cuda")
+        d_st = torch.ones(n, dtype=torch.int32, device="cuda")
+        assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), n, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        results.append((d_proofs.cpu(), d_cells.cpu(), d_st.cpu()))
+    assert ctx.set_option("fk20_segments", 1) == 0
+    status = results[0][2].tolist()
+    assert status[n - 3] != 0 and sum(1 for v in status if v) == 1
+    assert torch.equal(results[0][2], results[1][2]) and torch.equal(results[0][1], results[1][1])
+    keep = torch.ones(n * 6144, dtype=torch.bool)
+    keep[(n - 3) * 6144:(n - 2) * 6144] = False                      # the rejected blob's proofs are unspecified
+    assert torch.equal(results[0][0][keep], results[1][0][keep])
+    # and against the single-blob path for one of them
+    rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(blobs[5])
+    assert rc == 0 and bytes(results[0][0][5 * 6144:6 * 6144].numpy().tobytes()) == b"".join(proofs)

@@ -820,10 +820,12 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "fk20_bits_effective")) *value = q->fk20_bits_built;                   // 0 until the first call that needs the table
     else if (!strcmp(key, "host_chunk")) *value = q->opt_host_chunk;
     else if (!strcmp(key, "cells_chunk")) *value = q->opt_cells_chunk;
+    else if (!strcmp(key, "host_gather_tasks")) *value = q->opt_host_gather_tasks;
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
     else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
     else if (!strcmp(key, "host_wait")) *value = q->opt_host_wait;
     else if (!strcmp(key, "fk20_segments")) *value = q->opt_fk20_segments;
+    else if (!strcmp(key, "debug_serial")) *value = q->opt_debug_serial;
     else if (!strcmp(key, "cpu_share")) *value = q->cpu_share;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
     else if (!strcmp(key, "devices")) *value = c->peers.empty() ? 1 : (long)c->peers.size();

@@ -101,6 +101,9 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *   "lanes"               1..32 (default 32): calls that may be in flight on the context at once; lanes above the limit free their memory
  *   "trim"                (set only, any value) frees every lane's workspaces and pinned staging; they are rebuilt on demand
  *   "host_chunk"          blobs per chunk of the host-pointer commitment pipeline (gather / upload / kernels overlap per chunk; 128)
+ *   "host_gather_tasks"   host-pool tasks per chunk of that pipeline's gather (1..64)
+ *   "cells_chunk"         1..512 (default 256): blobs per piece of a ComputeCellsAndKZGProofs / recovery batch (a lane's FK20 workspace grows
+ *                         to the pieces it has seen, 1.6 MB per blob)
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
  *   "host_sha"            host-pointer verifiers: Fiat-Shamir challenges hashed by the host pool while the blobs upload (1),

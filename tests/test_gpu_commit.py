@@ -296,3 +296,28 @@ def test_msm_g1_gnark_layouts(gpu_ctx):
     for i, sv in enumerate(big_sc):
         folded[i % 256] = (folded[i % 256] + sv) % R
     assert compress(run(big_sc, big_pts)) == expect(folded, pts)
+
+
+def test_every_documented_option_reads_back_and_sets(product):
+    """every tuning knob that include/mi355kzg.h documents for mkzg_ctx_set_option can be read, and writing the value read back succeeds
+    (a knob that sets its value and then reports MKZG_ERR_BAD_ARGS slipped through once)"""
+    import os
+    import re
+    import torch
+    torch.cuda.init()
+    hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "mi355kzg.h")).read()
+    block = hdr[hdr.index("Tuning knobs"):hdr.index("int mkzg_ctx_set_option")]
+    keys = re.findall(r'^ \*   "([a-z0-9_]+)"', block, flags=re.M)
+    assert {"msm_window", "max_batch", "commit_direct_bits", "fk20_bits", "host_wait", "fk20_segments", "debug_serial", "lanes", "trim", "verify_shape"} <= set(keys)
+    ctx = product.Context()
+    for key in keys:
+        if key == "trim":                                             # set only
+            assert ctx.set_option(key, 1) == 0
+            continue
+        v = ctx.get_option(key)
+        assert v is not None, key
+        assert ctx.set_option(key, v) == 0, key
+        assert ctx.get_option(key) == v, key
+    for key in ("commit_direct_bits_effective", "fk20_bits_effective", "devices", "host_threads", "cpu_share", "tables_on_own_device"):
+        assert ctx.get_option(key) is not None, key
+    ctx.close()

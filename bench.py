@@ -793,9 +793,10 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
             out["compute_cells_and_kzg_proofs"]["blobs_per_s_256_per_call"] = round(256 / (by_batch["256"] * 1e-3), 1)
             del d_b4, d_c4, d_p4, d_s4
         out["compute_cells_and_kzg_proofs"]["ms_per_call_by_blobs"] = by_batch
-        # sustained: four caller threads on the shared context, one call of NB blobs in flight each -- one call's latency-bound network
-        # of 686 scalar multiplications (two thirds of the SIMDs, one wavefront each) runs beside another call's VALU-bound MSM
-        KC, reps = 4, 4
+        # sustained: eight caller threads on the shared context (four until round 3: 17.2-17.7 k blobs/s against 18.6-18.8 k), each
+        # pipelining calls of NB blobs on its own stream -- one call's latency-bound network of 686 scalar multiplications (two thirds
+        # of the SIMDs, one wavefront each) runs beside another call's VALU-bound MSM
+        KC, reps = 8, 4
         bufs = [(torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda"), torch.zeros(NB * 128 * 48, dtype=torch.uint8, device="cuda"),
                  torch.ones(NB, dtype=torch.int32, device="cuda")) for _ in range(KC)]
         torch.cuda.synchronize()

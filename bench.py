@@ -257,7 +257,7 @@ def main():
     elapsed = timed_region()                                  # THE timed region: `value` comes from this one
     prof = ctx.profile_read(reset=True)
     region_s = [elapsed] + [timed_region() for _ in range(max(0, args.repeats - 1))]
-    ctx.profile_read(reset=True)
+    prof_repeats = ctx.profile_read(reset=True)               # the same kernels over the repeated regions (what a profiler's average mixes in)
     ctx.profile_enable(False)
     assert all(int(t.abs().sum().item()) == 0 for t in d_stats), "some blobs were rejected"
     if NS > 1 and args.steps + args.warmup >= 2:
@@ -306,6 +306,10 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic_bytes"),
                     "avg_kernel_ms": round(avg_ms, 4), "launches": dom_n,
                     "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]}}
+        if not args.no_profile and prof_repeats.get(dom, (0, 0))[1]:
+            rep_ms, rep_n = prof_repeats[dom]
+            roofline["avg_kernel_ms_all_regions"] = round((dom_ms + rep_ms) / (dom_n + rep_n), 4)
+            roofline["launches_all_regions"] = dom_n + rep_n
         if pmc.get("stale"):
             roofline["traffic_note"] = pmc["stale"]
         if NS > 1:

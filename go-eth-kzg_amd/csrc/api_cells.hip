@@ -158,6 +158,13 @@ int ensure_fk20_ws(Lane* L, size_t n) {
     L->fk_cap = n;
     return MKZG_OK;
 }
+#ifndef MKZG_CV_SUBGROUP_WIDE_FROM
+// points (rows + proofs) from which the cell verifier's r-torsion test takes one lane per point; 0: never.  *Measured* (tools/
+// bench_cellverify_inflight.py with CV_BLOBS, quad / one lane, ms per call from one caller and M cells/s from six): 1024 cells 1.71 / 2.00
+// and 2.06 / 1.44; 2048 cells 1.92 / 1.86 and 2.70 / 3.55; 4096: 2.18 / 1.93 and 3.60 / 4.04; 6144: 2.48 / 2.42 and 4.91 / 6.51;
+// 8192: 2.88-2.91 / 2.26-2.50 and 5.7 / 6.7-7.0
+#define MKZG_CV_SUBGROUP_WIDE_FROM 2048
+#endif
 static int ensure_cv_ws(Lane* L, size_t n) {
     if (n <= L->cv_cap) return MKZG_OK;
     L->cv_cap = 0;
@@ -347,7 +354,11 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     lane_fork(L, s, s2, s3);
     KT(KT_DECOMPRESS, s2, g1_validate2_device(L->d_v_raw, (int)n_rows, aff_rows, st_rows, L->d_v_raw + cap * 48, (int)n, aff_q, st_q, s2, 1));
     HIPCHK(hipEventRecord(L->ev_decoded, s2));
-    KT(KT_SUBGROUP, s3, g1_validate2_device(L->d_v_raw, (int)n_rows, nullptr, sub_rows, L->d_v_raw + cap * 48, (int)n, nullptr, sub_q, s3, 2));
+    // the r-torsion test: a quad of lanes per point for calls of few cells (its 0.75 ms chain is what such a call waits for); one lane per
+    // point when the uploads, the interpolation and the MSMs take longer than the 1.3 ms chain anyway (half the instructions, and the
+    // other kernels' workgroups find free SIMDs: see k_g1_validate)
+    const int sub_mode = MKZG_CV_SUBGROUP_WIDE_FROM > 0 && n + n_rows >= (size_t)MKZG_CV_SUBGROUP_WIDE_FROM ? 4 : 2;
+    KT(KT_SUBGROUP, s3, g1_validate2_device(L->d_v_raw, (int)n_rows, nullptr, sub_rows, L->d_v_raw + cap * 48, (int)n, nullptr, sub_q, s3, sub_mode));
     HIPCHK(hipEventRecord(L->ev_join, s3));
     // uploads, part 2: the cells (n x 2 KiB, scattered host pointers) are gathered into the pinned staging area by the host pool running
     // AHEAD of this thread -- all chunks' tasks queued at once -- while the GPU validates the points; this thread waits for chunk k only

@@ -644,8 +644,12 @@ static const int VAL_PB = 16;                               // points per block 
 __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
                                                      const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode) {
     __shared__ int sub_ok[64];                              // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
-    const bool wide = mode == 3, both = mode == 0 || wide;
-    const int lane = threadIdx.x & 63, role = both ? (int)(threadIdx.x >> 6) : mode - 1;
+    // modes: 0 decoding + quad test (128 threads), 1 decoding only, 2 quad test only, 3 decoding + one-lane test (128 threads), 4 one-lane
+    // test only (64 threads: half the instructions of the quad test and a quarter of its wavefronts, a chain 1.7x as long -- for calls long
+    // enough to hide it: the quad test of 8192 proofs holds 516 wavefronts, each with a SIMD's whole register file, and every other
+    // kernel's multi-wavefront workgroups wait for a compute unit with four free SIMDs)
+    const bool wide = mode == 3 || mode == 4, both = mode == 0 || mode == 3;
+    const int lane = threadIdx.x & 63, role = both ? (int)(threadIdx.x >> 6) : (mode == 1 ? 0 : 1);
     const int total = n_a + n_b;
     // which point: the test gives a quad per point (16 per wavefront) unless wide; the decoding a lane per point -- 64 per block on
     // its own (mode 1) or beside the wide test (mode 3), the block's 16 (copied four times over the wavefront) beside the quad test
@@ -686,7 +690,7 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
         if (live) st[i] = rc;
         return;
     }
-    if (mode == 2) {                                        // r-torsion test only (64 threads, all role 1), its own status arrays
+    if (mode == 2 || mode == 4) {                           // r-torsion test only (64 threads, all role 1), its own status arrays
         if (live) st[i] = v == 0 ? MKZG_ERR_G1_NOT_IN_SUBGROUP : 0;
         return;
     }
@@ -1185,7 +1189,7 @@ void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
                          int mode) {
     const int n = n_a + n_b;
-    const int per_block = (mode == 1 || mode == 3) ? 64 : VAL_PB;
+    const int per_block = (mode == 1 || mode == 3 || mode == 4) ? 64 : VAL_PB;
     if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + per_block - 1) / per_block), dim3((mode == 0 || mode == 3) ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b,
                                   d_st_b, mode);
 }

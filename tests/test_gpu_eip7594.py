@@ -303,3 +303,52 @@ def test_fk20_table_widths_agree(product, oracle_ctx):
         assert outs[11] == outs[13] == outs[8] == outs[12]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n_blobs", [2, 20])
+def test_cell_verifier_rejects_points_outside_the_subgroup(gpu_ctx, n_blobs):
+    """VerifyCellKZGProofBatch runs the r-torsion test of its proofs and commitments on a quad of lanes per point for calls of few cells and
+    on ONE lane per point from 2048 points on (k_g1_validate modes 2 and 4): both must accept a good batch and answer a point of the
+    curve outside G1 -- the order-3 point (0, 2), random curve points, anywhere in the batch, proof or commitment -- with the decoder's
+    error, as gnark's SetBytes does under the reference (serialization.go:108-115, api_eip7594.go:190-213)."""
+    import random
+    from test_gpu_commit import rand_blob
+    from test_mont29_host import P, R, ec_mul, compress
+    NOT_IN_SUBGROUP = 13                                        # MKZG_ERR_G1_NOT_IN_SUBGROUP
+    rng = random.Random(78)
+    outside = [(0, 2)]
+    while len(outside) < 4:
+        x = rng.randrange(P)
+        rhs = (x * x * x + 4) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P == rhs and ec_mul(R, (x, y)) is not None:
+            outside.append((x, y))
+    blobs = [rand_blob(5000 + (i % 3)) for i in range(n_blobs)]
+    per_blob = {}
+    for b in set(blobs):
+        rc, cm = gpu_ctx.BlobToKZGCommitment(b)
+        assert rc == 0
+        rc, cells, proofs = gpu_ctx.ComputeCellsAndKZGProofs(b)
+        assert rc == 0
+        per_blob[b] = (cm, cells, proofs)
+    cms, idx, cells, proofs = [], [], [], []
+    for b in blobs:
+        cm, cs, ps = per_blob[b]
+        cms += [cm] * 128
+        idx += list(range(128))
+        cells += cs
+        proofs += ps
+    n = len(cells)
+    assert (n >= 2048) == (n_blobs == 20)
+    assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, proofs) == 0
+    for k, at in enumerate((0, n // 2 + 1, n - 1)):
+        bad = list(proofs)
+        bad[at] = compress(outside[k % len(outside)])
+        assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, bad) == NOT_IN_SUBGROUP, ("proof", at)
+    badc = list(cms)
+    for j in range(128 * (n_blobs - 1), n):                      # the last blob's commitment
+        badc[j] = compress(outside[1])
+    assert gpu_ctx.VerifyCellKZGProofBatch(badc, idx, cells, proofs) == NOT_IN_SUBGROUP
+    wrong = list(proofs)
+    wrong[7], wrong[8] = wrong[8], wrong[7]                      # in G1, simply wrong
+    assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, wrong) == 1

@@ -17,7 +17,7 @@ def main():
     torch.cuda.init()
     kzg = load_product()
     ctx = kzg.Context(device=0)
-    NB = 64
+    NB = int(os.environ.get("CV_BLOBS", "64"))
     blobs = [rand_blob(s) for s in range(NB)]
     d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
     d_cells = torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda")

@@ -164,6 +164,9 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
 #ifndef MKZG_TP_VALIDATE_MODE
 #define MKZG_TP_VALIDATE_MODE 3             // one lane per point (half the instructions of the quad form, a longer chain)
 #endif
+#ifndef MKZG_LAT_VALIDATE_MODE
+#define MKZG_LAT_VALIDATE_MODE(n) 0         // the latency shape: a quad of lanes per point
+#endif
 static bool throughput_shape(const mkzg_ctx* c) {
     if (c->opt_verify_shape >= 0) return c->opt_verify_shape == 1;
     return c->lanes_busy.load(std::memory_order_relaxed) >= 3;
@@ -236,7 +239,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     //    context with eight calls in flight had two of them progressing; one stream per call keeps one queue per call)
     hipStream_t s2 = tp ? s : lane_side_stream(L, s);
     const bool s_idle = lane_fork(L, s, s2);
-    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : 0));
+    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
     if (d_blobs) {
         //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
         //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions;

@@ -32,6 +32,7 @@ int ensure_verify_ws(Lane* L, size_t n) {
     if (!rc) rc = dev_realloc(L->d_v_st, 4 * cap * sizeof(int));        // commitments | proofs | blobs | scratch
     if (!rc) rc = dev_realloc(L->d_v_z, cap * 48);
     if (!rc) rc = dev_realloc(L->d_v_y, cap * 48);
+    if (!rc) rc = dev_realloc(L->d_v_zrows, cap * blob_eval_scratch_words() * 4);
     if (!rc) rc = dev_realloc(L->d_v_s1, cap * 32);
     if (!rc) rc = dev_realloc(L->d_v_s3, cap * 32);
     if (!rc) rc = dev_realloc(L->d_v_misc, (V_MISC_WORDS + VMSM_PART_WORDS) * 4);      // window sums for the host + slice sums (device only)
@@ -285,7 +286,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         if (tp) {
             // throughput shape: every launch is time on the call's hardware queue, which it shares with other calls' streams -- one
             // scalar kernel and ONE launch for the three MSMs of kzg_verify.go:150,225,179 instead of two of each
-            KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, s));
+            KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s));
             KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};

@@ -120,6 +120,7 @@ struct Lane {
     int* d_v_st = nullptr;                 // 3 v_cap ints (commitments | proofs | blobs)
     uint32_t* d_v_z = nullptr;             // v_cap Fr rows
     uint32_t* d_v_y = nullptr;
+    uint32_t* d_v_zrows = nullptr;          // v_cap x 14 rows of 12 words: what the evaluation needs of z alone (verify_kernels.hip k_blob_eval_prep)
     uint32_t* d_v_s1 = nullptr;            // v_cap x 8 words
     uint32_t* d_v_s3 = nullptr;
     uint32_t* d_v_misc = nullptr;          // [0..8) r, [8..16) e, [16 .. 16+4*32*48) window sums, then the slice sums of the MSMs

@@ -23,7 +23,10 @@ struct ShaJobs {
     int count;
 };
 void challenge_jobs_device(ShaJobs& jobs, hipStream_t s);
-void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s);
+// d_zrows: n x blob_eval_scratch_words() words of scratch (what depends on z alone, from a one-lane-per-blob kernel ahead of the evaluation)
+size_t blob_eval_scratch_words();
+void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, uint32_t* d_zrows,
+                      hipStream_t s);
 void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
                           int* d_status, hipStream_t s);
 // y_b = f_b(z_b) from coefficient rows (n x 4096 x 12 words, as cells_from_blobs_device publishes them); blobs with a non-zero status are skipped

@@ -395,7 +395,169 @@ __device__ __forceinline__ void block_sum_fr(fr_t& v, uint32_t* sh /* BT*9 words
     __syncthreads();
 }
 
-// MODE 0: y_b = f_b(z_b)                                  -> y_out
+// y_b = f_b(z_b) with the batch inversion of domain.go:193-235 run DOWN THE PRODUCT TREE OF THE DOMAIN (round 3; the throughput shape
+// of the blob verifier, where this kernel was 53 % of a call's instructions).  In bit-reversed order the aligned block of 2^L positions
+// j 2^L .. (j + 1) 2^L - 1 is a coset g <zeta> of the 2^L-th roots of unity with g^(2^L) = roots_brp[j], so the product of its
+// (z - w_p) is   N(L, j) = z^(2^L) - roots_brp[j]   -- every node of the tree a subtraction, the root z^4096 - 1.  Montgomery's trick
+// pays a multiplication per element for the prefix products, an inversion per lane and two more on the way back; here the up-pass is
+// free, ONE inversion per blob (the root) serves all 4096 leaves, and the way down costs a multiplication per node:
+//   1/N(L-1, 2j) = 1/N(L, j) * N(L-1, 2j+1),   1/N(L-1, 2j+1) = 1/N(L, j) * N(L-1, 2j).
+// A lane owns the 32 leaves of one level-5 node: 7 multiplications from the root to it (redundant across lanes), 62 inside (depth
+// first, six live values), 12 squarings for the powers of z: 2.5 multiplications per element + the one with f_i, where the per-lane
+// Montgomery trick took 4 and a divsteps inversion per 32 elements.  One pass over the blob (canonical check included).
+// What depends on z alone comes from a small kernel ahead (one lane per blob): the powers z^(2^L), L = 0..11, z^4096 - 1 and its inverse
+// -- computed by every lane of the evaluation kernel they were 29 % of its instructions (the inversion alone 21 %: a wavefront pays for
+// it whether one lane needs it or all).  Rows of 12 words: EVT_ROWS per blob.
+constexpr int EVT_T = 128, EVT_LOG = 5, EVT_PER = 1 << EVT_LOG;          // 128 lanes x 32 leaves = 4096
+constexpr int EVT_ROWS = 14;                                             // z^(2^0..2^11), z^4096 - 1, 1 / (z^4096 - 1)
+__global__ void __launch_bounds__(64) k_blob_eval_prep(const uint32_t* __restrict__ z_in, int n, uint32_t* __restrict__ zrows) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n) return;
+    fr_t zl, one, rootn, inv;
+    load_fr12(zl, z_in + (size_t)b * 12);
+    uint32_t* rows = zrows + (size_t)b * EVT_ROWS * 12;
+#pragma unroll 1
+    for (int l = 0; l < 12; l++) {
+        store_fr12(rows + l * 12, zl);
+        FrC::mul(zl, zl, zl);
+    }
+    Fr::set_one(one);
+    FrC::sub(rootn, zl, one);
+    store_fr12(rows + 12 * 12, rootn);
+    fr_inv_n(inv, rootn);                                   // 0 -> 0: z in the domain, the evaluation kernel does not use it then
+    store_fr12(rows + 13 * 12, inv);
+}
+__global__ void __launch_bounds__(EVT_T) k_blob_eval_tree(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ zrows, const uint32_t* __restrict__ roots_brp,
+                                                         uint32_t* __restrict__ y_out, int* __restrict__ status) {
+    __shared__ uint32_t sh[EVT_T * 9];
+    __shared__ int sh_found;
+    __shared__ int sh_bad;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint8_t* blob = blobs + (size_t)b * 131072;
+    if (t == 0) { sh_found = -1; sh_bad = 0; }
+    __syncthreads();
+    const uint32_t* rows = zrows + (size_t)b * EVT_ROWS * 12;
+    fr_t zp[EVT_LOG];                                       // z^(2^L) for the levels inside a lane's subtree
+#pragma unroll
+    for (int l = 0; l < EVT_LOG; l++) load_fr12(zp[l], rows + l * 12);
+    // the levels above: the product of this lane's siblings from level 5 up to level 11 (its way down from the root, in any order)
+    fr_t sibs, rootn;
+    Fr::set_one(sibs);
+#pragma unroll 1
+    for (int l = EVT_LOG; l < 12; l++) {
+        const int js = (t >> (l - EVT_LOG)) ^ 1;            // the sibling of this lane's node at level l
+        fr_t r, zl, nsib;
+        load_fr12(r, roots_brp + (size_t)js * 12);
+        load_fr12(zl, rows + l * 12);
+        FrC::sub(nsib, zl, r);
+        FrC::mul(sibs, sibs, nsib);
+    }
+    load_fr12(rootn, rows + 12 * 12);                       // z^4096 - 1
+    if (Fr::limbs_all_zero(rootn)) {
+        // z is a point of the domain (uniform over the block): the value is the corresponding evaluation (domain.go:204-207), once the
+        // blob has passed the canonical check
+        bool bad = false;
+        int found = -1;
+        for (int q = 0; q < EVT_PER; q++) {
+            const int p = t * EVT_PER + q;
+            uint32_t w[8];
+            load_be32_words(w, blob + (size_t)p * 32);
+            bad |= Fr::words32_geq_mod(w);
+            fr_t wi, d;
+            load_fr12(wi, roots_brp + (size_t)p * 12);
+            FrC::sub(d, zp[0], wi);
+            if (Fr::limbs_all_zero(d)) found = p;
+        }
+        if (bad) sh_bad = 1;
+        if (found >= 0) sh_found = found;
+        __syncthreads();
+        if (t == 0) {
+            status[b] = sh_bad ? MKZG_ERR_NON_CANONICAL_SCALAR : 0;
+            if (!sh_bad && sh_found >= 0) {
+                uint32_t w[8];
+                load_be32_words(w, blob + (size_t)sh_found * 32);
+                fr_t f;
+                fr_from_words(f, w);
+                store_fr12(y_out + (size_t)b * 12, f);
+            }
+        }
+        return;
+    }
+    // 1 / N(5, t) = the root's inverse times the siblings on the way down
+    fr_t inv[EVT_LOG + 1];
+    load_fr12(inv[EVT_LOG], rows + 13 * 12);
+    FrC::mul(inv[EVT_LOG], inv[EVT_LOG], sibs);
+    // depth first over the lane's 32 leaves: five nested two-way loops, one multiplication by the sibling's node value per step down
+    // (rolled: every level's code exists once, the six live inverses keep their registers)
+    fr_t s1, s2;
+    Fr::set_zero(s1);
+    Fr::set_zero(s2);
+    bool bad = false;
+    auto down = [&](fr_t& child, const fr_t& parent, int level, int node) {     // 1/N(level, node) from its parent's inverse
+        fr_t r, nsib;
+        load_fr12(r, roots_brp + (size_t)(node ^ 1) * 12);
+        FrC::sub(nsib, zp[level], r);
+        FrC::mul(child, parent, nsib);
+    };
+    const int n5 = t;
+#pragma unroll 1
+    for (int a = 0; a < 2; a++) {
+        const int n4 = 2 * n5 + a;
+        down(inv[4], inv[5], 4, n4);
+#pragma unroll 1
+        for (int c3 = 0; c3 < 2; c3++) {
+            const int n3 = 2 * n4 + c3;
+            down(inv[3], inv[4], 3, n3);
+#pragma unroll 1
+            for (int c2 = 0; c2 < 2; c2++) {
+                const int n2 = 2 * n3 + c2;
+                down(inv[2], inv[3], 2, n2);
+#pragma unroll 1
+                for (int c1 = 0; c1 < 2; c1++) {
+                    const int n1 = 2 * n2 + c1;
+                    down(inv[1], inv[2], 1, n1);
+#pragma unroll
+                    for (int c0 = 0; c0 < 2; c0++) {
+                        const int p = 2 * n1 + c0;
+                        down(inv[0], inv[1], 0, p);
+                        uint32_t w[8];
+                        load_be32_words(w, blob + (size_t)p * 32);
+                        bad |= Fr::words32_geq_mod(w);
+                        fr_t f, term;
+                        Fr::from_words32(f, w);             // plain; a non-canonical word fails the call below, whatever it adds here
+                        FrC::mul(term, f, inv[0]);          // plain f_p / (z - w_p): Montgomery product of a plain value with a Montgomery one
+                        FrC::add(s1, s1, term);
+                        FrC::add(s2, s2, f);
+                    }
+                }
+            }
+        }
+    }
+    if (bad) sh_bad = 1;
+    // sum_p f_p w_p / (z - w_p) = z sum_p f_p / (z - w_p) - sum_p f_p
+    fr_t part, s1m, s2m;
+    Fr::from_plain(s1m, s1);
+    Fr::reduce_once(s1m, s1m);
+    Fr::from_plain(s2m, s2);
+    Fr::reduce_once(s2m, s2m);
+    FrC::mul(part, s1m, zp[0]);
+    FrC::sub(part, part, s2m);
+    block_sum_fr<EVT_T>(part, sh);                          // (its barriers also publish sh_bad)
+    if (t == 0) {
+        if (sh_bad) {
+            status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
+        } else {
+            fr_t c, y;
+            Fr::set(c, FR_INV_4096);
+            FrC::mul(c, rootn, c);                          // (z^4096 - 1) / 4096
+            FrC::mul(y, c, part);
+            store_fr12(y_out + (size_t)b * 12, y);
+            status[b] = 0;
+        }
+    }
+}
+
+// MODE 0: y_b = f_b(z_b)                                  -> y_out   (the per-lane Montgomery trick; kept for MODE 1 and as the A/B of the tree)
 // MODE 1: q_b = (f_b - y_b)/(X - z_b) in evaluation form   -> quot_out (4096 rows of 12 words), also y_out
 // z comes from z_in (rows of 12 words); if y_given != nullptr MODE 1 trusts it (not used).
 template <int MODE>
@@ -1176,8 +1338,18 @@ void challenge_jobs_device(ShaJobs& jobs, hipStream_t s) {
     }
     if (blocks > 0) hipLaunchKernelGGL(k_challenge_sha256_jobs, dim3(blocks), dim3(256), 0, s, jobs);
 }
-void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, hipStream_t s) {
+size_t blob_eval_scratch_words() { return (size_t)EVT_ROWS * 12; }
+void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, uint32_t* d_zrows,
+                      hipStream_t s) {
+#ifdef MKZG_EVAL_LANE_TRICK
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);
+#else
+    (void)d_inv_roots;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_blob_eval_prep, dim3((n + 63) / 64), dim3(64), 0, s, d_z, n, d_zrows);
+        hipLaunchKernelGGL(k_blob_eval_tree, dim3(n), dim3(EVT_T), 0, s, d_blobs, d_zrows, d_roots, d_y, d_status);
+    }
+#endif
 }
 void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
                           int* d_status, hipStream_t s) {

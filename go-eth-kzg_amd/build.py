@@ -13,9 +13,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmi355kzg.so")
 SOURCES = ["api.hip", "api_verify.hip", "api_cells.hip", "api_multi.hip", "msm_kernels.hip", "verify_kernels.hip", "cells_kernels.hip", "fk20_kernels.hip", "recover_kernels.hip"]
-HEADERS = ["mont29.hpp", "modinv30.hpp", "g1.hpp", "g1_quad.hpp", "constants29.h", "msm_kernels.h", "verify_kernels.h", "cells_kernels.h", "fk20_kernels.h", "fk20_toom.h", "recover_kernels.h", "ctx.h", "api_multi.h", "host_pool.hpp", "host_sha256.hpp", "g1_decode.hpp", "host_field.hpp", "host_pairing.hpp", "host_g1.hpp",
-           os.path.join("..", "..", "include", "mi355kzg.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _deps(src, seen=None):
+    """the source and every header it includes, transitively (quoted includes only): a host-side header edit then recompiles the api*.hip
+    files and not the kernel files, which take minutes"""
+    import re
+    seen = set() if seen is None else seen
+    src = os.path.normpath(src)
+    if src in seen or not os.path.exists(src):
+        return seen
+    seen.add(src)
+    with open(src) as fh:
+        for inc in re.findall(r'^\s*#include\s+"([^"]+)"', fh.read(), flags=re.M):
+            _deps(os.path.join(os.path.dirname(src), inc), seen)
+    return seen
 
 
 def _stale(target, deps):
@@ -32,13 +45,12 @@ def build(force=False, verbose=False):
     # generated, not tracked (600 KB of digit strings): the FK20 transform stage's fixed scalars and network programs
     if _stale(os.path.join(CSRC, "fk20_toom.h"), [os.path.join(CSRC, "gen_fk20_toom.py")]):
         subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_fk20_toom.py")], stdout=subprocess.DEVNULL)
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
+        if force or _stale(obj, sorted(_deps(src))):
             jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
     if jobs:
         with ThreadPoolExecutor(max_workers=4) as ex:

@@ -479,7 +479,7 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
         const Chunk& ch = plan[(size_t)(t / TPC)];
         const int q = t % TPC;
         const size_t per = (ch.m + TPC - 1) / TPC;
-        for (size_t i = ch.lo + (size_t)q * per; i < std::min(ch.lo + ch.m, ch.lo + (size_t)(q + 1) * per); i++) memcpy(L->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB);
+        for (size_t i = ch.lo + (size_t)q * per; i < std::min(ch.lo + ch.m, ch.lo + (size_t)(q + 1) * per); i++) copy_to_staging(L->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB);
         left[(size_t)(t / TPC)].arrive();
     };
     c->pool->run_async(ntask, gather, &all_left);

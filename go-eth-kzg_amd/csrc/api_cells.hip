@@ -373,7 +373,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
         const std::function<void(int)> gather = [&](int t) {
             const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(n, lo + CH), per = (hi - lo + TPC - 1) / TPC, q = (size_t)(t % TPC);
             for (size_t i = lo + q * per; i < std::min(hi, lo + (q + 1) * per); i++) {
-                if (cells[i]) memcpy(L->h_stage + i * 2048, cells[i], 2048);
+                if (cells[i]) copy_to_staging(L->h_stage + i * 2048, cells[i], 2048);
                 else memset(L->h_stage + i * 2048, 0, 2048);           // stands in for nil entries (reported after the device work)
             }
             left[k].arrive();
@@ -535,7 +535,7 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
         c->pool->parallel(nthr, [&](int q) {
             for (size_t b = (size_t)q * per; b < std::min(n_blobs, (size_t)(q + 1) * per); b++) {
                 if (status[b]) continue;
-                for (size_t i = 0; i < n_cells[b]; i++) memcpy(L->h_stage + (base[b] + i) * 2048, cells[b][i], 2048);
+                for (size_t i = 0; i < n_cells[b]; i++) copy_to_staging(L->h_stage + (base[b] + i) * 2048, cells[b][i], 2048);
             }
         });
     }

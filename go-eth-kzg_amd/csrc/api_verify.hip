@@ -193,6 +193,44 @@ struct CpuProfPrinter { ~CpuProfPrinter() {
 #else
 #define CPU_LAP(k) ((void)0)
 #endif
+// the end of every fold: one round trip (statuses, e, window sums), the reference's error precedence, Horner over the window sums
+static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int y_bad, hipStream_t s, VerifyFold* out) {
+    const size_t cap = L->v_cap;
+    uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * cap * sizeof(int));
+    HIPCHK(hipGetLastError());
+    // 5. one round trip: statuses, e, window sums
+    int* h_st = (int*)L->h_v;
+    HIPCHK(hipMemcpyAsync(h_st, L->d_v_st, 3 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS * 4, hipMemcpyDeviceToHost, s));
+    LANE_SYNC(c, L, s);                     // polls for a lone caller, asks and sleeps when the context is crowded (ctx.h)
+    L->drained = true;                      // the side streams were joined into s by the caller; nothing of this call is left on the device
+    if (with_blobs) {
+        for (size_t i = 0; i < n; i++) {                           // verify.go:102-123 order: commitment, proof, blob
+            if (h_st[i]) return h_st[i];
+            if (h_st[cap + i]) return h_st[cap + i];
+            if (h_st[2 * cap + i]) return h_st[2 * cap + i];
+        }
+    } else {
+        for (size_t i = 0; i < n; i++) {                           // verify.go:15-33 order: y, z, commitment, proof
+            if (y_bad) return y_bad;
+            if (h_st[2 * cap + i]) return h_st[2 * cap + i];
+            if (h_st[i]) return h_st[i];
+            if (h_st[cap + i]) return h_st[cap + i];
+        }
+    }
+    // 6. Horner over the window sums (the 255 serial doublings stay on the host)
+    auto t_h0 = std::chrono::steady_clock::now();
+    const uint32_t* wsum = h_misc + 16;
+    auto horner = [&](int m, G1HX& o) { g1h_horner_words(o, wsum + (size_t)m * VMSM_WINDOWS * 48, VMSM_WINDOWS, VMSM_WINDOW_BITS); };
+    {   // three independent 255-doubling chains: one per host thread
+        G1HX* dst[3] = {&out->D, &out->A, &out->Cc};
+        const int job[3] = {2, 0, 1};
+        c->pool->parallel(3, [&](int i) { horner(job[i], *dst[i]); });
+    }
+    memcpy(out->e, h_misc + 8, 32);
+    L->last_host_finish_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
+    return MKZG_OK;
+}
 static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
                        uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out) {
     if (n == 0 || n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
@@ -226,7 +264,6 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     int* st_b = L->d_v_st + 2 * cap;
     int* st_x = L->d_v_st + 3 * cap;        // scratch: status of a second scalar array
     // 0. everything that needs r but not the challenges runs beside the challenge hash
-    uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * cap * sizeof(int));
     uint32_t r_words[8];                        // r travels in the kernel arguments (rwords.h), not through a 32-byte upload
     memcpy(r_words, r_le32, 32);
     uint32_t* d_parts = L->d_v_misc + V_MISC_WORDS;
@@ -286,21 +323,21 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         if (tp) {
             // throughput shape: every launch is time on the call's hardware queue, which it shares with other calls' streams -- one
             // scalar kernel and ONE launch for the three MSMs of kzg_verify.go:150,225,179 instead of two of each
-            KT(KT_EVAL, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s));
+            KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s));
             KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
             const int njob[3] = {(int)n, (int)n, (int)n};
             KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
         } else if (d_z32) {
-            KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
+            KT(KT_POLY_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
             KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
             const int njob[3] = {(int)n, (int)n, (int)n};
             KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s, 512, 1));       // 3 jobs x 32 windows x 2 slices at 1024 proofs: still a quad per bucket
         } else {
-            KT(KT_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
+            KT(KT_POLY_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
             // 3. what depends on the challenges: r^i z_i, sum r^i y_i, and the MSM sum r^i z_i Q_i (kzg_verify.go:179)
             KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
             const uint32_t* scal[1] = {L->d_v_s3};
@@ -328,42 +365,8 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
     }
     if (vrc) return MKZG_ERR_BAD_ARGS;
-    HIPCHK(hipGetLastError());
-    // 5. one round trip: statuses, e, window sums
-    int* h_st = (int*)L->h_v;
-    HIPCHK(hipMemcpyAsync(h_st, L->d_v_st, 3 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS * 4, hipMemcpyDeviceToHost, s));
     CPU_LAP(3);
-    LANE_SYNC(c, L, s);                     // polls for a lone caller, asks and sleeps when the context is crowded (ctx.h)
-    CPU_LAP(4);
-    L->drained = true;                      // the side stream was joined into s above; nothing of this call is left on the device
-    if (d_blobs) {
-        for (size_t i = 0; i < n; i++) {                           // verify.go:102-123 order: commitment, proof, blob
-            if (h_st[i]) return h_st[i];
-            if (h_st[cap + i]) return h_st[cap + i];
-            if (h_st[2 * cap + i]) return h_st[2 * cap + i];
-        }
-    } else {
-        for (size_t i = 0; i < n; i++) {                           // verify.go:15-33 order: y, z, commitment, proof
-            if (y_bad) return y_bad;
-            if (h_st[2 * cap + i]) return h_st[2 * cap + i];
-            if (h_st[i]) return h_st[i];
-            if (h_st[cap + i]) return h_st[cap + i];
-        }
-    }
-    // 6. Horner over the window sums (the 255 serial doublings stay on the host)
-    auto t_h0 = std::chrono::steady_clock::now();
-    const uint32_t* wsum = h_misc + 16;
-    auto horner = [&](int m, G1HX& o) { g1h_horner_words(o, wsum + (size_t)m * VMSM_WINDOWS * 48, VMSM_WINDOWS, VMSM_WINDOW_BITS); };
-    {   // three independent 255-doubling chains: one per host thread
-        G1HX* dst[3] = {&out->D, &out->A, &out->Cc};
-        const int job[3] = {2, 0, 1};
-        c->pool->parallel(3, [&](int i) { horner(job[i], *dst[i]); });
-    }
-    memcpy(out->e, h_misc + 8, 32);
-    L->last_host_finish_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
-    CPU_LAP(5);
-    return MKZG_OK;
+    return verify_fold_tail(c, L, n, d_blobs != nullptr, y_bad, s, out);
 }
 // kzg_verify.go:160-199: F = Cc - [e]G + D ; e(F, G2) e(-A, [alpha]G2) == 1
 int sd_verify_finish(mkzg_ctx* c, const VerifyFold& f) {
@@ -411,17 +414,190 @@ static int verify_device_all(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const
 // threads hash each transcript right after copying it (the blob is then still in their cache) and the device skips its own hash.
 // A nil blob stands in as the zero blob and is reported with the reference's precedence afterwards.
 // ---------------------------------------------------------------------------------------------
-// auto: the device hash is a latency chain of 2050 compressions per blob -- 2.7 ms whether the call brings 1 blob or 1024, and only after
-// the upload -- while a host core with SHA-NI hashes a blob in ~70 us right after gathering it, beside the upload.  Measured on the
-// 16-CPU box (tools/bench_verify_host.py, ms per call device / host hash): one caller 128 blobs 4.6 / 3.4, 256: 5.0 / 4.3, 512: 7.0 / 5.5,
-// 768: 7.4 / 6.9, 1024: 7.6 / 9.8; four callers prefer the host up to ~256 blobs (179 k against 117 k blobs/s) and the device above
-// (221 k against 176 k at 512).  So: blobs per pool thread -- 48 for a lone call, 20 with a few others in flight, 8 beyond that.
+// Where the challenges of a host-pointer call are hashed.  The device hash is a latency chain of 2050 compressions per blob -- 2.7 ms
+// whether the call brings 1 blob or 1024, and only after the upload; a host core with the SHA extensions hashes a PAIR of transcripts in
+// 71 us (two chains interleaved in one instruction stream, host_sha256.hpp: 35 us each against 53 us one at a time), beside the upload.
+// *Measured* on the 16-CPU boxes (tools/ubench_h2d.cpp): 1024 transcripts on the pool's 15 threads in 2.7 ms; gathered with streaming
+// stores and uploaded chunk by chunk at the same time, 134 MB are on the device after 2.8-2.9 ms (3.8-4.0 with memcpy: its
+// write-allocate reads compete with the DMA engine for the memory controllers).  So a LONE call hashes on the host (pipelined: below);
+// calls that share the context and its pool keep the host for the gather and hash on the device (the throughput shape's shared
+// rounds), as do calls beyond a few dozen blobs per pool thread.
 static bool use_host_sha(const mkzg_ctx* c, size_t m) {
     if (c->opt_host_sha >= 0) return c->opt_host_sha != 0;
     const int busy = c->lanes_busy.load(std::memory_order_relaxed);
-    const size_t per_thread = busy <= 1 ? 48 : (busy <= 4 ? 20 : 8);
+    const size_t per_thread = busy <= 1 ? 160 : (busy <= 4 ? 20 : 8);
     return m <= per_thread * (size_t)std::max(1, c->pool->size());
 }
+// Of a lone call's m transcripts, how many the DEVICE hashes (the first ones: they are uploaded first).  The host finishes its share at
+// about m x t_copy + (m - d) x t_hash, the device at t_launch + d x t_upload + 2.75 ms; d balances the two (nothing up to ~1100 blobs on 15
+// pool threads: *measured* at 1024 blobs 4.41 ms with none, 4.41 with 12 %, 4.74 with 25 %; 600 of a 2048-blob piece).  MKZG_DEV_HASH_PERCENT overrides (A/B).
+static size_t device_hash_share(const mkzg_ctx* c, size_t m) {
+    static const int forced = [] { const char* e = getenv("MKZG_DEV_HASH_PERCENT"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return std::min(m, m * (size_t)std::min(forced, 100) / 100);
+    const double T = (double)std::max(1, c->pool->size());
+    // per transcript over the whole pool (us): 35.3 per core for a pair's half; the copies mostly hide under the upload; a chunk goes up at ~47 GB/s
+    const double hash_us = 35.3 / T, copy_us = std::max(0.6, 6.0 / T), up_us = 2.8, chain_us = 2750.0 + 200.0;
+    const double d = ((copy_us + hash_us) * (double)m - chain_us) / (hash_us + up_us);
+    if (d < 64) return 0;
+    return std::min(m, (size_t)d / 64 * 64);
+}
+
+// Host-pointer blobs of one piece, PIPELINED (a lone call: nobody else's kernels fill the gaps, so every stage runs under the upload).
+//   host pool : copy tasks of all chunks first (streaming stores into the pinned staging area, chunk order), then hash tasks -- pairs of
+//               transcripts, read from the caller's blobs again (they come from the last-level cache or DRAM at 3.7 GB/s per thread) --
+//               for the blobs the device does not hash;
+//   copy stream : chunk k goes up the moment its copy tasks have signed off (a first small chunk starts the link early);
+//   side stream : commitments + proofs (uploaded first), decoding + r-torsion tests, the powers of r, the two MSMs that need nothing
+//               else (sum r^i Q_i, sum r^i C_i), and the inverse NTT of each chunk behind its upload when the main stream is taken;
+//   main stream : the device's share of the challenge hash (the first blobs: launched as soon as they are up), else the chunks' inverse
+//               NTTs; after the last challenge: evaluation (Horner from the coefficients), r^i z_i, the one MSM that needs the
+//               challenges, one round trip.
+// *Measured* (bench.py -> drop_in.verify_blob_kzg_proof_batch, N = 1024): 7.6-7.8 ms per call before (gather, upload, THEN the device
+// pipeline) -> see DESIGN.md section 4.2 for the current figure.
+static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t m, uint32_t exp_offset,
+                               const uint8_t* r_le32, VerifyFold* out) {
+    hipStream_t s = L->stream, s2 = L->side, cp = L->side2;
+    int rc = ensure_twiddles(c);
+    if (rc) return rc;
+    if (m > L->v_coeff_cap) {
+        L->v_coeff_cap = 0;
+        rc = dev_realloc(L->d_v_coeffs, m * 4096 * 48);
+        if (rc) return rc;
+        L->v_coeff_cap = m;
+    }
+    const size_t cap = L->v_cap;
+    uint32_t* aff_c = L->d_v_aff;
+    uint32_t* aff_q = L->d_v_aff + cap * 32;
+    int* st_c = L->d_v_st;
+    int* st_q = L->d_v_st + cap;
+    int* st_b = L->d_v_st + 2 * cap;
+    int* st_x = L->d_v_st + 3 * cap;
+    uint32_t r_words[8];
+    memcpy(r_words, r_le32, 32);
+    uint32_t* d_parts = L->d_v_misc + V_MISC_WORDS;
+    uint32_t* d_wsum = L->d_v_misc + 16;
+    const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
+    uint8_t* h_z = L->h_stage + m * MKZG_BYTES_PER_BLOB;              // m x 32 B
+    uint8_t* h_pts = h_z + m * 32;                                     // m x 48 B commitments | m x 48 B proofs
+    uint8_t* d_z = L->d_blobs + m * MKZG_BYTES_PER_BLOB;
+    const size_t n_dev = device_hash_share(c, m);                      // transcripts [0, n_dev) are hashed by the device
+    const bool early_msm = m >= 256;                                   // below that the three MSMs leave as one launch at the end
+    const bool ntt_on_side = n_dev > 0;
+    // chunk plan: a small first chunk starts the link early, then chunks of 128
+    struct Chunk { size_t lo, m; };
+    std::vector<Chunk> plan;
+    const size_t CH = 128;
+    for (size_t lo = 0; lo < m;) {
+        size_t k = std::min(m - lo, plan.empty() && m > 64 ? (size_t)32 : CH);
+        if (m - lo - k < 16 && m - lo <= CH + 16) k = m - lo;
+        plan.push_back({lo, k});
+        lo += k;
+    }
+    const size_t nch = plan.size();
+    // copy tasks: 8 blobs each; hash tasks: 4 transcripts (two pairs) each
+    const size_t CPT = 8, HPT = 4;
+    std::vector<size_t> ctask_chunk, ctask_lo;
+    std::vector<Countdown> left(nch);
+    for (size_t k = 0; k < nch; k++) {
+        int cnt = 0;
+        for (size_t lo = plan[k].lo; lo < plan[k].lo + plan[k].m; lo += CPT, cnt++) { ctask_chunk.push_back(k); ctask_lo.push_back(lo); }
+        left[k].set(cnt);
+    }
+    const int n_copy = (int)ctask_lo.size();
+    const int n_hash = (int)((m - n_dev + HPT - 1) / HPT);
+    Countdown copy_left(n_copy), hash_left(n_hash);
+    const std::function<void(int)> copy_task = [&](int t) {
+        const size_t k = ctask_chunk[(size_t)t], lo = ctask_lo[(size_t)t], hi = std::min(plan[k].lo + plan[k].m, lo + CPT);
+        for (size_t i = lo; i < hi; i++) {
+            uint8_t* dst = L->h_stage + i * MKZG_BYTES_PER_BLOB;
+            if (blobs[i]) copy_to_staging(dst, blobs[i], MKZG_BYTES_PER_BLOB);
+            else memset(dst, 0, MKZG_BYTES_PER_BLOB);
+        }
+        left[k].arrive();
+    };
+    const std::function<void(int)> hash_task = [&](int t) {
+        const size_t lo = n_dev + (size_t)t * HPT, hi = std::min(m, lo + HPT);
+        // a nil blob stands in as the zero blob (its staged copy): the call fails with the reference's precedence afterwards
+        auto src = [&](size_t i) { return blobs[i] ? blobs[i] : L->h_stage + i * MKZG_BYTES_PER_BLOB; };
+        size_t i = lo;
+        for (; i + 1 < hi; i += 2) host_compute_challenge_x2(h_z + i * 32, src(i), commitments48n + i * 48, h_z + (i + 1) * 32, src(i + 1), commitments48n + (i + 1) * 48);
+        if (i < hi) host_compute_challenge(h_z + i * 32, src(i), commitments48n + i * 48);
+    };
+    // points first: their chains are the longest thing on the side stream
+    memcpy(h_pts, commitments48n, m * 48);
+    memcpy(h_pts + m * 48, proofs48n, m * 48);
+    c->pool->run_async(n_copy, copy_task, &copy_left);
+    c->pool->run_async(n_hash, hash_task, &hash_left);
+    // every exit path below must wait for the tasks: they reference this frame
+    rc = [&]() -> int {
+        const bool idle = lane_fork(L, s, s2, cp);
+        (void)idle;
+        HIPCHK(hipMemcpyAsync(L->d_v_raw, h_pts, m * 48, hipMemcpyHostToDevice, s2));
+        HIPCHK(hipMemcpyAsync(L->d_v_raw + cap * 48, h_pts + m * 48, m * 48, hipMemcpyHostToDevice, s2));
+        if (n_dev) HIPCHK(hipEventRecord(L->ev_decoded, s2));                  // the commitments are up: the device's share of the hash may read them
+        KT(KT_SUBGROUP, s2, g1_validate2_device(L->d_v_raw, (int)m, aff_c, st_c, L->d_v_raw + cap * 48, (int)m, aff_q, st_q, s2, MKZG_LAT_VALIDATE_MODE(m)));
+        int vrc = 0;
+        if (early_msm) {
+            KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)m, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
+            const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
+            const uint32_t* pts[2] = {aff_q, aff_c};
+            const int njob[2] = {(int)m, (int)m};
+            KT(KT_VMSM, s2, vrc = vmsm_windows_device(scal, pts, njob, 2, d_parts, d_wsum, s2));
+            if (vrc) return MKZG_ERR_BAD_ARGS;
+        }
+        hipStream_t ntt_stream = ntt_on_side ? s2 : s;
+        bool hash_launched = n_dev == 0;
+        for (size_t k = 0; k < nch; k++) {
+            const size_t lo = plan[k].lo, n = plan[k].m;
+            c->pool->wait(left[k]);
+            HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, n * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, cp));
+            HIPCHK(hipEventRecord(L->ev_chunk[k & 7], cp));
+            if (!hash_launched && lo + n >= n_dev) {
+                // the device's share is up with this chunk: its 2.7 ms chain starts now, on the main stream
+                HIPCHK(hipStreamWaitEvent(s, L->ev_chunk[k & 7], 0));
+                HIPCHK(hipStreamWaitEvent(s, L->ev_decoded, 0));
+                KT(KT_SHA256, s, challenge_device(L->d_blobs, L->d_v_raw, (int)n_dev, L->d_v_z, s));
+                hash_launched = true;
+            }
+            HIPCHK(hipStreamWaitEvent(ntt_stream, L->ev_chunk[k & 7], 0));
+            KT(KT_CELLS_NTT, ntt_stream, cells_from_blobs_device(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs + lo * 4096 * 12, nullptr, st_b + lo, ntt_stream));
+        }
+        HIPCHK(hipEventRecord(L->ev_join, s2));
+        // the host's share of the challenges
+        c->pool->wait(hash_left);
+        if (n_dev < m) {
+            HIPCHK(hipMemcpyAsync(d_z + n_dev * 32, h_z + n_dev * 32, (m - n_dev) * 32, hipMemcpyHostToDevice, s));
+            scalars_to_fr_device(d_z + n_dev * 32, (int)(m - n_dev), L->d_v_z + n_dev * 12, st_x + n_dev, s);       // canonical by construction
+        }
+        HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
+        KT(KT_POLY_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)m, L->d_v_y, st_b, s));
+        if (early_msm) {
+            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)m, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
+            const uint32_t* scal[1] = {L->d_v_s3};
+            const uint32_t* pts[1] = {aff_q};
+            const int njob[1] = {(int)m};
+            KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 1, d_parts + 2 * parts_per_job, d_wsum + 2 * wsum_per_job, s, 256, 1));
+        } else {
+            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)m, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
+            const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
+            const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
+            const int njob[3] = {(int)m, (int)m, (int)m};
+            KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s, 512, 1));
+        }
+        if (vrc) return MKZG_ERR_BAD_ARGS;
+        return MKZG_OK;
+    }();
+    c->pool->wait(copy_left);
+    c->pool->wait(hash_left);
+    if (rc) {
+        // an early exit may have left the copy stream or the side stream with work the main stream never joined
+        L->failed = true;
+        return rc;
+    }
+    // the copy stream's last chunk was waited for by the NTT stream, and that one was joined into s
+    return verify_fold_tail(c, L, m, true, 0, s, out);
+}
+
 static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t m, uint32_t exp_offset,
                            const uint8_t* r_le32, VerifyFold* out, int* rc_nil /* out: MKZG_ERR_NIL_INPUT precedence result, or 0 */) {
     *rc_nil = 0;
@@ -432,44 +608,48 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
     if (rc) return rc;
     size_t first_nil = m;
     for (size_t i = 0; i < m; i++) if (!blobs[i]) { first_nil = i; break; }
-    uint8_t* h_z = L->h_stage + m * MKZG_BYTES_PER_BLOB;              // m x 32 B
-    uint8_t* h_pts = h_z + m * 32;                                     // m x 48 B commitments | m x 48 B proofs
-    uint8_t* d_z = L->d_blobs + m * MKZG_BYTES_PER_BLOB;
-    memcpy(h_pts, commitments48n, m * 48);
-    memcpy(h_pts + m * 48, proofs48n, m * 48);
-    HIPCHK(hipMemcpyAsync(L->d_v_raw, h_pts, m * 48, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(L->d_v_raw + L->v_cap * 48, h_pts + m * 48, m * 48, hipMemcpyHostToDevice, s));
-    // the gather runs ahead on the host pool (all chunks' tasks queued at once); this thread waits for chunk k only and puts its copy in flight
-    const size_t CH = 128;
-    const size_t nch = (m + CH - 1) / CH;
-    const int TPC = hsha ? (int)std::min<size_t>(std::min(m, CH), (size_t)std::max(1, c->pool->size())) : (m >= 16 ? 4 : 1);
-    std::vector<Countdown> left(nch);
-    for (auto& a : left) a.set(TPC);
-    Countdown all_left((int)nch * TPC);
-    const std::function<void(int)> gather = [&](int t) {
-        const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(m, lo + CH), per = (hi - lo + TPC - 1) / TPC;
-        const size_t q = (size_t)(t % TPC);
-        for (size_t i = lo + q * per; i < std::min(hi, lo + (q + 1) * per); i++) {
-            uint8_t* dst = L->h_stage + i * MKZG_BYTES_PER_BLOB;
-            if (blobs[i]) memcpy(dst, blobs[i], MKZG_BYTES_PER_BLOB);
-            else memset(dst, 0, MKZG_BYTES_PER_BLOB);
-            if (hsha) host_compute_challenge(h_z + i * 32, dst, commitments48n + i * 48);
-        }
-        left[k].arrive();
-    };
-    c->pool->run_async((int)nch * TPC, gather, &all_left);
-    rc = [&]() -> int {
-        for (size_t k = 0; k < nch; k++) {
-            const size_t lo = k * CH, hi = std::min(m, lo + CH);
-            c->pool->wait(left[k]);
-            HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, (hi - lo) * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, s));
-        }
-        return MKZG_OK;
-    }();
-    c->pool->wait(all_left);                      // the tasks reference this frame
-    if (rc) return rc;
-    if (hsha) HIPCHK(hipMemcpyAsync(d_z, h_z, m * 32, hipMemcpyHostToDevice, s));
-    rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out);
+    if (hsha && !throughput_shape(c)) {
+        rc = fold_host_pipelined(c, L, blobs, commitments48n, proofs48n, m, exp_offset, r_le32, out);
+    } else {
+        uint8_t* h_z = L->h_stage + m * MKZG_BYTES_PER_BLOB;              // m x 32 B
+        uint8_t* h_pts = h_z + m * 32;                                     // m x 48 B commitments | m x 48 B proofs
+        uint8_t* d_z = L->d_blobs + m * MKZG_BYTES_PER_BLOB;
+        memcpy(h_pts, commitments48n, m * 48);
+        memcpy(h_pts + m * 48, proofs48n, m * 48);
+        HIPCHK(hipMemcpyAsync(L->d_v_raw, h_pts, m * 48, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(L->d_v_raw + L->v_cap * 48, h_pts + m * 48, m * 48, hipMemcpyHostToDevice, s));
+        // the gather runs ahead on the host pool (all chunks' tasks queued at once); this thread waits for chunk k only and puts its copy in flight
+        const size_t CH = 128;
+        const size_t nch = (m + CH - 1) / CH;
+        const int TPC = hsha ? (int)std::min<size_t>(std::min(m, CH), (size_t)std::max(1, c->pool->size())) : (m >= 16 ? 8 : 1);
+        std::vector<Countdown> left(nch);
+        for (auto& a : left) a.set(TPC);
+        Countdown all_left((int)nch * TPC);
+        const std::function<void(int)> gather = [&](int t) {
+            const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(m, lo + CH), per = (hi - lo + TPC - 1) / TPC;
+            const size_t q = (size_t)(t % TPC);
+            for (size_t i = lo + q * per; i < std::min(hi, lo + (q + 1) * per); i++) {
+                uint8_t* dst = L->h_stage + i * MKZG_BYTES_PER_BLOB;
+                if (blobs[i]) copy_to_staging(dst, blobs[i], MKZG_BYTES_PER_BLOB);
+                else memset(dst, 0, MKZG_BYTES_PER_BLOB);
+                if (hsha) host_compute_challenge(h_z + i * 32, blobs[i] ? blobs[i] : dst, commitments48n + i * 48);
+            }
+            left[k].arrive();
+        };
+        c->pool->run_async((int)nch * TPC, gather, &all_left);
+        rc = [&]() -> int {
+            for (size_t k = 0; k < nch; k++) {
+                const size_t lo = k * CH, hi = std::min(m, lo + CH);
+                c->pool->wait(left[k]);
+                HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, (hi - lo) * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, s));
+            }
+            return MKZG_OK;
+        }();
+        c->pool->wait(all_left);                      // the tasks reference this frame
+        if (rc) return rc;
+        if (hsha) HIPCHK(hipMemcpyAsync(d_z, h_z, m * 32, hipMemcpyHostToDevice, s));
+        rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out);
+    }
     if (first_nil < m) {
         // the reference deserialises commitment i and proof i before blob i, so a nil blob only surfaces after their checks: an error
         // at an index below the nil blob (or at its commitment / proof) wins; otherwise nil

@@ -27,6 +27,7 @@
 #include "recover_kernels.h"
 #include "host_g1.hpp"
 #include "host_pool.hpp"
+#include "host_copy.hpp"
 
 using namespace kzg;
 

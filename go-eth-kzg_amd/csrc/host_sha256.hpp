@@ -82,6 +82,67 @@ __attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_ni(
     _mm_storeu_si128((__m128i*)&st[0], s0);
     _mm_storeu_si128((__m128i*)&st[4], s1);
 }
+// Two independent messages interleaved in one instruction stream: sha256rnds2 is a 4-cycle dependent chain per two rounds, so a lone
+// message leaves the unit idle more than half of the time; the second message's rounds fill those slots (measured per core in
+// tools/ubench_h2d.cpp; the gather threads of the host-pointer verifier hash their transcripts in pairs).
+__attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_ni_x2(uint32_t sta[8], const uint8_t* pa, uint32_t stb[8], const uint8_t* pb, size_t nblk) {
+    const __m128i BSWAP = _mm_set_epi64x(0x0c0d0e0f08090a0bLL, 0x0405060700010203LL);
+    __m128i a0, a1, b0, b1;
+    {
+        __m128i t = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i*)&sta[0]), 0xB1);
+        __m128i u = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i*)&sta[4]), 0x1B);
+        a0 = _mm_alignr_epi8(t, u, 8);
+        a1 = _mm_blend_epi16(u, t, 0xF0);
+        t = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i*)&stb[0]), 0xB1);
+        u = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i*)&stb[4]), 0x1B);
+        b0 = _mm_alignr_epi8(t, u, 8);
+        b1 = _mm_blend_epi16(u, t, 0xF0);
+    }
+    while (nblk--) {
+        const __m128i sa0 = a0, sa1 = a1, sb0 = b0, sb1 = b1;
+        __m128i ma[4], mb[4];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            __m128i wa, wb;
+            if (i < 4) {
+                wa = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pa + 16 * i)), BSWAP);
+                wb = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(pb + 16 * i)), BSWAP);
+            } else {
+                __m128i t = _mm_sha256msg1_epu32(ma[i & 3], ma[(i + 1) & 3]);
+                __m128i u = _mm_sha256msg1_epu32(mb[i & 3], mb[(i + 1) & 3]);
+                t = _mm_add_epi32(t, _mm_alignr_epi8(ma[(i + 3) & 3], ma[(i + 2) & 3], 4));
+                u = _mm_add_epi32(u, _mm_alignr_epi8(mb[(i + 3) & 3], mb[(i + 2) & 3], 4));
+                wa = _mm_sha256msg2_epu32(t, ma[(i + 3) & 3]);
+                wb = _mm_sha256msg2_epu32(u, mb[(i + 3) & 3]);
+            }
+            ma[i & 3] = wa;
+            mb[i & 3] = wb;
+            const __m128i k = _mm_loadu_si128((const __m128i*)&SHA256_K[4 * i]);
+            __m128i ga = _mm_add_epi32(wa, k), gb = _mm_add_epi32(wb, k);
+            a1 = _mm_sha256rnds2_epu32(a1, a0, ga);
+            b1 = _mm_sha256rnds2_epu32(b1, b0, gb);
+            ga = _mm_shuffle_epi32(ga, 0x0E);
+            gb = _mm_shuffle_epi32(gb, 0x0E);
+            a0 = _mm_sha256rnds2_epu32(a0, a1, ga);
+            b0 = _mm_sha256rnds2_epu32(b0, b1, gb);
+        }
+        a0 = _mm_add_epi32(a0, sa0);
+        a1 = _mm_add_epi32(a1, sa1);
+        b0 = _mm_add_epi32(b0, sb0);
+        b1 = _mm_add_epi32(b1, sb1);
+        pa += 64;
+        pb += 64;
+    }
+    {
+        __m128i t = _mm_shuffle_epi32(a0, 0x1B), u = _mm_shuffle_epi32(a1, 0xB1);
+        _mm_storeu_si128((__m128i*)&sta[0], _mm_blend_epi16(t, u, 0xF0));
+        _mm_storeu_si128((__m128i*)&sta[4], _mm_alignr_epi8(u, t, 8));
+        t = _mm_shuffle_epi32(b0, 0x1B);
+        u = _mm_shuffle_epi32(b1, 0xB1);
+        _mm_storeu_si128((__m128i*)&stb[0], _mm_blend_epi16(t, u, 0xF0));
+        _mm_storeu_si128((__m128i*)&stb[4], _mm_alignr_epi8(u, t, 8));
+    }
+}
 static inline bool sha256_have_ni() {
     static const bool have = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
     return have;
@@ -95,6 +156,14 @@ static inline void sha256_blocks(uint32_t st[8], const uint8_t* p, size_t nblk) 
     if (sha256_have_ni()) { sha256_blocks_ni(st, p, nblk); return; }
 #endif
     sha256_blocks_c(st, p, nblk);
+}
+// the same number of blocks of two messages
+static inline void sha256_blocks_x2(uint32_t sta[8], const uint8_t* pa, uint32_t stb[8], const uint8_t* pb, size_t nblk) {
+#if defined(__x86_64__)
+    if (sha256_have_ni()) { sha256_blocks_ni_x2(sta, pa, stb, pb, nblk); return; }
+#endif
+    sha256_blocks_c(sta, pa, nblk);
+    sha256_blocks_c(stb, pb, nblk);
 }
 static inline void sha256_init(uint32_t st[8]) {
     static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
@@ -119,24 +188,22 @@ static inline void sha256_digest(uint8_t out[32], const uint8_t* data, size_t le
 // compute_challenge (reference fiatshamir.go:22-33): SHA-256("FSBLOBVERIFY_V1_" || u128_be(4096) || blob || commitment) reduced
 // modulo r, written as 32 big-endian bytes (canonical).  The blob is hashed in place: only the first 32 and the last 32 bytes of it
 // are copied (they share a compression block with the 32-byte header and with the commitment).
-static inline void host_compute_challenge(uint8_t z32[32], const uint8_t* blob /* 131072 B */, const uint8_t commitment48[48]) {
-    uint32_t st[8];
-    sha256_init(st);
-    uint8_t blk[128];
+static inline void challenge_head_block(uint8_t blk[64], const uint8_t* blob) {
     memcpy(blk, "FSBLOBVERIFY_V1_", 16);
     memset(blk + 16, 0, 16);
     blk[30] = 0x10;                                        // 4096 = 0x1000, big-endian in the last 8 of the 16 bytes
     memcpy(blk + 32, blob, 32);
-    sha256_blocks(st, blk, 1);
-    sha256_blocks(st, blob + 32, (131072 - 64) / 64);      // blob[32 .. 131040)
-    memset(blk, 0, sizeof(blk));
+}
+static inline void challenge_tail_blocks(uint8_t blk[128], const uint8_t* blob, const uint8_t commitment48[48]) {
+    memset(blk, 0, 128);
     memcpy(blk, blob + 131072 - 32, 32);
     memcpy(blk + 32, commitment48, 48);
     blk[80] = 0x80;
     const uint64_t bits = (uint64_t)(32 + 131072 + 48) * 8;
     for (int i = 0; i < 8; i++) blk[127 - i] = (uint8_t)(bits >> (8 * i));
-    sha256_blocks(st, blk, 2);
-    // digest as a 256-bit big-endian integer, reduced mod r (r > 2^254: at most two subtractions)
+}
+// digest as a 256-bit big-endian integer, reduced mod r (r > 2^254: at most two subtractions), as 32 big-endian bytes
+static inline void challenge_reduce(uint8_t z32[32], const uint32_t st[8]) {
     static const uint32_t RW[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};   // little-endian words of r
     uint32_t w[8];
     for (int i = 0; i < 8; i++) w[i] = st[7 - i];
@@ -154,6 +221,33 @@ static inline void host_compute_challenge(uint8_t z32[32], const uint8_t* blob /
         }
     }
     for (int i = 0; i < 8; i++) { z32[4 * i] = (uint8_t)(w[7 - i] >> 24); z32[4 * i + 1] = (uint8_t)(w[7 - i] >> 16); z32[4 * i + 2] = (uint8_t)(w[7 - i] >> 8); z32[4 * i + 3] = (uint8_t)w[7 - i]; }
+}
+static inline void host_compute_challenge(uint8_t z32[32], const uint8_t* blob /* 131072 B */, const uint8_t commitment48[48]) {
+    uint32_t st[8];
+    sha256_init(st);
+    uint8_t blk[128];
+    challenge_head_block(blk, blob);
+    sha256_blocks(st, blk, 1);
+    sha256_blocks(st, blob + 32, (131072 - 64) / 64);      // blob[32 .. 131040)
+    challenge_tail_blocks(blk, blob, commitment48);
+    sha256_blocks(st, blk, 2);
+    challenge_reduce(z32, st);
+}
+// two transcripts at once (the two hash chains interleaved in one core's instruction stream: sha256_blocks_ni_x2)
+static inline void host_compute_challenge_x2(uint8_t z32a[32], const uint8_t* bloba, const uint8_t cma[48], uint8_t z32b[32], const uint8_t* blobb, const uint8_t cmb[48]) {
+    uint32_t sa[8], sb[8];
+    sha256_init(sa);
+    sha256_init(sb);
+    uint8_t ka[128], kb[128];
+    challenge_head_block(ka, bloba);
+    challenge_head_block(kb, blobb);
+    sha256_blocks_x2(sa, ka, sb, kb, 1);
+    sha256_blocks_x2(sa, bloba + 32, sb, blobb + 32, (131072 - 64) / 64);
+    challenge_tail_blocks(ka, bloba, cma);
+    challenge_tail_blocks(kb, blobb, cmb);
+    sha256_blocks_x2(sa, ka, sb, kb, 2);
+    challenge_reduce(z32a, sa);
+    challenge_reduce(z32b, sb);
 }
 
 }  // namespace kzg

@@ -8,10 +8,11 @@
 
 namespace kzg {
 
-enum KernelKind { KT_DIGITS_SORT = 0, KT_BUCKET_ACC, KT_REDUCE1, KT_REDUCE2, KT_DECOMPRESS, KT_SUBGROUP, KT_SHA256, KT_EVAL, KT_QUOTIENT, KT_RLC, KT_VMSM, KT_CELLS_NTT, KT_FK20_SCALARS, KT_FK20_MSM, KT_FK20_FFTS, KT_CELL_SCALARS, KT_RECOVER, KT_COMMIT_DIRECT, KT_COMMIT_DIRECT_FIN, KT_COUNT };
+enum KernelKind { KT_DIGITS_SORT = 0, KT_BUCKET_ACC, KT_REDUCE1, KT_REDUCE2, KT_DECOMPRESS, KT_SUBGROUP, KT_SHA256, KT_EVAL, KT_QUOTIENT, KT_RLC, KT_VMSM, KT_CELLS_NTT, KT_FK20_SCALARS, KT_FK20_MSM, KT_FK20_FFTS, KT_CELL_SCALARS, KT_RECOVER, KT_COMMIT_DIRECT, KT_COMMIT_DIRECT_FIN, KT_POLY_EVAL, KT_EVAL_TREE, KT_COUNT };
 static const char* const kKernelNames[KT_COUNT] = {"k_digits_sort", "k_bucket_accumulate", "k_bucket_reduce1", "k_bucket_reduce2", "k_g1_decompress",
                                                    "k_g1_validate", "k_challenge_sha256", "k_blob_eval", "k_blob_quotient", "k_rlc_scalars", "k_vmsm_window",
-                                                   "k_cells_ntt", "k_fk20_scalars", "k_fk20_msm", "k_fk20_ffts", "k_cell_verify_scalars", "k_recover_*", "k_commit_direct_acc", "k_commit_direct_fin"};
+                                                   "k_cells_ntt", "k_fk20_scalars", "k_fk20_msm", "k_fk20_ffts", "k_cell_verify_scalars", "k_recover_*", "k_commit_direct_acc", "k_commit_direct_fin",
+                                                   "k_poly_eval", "k_blob_eval_tree"};      // k_blob_eval: the per-lane-inversion form (proof path: k_blob_quotient = k_blob_eval<1>)
 
 // hipEvent bracket around each kernel launch, on the stream the kernel is launched on.
 struct KernelTimer {

@@ -22,4 +22,8 @@ void shim_sha256_c(const uint8_t* data, size_t len, uint8_t out[32]) {
     for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16); out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i]; }
 }
 void shim_challenge(const uint8_t* blob, const uint8_t* commitment48, uint8_t z32[32]) { kzg::host_compute_challenge(z32, blob, commitment48); }
+// two transcripts interleaved in one instruction stream (the gather threads of the host-pointer verifier hash in pairs)
+void shim_challenge_x2(const uint8_t* blob_a, const uint8_t* cm_a, uint8_t za[32], const uint8_t* blob_b, const uint8_t* cm_b, uint8_t zb[32]) {
+    kzg::host_compute_challenge_x2(za, blob_a, cm_a, zb, blob_b, cm_b);
+}
 }

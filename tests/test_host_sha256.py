@@ -19,6 +19,7 @@ def shim():
     L.shim_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
     L.shim_sha256_c.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
     L.shim_challenge.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.shim_challenge_x2.argtypes = [C.c_char_p] * 6
     return L
 
 
@@ -62,3 +63,15 @@ def test_challenge_kat_and_oracle(shim):
         shim.shim_challenge(b, cms[1], out)
         assert out.raw == _challenge(b, cms[1])
     assert seen_big >= 1
+
+
+def test_challenge_pairs_match_single(shim):
+    """host_compute_challenge_x2 (two hash chains interleaved per core) against the one-transcript form and hashlib"""
+    import oracle
+    blobs = [bytes(131072), oracle.rand_blob(11), oracle.rand_blob(12), (R - 1).to_bytes(32, "big") * 4096]
+    cms = [bytes([0xC0]) + bytes(47), bytes(range(48)), b"\xff" * 48, bytes(48)]
+    za, zb = C.create_string_buffer(32), C.create_string_buffer(32)
+    for i in range(4):
+        for j in range(4):
+            shim.shim_challenge_x2(blobs[i], cms[i], za, blobs[j], cms[j], zb)
+            assert za.raw == _challenge(blobs[i], cms[i]) and zb.raw == _challenge(blobs[j], cms[j]), (i, j)

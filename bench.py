@@ -23,7 +23,9 @@ The JSON line also carries
                  hipEvents on the launch stream inside the timed region, against 8 TB/s HBM;
   valu         : the ceiling that actually binds this integer path: VALU wave-instructions per second of the dominant kernel
                  against the hardware issue limit (SIMDs x clock / 4) and against this GPU's calibrated v_mad_u64_u32 rate;
-  drop_in      : what a caller of the reference API gets -- host pointers in, host bytes out (PCIe inclusive; never `value`);
+  drop_in      : what a caller of the reference API gets -- host pointers in, host bytes out (PCIe inclusive; never `value`): commitments,
+                 and VerifyBlobKZGProofBatch of 1024 separate host allocations from one caller and from K callers with DISTINCT blobs
+                 each, with a `pcie` object (GB/s over the link against 63 GB/s: the roofline that binds the host-pointer verifier);
   verify_blob_kzg_proof_batch : configs[2], single-call latency and sustained rate with several calls in flight;
   eip7594      : configs[3] and configs[4] (cells + proofs, cell batch verification, recovery);
                  every leg carries its own `roofline` (dominant kernel of the leg, algorithmic bytes of SURVEY.md 8d) and `valu`
@@ -104,6 +106,7 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents (roofline section is then empty)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drop-in", action="store_true")
+    ap.add_argument("--drop-in-callers", type=int, nargs="*", default=[4, 8], help="caller counts of the host-pointer VerifyBlobKZGProofBatch leg (each caller holds its own 1024 distinct blobs in host memory)")
     ap.add_argument("--verify-batch", type=int, default=1024, help="configs[2]: proofs per VerifyBlobKZGProofBatch call per GPU (0 = skip)")
     ap.add_argument("--verify-steps", type=int, default=3)
     ap.add_argument("--no-big-cells", action="store_true", help="skip the ComputeCellsAndKZGProofs calls of 128 / 192 / 256 blobs (PMC passes: a kernel's largest launches must be the 64-blob leg's)")
@@ -288,6 +291,9 @@ def main():
     verify = None
     if args.verify_batch > 0:
         verify = bench_verify(ctx, torch, dist, dist_on, dist_dev, world, rank, args, d_blobs, B, hw)
+    if rank == 0 and world == 1 and not dist_on and not args.no_drop_in and args.verify_batch > 0:
+        # the other half of the metric as the reference API sees it: host pointers in, PCIe-bound
+        drop_in["verify_blob_kzg_proof_batch"] = bench_drop_in_verify(ctx, kzg, torch, N=args.verify_batch, callers=tuple(args.drop_in_callers))
     eip7594 = None
     if args.cell_blobs > 0:
         eip7594 = bench_eip7594(ctx, kzg, torch, dist, dist_on, dist_dev, world, rank, args, hw)

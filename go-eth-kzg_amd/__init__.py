@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch", "mkzg_verify_cell_kzg_proof_batch_partial", "mkzg_verify_cell_kzg_proof_batch_finish", "mkzg_recover_cells_and_kzg_proofs_batch", "mkzg_msm_g1",
     "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
     "mkzg_verify_blob_kzg_proof_batch_partial_device", "mkzg_verify_blob_kzg_proof_batch_finish",
+    "mkzg_evaluate_blobs_device",
 ]
 
 
@@ -88,6 +89,7 @@ def lib():
                                                               C.c_char_p, C.c_char_p, C.POINTER(i32)]
         L.mkzg_recover_cells_and_kzg_proofs.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p, C.c_char_p]
         L.mkzg_recover_cells.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p]
+        L.mkzg_evaluate_blobs_device.argtypes = [vp, vp, C.c_char_p, sz, i32, C.c_char_p, C.POINTER(C.c_int), vp]
         L.mkzg_verify_blob_kzg_proof_batch_partial_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
         L.mkzg_verify_blob_kzg_proof_batch_finish.argtypes = [vp, C.c_char_p, sz]
         L.mkzg_profile_enable.argtypes = [vp, i32]
@@ -215,6 +217,16 @@ class Context:
 
     def verify_blob_kzg_proof_batch_device(self, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n, stream=0):
         return self._L.mkzg_verify_blob_kzg_proof_batch_device(self._h, d_blobs_ptr, d_commitments_ptr, d_proofs_ptr, n, stream)
+
+    def evaluate_blobs_device(self, d_blobs_ptr, zs, form, stream=0):
+        """Domain.EvaluateLagrangePolynomial (reference internal/domain/domain.go:193-235) for device-resident blobs at caller-chosen
+        points through evaluation kernel `form` (0 coefficients + Horner, 1 product tree, 2 per-lane batch inversion)
+        -> (rc, [y bytes], [status])"""
+        n = len(zs)
+        y = C.create_string_buffer(32 * max(1, n))
+        st = (C.c_int * max(1, n))()
+        rc = self._L.mkzg_evaluate_blobs_device(self._h, C.c_void_p(d_blobs_ptr), b"".join(zs), n, form, y, st, C.c_void_p(stream))
+        return rc, [y.raw[32 * i:32 * i + 32] for i in range(n)], list(st)[:n]
 
     # ---- EIP-7594 -------------------------------------------------------------------------
     def ComputeCells(self, blob, num_goroutines=0):

@@ -889,6 +889,54 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     return MKZG_OK;
 }
 
+// Domain.EvaluateLagrangePolynomial for caller-chosen points through each evaluation kernel (include/mi355kzg.h): the parity pin of the
+// three forms against each other and the oracle, on-domain points included
+int mkzg_evaluate_blobs_device(mkzg_ctx* c, const void* d_blobs, const uint8_t* z32n, size_t n, int form, uint8_t* y32n, int* status, void* stream) {
+    if (!c || form < 0 || form > 2 || n > 4096 || (n && (!d_blobs || !z32n || !y32n || !status))) return MKZG_ERR_BAD_ARGS;
+    if (!c->peers.empty() && !(c = ctx_for_pointer(c, d_blobs))) return MKZG_ERR_BAD_ARGS;
+    if (n == 0) return MKZG_OK;
+    LaneGuard G(c, (hipStream_t)stream);
+    Lane* L = G.L;
+    hipStream_t s = G.s;
+    int rc = ensure_verify_ws(L, n);
+    if (!rc && form == 0) rc = ensure_twiddles(c);
+    if (!rc && form == 0 && n > L->v_coeff_cap) {
+        L->v_coeff_cap = 0;
+        rc = dev_realloc(L->d_v_coeffs, n * 4096 * 48);
+        if (!rc) L->v_coeff_cap = n;
+    }
+    if (!rc && form == 2) rc = ensure_quot_ws(L, n, n);
+    if (rc) return G.fail(rc);
+    const size_t cap = L->v_cap;
+    int* st_b = L->d_v_st + 2 * cap;
+    int* st_z = L->d_v_st + 3 * cap;
+    const uint8_t* blobs = (const uint8_t*)d_blobs;
+    HIPCHK(hipMemcpyAsync(L->d_v_s3, z32n, n * 32, hipMemcpyHostToDevice, s));
+    scalars_to_fr_device((const uint8_t*)L->d_v_s3, (int)n, L->d_v_z, st_z, s);
+    if (form == 0) {
+        cells_from_blobs_device(blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s);
+        poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s);
+    } else if (form == 1) {
+        blob_eval_device(blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s);
+    } else {
+        blob_quotient_device(blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, L->d_quot, st_b, s);
+    }
+    fr_to_scalars_device(L->d_v_y, (int)n, (uint8_t*)L->d_v_s1, s);
+    HIPCHK(hipGetLastError());
+    std::vector<int> stb(n), stz(n);
+    HIPCHK(hipMemcpyAsync(y32n, L->d_v_s1, n * 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(stb.data(), st_b, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(stz.data(), st_z, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    LANE_SYNC(c, L, s);
+    L->drained = true;
+    int first = MKZG_OK;
+    for (size_t i = 0; i < n; i++) {
+        status[i] = stb[i] ? stb[i] : stz[i];
+        if (status[i] && !first) first = status[i];
+    }
+    return first;
+}
+
 // The finer seam of the reference, multiexp.MultiExpG1 (internal/multiexp/multiexp.go:20-26): sum s_i P_i with gnark-crypto's in-memory
 // layouts on both sides -- scalars n x 4 u64 (fr.Element, Montgomery R = 2^256), points n x 12 u64 (G1Affine: X, Y as fp.Element, Montgomery
 // R = 2^384, identity (0,0)), result one G1Affine.  Like the reference it does not validate the points.  Any n (pieces of 8192).

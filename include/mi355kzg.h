@@ -165,6 +165,17 @@ int mkzg_verify_blob_kzg_proof_batch_partial_device(mkzg_ctx* ctx, const void* d
                                                     uint64_t offset, const uint8_t r32[32], uint8_t record512[512], void* stream);
 int mkzg_verify_blob_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* records512, size_t n_records);
 
+/* Domain.EvaluateLagrangePolynomial (reference internal/domain/domain.go:193-235, with DeserializeBlob's canonicity check,
+ * serialization.go:134-146): y_i = f_i(z_i) for n device-resident blobs and n caller-chosen evaluation points (host memory, n x 32 B
+ * big-endian, canonical), points of the domain included (domain.go:163-171, :199-203).  The verifiers derive z from a hash and the
+ * proof path returns y beside its proof; this entry point evaluates alone, through each of the three kernels the library has for it:
+ *   form 0  inverse NTT + Horner on the coefficients (the batch verifier's latency shape),
+ *   form 1  barycentric formula down the product tree of the domain, one inversion per blob (the throughput shape),
+ *   form 2  barycentric formula with one batch inversion per lane (the proof path's kernel, whose quotient is discarded here).
+ * All forms must return the same bytes.  y32n / status: host memory (n x 32 B, n ints); status[i] is the blob's code, else z's.
+ * Returns the first non-zero status.  n <= 4096.  Synchronises `stream`. */
+int mkzg_evaluate_blobs_device(mkzg_ctx* ctx, const void* d_blobs, const uint8_t* z32n, size_t n, int form, uint8_t* y32n, int* status, void* stream);
+
 /* The finer seam: multiexp.MultiExpG1 (reference internal/multiexp/multiexp.go:20-26) with gnark-crypto's in-memory layouts.
  * scalars: n x 4 u64 (fr.Element, little-endian limbs, Montgomery R = 2^256); points: n x 12 u64 (G1Affine = X, Y as fp.Element,
  * Montgomery R = 2^384; the identity is (0, 0)); out: one G1Affine in the same layout.  No point validation (as the reference). */

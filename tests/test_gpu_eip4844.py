@@ -4,12 +4,15 @@ ComputeBlobKZGProof, VerifyKZGProof, VerifyBlobKZGProof, VerifyBlobKZGProofBatch
 Rules restated from the reference's consensus_specs_test.go:72-359: compute outputs byte-for-byte;
 verifiers: output true <=> rc == 0, false <=> rc == MKZG_VERIFY_FAILED (1), null <=> input error.
 """
+import hashlib
+
 import pytest
 
 from test_gpu_commit import rand_blob
 
 pytestmark = pytest.mark.gpu
 VERIFY_FAILED = 1
+R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 
 def _bad(*vals):
@@ -206,10 +209,19 @@ def test_batch_64_device_generated(gpu_ctx, oracle_ctx):
     assert gpu_ctx.VerifyBlobKZGProofBatch(blobs, cms, bad) == VERIFY_FAILED
 
 
-def test_sharded_verify_records_match_oracle(gpu_ctx, oracle_ctx, product):
+@pytest.fixture(params=[0, 1], ids=["latency_shape", "throughput_shape"])
+def verify_shape(request, gpu_ctx):
+    """both shapes of the blob verifier (api_verify.hip): 0 = inverse NTT + Horner, quad-lane subgroup tests, side streams;
+    1 = product-tree barycentric evaluation (k_blob_eval_tree), one lane per point, shared hash rounds -- forced, then put back"""
+    assert gpu_ctx.set_option("verify_shape", request.param) == 0
+    yield request.param
+    assert gpu_ctx.set_option("verify_shape", -1) == 0
+
+
+def test_sharded_verify_records_match_oracle(gpu_ctx, oracle_ctx, product, verify_shape):
     """The partial-sum records of the sharded verifier are deterministic once r is fixed, so the GPU fold
     can be compared byte-for-byte with the oracle's -- a parity check INSIDE the batch verifier that the
-    random r normally hides.  Also: GPU records finish on the oracle and vice versa."""
+    random r normally hides, under BOTH shapes of the verifier.  Also: GPU records finish on the oracle and vice versa."""
     import torch
     n = 7
     blobs = [rand_blob(500 + s) for s in range(n)]
@@ -538,3 +550,89 @@ def test_throughput_shape_respects_stream_order(product, oracle_ctx):
         stream.synchronize()
         assert ctx.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), NB, stream.cuda_stream) == 0
     ctx.close()
+
+
+def test_sharded_verify_records_match_oracle_64(gpu_ctx, oracle_ctx, verify_shape):
+    """the same byte-for-byte pin on 64 blobs (a whole workgroup of the challenge hash, 64 evaluation workgroups) under both shapes,
+    with one non-canonical blob in a second run: the record then carries the error of the reference's precedence"""
+    import torch
+    n = 64
+    blobs = [rand_blob(9000 + s) for s in range(n)]
+    d_b = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_c = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    d_p = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    d_s = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_ctx.blob_to_kzg_commitment_batch_device(d_b.data_ptr(), n, d_c.data_ptr(), d_s.data_ptr(), st) == 0
+    assert gpu_ctx.compute_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), n, d_p.data_ptr(), d_s.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    cms = [bytes(d_c[48 * i:48 * i + 48].cpu().numpy()) for i in range(n)]
+    prs = [bytes(d_p[48 * i:48 * i + 48].cpu().numpy()) for i in range(n)]
+    r32 = bytes(range(101, 133))
+    rc, rec = gpu_ctx.verify_blob_batch_partial_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, 3, r32, st)
+    rco, reco = oracle_ctx.verify_blob_batch_partial(blobs, cms, prs, 3, r32)
+    assert rc == 0 and rco == 0 and rec == reco
+    assert gpu_ctx.verify_blob_batch_finish([rec]) == 0
+    # blob 41: scalar 17 := r (non-canonical)
+    bad = bytearray(blobs[41])
+    bad[17 * 32:18 * 32] = R_MOD.to_bytes(32, "big")
+    d_b2 = d_b.clone()
+    d_b2[41 * 131072:42 * 131072] = torch.frombuffer(bad, dtype=torch.uint8).cuda()
+    rc, rec = gpu_ctx.verify_blob_batch_partial_device(d_b2.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, 3, r32, st)
+    rco, reco = oracle_ctx.verify_blob_batch_partial(blobs[:41] + [bytes(bad)] + blobs[42:], cms, prs, 3, r32)
+    assert rc == rco and rc != 0 and rec[:4] == reco[:4]
+
+
+def _domain_roots_brp():
+    """the 4096 evaluation points of a blob in the order its scalars are stored (api.go:127-132: bit-reversed powers of the 4096th root
+    of unity derived from the 2^32-th root of internal/domain/domain.go:61)"""
+    root32 = 10238227357739495823651030575849232062558860180284477541189508159991286009131
+    w = pow(root32, 1 << (32 - 12), R_MOD)
+    nat = [1] * 4096
+    for i in range(1, 4096):
+        nat[i] = nat[i - 1] * w % R_MOD
+    return [nat[int(format(i, "012b")[::-1], 2)] for i in range(4096)]
+
+
+def test_evaluation_kernels_agree_with_oracle(gpu_ctx, oracle_ctx):
+    """Domain.EvaluateLagrangePolynomial (reference internal/domain/domain.go:163-235) through each of the library's three evaluation
+    kernels -- inverse NTT + Horner, the product-tree barycentric form that carries the throughput shape (k_blob_eval_tree), the proof
+    path's per-lane batch inversion -- at caller-chosen points: random z, z = 0, z = r - 1, and POINTS OF THE DOMAIN (stored index 0 = the root
+    1, an odd index, index 4095, a middle one), where the barycentric formula divides by zero and the value is the stored scalar itself.
+    Each branch also with a non-canonical blob (status, no value) and a non-canonical z.  Byte-exact against the oracle."""
+    import torch
+    roots = _domain_roots_brp()
+    blobs = [rand_blob(31000 + s) for s in range(6)] + [bytes(131072), (R_MOD - 1).to_bytes(32, "big") * 4096]
+    bad_blob = bytearray(rand_blob(31100))
+    bad_blob[4095 * 32:] = (R_MOD + 5).to_bytes(32, "big")               # the LAST scalar: the on-domain branch must still look at every scalar
+    zs_off = [hashlib.sha256(b"z%d" % i).digest() for i in range(4)]
+    zs_off = [(int.from_bytes(z, "big") % R_MOD).to_bytes(32, "big") for z in zs_off] + [bytes(32), (R_MOD - 1).to_bytes(32, "big")]
+    on_idx = [0, 1, 2049, 4095, 1234]
+    zs_on = [roots[i].to_bytes(32, "big") for i in on_idx]
+    cases = []                                                             # (blob, z, expected rc)
+    for b in blobs:
+        for z in zs_off[:3] + zs_on[:4]:
+            cases.append((b, z))
+    for z in zs_off[3:] + zs_on[4:]:
+        cases.append((blobs[1], z))
+    for z in (zs_off[0], zs_on[0], zs_on[1], zs_on[3]):
+        cases.append((bytes(bad_blob), z))                                 # non-canonical blob in the off-domain and every on-domain branch
+    cases.append((blobs[2], R_MOD.to_bytes(32, "big")))                    # non-canonical z
+    n = len(cases)
+    d_b = torch.frombuffer(bytearray(b"".join(c[0] for c in cases)), dtype=torch.uint8).cuda()
+    want = [oracle_ctx.evaluate_blob(b, z) for b, z in cases]
+    assert sum(1 for rc, _ in want if rc) == 5
+    # on-domain sanity of the expectation itself: the value IS the stored scalar
+    for (b, z), (rc, y) in zip(cases, want):
+        if rc == 0 and z in zs_on:
+            i = roots.index(int.from_bytes(z, "big"))
+            assert y == b[32 * i:32 * i + 32]
+    for form in (0, 1, 2):
+        rc, ys, st = gpu_ctx.evaluate_blobs_device(d_b.data_ptr(), [z for _, z in cases], form, torch.cuda.current_stream().cuda_stream)
+        for i, ((rco, yo), y, sti) in enumerate(zip(want, ys, st)):
+            if rco:
+                assert sti != 0, (form, i)
+            else:
+                assert sti == 0 and y == yo, (form, i)
+        first = next((s for s in st if s), 0)
+        assert rc == first

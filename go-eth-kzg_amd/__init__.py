@@ -42,6 +42,8 @@ EXPORTED_SYMBOLS = [
     "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
     "mkzg_verify_blob_kzg_proof_batch_partial_device", "mkzg_verify_blob_kzg_proof_batch_finish",
     "mkzg_evaluate_blobs_device",
+    "mkzg_comm_unique_id", "mkzg_comm_init", "mkzg_comm_from_nccl", "mkzg_comm_free", "mkzg_comm_last_exchange_us",
+    "mkzg_verify_blob_kzg_proof_batch_exchange", "mkzg_verify_blob_kzg_proof_batch_exchange_device", "mkzg_verify_cell_kzg_proof_batch_exchange",
 ]
 
 
@@ -89,6 +91,16 @@ def lib():
                                                               C.c_char_p, C.c_char_p, C.POINTER(i32)]
         L.mkzg_recover_cells_and_kzg_proofs.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p, C.c_char_p]
         L.mkzg_recover_cells.argtypes = [vp, C.POINTER(C.c_uint64), sz, C.POINTER(C.c_char_p), sz, i32, C.c_char_p]
+        L.mkzg_comm_unique_id.argtypes = [C.c_char_p]
+        L.mkzg_comm_init.argtypes = [vp, C.c_char_p, i32, i32, C.POINTER(vp)]
+        L.mkzg_comm_from_nccl.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+        L.mkzg_comm_free.argtypes = [vp]
+        L.mkzg_comm_free.restype = None
+        L.mkzg_comm_last_exchange_us.argtypes = [vp]
+        L.mkzg_comm_last_exchange_us.restype = C.c_double
+        L.mkzg_verify_blob_kzg_proof_batch_exchange.argtypes = [vp, vp, C.c_char_p, C.c_char_p, sz, C.c_uint64]
+        L.mkzg_verify_blob_kzg_proof_batch_exchange_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, vp]
+        L.mkzg_verify_cell_kzg_proof_batch_exchange.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64]
         L.mkzg_evaluate_blobs_device.argtypes = [vp, vp, C.c_char_p, sz, i32, C.c_char_p, C.POINTER(C.c_int), vp]
         L.mkzg_verify_blob_kzg_proof_batch_partial_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
         L.mkzg_verify_blob_kzg_proof_batch_finish.argtypes = [vp, C.c_char_p, sz]

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmi355kzg.so")
-SOURCES = ["api.hip", "api_verify.hip", "api_cells.hip", "api_multi.hip", "msm_kernels.hip", "verify_kernels.hip", "cells_kernels.hip", "fk20_kernels.hip", "recover_kernels.hip"]
+SOURCES = ["api.hip", "api_verify.hip", "api_cells.hip", "api_multi.hip", "api_exchange.hip", "msm_kernels.hip", "verify_kernels.hip", "cells_kernels.hip", "fk20_kernels.hip", "recover_kernels.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
 

@@ -165,6 +165,40 @@ int mkzg_verify_blob_kzg_proof_batch_partial_device(mkzg_ctx* ctx, const void* d
                                                     uint64_t offset, const uint8_t r32[32], uint8_t record512[512], void* stream);
 int mkzg_verify_blob_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* records512, size_t n_records);
 
+/* ---- multi-process jobs: the batch verifiers' exchange step inside the library ------------------------------------------------
+ * One process per GPU.  Commitments, proofs, cells and recovery shard by blob and need nothing below.  The two batch
+ * verifiers fold a random linear combination over the WHOLE batch (reference internal/kzg/kzg_verify.go:111-202,
+ * internal/kzg_multi/kzg_verify.go:16-105), so the ranks meet once: all-gather of the shard sizes (offset = prefix sum: the shards
+ * must tile the announced batch), broadcast of r from rank 0, all-gather of one 512-byte record per rank; every rank then adds the
+ * partial sums and runs the one pairing check.  The collectives are RCCL's, issued by the library: the host program (Go over cgo)
+ * needs no RCCL binding of its own, and librccl is dlopen'ed by the first call below -- single-GPU users need no RCCL installed
+ * (MKZG_RCCL_LIB overrides the library name).  The `_partial` / `_finish` pairs above remain for hosts that move the records
+ * themselves (go-eth-kzg_amd/distributed.py does, through torch.distributed).
+ *   mkzg_comm_unique_id   rank 0: 128 opaque bytes for every rank of the job, by whatever channel the host program has
+ *   mkzg_comm_init        collective: same id, own rank, own single-device context -> a communicator (ncclCommInitRank inside)
+ *   mkzg_comm_from_nccl   instead: wrap an ncclComm_t the host program already has (not destroyed by mkzg_comm_free)
+ * The `_exchange` calls are COLLECTIVE: every rank of the communicator makes the same call with its own shard (the ranks' shards in
+ * rank order are the batch; a rank may bring none) and the same n_global, and every rank gets the verdict of the whole batch: 0,
+ * MKZG_VERIFY_FAILED, the input error of the lowest failing rank (the reference's precedence over the concatenated batch,
+ * verify.go:102-123), or MKZG_ERR_BATCH_LENGTH on every rank when the shards do not add up to n_global.  One exchange at a time per
+ * communicator (serialised inside). */
+typedef struct mkzg_comm mkzg_comm;
+int mkzg_comm_unique_id(uint8_t id128[128]);
+int mkzg_comm_init(mkzg_ctx* ctx, const uint8_t id128[128], int rank, int world, mkzg_comm** out);
+int mkzg_comm_from_nccl(mkzg_ctx* ctx, void* nccl_comm, int rank, int world, mkzg_comm** out);
+void mkzg_comm_free(mkzg_comm* comm);
+/* microseconds this rank spent in the three collectives of its last exchange (waiting for slower ranks included) */
+double mkzg_comm_last_exchange_us(mkzg_comm* comm);
+/* Context.VerifyBlobKZGProofBatch (reference verify.go:88-143) over the ranks: host pointers as in the reference ... */
+int mkzg_verify_blob_kzg_proof_batch_exchange(mkzg_comm* comm, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n_local,
+                                              uint64_t n_global);
+/* ... or this rank's shard contiguous in HBM */
+int mkzg_verify_blob_kzg_proof_batch_exchange_device(mkzg_comm* comm, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n_local, uint64_t n_global,
+                                                     void* stream);
+/* Context.VerifyCellKZGProofBatch (reference api_eip7594.go:163-214) over the ranks: this rank's (commitment, index, cell, proof) tuples */
+int mkzg_verify_cell_kzg_proof_batch_exchange(mkzg_comm* comm, const uint8_t* commitments48n, const uint64_t* cell_indices, const uint8_t* const* cells,
+                                              const uint8_t* proofs48n, size_t n_local, uint64_t n_global);
+
 /* Domain.EvaluateLagrangePolynomial (reference internal/domain/domain.go:193-235, with DeserializeBlob's canonicity check,
  * serialization.go:134-146): y_i = f_i(z_i) for n device-resident blobs and n caller-chosen evaluation points (host memory, n x 32 B
  * big-endian, canonical), points of the domain included (domain.go:163-171, :199-203).  The verifiers derive z from a hash and the

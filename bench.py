@@ -818,6 +818,41 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
                                  "note": f"one global batch of {G} proofs cut over {world} rank(s) ({N} distinct triples per rank, repeated to fill its shard); "
                                          "broadcast(r) + all_gather(sizes) + all_gather(512 B records), one pairing on every rank"}
         del sb, sc, sp, spb
+    if dist_on and dev is not None and dev.type == "cuda":
+        # the same sharded call with the exchange step INSIDE the library (csrc/api_exchange.hip: RCCL all-gather of the shard sizes,
+        # broadcast of r, all-gather of the 512-byte records, issued by libmi355kzg.so itself -- what a Go host calls; torch.distributed
+        # only carries the 128-byte communicator id here)
+        try:
+            Lc = sys.modules["goethkzg_amd"].lib()
+            ident = [None]
+            if rank == 0:
+                buf = ctypes.create_string_buffer(128)
+                assert Lc.mkzg_comm_unique_id(buf) == 0
+                ident = [buf.raw]
+            dist.broadcast_object_list(ident, src=0)
+            hcomm = ctypes.c_void_p()
+            rc = Lc.mkzg_comm_init(ctx._h, ident[0], rank, world, ctypes.byref(hcomm))
+            assert rc == 0, f"mkzg_comm_init rc={rc}"
+
+            def lib_call(proofs):
+                return Lc.mkzg_verify_blob_kzg_proof_batch_exchange_device(hcomm, d_blobs.data_ptr(), d_cm.data_ptr(), proofs.data_ptr(), N, N * world, st)
+
+            assert lib_call(d_pr) == 0
+            assert lib_call(d_bad) == 1, "a wrong proof in rank shards went unnoticed by the library's exchange"
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ex_us = 0.0
+            for _ in range(args.verify_steps):
+                assert lib_call(d_pr) == 0
+                ex_us += Lc.mkzg_comm_last_exchange_us(hcomm)
+            dist.barrier()
+            dtl = maxed(time.perf_counter() - t0) / args.verify_steps
+            out["library_exchange"] = {"ms_per_call": round(dtl * 1e3, 3), "blobs_per_s": round(N * world / dtl, 1), "exchange_us_per_call_this_rank": round(ex_us / args.verify_steps, 1),
+                                       "note": "mkzg_verify_blob_kzg_proof_batch_exchange_device on a communicator made by mkzg_comm_init: the three collectives are issued by the library (RCCL, dlopen'ed)"}
+            Lc.mkzg_comm_free(hcomm)
+        except Exception as e:      # noqa: BLE001
+            out["library_exchange"] = {"error": repr(e)}
     if world == 1 and not dist_on:
         # the reference's own API shape at the sizes a block carries: host pointers in (Go's []*Blob), one synchronous caller
         hb = d_blobs[: min(N, 48) * BLOB].cpu().numpy().tobytes()

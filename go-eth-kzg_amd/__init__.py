@@ -24,7 +24,9 @@ CELLS_PER_EXT_BLOB = 128
 
 OK = 0
 VERIFY_FAILED = 1
+ERR_BATCH_LENGTH = 2
 ERR_NON_CANONICAL_SCALAR = 3
+ERR_INVALID_CELL_ID = 4
 ERR_NIL_INPUT = 6
 ERR_TOO_MANY_GOROUTINES = 14
 ERR_INVALID_POLY_SIZE = 15

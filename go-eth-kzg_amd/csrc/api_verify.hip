@@ -517,8 +517,10 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
     };
     const std::function<void(int)> hash_task = [&](int t) {
         const size_t lo = n_dev + (size_t)t * HPT, hi = std::min(m, lo + HPT);
-        // a nil blob stands in as the zero blob (its staged copy): the call fails with the reference's precedence afterwards
-        auto src = [&](size_t i) { return blobs[i] ? blobs[i] : L->h_stage + i * MKZG_BYTES_PER_BLOB; };
+        // a nil blob stands in as the zero blob: the call fails with the reference's precedence afterwards (not its staged copy: a copy
+        // task may still be writing that one)
+        static const uint8_t zero_blob[MKZG_BYTES_PER_BLOB] = {0};
+        auto src = [&](size_t i) { return blobs[i] ? blobs[i] : zero_blob; };
         size_t i = lo;
         for (; i + 1 < hi; i += 2) host_compute_challenge_x2(h_z + i * 32, src(i), commitments48n + i * 48, h_z + (i + 1) * 32, src(i + 1), commitments48n + (i + 1) * 48);
         if (i < hi) host_compute_challenge(h_z + i * 32, src(i), commitments48n + i * 48);

@@ -102,6 +102,123 @@ static void run(const std::string& js, const std::vector<int>& devices, int thre
     mkzg_ctx_free(ctx);
 }
 
+// The exchange step of the batch verifiers inside the library (api_exchange.hip) with `world` ranks = threads, each with a context on
+// its own stub device, over the in-process stand-in for librccl (stub_rccl.cpp, named through MKZG_RCCL_LIB).  The kernels are stubs, so
+// what is checked is the protocol: every rank returns the SAME code; shards that do not add up to the announced batch are refused on
+// every rank; an input error found on the host in one rank's shard (a nil blob, a nil cell) is returned by every rank; a rank may
+// bring nothing; nobody hangs; TSan stays silent.
+static void exchange_scenario(const std::string& js, int world) {
+    uint8_t id[128];
+    CHECK(mkzg_comm_unique_id(id) == MKZG_OK);
+    std::vector<int> got(5 * (size_t)world, -1);
+    std::vector<std::thread> th;
+    for (int rank = 0; rank < world; rank++) th.emplace_back([&, rank] {
+        CHECK(hipSetDevice((rank + 1) % world) == hipSuccess);                  // the caller sits on another device than its context's
+        mkzg_ctx* ctx = nullptr;
+        const int dev = rank;
+        CHECK(mkzg_ctx_new(js.data(), js.size(), &dev, 1, &ctx) == MKZG_OK && ctx);
+        mkzg_comm* cm = nullptr;
+        CHECK(mkzg_comm_init(ctx, id, rank, world, &cm) == MKZG_OK && cm);
+        const size_t NB = 3 + (size_t)rank;                                     // uneven shards
+        std::vector<std::vector<uint8_t>> blobs(NB, std::vector<uint8_t>(MKZG_BYTES_PER_BLOB, 0));
+        std::vector<const uint8_t*> bp(NB);
+        for (size_t b = 0; b < NB; b++) bp[b] = blobs[b].data();
+        std::vector<uint8_t> cms(NB * 48, 0), prs(NB * 48, 0);
+        for (size_t b = 0; b < NB; b++) { cms[48 * b] = 0xc0; prs[48 * b] = 0xc0; }
+        uint64_t total = 0;
+        for (int k = 0; k < world; k++) total += 3 + (uint64_t)k;
+        int* g = &got[5 * (size_t)rank];
+        g[0] = mkzg_verify_blob_kzg_proof_batch_exchange(cm, bp.data(), cms.data(), prs.data(), NB, total);
+        g[1] = mkzg_verify_blob_kzg_proof_batch_exchange(cm, bp.data(), cms.data(), prs.data(), NB, total + 1);        // announced size is wrong
+        if (rank == world - 1) bp[1] = nullptr;                                                                          // a nil blob in the LAST shard
+        g[2] = mkzg_verify_blob_kzg_proof_batch_exchange(cm, bp.data(), cms.data(), prs.data(), NB, total);
+        bp[1] = blobs[1].data();
+        // cells: rank 0 brings nothing; rank 1 (if any) a nil cell
+        const size_t NC = rank == 0 ? 0 : 8;
+        std::vector<std::vector<uint8_t>> cellv(8, std::vector<uint8_t>(2048, 0));
+        std::vector<const uint8_t*> cp(8);
+        std::vector<uint64_t> idx(8);
+        std::vector<uint8_t> ccm(8 * 48, 0), cpr(8 * 48, 0);
+        for (int i = 0; i < 8; i++) { cp[i] = cellv[i].data(); idx[i] = (uint64_t)i; ccm[48 * i] = 0xc0; cpr[48 * i] = 0xc0; }
+        g[3] = mkzg_verify_cell_kzg_proof_batch_exchange(cm, ccm.data(), idx.data(), cp.data(), cpr.data(), NC, 8 * (uint64_t)(world - 1));
+        if (rank == 1) cp[5] = nullptr;
+        g[4] = mkzg_verify_cell_kzg_proof_batch_exchange(cm, ccm.data(), idx.data(), cp.data(), cpr.data(), NC, 8 * (uint64_t)(world - 1));
+        CHECK(mkzg_comm_last_exchange_us(cm) >= 0.0);
+        int d = -1;
+        CHECK(hipGetDevice(&d) == hipSuccess && d == (rank + 1) % world);
+        mkzg_comm_free(cm);
+        mkzg_ctx_free(ctx);
+    });
+    for (auto& t : th) t.join();
+    for (int rank = 1; rank < world; rank++)
+        for (int q = 0; q < 5; q++) CHECK(got[5 * (size_t)rank + q] == got[q]);           // every rank the same verdict
+    CHECK(soft(got[0]));
+    CHECK(got[1] == MKZG_ERR_BATCH_LENGTH);
+    CHECK(got[2] == MKZG_ERR_NIL_INPUT);
+    CHECK(soft(got[3]));
+    CHECK(world < 2 || got[4] == MKZG_ERR_NIL_INPUT);
+}
+
+// An eight-device context (api_multi.hip): one full context per device behind the front, host-pointer batches cut into contiguous
+// shards.  Checked: the devices option, every shared table on its own device after calls that build them, the pools' sizes (eight
+// contexts share the CPUs), per-item results at the right positions across the shards (a blob with too few cells in the recovery batch,
+// nil inputs in the last shard of both verifiers).
+static void eight_device_scenario(const std::string& js) {
+    const int devs[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    mkzg_ctx* ctx = nullptr;
+    CHECK(mkzg_ctx_new(js.data(), js.size(), devs, 8, &ctx) == MKZG_OK && ctx);
+    if (!ctx) return;
+    long v = 0;
+    CHECK(mkzg_ctx_get_option(ctx, "devices", &v) == MKZG_OK && v == 8);
+    CHECK(mkzg_ctx_get_option(ctx, "host_threads", &v) == MKZG_OK && v >= 1 && v <= 16);
+    const long share_threads = v;
+    CHECK(mkzg_ctx_get_option(ctx, "cpu_share", &v) == MKZG_OK && v >= 2 && share_threads <= v);    // a device's pool never exceeds its share of the CPUs
+    const size_t NB = 19;                                                       // 8 shards of 2 or 3
+    std::vector<std::vector<uint8_t>> blobs(NB, std::vector<uint8_t>(MKZG_BYTES_PER_BLOB, 0));
+    std::vector<const uint8_t*> bp(NB);
+    for (size_t b = 0; b < NB; b++) { blobs[b][31] = (uint8_t)(b + 1); bp[b] = blobs[b].data(); }
+    std::vector<uint8_t> cms(NB * 48, 0), prs(NB * 48, 0), out(NB * 48);
+    for (size_t b = 0; b < NB; b++) { cms[48 * b] = 0xc0; prs[48 * b] = 0xc0; }
+    std::vector<int> st(NB, -1);
+    CHECK(soft(mkzg_blob_to_kzg_commitment_batch(ctx, bp.data(), NB, out.data(), st.data())));
+    CHECK(soft(mkzg_verify_blob_kzg_proof_batch(ctx, bp.data(), cms.data(), prs.data(), NB, NB, NB)));
+    bp[NB - 1] = nullptr;                                                       // last item of the last shard
+    CHECK(mkzg_verify_blob_kzg_proof_batch(ctx, bp.data(), cms.data(), prs.data(), NB, NB, NB) == MKZG_ERR_NIL_INPUT);
+    CHECK(mkzg_blob_to_kzg_commitment_batch(ctx, bp.data(), NB, out.data(), st.data()) == MKZG_ERR_NIL_INPUT);
+    bp[NB - 1] = blobs[NB - 1].data();
+    // cells
+    const size_t NC = 8 * 16;
+    std::vector<std::vector<uint8_t>> cellv(NC, std::vector<uint8_t>(2048, 0));
+    std::vector<const uint8_t*> cp(NC);
+    std::vector<uint64_t> idx(NC);
+    std::vector<uint8_t> ccm(NC * 48, 0), cpr(NC * 48, 0);
+    for (size_t i = 0; i < NC; i++) { cp[i] = cellv[i].data(); idx[i] = (uint64_t)(i % 128); ccm[48 * i] = 0xc0; cpr[48 * i] = 0xc0; }
+    CHECK(soft(mkzg_verify_cell_kzg_proof_batch(ctx, ccm.data(), NC, idx.data(), NC, cp.data(), NC, cpr.data(), NC)));
+    cp[NC - 3] = nullptr;
+    CHECK(mkzg_verify_cell_kzg_proof_batch(ctx, ccm.data(), NC, idx.data(), NC, cp.data(), NC, cpr.data(), NC) == MKZG_ERR_NIL_INPUT);
+    cp[NC - 3] = cellv[NC - 3].data();
+    idx[NC - 2] = 128;                                                          // checked for the whole batch before anything else (api_eip7594.go:184-188)
+    cp[1] = nullptr;
+    CHECK(mkzg_verify_cell_kzg_proof_batch(ctx, ccm.data(), NC, idx.data(), NC, cp.data(), NC, cpr.data(), NC) == MKZG_ERR_INVALID_CELL_ID);
+    idx[NC - 2] = (NC - 2) % 128;
+    cp[1] = cellv[1].data();
+    // recovery batch: 11 blobs over 8 devices, blob 9 with 63 cells only -> its status alone carries the error
+    const size_t RB = 11;
+    std::vector<uint64_t> ids(64);
+    for (int i = 0; i < 64; i++) ids[(size_t)i] = (uint64_t)(2 * i);
+    std::vector<const uint64_t*> pid(RB, ids.data());
+    std::vector<const uint8_t* const*> pcl(RB, cp.data());
+    std::vector<size_t> nid(RB, 64);
+    nid[9] = 63;
+    std::vector<uint8_t> oc(RB * 262144), op(RB * 6144);
+    std::vector<int> rst(RB, -1);
+    const int rrc = mkzg_recover_cells_and_kzg_proofs_batch(ctx, RB, pid.data(), nid.data(), pcl.data(), nid.data(), oc.data(), op.data(), rst.data());
+    CHECK(rrc == MKZG_ERR_NOT_ENOUGH_CELLS);
+    for (size_t b = 0; b < RB; b++) CHECK(b == 9 ? rst[b] == MKZG_ERR_NOT_ENOUGH_CELLS : soft(rst[b]) && rst[b] != MKZG_ERR_NOT_ENOUGH_CELLS);
+    CHECK(mkzg_ctx_get_option(ctx, "tables_on_own_device", &v) == MKZG_OK && v == 1);
+    mkzg_ctx_free(ctx);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: %s trusted_setup.json\n", argv[0]); return 2; }
     FILE* f = fopen(argv[1], "rb");
@@ -115,6 +232,12 @@ int main(int argc, char** argv) {
     run(js, {0}, 10, 45);              // one device, ten callers: lanes, hash rounds, lazy tables, options under load
     run(js, {1}, 4, 18);               // a context on the device the callers are NOT on
     run(js, {0, 1}, 6, 27);            // the multi-device front
+    eight_device_scenario(js);         // eight devices behind one front: shard placement, pool sizes, results at the right positions
+    if (getenv("MKZG_RCCL_LIB")) {     // the exchange step over the in-process stand-in for librccl
+        exchange_scenario(js, 1);
+        exchange_scenario(js, 2);
+        exchange_scenario(js, 8);
+    }
     CHECK(stub_hip_live_allocations() == before);       // everything a context allocated on the "device" came back
     printf("stub_device_driver: %d failed checks\n", g_bad.load());
     return g_bad.load() ? 1 : 0;

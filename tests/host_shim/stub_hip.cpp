@@ -1,6 +1,6 @@
 // tests/host_shim/stub_hip.cpp -- a HIP runtime made of host memory, for driving the product's HOST layer on a CPU under ThreadSanitizer
 // (tests/test_host_sanitizers.py; no GPU, no libamdhip64).  "Device" memory is zero-filled host memory tagged with the device that was
-// current when it was allocated, copies happen at once, streams and events are inert handles that are always complete, and every
+// current when it was allocated (eight devices), copies happen at once, streams and events are inert handles that are always complete, and every
 // thread has its own current device -- which is what the product's DeviceScope and the placement of the lazily built tables are
 // checked against.  Test infrastructure only: nothing here is linked into libmi355kzg.so.
 #include <hip/hip_runtime.h>
@@ -10,7 +10,7 @@
 #include <unordered_map>
 
 namespace {
-constexpr int N_DEVICES = 2;
+constexpr int N_DEVICES = 8;          // the multi-device scenarios list up to eight
 thread_local int tl_device = 0;
 std::mutex g_mu;
 std::unordered_map<const void*, int> g_owner;          // allocation -> device

@@ -88,3 +88,7 @@ def test_exchange_on_rccl_with_one_rank():
     v = d["verify_blob_kzg_proof_batch"]
     assert "sharded x1" in v["single_call"]["parallelism"] and v["strong_scaling"]["per_rank"] == 8192
     assert d["eip7594"]["verify_cell_kzg_proof_batch"]["strong_scaling"]["per_rank"] == 65536
+    # ... and the same sharded call with the collectives issued by the LIBRARY (mkzg_comm_init + mkzg_verify_blob_kzg_proof_batch_exchange_device)
+    le = v["library_exchange"]
+    assert "error" not in le and le["blobs_per_s"] > 0 and le["exchange_us_per_call_this_rank"] > 0, le
+    assert d["verify_metric"]["value"] == v["value"] and d["verify_metric"]["n_gpus"] == 1

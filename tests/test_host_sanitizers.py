@@ -64,11 +64,14 @@ def test_host_layer_on_stub_device_under_tsan():
     subprocess.check_call([sys.executable, os.path.join(SHIM_DIR, "gen_stub_device.py"), gen], stdout=subprocess.DEVNULL)
     exe = os.path.join(SHIM_DIR, "stub_device_tsan")
     cmd = ["g++", "-O2", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-Wno-unused-result", "-w", "-x", "c++"]
-    cmd += [os.path.join(csrc, f) for f in ("api.hip", "api_verify.hip", "api_cells.hip", "api_multi.hip")]
-    cmd += ["-x", "none", os.path.join(SHIM_DIR, "stub_hip.cpp"), gen, os.path.join(SHIM_DIR, "stub_device_driver.cpp"), "-o", exe]
+    cmd += [os.path.join(csrc, f) for f in ("api.hip", "api_verify.hip", "api_cells.hip", "api_multi.hip", "api_exchange.hip")]
+    cmd += ["-x", "none", os.path.join(SHIM_DIR, "stub_hip.cpp"), gen, os.path.join(SHIM_DIR, "stub_device_driver.cpp"), "-ldl", "-o", exe]
     subprocess.check_call(cmd)
+    # the in-process stand-in for librccl that the library's exchange step dlopens (ranks = threads): 1, 2 and 8 ranks
+    stub_rccl = os.path.join(SHIM_DIR, "libstub_rccl.so")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-shared", "-fPIC", "-pthread", "-o", stub_rccl, os.path.join(SHIM_DIR, "stub_rccl.cpp")])
     for rep in range(2):
-        r = subprocess.run([exe, os.path.join(ROOT, "go-eth-kzg_amd", "trusted_setup.json")], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1"),
+        r = subprocess.run([exe, os.path.join(ROOT, "go-eth-kzg_amd", "trusted_setup.json")], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1", MKZG_RCCL_LIB=stub_rccl),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "0 failed checks" in r.stdout, (r.stdout[-2000:], r.stderr[-6000:])
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]

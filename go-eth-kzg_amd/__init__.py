@@ -43,7 +43,8 @@ EXPORTED_SYMBOLS = [
     "mkzg_compute_cells_and_kzg_proofs", "mkzg_compute_cells_and_kzg_proofs_batch_device", "mkzg_verify_cell_kzg_proof_batch", "mkzg_verify_cell_kzg_proof_batch_partial", "mkzg_verify_cell_kzg_proof_batch_finish", "mkzg_recover_cells_and_kzg_proofs_batch", "mkzg_msm_g1",
     "mkzg_recover_cells_and_kzg_proofs", "mkzg_recover_cells",
     "mkzg_verify_blob_kzg_proof_batch_partial_device", "mkzg_verify_blob_kzg_proof_batch_finish",
-    "mkzg_evaluate_blobs_device",
+    "mkzg_recover_cells_and_kzg_proofs_batch_device",
+    "mkzg_evaluate_blobs_device", "mkzg_verify_cell_kzg_proof_batch_device", "mkzg_verify_cell_kzg_proof_batch_partial_device",
     "mkzg_comm_unique_id", "mkzg_comm_init", "mkzg_comm_from_nccl", "mkzg_comm_free", "mkzg_comm_last_exchange_us",
     "mkzg_verify_blob_kzg_proof_batch_exchange", "mkzg_verify_blob_kzg_proof_batch_exchange_device", "mkzg_verify_cell_kzg_proof_batch_exchange",
 ]
@@ -103,6 +104,9 @@ def lib():
         L.mkzg_verify_blob_kzg_proof_batch_exchange.argtypes = [vp, vp, C.c_char_p, C.c_char_p, sz, C.c_uint64]
         L.mkzg_verify_blob_kzg_proof_batch_exchange_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, vp]
         L.mkzg_verify_cell_kzg_proof_batch_exchange.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64]
+        L.mkzg_verify_cell_kzg_proof_batch_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, vp]
+        L.mkzg_verify_cell_kzg_proof_batch_partial_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
+        L.mkzg_recover_cells_and_kzg_proofs_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]
         L.mkzg_evaluate_blobs_device.argtypes = [vp, vp, C.c_char_p, sz, i32, C.c_char_p, C.POINTER(C.c_int), vp]
         L.mkzg_verify_blob_kzg_proof_batch_partial_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
         L.mkzg_verify_blob_kzg_proof_batch_finish.argtypes = [vp, C.c_char_p, sz]
@@ -278,6 +282,34 @@ class Context:
         arr = (C.c_char_p * max(1, len(cells)))(*keep)
         return self._L.mkzg_verify_cell_kzg_proof_batch(self._h, b"".join(commitments), len(commitments), idx, len(cell_indices), arr, len(cells),
                                                         b"".join(proofs), len(proofs))
+
+    def verify_cell_kzg_proof_batch_device(self, commitments, cell_indices, d_cells_ptr, proofs, stream=0):
+        """VerifyCellKZGProofBatch with the cells contiguous in HBM (n x 2048 B at d_cells_ptr), the other three arrays on the host"""
+        n = len(cell_indices)
+        if len(commitments) != n or len(proofs) != n:
+            return ERR_BATCH_LENGTH
+        idx = (C.c_uint64 * max(1, n))(*cell_indices)
+        return self._L.mkzg_verify_cell_kzg_proof_batch_device(self._h, b"".join(commitments), C.cast(idx, C.c_void_p), C.c_void_p(d_cells_ptr), b"".join(proofs), n, C.c_void_p(stream))
+
+    def verify_cell_batch_partial_device(self, commitments, cell_indices, d_cells_ptr, proofs, offset, r32, stream=0):
+        n = len(cell_indices)
+        idx = (C.c_uint64 * max(1, n))(*cell_indices)
+        rec = C.create_string_buffer(512)
+        rc = self._L.mkzg_verify_cell_kzg_proof_batch_partial_device(self._h, b"".join(commitments), C.cast(idx, C.c_void_p), C.c_void_p(d_cells_ptr), b"".join(proofs), n, offset,
+                                                                     bytes(r32), rec, C.c_void_p(stream))
+        return rc, rec.raw
+
+    def recover_batch_device(self, ids_per_blob, d_cells_ptr, d_cells_out_ptr, d_proofs_out_ptr, stream=0):
+        """mkzg_recover_cells_and_kzg_proofs_batch_device: ids_per_blob = list of id lists; the supplied cells concatenated in HBM; results
+        stay in HBM (d_proofs_out_ptr 0: cells only) -> (rc, [status per blob])"""
+        nb = len(ids_per_blob)
+        arrs = [(C.c_uint64 * max(1, len(x)))(*x) for x in ids_per_blob]
+        pid = (C.POINTER(C.c_uint64) * max(1, nb))(*[C.cast(a, C.POINTER(C.c_uint64)) for a in arrs])
+        nid = (C.c_size_t * max(1, nb))(*[len(x) for x in ids_per_blob])
+        st = (C.c_int * max(1, nb))()
+        rc = self._L.mkzg_recover_cells_and_kzg_proofs_batch_device(self._h, nb, C.cast(pid, C.c_void_p), C.cast(nid, C.c_void_p), C.c_void_p(d_cells_ptr), C.c_void_p(d_cells_out_ptr),
+                                                                     C.c_void_p(d_proofs_out_ptr) if d_proofs_out_ptr else None, st, C.c_void_p(stream))
+        return rc, list(st)[:nb]
 
     def verify_cell_batch_partial(self, commitments, cell_indices, cells, proofs, offset, r32):
         """this rank's share of a sharded VerifyCellKZGProofBatch -> (rc, 512-byte record); see include/mi355kzg.h"""

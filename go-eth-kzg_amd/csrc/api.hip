@@ -108,6 +108,7 @@ void free_lane(Lane* L) {
     dev_free(L->d_cv_cells); dev_free(L->d_cv_cell_idx); dev_free(L->d_cv_row_idx); dev_free(L->d_cv_rp); dev_free(L->d_cv_weights); dev_free(L->d_cv_partials);
     dev_free(L->d_cv_interp); dev_free(L->d_cv_st);
     L->cv_cap = 0;
+    L->cv_cells_cap = 0;
     dev_free(L->d_rec_scratch); dev_free(L->d_rec_pos);
     L->rec_cap = 0;
     dev_free(L->d_fk_scalars); dev_free(L->d_fk_results); dev_free(L->d_fk_parts); dev_free(L->d_fk_proofs); dev_free(L->d_fk_seg);

@@ -165,12 +165,19 @@ int ensure_fk20_ws(Lane* L, size_t n) {
 // 8192: 2.88-2.91 / 2.26-2.50 and 5.7 / 6.7-7.0
 #define MKZG_CV_SUBGROUP_WIDE_FROM 2048
 #endif
-static int ensure_cv_ws(Lane* L, size_t n) {
+// n_cells: cells the lane stages itself (host-pointer calls; 0 when the caller's cells are already in HBM); n: entries of the call
+static int ensure_cv_ws(Lane* L, size_t n_cells, size_t n) {
+    if (n_cells > L->cv_cells_cap) {
+        L->cv_cells_cap = 0;
+        const size_t cc = std::max<size_t>(n_cells, 128);
+        int rc = dev_realloc(L->d_cv_cells, cc * 2048);
+        if (rc) return rc;
+        L->cv_cells_cap = cc;
+    }
     if (n <= L->cv_cap) return MKZG_OK;
     L->cv_cap = 0;
     const size_t cap = std::max<size_t>(n, 128);
-    int rc = dev_realloc(L->d_cv_cells, cap * 2048);
-    if (!rc) rc = dev_realloc(L->d_cv_cell_idx, cap * 8);
+    int rc = dev_realloc(L->d_cv_cell_idx, cap * 8);
     if (!rc) rc = dev_realloc(L->d_cv_row_idx, cap * 4);
     if (!rc) rc = dev_realloc(L->d_cv_rp, cap * 48);
     if (!rc) rc = dev_realloc(L->d_cv_weights, cap * 32);
@@ -300,8 +307,10 @@ int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* c, const uint8_t* blob, int num_
 static const size_t CELL_PIECE = VMSM_MAX_N;       // cells per fold (the variable-base MSM kernels take up to 8192 points per job)
 
 // one piece (n <= CELL_PIECE) in lane L; r_words: the batch-wide scalar as 8 little-endian words
-static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, const uint64_t* cell_indices, const uint8_t* const* cells, const uint8_t* proofs48n, size_t n,
-                           uint32_t exp_offset, const uint32_t r_words[8], CellFold* out) {
+// cells: host pointers (the reference's []*Cell), or d_cells: the piece's n x 2048 B contiguous in HBM (no gather, no upload; s is then the
+// caller's stream)
+static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, const uint64_t* cell_indices, const uint8_t* const* cells, const uint8_t* d_cells,
+                           const uint8_t* proofs48n, size_t n, uint32_t exp_offset, const uint32_t r_words[8], hipStream_t s, CellFold* out) {
     // deduplicateKZGCommitments (api_eip7594.go:238-265); per piece -- the sum over rows is linear, so pieces need not agree on the rows
     std::unordered_map<std::string, uint32_t> seen;
     std::vector<uint32_t> row_idx(n);
@@ -319,17 +328,16 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     }
     const size_t n_rows = seen.size();
     size_t first_nil = n;
-    for (size_t i = 0; i < n; i++) if (!cells[i]) { first_nil = i; break; }
-    hipStream_t s = L->stream;
+    if (!d_cells) for (size_t i = 0; i < n; i++) if (!cells[i]) { first_nil = i; break; }
     int rc = ensure_verify_ws(L, n);
-    if (!rc) rc = ensure_cv_ws(L, n);
-    if (!rc) rc = ensure_staging(L, 1, n * 2048 + n_rows * 48 + n * 48 + n * 12 + 64);
+    if (!rc) rc = ensure_cv_ws(L, d_cells ? 0 : n, n);
+    if (!rc) rc = ensure_staging(L, 1, (d_cells ? 0 : n * 2048) + n_rows * 48 + n * 48 + n * 12 + 64);
     if (rc) return rc;
     const size_t cap = L->v_cap;
     uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * cap * sizeof(int));
     // uploads, part 1: the points (small) -- their validation starts on the side stream before the 2 KiB cells are staged.  Everything
     // the device reads asynchronously sits in the lane's pinned staging area: [cells | rows | proofs | cell indices | row indices]
-    uint8_t* h_rows = L->h_stage + n * 2048;
+    uint8_t* h_rows = L->h_stage + (d_cells ? 0 : n * 2048);
     uint8_t* h_proofs = h_rows + n_rows * 48;
     uint8_t* h_cidx = h_proofs + n * 48;
     uint8_t* h_ridx = h_cidx + n * 8;
@@ -348,7 +356,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     // Decoding (0.43 ms) and the y-free subgroup test (0.97 ms) as two launches on two streams: the MSMs below need the decoded rows
     // only, so they start as soon as the scalars are ready instead of after the longer chain.  A point outside the subgroup is still a
     // point of the curve (the group law is total there), and its verdict makes the call fail before any sum is looked at.
-    hipStream_t s2 = L->side, s3 = L->side2;
+    hipStream_t s2 = lane_side_stream(L, s), s3 = L->side2;
     int* sub_rows = L->d_cv_st + L->cv_cap;
     int* sub_q = L->d_cv_st + 2 * L->cv_cap;
     lane_fork(L, s, s2, s3);
@@ -363,7 +371,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     // uploads, part 2: the cells (n x 2 KiB, scattered host pointers) are gathered into the pinned staging area by the host pool running
     // AHEAD of this thread -- all chunks' tasks queued at once -- while the GPU validates the points; this thread waits for chunk k only
     // and puts its copy in flight
-    {
+    if (!d_cells) {
         const size_t CH = 2048;
         const size_t nch = (n + CH - 1) / CH;
         const int TPC = n >= 256 ? 4 : 1;
@@ -389,11 +397,11 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
         }();
         c->pool->wait(all_left);                  // the tasks reference this frame
         if (urc) return urc;
-        HIPCHK(hipMemcpyAsync(L->d_cv_cell_idx, h_cidx, n * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(L->d_cv_row_idx, h_ridx, n * 4, hipMemcpyHostToDevice, s));
     }
+    HIPCHK(hipMemcpyAsync(L->d_cv_cell_idx, h_cidx, n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(L->d_cv_row_idx, h_ridx, n * 4, hipMemcpyHostToDevice, s));
     // scalars
-    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, L->d_cv_cell_idx, L->d_cv_row_idx, L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,
+    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, L->d_cv_cell_idx, L->d_cv_row_idx, d_cells ? d_cells : L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,
                                                        L->d_v_s1, L->d_v_s3, L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s));
     HIPCHK(hipStreamWaitEvent(s, L->ev_decoded, 0));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
@@ -437,13 +445,13 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
 // pieces are folded in order, so among several invalid inputs the error reported is the one of the earliest piece -- the vectors and
 // the reference's tests pin error-vs-failure only.
 int sd_cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells, size_t n_cells,
-                        const uint8_t* proofs48n, size_t n_p, uint64_t exp_offset, const uint8_t* r_be32, CellFold* out) {
+                        const uint8_t* proofs48n, size_t n_p, uint64_t exp_offset, const uint8_t* r_be32, CellFold* out, const uint8_t* d_cells, hipStream_t user_stream) {
     for (int m = 0; m < 4; m++) G1H::set_inf(out->sums[m]);
     if (!c) return MKZG_ERR_BAD_ARGS;
     const size_t n = n_c;
     if (n != n_i || n != n_cells || n != n_p) return MKZG_ERR_BATCH_LENGTH;          // api_eip7594.go:166-171
     if (n == 0) return MKZG_OK;                                                        // :173-175
-    if (!commitments48n || !cell_indices || !cells || !proofs48n) return MKZG_ERR_BAD_ARGS;
+    if (!commitments48n || !cell_indices || (!cells && !d_cells) || !proofs48n) return MKZG_ERR_BAD_ARGS;
     for (size_t i = 0; i < n; i++) if (cell_indices[i] >= MKZG_CELLS_PER_EXT_BLOB) return MKZG_ERR_INVALID_CELL_ID;   // :184-188
     if (exp_offset + n > 0xffffffffull) return MKZG_ERR_BAD_ARGS;
     if (c->g2_alpha64.lines.empty()) return MKZG_ERR_BAD_TRUSTED_SETUP;
@@ -456,11 +464,13 @@ int sd_cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, 
     } else if (getrandom(r_words, 32, 0) != 32) {
         return MKZG_ERR_HIP;
     }
-    LaneGuard G(c);
+    std::unique_ptr<LaneGuard> guard(d_cells ? new LaneGuard(c, user_stream) : new LaneGuard(c));
+    LaneGuard& G = *guard;
     CellFold f;
     for (size_t off = 0; off < n; off += CELL_PIECE) {
         const size_t m = std::min(CELL_PIECE, n - off);
-        rc = cell_fold_piece(c, G.L, commitments48n + off * 48, cell_indices + off, cells + off, proofs48n + off * 48, m, (uint32_t)(exp_offset + off), r_words, &f);
+        rc = cell_fold_piece(c, G.L, commitments48n + off * 48, cell_indices + off, d_cells ? nullptr : cells + off, d_cells ? d_cells + off * 2048 : nullptr, proofs48n + off * 48, m,
+                             (uint32_t)(exp_offset + off), r_words, G.s, &f);
         if (rc) return G.fail(rc);
         for (int q = 0; q < 4; q++) G1H::add(out->sums[q], out->sums[q], f.sums[q]);
     }
@@ -483,22 +493,24 @@ int sd_cell_verify_finish(mkzg_ctx* c, const CellFold& f) {
 // recoveries: per-blob validation in the reference's order, then ONE set of launches over the blobs that passed (blockIdx.y = blob),
 // so that a batch runs the NTT stages and FK20 at batch efficiency (a single recovery is a chain of latency-bound launches).
 // status[b] receives the reference's error for blob b; device outputs: L->d_cells (n x 128 x 2048 B), L->d_fk_proofs (n x 128 x 48 B).
-static int recover_validate(const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells) {
+static int recover_validate(const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, bool cells_on_device = false) {
     if (n_ids != n_cells) return MKZG_ERR_NUM_CELL_IDS;                                  // :94-96
-    if ((n_ids && !cell_ids) || (n_cells && !cells)) return MKZG_ERR_BAD_ARGS;
+    if ((n_ids && !cell_ids) || (n_cells && !cells && !cells_on_device)) return MKZG_ERR_BAD_ARGS;
     for (size_t i = 1; i < n_ids; i++) if (cell_ids[i] <= cell_ids[i - 1]) return MKZG_ERR_CELL_IDS_NOT_ORDERED;   // :99-101
     for (size_t i = 0; i < n_ids; i++) if (cell_ids[i] >= MKZG_CELLS_PER_EXT_BLOB) return MKZG_ERR_FOUND_INVALID_CELL_ID;   // :104-108
     if (n_ids < 64) return MKZG_ERR_NOT_ENOUGH_CELLS;                                    // :111-113
-    for (size_t i = 0; i < n_cells; i++) if (!cells[i]) return MKZG_ERR_NIL_INPUT;       // serialization.go:197-199
+    if (!cells_on_device) for (size_t i = 0; i < n_cells; i++) if (!cells[i]) return MKZG_ERR_NIL_INPUT;       // serialization.go:197-199
     return MKZG_OK;
 }
+// d_cells_in: the supplied cells already in HBM -- blob b's n_ids[b] cells in id order, the blobs back to back (rejected blobs' cells
+// included: the layout is the caller's) -- instead of host pointers; d_cells_out / d_proofs_out: where the kernels leave the results
+// (null: the lane's own buffers).  s: the call's stream.
 static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* const* cell_ids, const size_t* n_ids, const uint8_t* const* const* cells, const size_t* n_cells,
-                         bool with_proofs, int* status) {
-    hipStream_t s = L->stream;
+                         bool with_proofs, int* status, hipStream_t s, const uint8_t* d_cells_in = nullptr, uint8_t* d_cells_out = nullptr, uint8_t* d_proofs_out = nullptr) {
     size_t total_cells = 0;
     for (size_t b = 0; b < n_blobs; b++) {
-        status[b] = recover_validate(cell_ids[b], n_ids[b], cells[b], n_cells[b]);
-        if (!status[b]) total_cells += n_cells[b];
+        status[b] = recover_validate(cell_ids[b], n_ids[b], d_cells_in ? nullptr : cells[b], n_cells[b], d_cells_in != nullptr);
+        if (!status[b] && !d_cells_in) total_cells += n_cells[b];
     }
     int rc = ensure_rec_tables(c);
     if (!rc && with_proofs) rc = ensure_fk20_tables(c);
@@ -515,7 +527,7 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
     for (size_t b = 0; b < n_blobs; b++) {
         int* pb = pos + b * 192;
         nmiss[b] = 0;
-        if (status[b]) continue;              // rejected blob: everything absent and no missing ids -- the stages then run on zeros, output ignored
+        if (status[b]) { if (d_cells_in) at += n_cells[b]; continue; }    // rejected blob: everything absent and no missing ids -- the stages then run on zeros, output ignored
         for (size_t i = 0; i < n_ids[b]; i++) pb[cell_ids[b][i]] = (int)(at + i);
         for (uint32_t cid = 0; cid < 128; cid++) {
             if (pb[cid] < 0) {
@@ -527,7 +539,7 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
         at += n_cells[b];
     }
     // gather the supplied cells into the pinned staging area (the host pool shares the blobs)
-    {
+    if (!d_cells_in) {
         std::vector<size_t> base(n_blobs + 1, 0);
         for (size_t b = 0; b < n_blobs; b++) base[b + 1] = base[b] + (status[b] ? 0 : n_cells[b]);
         const int nthr = total_cells >= 1024 ? 8 : 1;
@@ -541,13 +553,13 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
     }
     if (total_cells) HIPCHK(hipMemcpyAsync(L->d_blobs, L->h_stage, total_cells * 2048, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(L->d_rec_pos, pos, pos_bytes, hipMemcpyHostToDevice, s));
-    KT(KT_RECOVER, s, recover_coeffs_device(L->d_blobs, L->d_rec_pos, L->d_rec_pos + n_blobs * 192, (int)n_blobs, c->d_tw_fwd, c->d_tw_inv, c->d_pow7, c->d_ipow7,
+    KT(KT_RECOVER, s, recover_coeffs_device(d_cells_in ? d_cells_in : L->d_blobs, L->d_rec_pos, L->d_rec_pos + n_blobs * 192, (int)n_blobs, c->d_tw_fwd, c->d_tw_inv, c->d_pow7, c->d_ipow7,
                                             L->d_rec_scratch, L->d_coeffs, L->d_cell_st, s));
-    KT(KT_CELLS_NTT, s, cells_from_coeffs_device(L->d_coeffs, (int)n_blobs, c->d_tw_fwd, c->d_tw_inv, L->d_cells, L->d_cell_st, s));
+    KT(KT_CELLS_NTT, s, cells_from_coeffs_device(L->d_coeffs, (int)n_blobs, c->d_tw_fwd, c->d_tw_inv, d_cells_out ? d_cells_out : L->d_cells, L->d_cell_st, s));
     if (with_proofs) {
         KT(KT_FK20_SCALARS, s, fk20_scalars_device(L->d_coeffs, (int)n_blobs, c->d_tw_fwd, L->d_cell_st, L->d_fk_scalars, s));
         KT(KT_FK20_MSM, s, fk20_msm_device(L->d_fk_scalars, c->d_fk_table, c->fk20_bits_built, (int)n_blobs, L->d_cell_st, L->d_fk_parts, L->d_fk_results, s));
-        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)n_blobs, L->d_cell_st, L->d_fk_proofs, L->d_fk_parts, c->opt_fk20_segments.load(std::memory_order_relaxed) && fk20_seg_bytes((int)n_blobs) <= L->fk_seg_bytes ? L->d_fk_seg : nullptr, s));
+        KT(KT_FK20_FFTS, s, fk20_ffts_device(L->d_fk_results, L->d_fk_results + L->fk_cap * 128 * 64, (int)n_blobs, L->d_cell_st, d_proofs_out ? d_proofs_out : L->d_fk_proofs, L->d_fk_parts, c->opt_fk20_segments.load(std::memory_order_relaxed) && fk20_seg_bytes((int)n_blobs) <= L->fk_seg_bytes ? L->d_fk_seg : nullptr, s));
     }
     HIPCHK(hipGetLastError());
     // device-side statuses (non-canonical field elements in the cells) join the host-side ones
@@ -575,6 +587,18 @@ int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* c, const uint8_t* commitments48n,
     if (rc) return rc;
     return sd_cell_verify_finish(c, f);
 }
+// the same with the cells -- the bulk of the call's bytes -- already in HBM (n x 2048 B, contiguous, in the order of the other three
+// arrays, which stay host arrays as in the reference: 104 B per cell); synchronises `stream` (the verdict needs the host pairing)
+int mkzg_verify_cell_kzg_proof_batch_device(mkzg_ctx* c, const uint8_t* commitments48n, const uint64_t* cell_indices, const void* d_cells, const uint8_t* proofs48n, size_t n, void* stream) {
+    if (!c) return MKZG_ERR_BAD_ARGS;
+    if (n == 0) return MKZG_OK;                                                            // api_eip7594.go:173-175
+    if (!commitments48n || !cell_indices || !d_cells || !proofs48n) return MKZG_ERR_BAD_ARGS;
+    if (!c->peers.empty() && !(c = ctx_for_pointer(c, d_cells))) return MKZG_ERR_BAD_ARGS;
+    CellFold f;
+    int rc = sd_cell_verify_fold(c, commitments48n, n, cell_indices, n, nullptr, n, proofs48n, n, 0, nullptr, &f, (const uint8_t*)d_cells, (hipStream_t)stream);
+    if (rc) return rc;
+    return sd_cell_verify_finish(c, f);
+}
 // Sharded form (see CellFold): record = status@0 (int32), compressed sums[0..3] at 16, 64, 112, 160.
 int mkzg_verify_cell_kzg_proof_batch_partial(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
                                              size_t n_cells, const uint8_t* proofs48n, size_t n_p, uint64_t offset, const uint8_t r32[32], uint8_t record512[512]) {
@@ -583,6 +607,25 @@ int mkzg_verify_cell_kzg_proof_batch_partial(mkzg_ctx* c, const uint8_t* commitm
     memset(record512, 0, 512);
     CellFold f;
     int rc = sd_cell_verify_fold(c, commitments48n, n_c, cell_indices, n_i, cells, n_cells, proofs48n, n_p, offset, r32, &f);
+    int32_t st = rc;
+    memcpy(record512, &st, 4);
+    if (rc == MKZG_OK) {
+        for (int m = 0; m < 4; m++) {
+            G1AffH a;
+            g1h_to_affine(a, f.sums[m]);
+            g1h_compress(record512 + 16 + 48 * m, a);
+        }
+    }
+    return rc;
+}
+// sharded form over device-resident cells (this rank's shard)
+int mkzg_verify_cell_kzg_proof_batch_partial_device(mkzg_ctx* c, const uint8_t* commitments48n, const uint64_t* cell_indices, const void* d_cells, const uint8_t* proofs48n, size_t n,
+                                                    uint64_t offset, const uint8_t r32[32], uint8_t record512[512], void* stream) {
+    if (!c || !r32 || !record512 || (n && !d_cells)) return MKZG_ERR_BAD_ARGS;
+    if (!c->peers.empty() && n && !(c = ctx_for_pointer(c, d_cells))) return MKZG_ERR_BAD_ARGS;
+    memset(record512, 0, 512);
+    CellFold f;
+    int rc = sd_cell_verify_fold(c, commitments48n, n, cell_indices, n, nullptr, n, proofs48n, n, offset, r32, &f, (const uint8_t*)d_cells, (hipStream_t)stream);
     int32_t st = rc;
     memcpy(record512, &st, 4);
     if (rc == MKZG_OK) {
@@ -628,7 +671,7 @@ int mkzg_recover_cells_and_kzg_proofs(mkzg_ctx* c, const uint64_t* cell_ids, siz
     c = md_pick(c);
     LaneGuard G(c);
     Lane* L = G.L;
-    int rc = recover_front(c, L, 1, &cell_ids, &n_ids, &cells, &n_cells, true, &st);
+    int rc = recover_front(c, L, 1, &cell_ids, &n_ids, &cells, &n_cells, true, &st, G.s);
     if (rc) return G.fail(rc);
     if (st) return st;
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
@@ -651,7 +694,7 @@ int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* c, size_t n_blobs, const u
     const size_t chunk_max = (size_t)c->opt_cells_chunk, pieces = (n_blobs + chunk_max - 1) / chunk_max, even = (n_blobs + pieces - 1) / pieces;
     for (size_t done = 0; done < n_blobs; done += even) {               // even pieces of at most cells_chunk blobs bound the workspaces
         const size_t m = std::min<size_t>(even, n_blobs - done);
-        int rc = recover_front(c, L, m, cell_ids + done, n_ids + done, cells + done, n_cells + done, true, status + done);
+        int rc = recover_front(c, L, m, cell_ids + done, n_ids + done, cells + done, n_cells + done, true, status + done, G.s);
         if (rc) return G.fail(rc);
         // good blobs leave through the lane's pinned staging area (a device-to-pageable copy is staged by the runtime at a fraction of
         // the PCIe rate): one device copy per run of good blobs, then the host pool spreads them to the caller's buffers
@@ -681,6 +724,33 @@ int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* c, size_t n_blobs, const u
     }
     return first;
 }
+// RecoverCellsAndComputeKZGProofs / RecoverCells for a batch whose supplied cells are already in HBM and whose results stay there
+// (include/mi355kzg.h).  d_cells: blob b's n_ids[b] cells in the order of its ids, the blobs back to back; d_cells_out: n_blobs x 128 x
+// 2048 B; d_proofs_out: n_blobs x 128 x 48 B, or null for the cells alone.  Synchronises `stream` (the per-blob statuses come back).
+int mkzg_recover_cells_and_kzg_proofs_batch_device(mkzg_ctx* c, size_t n_blobs, const uint64_t* const* cell_ids, const size_t* n_ids, const void* d_cells, void* d_cells_out,
+                                                   void* d_proofs_out, int* status, void* stream) {
+    if (!c || (n_blobs && (!cell_ids || !n_ids || !d_cells || !d_cells_out || !status))) return MKZG_ERR_BAD_ARGS;
+    if (n_blobs == 0) return MKZG_OK;
+    if (!c->peers.empty() && !(c = ctx_for_pointer(c, d_cells))) return MKZG_ERR_BAD_ARGS;
+    LaneGuard G(c, (hipStream_t)stream);
+    Lane* L = G.L;
+    int first = MKZG_OK;
+    const bool with_proofs = d_proofs_out != nullptr;
+    const size_t chunk_max = (size_t)c->opt_cells_chunk, pieces = (n_blobs + chunk_max - 1) / chunk_max, even = (n_blobs + pieces - 1) / pieces;
+    size_t cell_off = 0;
+    for (size_t done = 0; done < n_blobs; done += even) {
+        const size_t m = std::min<size_t>(even, n_blobs - done);
+        int rc = recover_front(c, L, m, cell_ids + done, n_ids + done, nullptr, n_ids + done, with_proofs, status + done, G.s, (const uint8_t*)d_cells + cell_off * 2048,
+                               (uint8_t*)d_cells_out + done * 262144, with_proofs ? (uint8_t*)d_proofs_out + done * 128 * 48 : nullptr);
+        if (rc) return G.fail(rc);
+        for (size_t b = 0; b < m; b++) {
+            cell_off += n_ids[done + b];
+            if (status[done + b] && !first) first = status[done + b];
+        }
+    }
+    G.L->drained = true;                       // recover_front waited for the statuses on the call's stream
+    return first;
+}
 // Context.RecoverCells (reference api_eip.go:8-15)
 int mkzg_recover_cells(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads, uint8_t* cells_out) {
     (void)num_threads;
@@ -690,7 +760,7 @@ int mkzg_recover_cells(mkzg_ctx* c, const uint64_t* cell_ids, size_t n_ids, cons
     c = md_pick(c);
     LaneGuard G(c);
     Lane* L = G.L;
-    int rc = recover_front(c, L, 1, &cell_ids, &n_ids, &cells, &n_cells, false, &st);
+    int rc = recover_front(c, L, 1, &cell_ids, &n_ids, &cells, &n_cells, false, &st, G.s);
     if (rc) return G.fail(rc);
     if (st) return st;
     HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));

@@ -22,7 +22,8 @@ int draw_rlc_scalar(uint8_t r_le32[32]);
 // ---- EIP-7594 cell batch verifier, split at its four group sums (reference internal/kzg_multi/kzg_verify.go:32,41,68,80)
 struct CellFold { G1HX sums[4]; };
 int sd_cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells, size_t n_cells,
-                        const uint8_t* proofs48n, size_t n_p, uint64_t exp_offset, const uint8_t* r_be32 /* null: draw */, CellFold* out);
+                        const uint8_t* proofs48n, size_t n_p, uint64_t exp_offset, const uint8_t* r_be32 /* null: draw */, CellFold* out,
+                        const uint8_t* d_cells = nullptr /* the cells contiguous in HBM instead of host pointers */, hipStream_t user_stream = nullptr);
 int sd_cell_verify_finish(mkzg_ctx* c, const CellFold& f);
 
 // ---- multi-device fronts (c->peers non-empty)

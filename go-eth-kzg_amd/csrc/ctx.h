@@ -141,7 +141,8 @@ struct Lane {
     uint8_t* d_cells = nullptr;            // cell_cap x 262144 B
     int* d_cell_st = nullptr;
     size_t cv_cap = 0;                     // VerifyCellKZGProofBatch workspace, cv_cap cells
-    uint8_t* d_cv_cells = nullptr;         // cv_cap x 2048 B
+    size_t cv_cells_cap = 0;               // cells the lane can stage itself (host-pointer calls; device-pointer calls bring theirs)
+    uint8_t* d_cv_cells = nullptr;         // cv_cells_cap x 2048 B
     uint64_t* d_cv_cell_idx = nullptr;
     uint32_t* d_cv_row_idx = nullptr;
     uint32_t* d_cv_rp = nullptr;           // cv_cap Fr rows

@@ -229,6 +229,10 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* ctx, const void* d_
  * proof per entry; the four counts mirror the four Go slices.  Any number of cells. */
 int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* commitments48n, size_t n_commitments, const uint64_t* cell_indices, size_t n_indices,
                                      const uint8_t* const* cells, size_t n_cells, const uint8_t* proofs48n, size_t n_proofs);
+/* same with the cells -- 2048 of a tuple's 2152 bytes -- contiguous in HBM (n x 2048 B, in the order of the other three arrays, which
+ * stay host arrays as in the reference); skips the gather and the 16 MiB upload of an 8192-cell call.  Synchronises `stream`. */
+int mkzg_verify_cell_kzg_proof_batch_device(mkzg_ctx* ctx, const uint8_t* commitments48n, const uint64_t* cell_indices, const void* d_cells, const uint8_t* proofs48n, size_t n,
+                                            void* stream);
 /* Sharded form for multi-GPU jobs (the algebra of reference internal/kzg_multi/kzg_verify.go:16-105 split at its
  * four group sums): a rank folds ITS cells -- global positions offset .. offset + n - 1 of the batch -- with the batch-wide
  * scalar r32 (32 bytes, big-endian, reduced mod r; the same on every rank) into a 512-byte record: int32 status at 0, then
@@ -238,6 +242,8 @@ int mkzg_verify_cell_kzg_proof_batch(mkzg_ctx* ctx, const uint8_t* commitments48
 int mkzg_verify_cell_kzg_proof_batch_partial(mkzg_ctx* ctx, const uint8_t* commitments48n, size_t n_commitments, const uint64_t* cell_indices, size_t n_indices,
                                              const uint8_t* const* cells, size_t n_cells, const uint8_t* proofs48n, size_t n_proofs, uint64_t offset,
                                              const uint8_t r32[32], uint8_t record512[512]);
+int mkzg_verify_cell_kzg_proof_batch_partial_device(mkzg_ctx* ctx, const uint8_t* commitments48n, const uint64_t* cell_indices, const void* d_cells, const uint8_t* proofs48n,
+                                                    size_t n, uint64_t offset, const uint8_t r32[32], uint8_t record512[512], void* stream);
 int mkzg_verify_cell_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* records512, size_t n_records);
 
 /* Context.RecoverCellsAndComputeKZGProofs (reference api_eip7594.go:144-161): cell_ids strictly ascending, < 128,
@@ -252,6 +258,13 @@ int mkzg_recover_cells_and_kzg_proofs_batch(mkzg_ctx* ctx, size_t n_blobs, const
                                             const size_t* n_cells, uint8_t* cells_out, uint8_t* proofs_out, int* status);
 /* Context.RecoverCells (reference api_eip.go:8-15). */
 int mkzg_recover_cells(mkzg_ctx* ctx, const uint64_t* cell_ids, size_t n_ids, const uint8_t* const* cells, size_t n_cells, int num_threads, uint8_t* cells_out);
+/* RecoverCellsAndComputeKZGProofs / RecoverCells (reference api_eip7594.go:144-161, api_eip.go:8-15) for a batch whose supplied cells
+ * are already in HBM and whose results stay there: d_cells = blob b's n_ids[b] cells in the order of its ids, the blobs back to back
+ * (every blob's cells, rejected ones included: the layout is the caller's); d_cells_out n_blobs x 128 x 2048 B; d_proofs_out n_blobs x
+ * 128 x 48 B, or NULL for the cells alone; ids and per-blob status on the host.  Outputs of blobs with a non-zero status are undefined.
+ * Returns the first non-zero status.  Synchronises `stream`. */
+int mkzg_recover_cells_and_kzg_proofs_batch_device(mkzg_ctx* ctx, size_t n_blobs, const uint64_t* const* cell_ids, const size_t* n_ids, const void* d_cells, void* d_cells_out,
+                                                   void* d_proofs_out, int* status, void* stream);
 
 /* ---- profiling hooks (bench.py's roofline section) ------------------------------------------ */
 /* When enabled, every kernel launch of the hot path is bracketed by hipEvents on its stream. */

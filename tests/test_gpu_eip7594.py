@@ -82,6 +82,32 @@ def test_verify_cell_kzg_proof_batch_vectors(vectors, gpu_ctx):
         _check_verifier(gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs), exp, c["name"])
 
 
+def test_verify_cell_kzg_proof_batch_vectors_device_cells(vectors, gpu_ctx):
+    """the same 30 vectors through mkzg_verify_cell_kzg_proof_batch_device: the cells contiguous in HBM, commitments / indices / proofs on
+    the host; and for the valid ones the sharded record of the device form equals the host-pointer form's for a fixed r"""
+    import torch
+    n_run = 0
+    for c in vectors.cases("verify_cell_kzg_proof_batch"):
+        i = c["input"]
+        cms, idx, cells, prs = (vectors.val(i[k]) for k in ("commitments", "cell_indices", "cells", "proofs"))
+        exp = vectors.val(c["output"])
+        if _bad(*cms, *cells, *prs) or any(len(x) != 48 for x in cms) or any(len(x) != 2048 for x in cells) or any(len(x) != 48 for x in prs):
+            continue
+        if len(cells) != len(idx) or not cells:
+            continue                                          # length mismatches and the empty batch have no device form of their own
+        d_cells = torch.frombuffer(bytearray(b"".join(cells)), dtype=torch.uint8).cuda()
+        rc = gpu_ctx.verify_cell_kzg_proof_batch_device(cms, idx, d_cells.data_ptr(), prs, torch.cuda.current_stream().cuda_stream)
+        _check_verifier(rc, exp, c["name"])
+        assert rc == gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs), c["name"]
+        if exp is True:
+            r32 = bytes(range(1, 33))
+            rc1, rec1 = gpu_ctx.verify_cell_batch_partial_device(cms, idx, d_cells.data_ptr(), prs, 5, r32)
+            rc2, rec2 = gpu_ctx.verify_cell_batch_partial(cms, idx, cells, prs, 5, r32)
+            assert rc1 == 0 and rc2 == 0 and rec1 == rec2
+        n_run += 1
+    assert n_run >= 20
+
+
 def test_verify_cells_two_blobs(gpu_ctx):
     """cells of two blobs, interleaved (dedup path), then a wrong cell must be rejected"""
     items = []
@@ -209,6 +235,37 @@ def test_recover_batch(gpu_ctx, oracle_ctx):
     poisoned[3] = b"\xff" * 2048
     rc, res2 = gpu_ctx.RecoverCellsAndComputeKZGProofsBatch([(jobs[0][0], poisoned), jobs[1]])
     assert rc == 3 and res2[0][0] == 3 and res2[1][0] == 0 and res2[1][1] == res[1][1]
+
+
+def test_recover_batch_device(gpu_ctx, oracle_ctx):
+    """mkzg_recover_cells_and_kzg_proofs_batch_device: supplied cells concatenated in HBM, results left in HBM; ragged id sets, one blob with
+    too few cells and one with unordered ids in the middle (their cells still occupy their place in the caller's buffer), cells-only form"""
+    import torch
+    patterns = [list(range(0, 128, 2)), list(range(64)), list(range(64, 128)), list(range(10, 90)), list(range(63)), [1, 0] + list(range(2, 70)), list(range(128)),
+                sorted(set(range(0, 128, 3)) | set(range(1, 128, 3)))]
+    blobs = [rand_blob(4400 + i) for i in range(len(patterns))]
+    full = [oracle_ctx.compute_cells_and_kzg_proofs(b) for b in blobs]
+    supplied = b"".join(b"".join(full[k][1][2048 * i:2048 * i + 2048] for i in ids) for k, ids in enumerate(patterns))
+    d_in = torch.frombuffer(bytearray(supplied), dtype=torch.uint8).cuda()
+    nb = len(patterns)
+    d_oc = torch.zeros(nb * 262144, dtype=torch.uint8, device="cuda")
+    d_op = torch.zeros(nb * 6144, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    rc, sts = gpu_ctx.recover_batch_device(patterns, d_in.data_ptr(), d_oc.data_ptr(), d_op.data_ptr(), st)
+    assert sts[4] == 10 and sts[5] == 8 and rc == 10                 # ErrNotEnoughCellsForReconstruction, ErrCellIDsNotOrdered
+    oc, op = d_oc.cpu().numpy().tobytes(), d_op.cpu().numpy().tobytes()
+    for k in range(nb):
+        if k in (4, 5):
+            continue
+        assert sts[k] == 0
+        assert oc[k * 262144:(k + 1) * 262144] == full[k][1] and op[k * 6144:(k + 1) * 6144] == full[k][2], k
+    d_oc2 = torch.zeros(nb * 262144, dtype=torch.uint8, device="cuda")
+    rc, sts2 = gpu_ctx.recover_batch_device(patterns, d_in.data_ptr(), d_oc2.data_ptr(), 0, st)
+    assert sts2 == sts
+    oc2 = d_oc2.cpu().numpy().tobytes()
+    for k in range(nb):
+        if k not in (4, 5):
+            assert oc2[k * 262144:(k + 1) * 262144] == oc[k * 262144:(k + 1) * 262144]
 
 
 def test_cells_and_proofs_async_on_two_streams(gpu_ctx, oracle_ctx):

@@ -604,7 +604,21 @@ def bench_drop_in(ctx, kzg, host_blobs, d_expect):
         t.join()
     dt2 = (time.perf_counter() - t0) / (2 * reps)
     assert all(r == expect for r in res)
+    # the same batch device-resident from one SYNCHRONOUS caller on this box, right now: what the host-pointer caller could get at best
+    d_in = torch.frombuffer(bytearray(b"".join(host_blobs)), dtype=torch.uint8).cuda()
+    d_o = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    d_s = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    dts = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        assert ctx.blob_to_kzg_commitment_batch_device(d_in.data_ptr(), n, d_o.data_ptr(), d_s.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    dtd = sorted(dts[2:])[len(dts[2:]) // 2]
     return {"blobs_per_s_one_caller": round(n / dt1, 1), "ms_per_call": round(dt1 * 1e3, 3), "blobs_per_s_two_callers": round(n / dt2, 1), "batch": n,
+            "device_resident_one_synchronous_caller": {"ms_per_call": round(dtd * 1e3, 3), "blobs_per_s": round(n / dtd, 1)},
+            "one_caller_over_device_resident": round(dtd / dt1, 3), "two_callers_over_device_resident": round(dtd / dt2, 3),
             "note": "PCIe inclusive: pageable host blobs in (gathered into pinned staging chunk by chunk), host bytes out"}
 
 

@@ -286,7 +286,16 @@ int ensure_commit_table(mkzg_ctx* c) {
 // Direct window table.  The table is sized for an otherwise empty 288 GB part; a drop-in must degrade, not fail: if the width asked
 // for cannot be allocated the next narrower one is tried, and when none fits the context falls back to the bucket method
 // (direct_bits_built == 0, direct_failed) -- same bytes out either way.
-static const size_t DIRECT_HEADROOM = (size_t)40 << 30;      // left free for the FK20 table (25.8 GB) and the lanes' workspaces
+// What the auto-sized table (commit_direct_bits -1) leaves free: the widest FK20 table this context will try, unless one is built
+// already (whichever table comes first must not push the other one down a width: with both at their defaults -- 146 GB and the 47 GB
+// 12-bit FK20 table -- an empty 288 GB device holds both), the lanes' workspaces and pinned-side device buffers (0.1-0.6 GB per lane that
+// has run a call; a third of a gigabyte each on average) and 4 GB of slack for the caller's own allocations.
+static size_t direct_headroom(const mkzg_ctx* c) {
+    size_t h = (size_t)4 << 30;
+    h += (size_t)c->opt_lanes * ((size_t)340 << 20);
+    if (!c->fk_ready.load(std::memory_order_acquire)) h += fk20_table_bytes(std::min(13, std::max(8, c->opt_fk20_bits)));
+    return h;
+}
 int ensure_direct(mkzg_ctx* c) {
     std::lock_guard<std::mutex> g(c->init_mu);
     if (c->opt_direct_bits == 0 || c->direct_failed) return MKZG_OK;
@@ -298,7 +307,7 @@ int ensure_direct(mkzg_ctx* c) {
     if (want < 0) want = 15;                                  // auto: the widest table that leaves the headroom free
     for (int cb = want; cb >= 12; cb--) {
         const size_t bytes = direct_table_bytes(cb);
-        if (c->opt_direct_bits < 0 && free_b && bytes + DIRECT_HEADROOM > free_b) continue;
+        if (c->opt_direct_bits < 0 && free_b && bytes + direct_headroom(c) > free_b) continue;
         if (free_b && bytes + ((size_t)1 << 30) > free_b) continue;               // cannot fit: do not even ask
         const int nwin = (255 + cb - 1) / cb;
         uint32_t* tmp = nullptr;

@@ -131,7 +131,11 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
         if (leader && prev) c->hash_cv.wait(lk, [&] { return prev->launched; });
     }
     if (leader) {
-        if (prev && prev->done) (void)hipEventSynchronize(prev->done);       // the launch two rounds back has finished: its stream is free
+        if (prev && prev->done) {                                            // the launch two rounds back has finished: its stream is free
+            // (a crowded context sleeps here too: hipEventSynchronize polls on this runtime, and one leader per round would keep a CPU spinning)
+            if (wait_sleeping(c)) (void)wait_event_sleeping(prev->done);
+            else (void)hipEventSynchronize(prev->done);
+        }
         hipStream_t hs;
         {
             std::lock_guard<std::mutex> g(c->hash_mu);
@@ -310,8 +314,16 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, s_idle ? nullptr : L->ev_fork, &round);   // ev_fork: recorded on s before any of this call's kernels
             CPU_LAP(1);
             if (round && round->done) {                                      // on the host: a device-side wait would hold the call's queue
-                if (wait_sleeping(c)) { const int wr = wait_event_sleeping(round->done); if (wr) return wr; }
-                else HIPCHK(hipEventSynchronize(round->done));
+                int wr = MKZG_OK;
+                if (wait_sleeping(c)) wr = wait_event_sleeping(round->done);
+                else if (hipEventSynchronize(round->done) != hipSuccess) { (void)hipGetLastError(); wr = MKZG_ERR_HIP; }
+                if (wr) {
+                    // the round's kernel may still be writing this lane's challenges: nobody gets the lane before both hash streams are idle
+                    tl_hip_error = true;
+                    for (auto& hs : c->hash_stream) if (hs) (void)hipStreamSynchronize(hs);
+                    (void)hipGetLastError();
+                    return wr;
+                }
             }
             CPU_LAP(2);
             if (rc) return rc;

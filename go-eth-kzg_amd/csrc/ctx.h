@@ -207,7 +207,7 @@ struct mkzg_ctx {
     int opt_max_batch = 256;
     int opt_fk20_bits = 12;                // widest FK20 direct table to try: 13 (86 GB), 12 (47 GB), 11 (25.8 GB), 8 (4.3 GB); narrower ones are the fallback
     std::atomic<int> opt_host_chunk{128};              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
-    std::atomic<int> opt_host_gather_tasks{4};         // gather tasks per chunk of the host-pointer commitment pipeline
+    std::atomic<int> opt_host_gather_tasks{16};        // gather tasks per chunk of the host-pointer commitment pipeline (measured, tools/sweep_host_commit.py: 3.37 ms per 256 blobs with 16, 3.55 with 4)
     std::atomic<int> opt_host_zero_copy{1};            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
     std::atomic<int> opt_verify_shape{-1};             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
     int opt_cells_chunk = 256;             // most blobs per launch set of a ComputeCellsAndKZGProofs batch (a lane's FK20 workspace grows to the pieces it has seen: 1.6 MB per blob)

@@ -36,6 +36,8 @@ struct Countdown {
     void set(int n) { v.store(n, std::memory_order_relaxed); }
     bool done() const { return v.load(std::memory_order_acquire) == 0; }
     void arrive() {
+        // the wake follows the decrement: a waiter that saw 0 meanwhile may already have returned and destroyed this object -- the
+        // futex call then names a dead address, which the kernel treats as "nobody waits there"; nothing is read or written through it
         if (v.fetch_sub(1, std::memory_order_acq_rel) == 1) (void)syscall(SYS_futex, reinterpret_cast<int*>(&v), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
     }
     void park() {                               // returns when the counter may have changed
@@ -65,7 +67,8 @@ class HostPool {
     HostPool& operator=(const HostPool&) = delete;
 
     // f(0), ..., f(k-1) queued for the workers; returns at once.  left must hold k on entry and reaches 0 when all have finished
-    // (the caller keeps f and left alive until then: wait(left) on every exit path).
+    // (the caller keeps f and left alive until then: wait(left) on every exit path -- which is also what runs the tasks of a pool
+    // without workers: wait() executes queued tasks itself in pools of up to three workers, front first).
     void run_async(int k, const std::function<void(int)>& f, Countdown* left) {
         if (k <= 0) return;
         {

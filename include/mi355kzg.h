@@ -76,8 +76,10 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
 /* Tuning knobs.  Changing one waits for the calls in flight on the context.
  *   "msm_window"          11..13: window width of the bucket method
  *   "max_batch"           blobs per launch of the commitment kernels (workspace size)
- *   "commit_direct_bits"  -1 (library default) = the widest direct window table that leaves 40 GB of the device's free memory
- *                         untouched; 12..15 = that width (24 GB .. 146 GB of HBM; fewer group additions the wider); 0 = bucket method
+ *   "commit_direct_bits"  -1 (library default) = the widest direct window table that leaves room in the device's free memory for the
+ *                         widest FK20 table "fk20_bits" allows (unless one is built already), a third of a gigabyte per lane and 4 GB of
+ *                         slack -- 62 GB with the defaults, so that an empty 288 GB device holds both tables at their default widths
+ *                         whichever is built first; 12..15 = that width (24 GB .. 146 GB of HBM; fewer group additions the wider); 0 = bucket method
  *                         (10.5 MB table + 0.5 GB workspace per lane).  The table is built by the first commitment / proof call.  If
  *                         it cannot be allocated the next narrower one is tried and finally the bucket method is used: the call
  *                         still succeeds with the same bytes; "commit_direct_bits_effective" (get) reports what is in use.
@@ -101,15 +103,16 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *   "lanes"               1..32 (default 32): calls that may be in flight on the context at once; lanes above the limit free their memory
  *   "trim"                (set only, any value) frees every lane's workspaces and pinned staging; they are rebuilt on demand
  *   "host_chunk"          blobs per chunk of the host-pointer commitment pipeline (gather / upload / kernels overlap per chunk; 128)
- *   "host_gather_tasks"   host-pool tasks per chunk of that pipeline's gather (1..64)
+ *   "host_gather_tasks"   host-pool tasks per chunk of that pipeline's gather (1..64; 16)
  *   "cells_chunk"         1..512 (default 256): blobs per piece of a ComputeCellsAndKZGProofs / recovery batch (a lane's FK20 workspace grows
  *                         to the pieces it has seen, 1.6 MB per blob)
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
  *   "host_sha"            host-pointer verifiers: Fiat-Shamir challenges hashed by the host pool while the blobs upload (1),
- *                         on the device after the upload (0), library's choice (-1, default: the host for calls of up to 48 blobs per pool
- *                         thread -- a 70 us hash per blob beside the upload instead of the device's 2.7 ms chain after it -- fewer when
- *                         other calls are in flight, the device above that);
+ *                         on the device after the upload (0), library's choice (-1, default: a call that is alone on the context hashes on
+ *                         the host -- pairs of transcripts interleaved per core, 35 us each, under the chunked upload, the device taking
+ *                         the first transcripts of very large pieces -- up to 160 blobs per pool thread; with other calls in flight 20,
+ *                         then 8 per thread, and the device's shared hash rounds above that);
  *                         ComputeBlobKZGProof follows the same switch
  *   "verify_shape"        VerifyBlobKZGProofBatch: 0 = latency shape (inverse NTT of the blobs beside the challenge hash, then a short
  *                         Horner pass; a quad of lanes per point in the subgroup tests), 1 = throughput shape (barycentric evaluation

@@ -405,3 +405,42 @@ def test_pipelined_calls_on_one_stream_keep_one_lane(product):
         assert int(outs[k][2].abs().sum().item()) == 0
         assert torch.equal(outs[k][0], outs[0][0]) and torch.equal(outs[k][1], outs[0][1])
     ctx.close()
+
+
+def test_default_tables_do_not_push_each_other_down(product, oracle_ctx):
+    """Both window tables at their DEFAULT options on a device with 200 GB free (a shared GPU, or several ranks per GPU): the commitment
+    table is sized so that the FK20 table still gets its default width afterwards -- 14 bits (82 GB) + 12 bits (47 GB), not 15 bits
+    (146 GB) and then a degraded FK20 table -- and, built in the other order, the FK20 table already in place is not reserved twice.
+    `commit_direct_bits_effective` / `fk20_bits_effective` say what is in use; same bytes out as the oracle either way."""
+    import torch
+    torch.cuda.init()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < (230 << 30):
+        pytest.skip("needs an (almost) empty 288 GB device")
+    hog = torch.empty(free - (200 << 30), dtype=torch.uint8, device="cuda")
+    blob = rand_blob(77)
+    exp_cm = oracle_ctx.blob_to_kzg_commitment(blob)[1]
+    rc_o, exp_cells, exp_proofs = oracle_ctx.compute_cells_and_kzg_proofs(blob)
+    try:
+        for order in ("commit_first", "fk20_first"):
+            ctx = product.Context()
+            try:
+                def commit():
+                    rc, cm = ctx.BlobToKZGCommitment(blob)
+                    assert rc == 0 and cm == exp_cm
+
+                def cells():
+                    rc, cl, pr = ctx.ComputeCellsAndKZGProofs(blob)
+                    assert rc == 0 and b"".join(cl) == exp_cells and b"".join(pr) == exp_proofs
+
+                for step in ((commit, cells) if order == "commit_first" else (cells, commit)):
+                    step()
+                assert ctx.get_option("fk20_bits_effective") == 12, order
+                # 200 GB free: 15 bits would need 146 + (47 +) 11 + 4 GB; 14 bits (82 GB) fits in both orders
+                assert ctx.get_option("commit_direct_bits_effective") == 14, (order, ctx.get_option("commit_direct_bits_effective"))
+            finally:
+                ctx.close()
+    finally:
+        del hog
+        torch.cuda.empty_cache()

@@ -738,6 +738,8 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
     assert ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), N, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
     torch.cuda.synchronize()
     proofs_per_s = N / (time.perf_counter() - tp0)
+    if args.verify_shape >= 0:
+        assert ctx.set_option("verify_shape", args.verify_shape) == 0
     rc = ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st)     # warm-up + correctness
     assert rc == 0, f"valid batch rejected rc={rc}"
     d_bad = d_pr.clone()
@@ -760,8 +762,6 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
             return D.verify_blob_kzg_proof_batch_sharded(eng, (d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st), N * world, dist, dev)
         return ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st)
 
-    if args.verify_shape >= 0:
-        assert ctx.set_option("verify_shape", args.verify_shape) == 0
     # per-kernel durations from one profiled call (hipEvent brackets); the timed calls run without them
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)

@@ -577,8 +577,8 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
             KT(KT_CELLS_NTT, ntt_stream, cells_from_blobs_device(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs + lo * 4096 * 12, nullptr, st_b + lo, ntt_stream));
         }
         HIPCHK(hipEventRecord(L->ev_join, s2));
-        // the host's share of the challenges
-        c->pool->wait(hash_left);
+        // the host's share of the challenges: what the call waits for from here on, so this thread hashes too
+        c->pool->wait(hash_left, true);
         if (n_dev < m) {
             HIPCHK(hipMemcpyAsync(d_z + n_dev * 32, h_z + n_dev * 32, (m - n_dev) * 32, hipMemcpyHostToDevice, s));
             scalars_to_fr_device(d_z + n_dev * 32, (int)(m - n_dev), L->d_v_z + n_dev * 12, st_x + n_dev, s);       // canonical by construction

@@ -78,9 +78,10 @@ class HostPool {
         if (k == 1) cv_.notify_one(); else cv_.notify_all();
     }
     // Blocks until left reaches 0.  In a small pool the caller runs queued tasks meanwhile (front first: the tasks of the chunk it
-    // waits for were queued before those of later chunks).
-    void wait(Countdown& left) {
-        const bool help = th_.size() <= 3;
+    // waits for were queued before those of later chunks).  always_help: also in a large pool -- for a caller whose wait IS the call's
+    // critical path (the lone host-pointer verifier waiting for its challenge hashes: a sixteenth pair of hands instead of a parked thread).
+    void wait(Countdown& left, bool always_help = false) {
+        const bool help = always_help || th_.size() <= 3;
         while (!left.done()) {
             std::function<void()> job;
             if (help) {

@@ -407,23 +407,64 @@ def test_pipelined_calls_on_one_stream_keep_one_lane(product):
     ctx.close()
 
 
+def _direct_bytes(cb):
+    return -(-255 // cb) * 4096 * (1 << (cb - 1)) * 128
+
+
+def _expected_widths(free_bytes, order):
+    """the library's sizing rule restated (api.hip direct_headroom / ensure_direct, api_cells.hip ensure_fk20_tables) -> (commit bits, fk20 bits,
+    smallest distance of a decision from its threshold)"""
+    fk12 = 8192 * 22 * 2048 * 128
+    lanes = 32 * (340 << 20)
+    slack = 4 << 30
+    margin = 1 << 62
+
+    def commit(free, fk_built):
+        nonlocal margin
+        head = slack + lanes + (0 if fk_built else fk12)
+        for cb in (15, 14, 13, 12):
+            margin = min(margin, abs(free - (_direct_bytes(cb) + head)))
+            if _direct_bytes(cb) + head <= free:
+                return cb
+        return 0
+
+    if order == "commit_first":
+        cb = commit(free_bytes, False)
+        left = free_bytes - (_direct_bytes(cb) if cb else 0)
+        margin = min(margin, abs(left - fk12 - (1 << 30)))
+        return cb, (12 if fk12 + (1 << 30) <= left else None), margin
+    margin = min(margin, abs(free_bytes - fk12 - (1 << 30)))
+    if fk12 + (1 << 30) > free_bytes:
+        return None, None, margin
+    return commit(free_bytes - fk12, True), 12, margin
+
+
 def test_default_tables_do_not_push_each_other_down(product, oracle_ctx):
-    """Both window tables at their DEFAULT options on a device with 200 GB free (a shared GPU, or several ranks per GPU): the commitment
-    table is sized so that the FK20 table still gets its default width afterwards -- 14 bits (82 GB) + 12 bits (47 GB), not 15 bits
-    (146 GB) and then a degraded FK20 table -- and, built in the other order, the FK20 table already in place is not reserved twice.
-    `commit_direct_bits_effective` / `fk20_bits_effective` say what is in use; same bytes out as the oracle either way."""
+    """Both window tables at their DEFAULT options on a device that is NOT empty (a shared GPU, several ranks per GPU; here: 180 GiB free,
+    or what the session's other contexts leave): the commitment table is sized so that the FK20 table still gets its default width
+    afterwards -- with 180 GiB free 14 bits (82 GB) + 12 bits (47 GB), not 15 bits (146 GB) and then a degraded FK20 table -- and, built
+    in the other order, the FK20 table already in place is not reserved twice.  `commit_direct_bits_effective` / `fk20_bits_effective`
+    say what is in use; same bytes out as the oracle either way."""
     import torch
     torch.cuda.init()
     torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info()
-    if free < (230 << 30):
-        pytest.skip("needs an (almost) empty 288 GB device")
-    hog = torch.empty(free - (200 << 30), dtype=torch.uint8, device="cuda")
+    # 180 GiB is the telling size (15 bits would fit beside a fixed 40 GB reserve and then push the FK20 table down a width); further down
+    # the list: what the session's other contexts leave, at a size where no decision sits within 3 GiB of its threshold
+    target = next((t << 30 for t in (180, 150, 120, 95, 85, 70) if (t << 30) <= free - (2 << 30) and
+                   all(_expected_widths(t << 30, o)[1] is not None and _expected_widths(t << 30, o)[2] >= (3 << 30) for o in ("commit_first", "fk20_first"))), None)
+    if target is None:
+        pytest.skip(f"needs 72 GiB of free HBM, {free >> 30} GiB are free")
+    hog = torch.empty(free - target, dtype=torch.uint8, device="cuda")
     blob = rand_blob(77)
     exp_cm = oracle_ctx.blob_to_kzg_commitment(blob)[1]
     rc_o, exp_cells, exp_proofs = oracle_ctx.compute_cells_and_kzg_proofs(blob)
+    checked = 0
     try:
         for order in ("commit_first", "fk20_first"):
+            want_cb, want_fk, margin = _expected_widths(target, order)
+            if want_fk is None or margin < (3 << 30):
+                continue                                   # a decision within 3 GB of its threshold: the lanes' own allocations could tip it
             ctx = product.Context()
             try:
                 def commit():
@@ -436,11 +477,12 @@ def test_default_tables_do_not_push_each_other_down(product, oracle_ctx):
 
                 for step in ((commit, cells) if order == "commit_first" else (cells, commit)):
                     step()
-                assert ctx.get_option("fk20_bits_effective") == 12, order
-                # 200 GB free: 15 bits would need 146 + (47 +) 11 + 4 GB; 14 bits (82 GB) fits in both orders
-                assert ctx.get_option("commit_direct_bits_effective") == 14, (order, ctx.get_option("commit_direct_bits_effective"))
+                assert ctx.get_option("fk20_bits_effective") == want_fk, order
+                assert ctx.get_option("commit_direct_bits_effective") == want_cb, (order, target >> 30, ctx.get_option("commit_direct_bits_effective"), want_cb)
+                checked += 1
             finally:
                 ctx.close()
     finally:
         del hog
         torch.cuda.empty_cache()
+    assert checked >= 1

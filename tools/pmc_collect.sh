@@ -7,6 +7,8 @@
 #   bash tools/pmc_collect.sh r03c                                                          (commit: batch 256, defaults + bucket-method cross-check)
 #   bash tools/pmc_collect.sh r03v --verify-batch 1024 --verify-inflight 1 --no-strong     (verify: single calls only)
 #   bash tools/pmc_collect.sh r03e --cell-blobs 64                                          (eip7594; --no-big-cells is always passed)
+#   PMC_GRIDS="k_g1_validate=4096" bash tools/pmc_collect.sh r04t --verify-batch 1024 --verify-inflight 1 --no-strong --verify-shape 1
+#                                                                                           (verify_tp: the throughput shape's kernels, one call at a time)
 # then, on the build host: python3 tools/pmc_merge.py profiles/r03_traffic.json commit=gpurun_out/r03c_traffic.json verify=... eip7594=...
 set -u
 TAG=${1:-r01}; shift || true

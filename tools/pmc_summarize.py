@@ -25,6 +25,11 @@ for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive
     gmax = defaultdict(int)
     for (d, k), g in grid.items():
         gmax[k] = max(gmax[k], g)
+    # PMC_GRIDS="kernel=grid,kernel=grid": keep the launches of exactly that grid instead (a leg whose launches of a kernel are not that
+    # kernel's largest in the run: the throughput shape's one-lane-per-point validation beside the proof path's quad form)
+    for kv in filter(None, os.environ.get("PMC_GRIDS", "").split(",")):
+        k, g = kv.split("=")
+        gmax[k] = int(g)
     for (d, k, c), v in per_dispatch.items():
         if grid[(d, k)] != gmax[k]:
             continue

@@ -98,7 +98,7 @@ void free_lane(Lane* L) {
     L->h_stage_bytes = 0; L->h_out_items = 0; L->h_v_bytes = 0;
     dev_free(L->d_blobs); dev_free(L->d_out); dev_free(L->d_status);
     L->d_blobs_bytes = 0; L->d_out_items = 0;
-    dev_free(L->d_v_raw); dev_free(L->d_v_aff); dev_free(L->d_v_st); dev_free(L->d_v_z); dev_free(L->d_v_y); dev_free(L->d_v_zrows); dev_free(L->d_v_s1); dev_free(L->d_v_s3);
+    dev_free(L->d_v_raw); dev_free(L->d_v_aff); dev_free(L->d_v_st); dev_free(L->d_v_z); dev_free(L->d_v_y); dev_free(L->d_v_zrows); dev_free(L->d_v_s1); dev_free(L->d_v_s3); dev_free(L->d_v_ry);
     dev_free(L->d_v_misc); dev_free(L->d_v_coeffs);
     L->v_cap = 0; L->v_coeff_cap = 0;
     dev_free(L->d_quot); dev_free(L->d_q_z); dev_free(L->d_q_y); dev_free(L->d_q_st);

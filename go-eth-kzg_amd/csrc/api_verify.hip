@@ -35,11 +35,12 @@ int ensure_verify_ws(Lane* L, size_t n) {
     if (!rc) rc = dev_realloc(L->d_v_zrows, cap * blob_eval_scratch_words() * 4);
     if (!rc) rc = dev_realloc(L->d_v_s1, cap * 32);
     if (!rc) rc = dev_realloc(L->d_v_s3, cap * 32);
+    if (!rc) rc = dev_realloc(L->d_v_ry, cap * 32);
     if (!rc) rc = dev_realloc(L->d_v_misc, (V_MISC_WORDS + VMSM_PART_WORDS) * 4);      // window sums for the host + slice sums (device only)
     L->h_v_bytes = 0;
-    if (!rc) rc = pinned_realloc(L->h_v, 3 * cap * sizeof(int) + V_MISC_WORDS * 4 + 64);
+    if (!rc) rc = pinned_realloc(L->h_v, 3 * cap * sizeof(int) + V_MISC_WORDS * 4 + 64 + cap * 32);      // statuses | misc | r^i y_i words (throughput shape)
     if (rc) return rc;
-    L->h_v_bytes = 3 * cap * sizeof(int) + V_MISC_WORDS * 4 + 64;
+    L->h_v_bytes = 3 * cap * sizeof(int) + V_MISC_WORDS * 4 + 64 + cap * 32;
     L->v_cap = cap;
     return MKZG_OK;
 }
@@ -100,7 +101,7 @@ int draw_rlc_scalar(uint8_t r_le32[32]) { return getrandom(r_le32, 32, 0) == 32 
 // the round and launches ONE kernel over all its jobs on one of the context's two hash streams (rounds alternate, two are in flight)
 // -- streams of the lowest priority, so that no other stream of the process shares their queues.  Everyone then waits for the round on the host (the call is synchronous anyway; a device-side wait
 // would hold the call's own queue, and with it whatever else HIP mapped there) and carries on in its own stream.
-static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipEvent_t ready, std::shared_ptr<HashRound>* out) {
+static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, uint32_t* d_zrows, hipEvent_t ready, std::shared_ptr<HashRound>* out) {
     std::shared_ptr<HashRound> r, prev;
     bool leader = false;
     {
@@ -126,6 +127,7 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
         r->jobs.blobs[j] = d_blobs;
         r->jobs.commitments[j] = d_commitments;
         r->jobs.z_out[j] = d_z;
+        r->jobs.zrows_out[j] = d_zrows;
         r->jobs.n[j] = n;
         r->ready[j] = ready;
         if (leader && prev) c->hash_cv.wait(lk, [&] { return prev->launched; });
@@ -198,7 +200,7 @@ struct CpuProfPrinter { ~CpuProfPrinter() {
 #define CPU_LAP(k) ((void)0)
 #endif
 // the end of every fold: one round trip (statuses, e, window sums), the reference's error precedence, Horner over the window sums
-static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int y_bad, hipStream_t s, VerifyFold* out) {
+static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int y_bad, hipStream_t s, VerifyFold* out, bool sum_ry_on_host = false) {
     const size_t cap = L->v_cap;
     uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * cap * sizeof(int));
     HIPCHK(hipGetLastError());
@@ -206,6 +208,8 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
     int* h_st = (int*)L->h_v;
     HIPCHK(hipMemcpyAsync(h_st, L->d_v_st, 3 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS * 4, hipMemcpyDeviceToHost, s));
+    uint32_t* h_ry = h_misc + V_MISC_WORDS + 16;
+    if (sum_ry_on_host) HIPCHK(hipMemcpyAsync(h_ry, L->d_v_ry, n * 32, hipMemcpyDeviceToHost, s));
     LANE_SYNC(c, L, s);                     // polls for a lone caller, asks and sleeps when the context is crowded (ctx.h)
     L->drained = true;                      // the side streams were joined into s by the caller; nothing of this call is left on the device
     if (with_blobs) {
@@ -231,7 +235,12 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
         const int job[3] = {2, 0, 1};
         c->pool->parallel(3, [&](int i) { horner(job[i], *dst[i]); });
     }
-    memcpy(out->e, h_misc + 8, 32);
+    if (sum_ry_on_host) {
+        memset(out->e, 0, 32);
+        for (size_t i = 0; i < n; i++) fr_words_add(out->e, out->e, h_ry + 8 * i);
+    } else {
+        memcpy(out->e, h_misc + 8, 32);
+    }
     L->last_host_finish_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
     return MKZG_OK;
 }
@@ -274,6 +283,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     uint32_t* d_wsum = L->d_v_misc + 16;
     const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
     int vrc = 0;
+    bool tp_ry = false;                         // the call's sum r^i y_i is added up on the host from L->d_v_ry (throughput shape)
     // 1. decode + validate the points (serialization.go:108-115)
     //    on the side stream, beside the (longer, latency-bound) SHA-256 chain
     //    (throughput shape: on the call's own stream, ahead of the hash -- HIP multiplexes all streams of the process onto a few hardware
@@ -311,7 +321,8 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         } else if (tp) {
             std::shared_ptr<HashRound> round;                                // the hash of this call and of whoever else is waiting for one
             CPU_LAP(0);
-            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, s_idle ? nullptr : L->ev_fork, &round);   // ev_fork: recorded on s before any of this call's kernels
+            // (the round's launch also leaves what the evaluation needs of each z alone: L->d_v_zrows)
+            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->d_v_zrows, s_idle ? nullptr : L->ev_fork, &round);   // ev_fork: recorded on s before any of this call's kernels
             CPU_LAP(1);
             if (round && round->done) {                                      // on the host: a device-side wait would hold the call's queue
                 int wr = MKZG_OK;
@@ -333,10 +344,13 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
         if (tp) {
-            // throughput shape: every launch is time on the call's hardware queue, which it shares with other calls' streams -- one
-            // scalar kernel and ONE launch for the three MSMs of kzg_verify.go:150,225,179 instead of two of each
-            KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s));
-            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
+            // throughput shape: every launch is time on the call's hardware queue, which it shares with other calls' streams -- the
+            // evaluation's z-only rows came with the round's hash launch, the evaluation kernel's last lane leaves the blob's r^i, r^i z_i and
+            // r^i y_i (the host adds the latter up), and ONE launch takes the three MSMs of kzg_verify.go:150,225,179
+            const bool rows_ready = !d_z32;
+            KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s, rows_ready, r_words, exp_offset, L->d_v_s1,
+                                                 L->d_v_s3, L->d_v_ry));
+            tp_ry = true;
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
             const int njob[3] = {(int)n, (int)n, (int)n};
@@ -378,7 +392,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     }
     if (vrc) return MKZG_ERR_BAD_ARGS;
     CPU_LAP(3);
-    return verify_fold_tail(c, L, n, d_blobs != nullptr, y_bad, s, out);
+    return verify_fold_tail(c, L, n, d_blobs != nullptr, y_bad, s, out, tp_ry);
 }
 // kzg_verify.go:160-199: F = Cc - [e]G + D ; e(F, G2) e(-A, [alpha]G2) == 1
 int sd_verify_finish(mkzg_ctx* c, const VerifyFold& f) {

@@ -124,6 +124,7 @@ struct Lane {
     uint32_t* d_v_zrows = nullptr;          // v_cap x 14 rows of 12 words: what the evaluation needs of z alone (verify_kernels.hip k_blob_eval_prep)
     uint32_t* d_v_s1 = nullptr;            // v_cap x 8 words
     uint32_t* d_v_s3 = nullptr;
+    uint32_t* d_v_ry = nullptr;            // v_cap x 8 words: r^i y_i per blob (throughput shape: the evaluation kernel writes them, the host adds them up)
     uint32_t* d_v_misc = nullptr;          // [0..8) r, [8..16) e, [16 .. 16+4*32*48) window sums, then the slice sums of the MSMs
     uint8_t* h_v = nullptr;                // pinned: statuses + misc
     size_t h_v_bytes = 0;

@@ -18,6 +18,7 @@ struct ShaJobs {
     const uint8_t* blobs[SHA_MAX_JOBS];
     const uint8_t* commitments[SHA_MAX_JOBS];
     uint32_t* z_out[SHA_MAX_JOBS];
+    uint32_t* zrows_out[SHA_MAX_JOBS];      // per job, may be null: blob_eval_scratch_words() words per blob, what the tree evaluation needs of z alone
     int n[SHA_MAX_JOBS];
     int first_block[SHA_MAX_JOBS];
     int count;
@@ -25,8 +26,13 @@ struct ShaJobs {
 void challenge_jobs_device(ShaJobs& jobs, hipStream_t s);
 // d_zrows: n x blob_eval_scratch_words() words of scratch (what depends on z alone, from a one-lane-per-blob kernel ahead of the evaluation)
 size_t blob_eval_scratch_words();
+// rows_ready: d_zrows were written by the challenge launch already (ShaJobs::zrows_out).  h_r8 (HOST pointer to the eight words of r, may be
+// null): the evaluation kernel's last lane also leaves the blob's share of the random linear combination -- d_s1[b] = r^(exp_offset + b),
+// d_s3[b] = r^i z_b (8 plain words each, the MSM scalars), d_ry[b] = r^i y_b (8 plain words: the host adds them up) -- instead of a
+// k_rlc_scalars launch behind it
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, uint32_t* d_zrows,
-                      hipStream_t s);
+                      hipStream_t s, bool rows_ready = false, const uint32_t* h_r8 = nullptr, uint32_t exp_offset = 0, uint32_t* d_s1 = nullptr, uint32_t* d_s3 = nullptr,
+                      uint32_t* d_ry = nullptr);
 void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, uint32_t* d_quot,
                           int* d_status, hipStream_t s);
 // y_b = f_b(z_b) from coefficient rows (n x 4096 x 12 words, as cells_from_blobs_device publishes them); blobs with a non-zero status are skipped

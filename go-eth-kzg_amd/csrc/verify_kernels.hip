@@ -137,6 +137,21 @@ __device__ __forceinline__ void sha_load_block(uint32_t w[16], int k, const uint
     }
 }
 constexpr int SHA_NBLOCKS = 2050;
+constexpr int EVT_ROWS = 14;       // what k_blob_eval_tree needs of z alone, 12-word rows: z^(2^0..2^11), z^4096 - 1, 1 / (z^4096 - 1)
+// the rows of one challenge (one lane per blob): twelve squarings, one inversion -- a 0.3-0.4 ms chain for a lone wavefront
+__device__ __forceinline__ void eval_prep_rows(const fr_t& z, uint32_t* __restrict__ rows, bool store) {
+    fr_t zl = z, one, rootn, inv;
+#pragma unroll 1
+    for (int l = 0; l < 12; l++) {
+        if (store) store_fr12(rows + l * 12, zl);
+        FrC::mul(zl, zl, zl);
+    }
+    Fr::set_one(one);
+    FrC::sub(rootn, zl, one);
+    if (store) store_fr12(rows + 12 * 12, rootn);
+    fr_inv_n(inv, rootn);                                   // 0 -> 0: z in the domain, the evaluation kernel does not use it then
+    if (store) store_fr12(rows + 13 * 12, inv);
+}
 // The consumer splits every round over a PAIR of lanes, mirror images within a row of 16 (lane i and lane 15 - i): the "E" lane
 // (lanes 0..7 of the row: DPP banks 0, 1) holds (e, f, g, h), the "A" lane (banks 2, 3) holds (a, b, c, d), and both execute the SAME
 // instructions: per-lane rotation amounts give S1(e) / S0(a), and Maj(a,b,c) = Ch(a ^ c, b, c) shares the Ch instruction.
@@ -221,7 +236,10 @@ __device__ __forceinline__ uint32_t sha_from_e_lane(uint32_t x) {   // A lanes: 
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xC, false);   // row_mirror
 }
 // the body for one workgroup: blobs blk * 64 .. blk * 64 + 63 of one (blobs, commitments, n, z_out) job
-__device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out, int blk) {
+// zrows_out (may be null): the evaluation's rows of every challenge (eval_prep_rows) written by the same lanes right behind the digest --
+// in the throughput shape this chain then sits in the ROUND's launch, shared by all its calls, instead of in every call's own stream
+__device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out, int blk,
+                                                    uint32_t* __restrict__ zrows_out = nullptr) {
     __shared__ uint4 wk[5][16][64];                 // [message block mod 4][round / 4][blob]: four W + K per 16-byte LDS access; [4] stays zero
     // every verifier call waits for this chain and it needs few issue slots: its wavefronts go first on their SIMDs (beside the other
     // kernels of eight calls in flight a launch took 3.8 ms instead of 2.7 without this)
@@ -329,12 +347,14 @@ __device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ 
                  SHA_BOUNDARY_A
                  : SHA_STATE_OPS, SHA_HS_OPS, SHA_TMP_OPS
                  : SHA_CONST_OPS, [w1] "v"(m_a & 1u));
-    // the A lane holds h[0..3], its E lane h[4..7]: gather the digest in the A lane
-    const uint32_t h0 = hs0, h1 = hs1, h2 = hs2, h3 = hs3;
-    const uint32_t g0 = sha_from_e_lane(hs0), g1 = sha_from_e_lane(hs1), g2 = sha_from_e_lane(hs2), g3 = sha_from_e_lane(hs3);
-    if (!a_side || b0 >= n) return;
+    // the A lane holds h[0..3], its E lane h[4..7]: every lane fetches its partner's four words, so BOTH lanes of a pair hold the digest --
+    // the A lane stores; the E lane runs the same instructions as a shadow when the evaluation's rows follow (a wavefront with 32 or fewer
+    // active lanes issues a dependent chain at 7.9 instead of 5.9 cycles per instruction)
+    const uint32_t m0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hs0, 0x140, 0xf, 0xf, false), m1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hs1, 0x140, 0xf, 0xf, false),
+                   m2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hs2, 0x140, 0xf, 0xf, false), m3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hs3, 0x140, 0xf, 0xf, false);
+    if (b0 >= n || (!a_side && !zrows_out)) return;
     const int b = b0;
-    const uint32_t h[8] = {h0, h1, h2, h3, g0, g1, g2, g3};
+    const uint32_t h[8] = {a_side ? hs0 : m0, a_side ? hs1 : m1, a_side ? hs2 : m2, a_side ? hs3 : m3, a_side ? m0 : hs0, a_side ? m1 : hs1, a_side ? m2 : hs2, a_side ? m3 : hs3};
     // digest (big-endian h[0..7]) as little-endian words, reduced mod r (2^256 < 3r: at most two subtractions)
     uint32_t v[8];
 #pragma unroll
@@ -352,7 +372,8 @@ __device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ 
     }
     fr_t z;
     fr_from_words(z, v);
-    store_fr12(z_out + (size_t)b * 12, z);
+    if (a_side) store_fr12(z_out + (size_t)b * 12, z);
+    if (zrows_out) eval_prep_rows(z, zrows_out + (size_t)b * EVT_ROWS * 12, a_side);
 }
 __global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
     sha_challenge_block(blobs, commitments48, n, z_out, (int)blockIdx.x);
@@ -363,7 +384,7 @@ __global__ void __launch_bounds__(256) k_challenge_sha256_jobs(ShaJobs jobs) {
     int j = 0;
 #pragma unroll 1
     while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.first_block[j + 1]) j++;
-    sha_challenge_block(jobs.blobs[j], jobs.commitments[j], jobs.n[j], jobs.z_out[j], (int)blockIdx.x - jobs.first_block[j]);
+    sha_challenge_block(jobs.blobs[j], jobs.commitments[j], jobs.n[j], jobs.z_out[j], (int)blockIdx.x - jobs.first_block[j], jobs.zrows_out[j]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -409,26 +430,58 @@ __device__ __forceinline__ void block_sum_fr(fr_t& v, uint32_t* sh /* BT*9 words
 // -- computed by every lane of the evaluation kernel they were 29 % of its instructions (the inversion alone 21 %: a wavefront pays for
 // it whether one lane needs it or all).  Rows of 12 words: EVT_ROWS per blob.
 constexpr int EVT_T = 128, EVT_LOG = 5, EVT_PER = 1 << EVT_LOG;          // 128 lanes x 32 leaves = 4096
-constexpr int EVT_ROWS = 14;                                             // z^(2^0..2^11), z^4096 - 1, 1 / (z^4096 - 1)
 __global__ void __launch_bounds__(64) k_blob_eval_prep(const uint32_t* __restrict__ z_in, int n, uint32_t* __restrict__ zrows) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n) return;
-    fr_t zl, one, rootn, inv;
-    load_fr12(zl, z_in + (size_t)b * 12);
-    uint32_t* rows = zrows + (size_t)b * EVT_ROWS * 12;
-#pragma unroll 1
-    for (int l = 0; l < 12; l++) {
-        store_fr12(rows + l * 12, zl);
-        FrC::mul(zl, zl, zl);
+    fr_t z;
+    load_fr12(z, z_in + (size_t)b * 12);
+    eval_prep_rows(z, zrows + (size_t)b * EVT_ROWS * 12, true);
+}
+// The scalars of the random linear combination that belong to ONE blob (kzg_verify.go:141-179: r^i, r^i z_i, r^i y_i with the global index
+// i = exp_offset + b), by the lane that has just finished y_b: in the throughput shape they ride in the evaluation kernel's tail instead of
+// a kernel of their own in every call's stream (k_rlc_scalars: one workgroup, 0.19 ms of queue time per call under load).  The Fr sum
+// sum r^i y_i is left to the host: n x 8 plain words come back with the statuses.
+struct RlcOut { uint32_t* s1; uint32_t* s3; uint32_t* ry; uint32_t exp_offset; RWords r; };
+// (inlined: as a called routine its fr_t& arguments travel through scratch memory -- 288 bytes per lane of the whole launch and 27 % more
+// HBM-side traffic for the kernel, PMC -- at the same rate: 1.94-1.95 against 1.89-1.92 M blobs/s sustained, within the noise of the box)
+__device__ __forceinline__ void rlc_one_blob(const RlcOut& o, int b, const fr_t& z, const fr_t& y) {
+    uint32_t rw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rw[i] = o.r.w[i];
+    for (int rep = 0; rep < 2; rep++) {
+        if (Fr::words32_geq_mod(rw)) {
+            uint64_t br = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { uint64_t v = (uint64_t)rw[i] - FrParams::MOD32[i] - br; rw[i] = (uint32_t)v; br = (v >> 32) & 1; }
+        }
     }
-    Fr::set_one(one);
-    FrC::sub(rootn, zl, one);
-    store_fr12(rows + 12 * 12, rootn);
-    fr_inv_n(inv, rootn);                                   // 0 -> 0: z in the domain, the evaluation kernel does not use it then
-    store_fr12(rows + 13 * 12, inv);
+    fr_t base, rp, t, pl;
+    fr_from_words(base, rw);
+    Fr::set_one(rp);
+    Fr::reduce_once(rp, rp);
+#pragma unroll 1
+    for (uint32_t e = o.exp_offset + (uint32_t)b; e; e >>= 1) {
+        if (e & 1) fr_mul_n(rp, rp, base);
+        fr_mul_n(base, base, base);
+    }
+    uint32_t w[8];
+    Fr::to_plain(pl, rp);
+    Fr::to_words32(w, pl);
+#pragma unroll
+    for (int q = 0; q < 8; q++) o.s1[(size_t)b * 8 + q] = w[q];
+    fr_mul_n(t, rp, z);
+    Fr::to_plain(pl, t);
+    Fr::to_words32(w, pl);
+#pragma unroll
+    for (int q = 0; q < 8; q++) o.s3[(size_t)b * 8 + q] = w[q];
+    fr_mul_n(t, rp, y);
+    Fr::to_plain(pl, t);
+    Fr::to_words32(w, pl);
+#pragma unroll
+    for (int q = 0; q < 8; q++) o.ry[(size_t)b * 8 + q] = w[q];
 }
 __global__ void __launch_bounds__(EVT_T) k_blob_eval_tree(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ zrows, const uint32_t* __restrict__ roots_brp,
-                                                         uint32_t* __restrict__ y_out, int* __restrict__ status) {
+                                                         uint32_t* __restrict__ y_out, int* __restrict__ status, const RlcOut rlc) {
     __shared__ uint32_t sh[EVT_T * 9];
     __shared__ int sh_found;
     __shared__ int sh_bad;
@@ -479,6 +532,7 @@ __global__ void __launch_bounds__(EVT_T) k_blob_eval_tree(const uint8_t* __restr
                 fr_t f;
                 fr_from_words(f, w);
                 store_fr12(y_out + (size_t)b * 12, f);
+                if (rlc.s1) rlc_one_blob(rlc, b, zp[0], f);
             }
         }
         return;
@@ -553,6 +607,7 @@ __global__ void __launch_bounds__(EVT_T) k_blob_eval_tree(const uint8_t* __restr
             FrC::mul(y, c, part);
             store_fr12(y_out + (size_t)b * 12, y);
             status[b] = 0;
+            if (rlc.s1) rlc_one_blob(rlc, b, zp[0], y);
         }
     }
 }
@@ -1340,14 +1395,20 @@ void challenge_jobs_device(ShaJobs& jobs, hipStream_t s) {
 }
 size_t blob_eval_scratch_words() { return (size_t)EVT_ROWS * 12; }
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, uint32_t* d_zrows,
-                      hipStream_t s) {
+                      hipStream_t s, bool rows_ready, const uint32_t* h_r8, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_ry) {
 #ifdef MKZG_EVAL_LANE_TRICK
     if (n > 0) hipLaunchKernelGGL((k_blob_eval<0>), dim3(n), dim3(EVB_T), 0, s, d_blobs, d_z, d_roots, d_inv_roots, d_y, (uint32_t*)nullptr, d_status);
 #else
     (void)d_inv_roots;
     if (n > 0) {
-        hipLaunchKernelGGL(k_blob_eval_prep, dim3((n + 63) / 64), dim3(64), 0, s, d_z, n, d_zrows);
-        hipLaunchKernelGGL(k_blob_eval_tree, dim3(n), dim3(EVT_T), 0, s, d_blobs, d_zrows, d_roots, d_y, d_status);
+        RlcOut rlc;
+        rlc.s1 = h_r8 ? d_s1 : nullptr;
+        rlc.s3 = d_s3;
+        rlc.ry = d_ry;
+        rlc.exp_offset = exp_offset;
+        for (int i = 0; i < 8; i++) rlc.r.w[i] = h_r8 ? h_r8[i] : 0;
+        if (!rows_ready) hipLaunchKernelGGL(k_blob_eval_prep, dim3((n + 63) / 64), dim3(64), 0, s, d_z, n, d_zrows);
+        hipLaunchKernelGGL(k_blob_eval_tree, dim3(n), dim3(EVT_T), 0, s, d_blobs, d_zrows, d_roots, d_y, d_status, rlc);
     }
 #endif
 }

@@ -469,8 +469,9 @@ def leg_roofline(kern_ms, algo_bytes, hw, pmc_valid_for_size=True, leg="verify",
 
 
 # the kernels of ONE VerifyBlobKZGProofBatch call in the throughput shape (api_verify.hip): profile kind -> kernels x launches
-TP_KINDS = {"k_g1_validate": {"k_g1_validate": 1}, "k_challenge_sha256": {"k_challenge_sha256_jobs": 1}, "k_blob_eval_tree": {"k_blob_eval_prep": 1, "k_blob_eval_tree": 1},
-            "k_rlc_scalars": {"k_rlc_scalars": 1}, "k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_combine": 1}}
+# (the evaluation's z-only rows ride in the hash launch and the scalars of the linear combination in the evaluation kernel's tail)
+TP_KINDS = {"k_g1_validate": {"k_g1_validate": 1}, "k_challenge_sha256": {"k_challenge_sha256_jobs": 1}, "k_blob_eval_tree": {"k_blob_eval_tree": 1},
+            "k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_combine": 1}}
 
 
 def sustained_roofline(kinds, leg, algo_bytes_per_call, calls_per_s, hw, pmc_valid_for_size=True):

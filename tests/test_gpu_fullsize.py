@@ -84,6 +84,71 @@ def test_verify_batch_1024(gpu_ctx, oracle_ctx):
         assert gpu_ctx.set_option("verify_shape", -1) == 0
 
 
+def test_verify_batch_host_pointers_1024_and_beyond(gpu_ctx, product):
+    """VerifyBlobKZGProofBatch as the reference API hands it over (verify.go:88: []*Blob, host memory) at the BASELINE size and beyond one
+    staging piece, through every route of the host-pointer verifier: the lone caller's pipelined path with the challenges hashed in pairs
+    on the host pool (host_sha -1 / 1), the device hash after the upload (host_sha 0), the forced throughput shape (shared hash rounds),
+    and -- at 2100 blobs, a piece of 2048 + one of 52 -- the device taking the FIRST transcripts of the big piece.  Accept; one wrong
+    proof at the first, a middle and the last position (in the device-hashed and in the host-hashed range); a non-canonical blob; an
+    undecodable commitment; nil blobs with the reference's precedence (an error at a lower index wins)."""
+    import ctypes as C
+    import torch
+    L = product.lib()
+    D = 64
+    blobs = _blobs(D, 20_000)
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cm = torch.zeros(D * 48, dtype=torch.uint8, device="cuda")
+    d_pr = torch.zeros(D * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(D, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), D, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
+    assert gpu_ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), D, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    cm, pr = bytes(d_cm.cpu().tolist()), bytes(d_pr.cpu().tolist())
+    keep = [C.create_string_buffer(b, 131072) for b in blobs]
+    noncanon = bytearray(blobs[3])
+    noncanon[32 * 4000:32 * 4001] = b"\xff" * 32
+    keep_bad = C.create_string_buffer(bytes(noncanon), 131072)
+
+    def run(n, proofs=None, cms_=None, swap=None):
+        ptrs = [C.cast(keep[i % D], C.c_char_p) for i in range(n)]
+        for i, what in (swap or {}).items():
+            ptrs[i] = None if what is None else C.cast(what, C.c_char_p)
+        arr = (C.c_char_p * n)(*ptrs)
+        cj = cms_ if cms_ is not None else b"".join(cm[48 * (i % D):48 * (i % D) + 48] for i in range(n))
+        pj = proofs if proofs is not None else b"".join(pr[48 * (i % D):48 * (i % D) + 48] for i in range(n))
+        return L.mkzg_verify_blob_kzg_proof_batch(gpu_ctx._h, arr, cj, pj, n, n, n)
+
+    def wrong_at(n, v):
+        pj = bytearray(b"".join(pr[48 * (i % D):48 * (i % D) + 48] for i in range(n)))
+        o = (v + 1) % D
+        pj[48 * v:48 * v + 48] = pr[48 * o:48 * o + 48]
+        return bytes(pj)
+
+    try:
+        for host_sha, shape in ((-1, -1), (1, -1), (0, -1), (-1, 1)):
+            assert gpu_ctx.set_option("host_sha", host_sha) == 0 and gpu_ctx.set_option("verify_shape", shape) == 0
+            n = 1024
+            assert run(n) == 0, (host_sha, shape)
+            for v in (0, 700, 1023):
+                assert run(n, proofs=wrong_at(n, v)) == 1, (host_sha, shape, v)
+            assert run(n, swap={3 + 64 * 14: keep_bad}) == 3                              # ErrNonCanonicalScalar
+            badc = bytearray(b"".join(cm[48 * (i % D):48 * (i % D) + 48] for i in range(n)))
+            badc[48 * 2] = 0x00
+            assert run(n, cms_=bytes(badc)) == 11                                        # undecodable commitment
+            assert run(n, swap={5: None}) == 6                                           # ErrDeserializeNilInput
+            assert run(n, cms_=bytes(badc), swap={905: None}) == 11                      # the commitment at index 2 comes first
+            assert run(n, swap={905: None, 3 + 64 * 14: keep_bad}) == 3                  # ... and so does the blob at index 899
+        assert gpu_ctx.set_option("host_sha", -1) == 0 and gpu_ctx.set_option("verify_shape", -1) == 0
+        n = 2100                                  # 2048 + 52: the big piece's first transcripts are hashed by the device, the rest by the host pool
+        assert run(n) == 0
+        for v in (100, 1500, 2047, 2048, 2099):
+            assert run(n, proofs=wrong_at(n, v)) == 1, v
+        assert run(n, swap={2090: None}) == 6
+    finally:
+        assert gpu_ctx.set_option("host_sha", -1) == 0 and gpu_ctx.set_option("verify_shape", -1) == 0
+
+
 def test_cells_and_proofs_batch_64(gpu_ctx, oracle_ctx):
     import torch
     NB = 64

@@ -10,6 +10,8 @@
 #include <functional>
 #include <thread>
 #include <sys/prctl.h>
+#include <ctype.h>
+#include <sched.h>
 #include <time.h>
 #include "ctx.h"
 #include "api_multi.h"
@@ -609,9 +611,56 @@ static int pool_workers_for(int sharers) {
     }
     return (int)std::min(15u, cpu_share_for(sharers) - 1);
 }
+// CPUs of the NUMA node the device hangs off (sysfs: the PCI function's numa_node, the node's cpulist), intersected with the CPUs this
+// process may run on; empty when anything is missing, when the machine has one node, when fewer CPUs than the pool needs remain -- and
+// unless MKZG_POOL_AFFINITY=1 asks for it.  HIP places pinned host allocations on that node, but where the CALLER's blobs live decides more:
+// *measured* on a two-socket box (host-pointer VerifyBlobKZGProofBatch(1024), ms per lone call): the whole process on the GPU's node
+// (taskset) 3.92-3.96, on the other node 4.0-4.9; only the pool bound to the GPU's node 3.9 / 4.8 / 5.8 over three processes (the
+// caller's blobs sat on the other socket in two of them: every gather and hash a remote read), pool floating 4.0 / 4.2 / 4.0.  So the
+// workers float by default -- the scheduler keeps them near the data they stream -- and a host that allocates its blobs on the GPU's node
+// can opt in.
+static cpu_set_t device_node_cpus(int device, int need) {
+    cpu_set_t out;
+    CPU_ZERO(&out);
+    const char* e = getenv("MKZG_POOL_AFFINITY");
+    if (!e || atoi(e) == 0) return out;
+    char bdf[32] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return out; }
+    for (char* q = bdf; *q; q++) *q = (char)tolower(*q);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+    if (node < 0) return out;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) return out;
+    char list[4096] = {0};
+    const bool got = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!got) return out;
+    cpu_set_t mine;
+    CPU_ZERO(&mine);
+    if (sched_getaffinity(0, sizeof mine, &mine) != 0) return out;
+    int n_all = CPU_COUNT(&mine);
+    for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1) b = a;
+        if (k < 1) continue;
+        for (int cpu = a; cpu <= b && cpu < CPU_SETSIZE; cpu++) if (CPU_ISSET(cpu, &mine)) CPU_SET(cpu, &out);
+    }
+    if (CPU_COUNT(&out) == n_all || CPU_COUNT(&out) < std::max(2, need)) CPU_ZERO(&out);      // one node, or too few CPUs left: leave the scheduler alone
+    return out;
+}
 static int ctx_create_one(const char* js, size_t len, int device, int sharers, mkzg_ctx** out) {
     mkzg_ctx* c = new mkzg_ctx();
-    c->pool = new kzg::HostPool(pool_workers_for(sharers));
+    {
+        const int workers = pool_workers_for(sharers);
+        const cpu_set_t cpus = device_node_cpus(device, workers);
+        c->pool = new kzg::HostPool(workers, &cpus);
+        c->pool_node_cpus = CPU_COUNT(&cpus);
+    }
     c->cpu_share = (int)cpu_share_for(sharers);
     c->device = device;
     // reference api.go:93-95 (ErrMinSRSSize) and the fixed-size arrays of trusted_setup.go:23-27
@@ -851,6 +900,7 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
         }
     }
     else if (!strcmp(key, "lanes")) *value = q->opt_lanes;
+    else if (!strcmp(key, "pool_node_cpus")) *value = q->pool_node_cpus;                        // CPUs of the GPU's NUMA node the pool's workers are bound to (0: not bound)
     else if (!strcmp(key, "host_threads")) *value = q->pool->size() + 1;                         // workers of one device's pool + the calling thread
     else return MKZG_ERR_BAD_ARGS;
     return MKZG_OK;

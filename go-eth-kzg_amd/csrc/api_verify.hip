@@ -520,8 +520,11 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
         lo += k;
     }
     const size_t nch = plan.size();
-    // copy tasks: 8 blobs each; hash tasks: 4 transcripts (two pairs) each
-    const size_t CPT = 8, HPT = 4;
+    // copy tasks: 8 blobs each; hash tasks: 4 transcripts (two SHA-NI pairs) each -- or 16, one per AVX-512 lane, when the host's share
+    // gives every pool thread (and this one) at least one such task
+    static const bool no_wide = getenv("MKZG_NO_WIDE_SHA") != nullptr;          // A/B aid
+    const bool wide_sha = !no_wide && sha256_have_avx512() && m - n_dev >= 16 * (size_t)(c->pool->size() + 1);
+    const size_t CPT = 8, HPT = wide_sha ? 16 : 4;
     std::vector<size_t> ctask_chunk, ctask_lo;
     std::vector<Countdown> left(nch);
     for (size_t k = 0; k < nch; k++) {
@@ -548,6 +551,15 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
         static const uint8_t zero_blob[MKZG_BYTES_PER_BLOB] = {0};
         auto src = [&](size_t i) { return blobs[i] ? blobs[i] : zero_blob; };
         size_t i = lo;
+#if defined(__x86_64__)
+        if (wide_sha && hi - lo == 16) {
+            const uint8_t* bp[16];
+            const uint8_t* cp16[16];
+            for (int q = 0; q < 16; q++) { bp[q] = src(lo + (size_t)q); cp16[q] = commitments48n + (lo + (size_t)q) * 48; }
+            host_compute_challenge_x16(h_z + lo * 32, bp, cp16);
+            return;
+        }
+#endif
         for (; i + 1 < hi; i += 2) host_compute_challenge_x2(h_z + i * 32, src(i), commitments48n + i * 48, h_z + (i + 1) * 32, src(i + 1), commitments48n + (i + 1) * 48);
         if (i < hi) host_compute_challenge(h_z + i * 32, src(i), commitments48n + i * 48);
     };

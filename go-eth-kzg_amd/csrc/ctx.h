@@ -215,6 +215,7 @@ struct mkzg_ctx {
     int opt_lanes = NLANE;                 // lanes calls may occupy at once (each keeps its workspaces and pinned staging until trimmed or destroyed)
     std::atomic<int> opt_fk20_segments{1}; // the FK20 products of calls of 65..192 blobs in segments (fk20_kernels.hip k_fk20_toom_seg); 0: whole products -- same bytes, for A/B and tests
     std::atomic<int> opt_host_wait{-1};    // how a call waits for the GPU: 0 the runtime's own wait (polls), 1 query + sleep, -1 by the calls in flight and the CPUs of the context's share; lane_sync (api.hip)
+    int pool_node_cpus = 0;                // CPUs of the GPU's NUMA node the pool's workers are bound to (0: not bound)
     int cpu_share = 1;                     // CPUs this context may count on: the cgroup's, divided by the ranks on the node / the devices of the context
     std::atomic<int> opt_debug_serial{0};  // measurement aid: the blob verifier waits for its side stream before it launches the challenge hash (the hash kernel alone on the chip)
     std::atomic<int> opt_host_sha{-1};                 // host-pointer verifiers: challenges by SHA-NI on the host pool (1), on the device (0), auto (-1)

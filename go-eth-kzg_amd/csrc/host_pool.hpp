@@ -13,6 +13,7 @@
 #pragma once
 #include <linux/futex.h>
 #include <pthread.h>
+#include <sched.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 #include <atomic>
@@ -51,8 +52,12 @@ class HostPool {
    public:
     static constexpr int SPIN_US = 50;          // yield-spin this long before parking (a futex wake-up costs 5-20 us)
 
-    explicit HostPool(int n_workers) {
+    // cpus (may be null / empty = the default): the workers are bound to these CPUs (api.hip device_node_cpus: opt-in, with the measurement
+    // that made it opt-in).  Failure to bind is not an error.
+    explicit HostPool(int n_workers, const cpu_set_t* cpus = nullptr) {
         for (int i = 0; i < n_workers; i++) th_.emplace_back([this] { loop(); });
+        if (cpus && CPU_COUNT(cpus) > 0)
+            for (auto& t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(cpu_set_t), cpus);
     }
     ~HostPool() {
         {

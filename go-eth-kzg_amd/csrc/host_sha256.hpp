@@ -143,12 +143,66 @@ __attribute__((target("sha,sse4.1,ssse3"))) static inline void sha256_blocks_ni_
         _mm_storeu_si128((__m128i*)&stb[4], _mm_alignr_epi8(u, t, 8));
     }
 }
+// SIXTEEN independent messages, one per 32-bit lane of a 512-bit register (AVX-512F/BW: vprord rotations, vpternlogd for the sigmas, Ch
+// and Maj): the message blocks are loaded 64 bytes per message, byte-swapped and transposed (16 x 16 words), then every round is ~9 vector
+// instructions for 16 messages.  *Measured* (tools/ubench_h2d.cpp): faster per transcript than two interleaved SHA-NI chains on the
+// cores that have full-width AVX-512; the host-pointer verifier's hash tasks take it when a call brings enough transcripts to give every
+// pool thread sixteen.  p[i] + off: start of message i's next block; all messages advance together.
+__attribute__((target("avx512f,avx512bw"))) static inline void sha256_transpose16(__m512i r[16]) {
+    __m512i t[16];
+    for (int i = 0; i < 16; i += 2) { t[i] = _mm512_unpacklo_epi32(r[i], r[i + 1]); t[i + 1] = _mm512_unpackhi_epi32(r[i], r[i + 1]); }
+    for (int i = 0; i < 16; i += 4) {
+        r[i] = _mm512_unpacklo_epi64(t[i], t[i + 2]); r[i + 1] = _mm512_unpackhi_epi64(t[i], t[i + 2]);
+        r[i + 2] = _mm512_unpacklo_epi64(t[i + 1], t[i + 3]); r[i + 3] = _mm512_unpackhi_epi64(t[i + 1], t[i + 3]);
+    }
+    for (int i = 0; i < 4; i++) {
+        t[i] = _mm512_shuffle_i32x4(r[i], r[i + 4], 0x88); t[i + 4] = _mm512_shuffle_i32x4(r[i], r[i + 4], 0xdd);
+        t[i + 8] = _mm512_shuffle_i32x4(r[i + 8], r[i + 12], 0x88); t[i + 12] = _mm512_shuffle_i32x4(r[i + 8], r[i + 12], 0xdd);
+    }
+    for (int i = 0; i < 4; i++) {
+        r[i] = _mm512_shuffle_i32x4(t[i], t[i + 8], 0x88); r[i + 8] = _mm512_shuffle_i32x4(t[i], t[i + 8], 0xdd);
+        r[i + 4] = _mm512_shuffle_i32x4(t[i + 4], t[i + 12], 0x88); r[i + 12] = _mm512_shuffle_i32x4(t[i + 4], t[i + 12], 0xdd);
+    }
+}
+__attribute__((target("avx512f,avx512bw"))) static inline void sha256_blocks_avx512_x16(__m512i st[8], const uint8_t* const p[16], size_t off, size_t nblk) {
+    const __m512i BSW = _mm512_set4_epi32(0x0c0d0e0f, 0x08090a0b, 0x04050607, 0x00010203);
+    __m512i a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+    for (size_t k = 0; k < nblk; k++) {
+        __m512i w[16];
+        for (int i = 0; i < 16; i++) w[i] = _mm512_shuffle_epi8(_mm512_loadu_si512((const void*)(p[i] + off + 64 * k)), BSW);
+        sha256_transpose16(w);                    // w[j], lane i = word j of message i's block
+        const __m512i sa = a, sb = b, sc = c, sd = d, se = e, sf = f, sg = g, sh = h;
+#pragma GCC unroll 64
+        for (int i = 0; i < 64; i++) {
+            if (i >= 16) {
+                const __m512i w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+                const __m512i s0 = _mm512_ternarylogic_epi32(_mm512_ror_epi32(w15, 7), _mm512_ror_epi32(w15, 18), _mm512_srli_epi32(w15, 3), 0x96);
+                const __m512i s1 = _mm512_ternarylogic_epi32(_mm512_ror_epi32(w2, 17), _mm512_ror_epi32(w2, 19), _mm512_srli_epi32(w2, 10), 0x96);
+                w[i & 15] = _mm512_add_epi32(_mm512_add_epi32(w[i & 15], s0), _mm512_add_epi32(w[(i - 7) & 15], s1));
+            }
+            const __m512i S1 = _mm512_ternarylogic_epi32(_mm512_ror_epi32(e, 6), _mm512_ror_epi32(e, 11), _mm512_ror_epi32(e, 25), 0x96);
+            const __m512i ch = _mm512_ternarylogic_epi32(e, f, g, 0xca);
+            const __m512i t1 = _mm512_add_epi32(_mm512_add_epi32(h, S1), _mm512_add_epi32(_mm512_add_epi32(ch, _mm512_set1_epi32((int)SHA256_K[i])), w[i & 15]));
+            const __m512i S0 = _mm512_ternarylogic_epi32(_mm512_ror_epi32(a, 2), _mm512_ror_epi32(a, 13), _mm512_ror_epi32(a, 22), 0x96);
+            const __m512i mj = _mm512_ternarylogic_epi32(a, b, c, 0xe8);
+            h = g; g = f; f = e; e = _mm512_add_epi32(d, t1); d = c; c = b; b = a; a = _mm512_add_epi32(t1, _mm512_add_epi32(S0, mj));
+        }
+        a = _mm512_add_epi32(a, sa); b = _mm512_add_epi32(b, sb); c = _mm512_add_epi32(c, sc); d = _mm512_add_epi32(d, sd);
+        e = _mm512_add_epi32(e, se); f = _mm512_add_epi32(f, sf); g = _mm512_add_epi32(g, sg); h = _mm512_add_epi32(h, sh);
+    }
+    st[0] = a; st[1] = b; st[2] = c; st[3] = d; st[4] = e; st[5] = f; st[6] = g; st[7] = h;
+}
+static inline bool sha256_have_avx512() {
+    static const bool have = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw");
+    return have;
+}
 static inline bool sha256_have_ni() {
     static const bool have = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
     return have;
 }
 #else
 static inline bool sha256_have_ni() { return false; }
+static inline bool sha256_have_avx512() { return false; }
 #endif
 
 static inline void sha256_blocks(uint32_t st[8], const uint8_t* p, size_t nblk) {
@@ -249,5 +303,30 @@ static inline void host_compute_challenge_x2(uint8_t z32a[32], const uint8_t* bl
     challenge_reduce(z32a, sa);
     challenge_reduce(z32b, sb);
 }
+
+#if defined(__x86_64__)
+// sixteen transcripts at once (sha256_blocks_avx512_x16); the caller has checked sha256_have_avx512()
+__attribute__((target("avx512f,avx512bw"))) static inline void host_compute_challenge_x16(uint8_t* z32x16 /* 16 x 32 B */, const uint8_t* const blobs[16], const uint8_t* const cms[16]) {
+    uint32_t iv[8];
+    sha256_init(iv);
+    __m512i st[8];
+    for (int q = 0; q < 8; q++) st[q] = _mm512_set1_epi32((int)iv[q]);
+    alignas(64) uint8_t tmp[16][128];
+    const uint8_t* p[16];
+    for (int i = 0; i < 16; i++) { challenge_head_block(tmp[i], blobs[i]); p[i] = tmp[i]; }
+    sha256_blocks_avx512_x16(st, p, 0, 1);
+    for (int i = 0; i < 16; i++) p[i] = blobs[i] + 32;
+    sha256_blocks_avx512_x16(st, p, 0, (131072 - 64) / 64);
+    for (int i = 0; i < 16; i++) { challenge_tail_blocks(tmp[i], blobs[i], cms[i]); p[i] = tmp[i]; }
+    sha256_blocks_avx512_x16(st, p, 0, 2);
+    alignas(64) uint32_t o[8][16];
+    for (int q = 0; q < 8; q++) _mm512_store_si512((void*)o[q], st[q]);
+    for (int m = 0; m < 16; m++) {
+        uint32_t d[8];
+        for (int q = 0; q < 8; q++) d[q] = o[q][m];
+        challenge_reduce(z32x16 + 32 * m, d);
+    }
+}
+#endif
 
 }  // namespace kzg

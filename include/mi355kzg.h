@@ -121,7 +121,9 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
 /* reads an option back; also "commit_direct_bits_effective", "fk20_bits_effective", "devices", "host_threads" (threads of one device's
  * host pool including the caller: the CPUs the cgroup grants divided by LOCAL_WORLD_SIZE or the context's devices; the environment
- * variable MKZG_HOST_THREADS overrides) */
+ * variable MKZG_HOST_THREADS overrides), "pool_node_cpus" (CPUs the pool's workers are bound to when MKZG_POOL_AFFINITY=1 is set in the
+ * environment: those of the NUMA node the GPU hangs off, within the process's own affinity mask -- for hosts that keep their blobs on
+ * that node; 0 = the workers float, the default) */
 int mkzg_ctx_get_option(mkzg_ctx* ctx, const char* key, long* value);
 
 /* ---- EIP-4844 ------------------------------------------------------------------------------ */

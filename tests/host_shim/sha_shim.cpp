@@ -22,6 +22,19 @@ void shim_sha256_c(const uint8_t* data, size_t len, uint8_t out[32]) {
     for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16); out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i]; }
 }
 void shim_challenge(const uint8_t* blob, const uint8_t* commitment48, uint8_t z32[32]) { kzg::host_compute_challenge(z32, blob, commitment48); }
+// sixteen transcripts, one per AVX-512 lane (returns 0 when the CPU has no AVX-512: nothing written)
+int shim_challenge_x16(const uint8_t* blobs16 /* 16 x 131072 */, const uint8_t* cms16 /* 16 x 48 */, uint8_t* z16 /* 16 x 32 */) {
+#if defined(__x86_64__)
+    if (!kzg::sha256_have_avx512()) return 0;
+    const uint8_t* b[16];
+    const uint8_t* c[16];
+    for (int i = 0; i < 16; i++) { b[i] = blobs16 + (size_t)i * 131072; c[i] = cms16 + i * 48; }
+    kzg::host_compute_challenge_x16(z16, b, c);
+    return 1;
+#else
+    return 0;
+#endif
+}
 // two transcripts interleaved in one instruction stream (the gather threads of the host-pointer verifier hash in pairs)
 void shim_challenge_x2(const uint8_t* blob_a, const uint8_t* cm_a, uint8_t za[32], const uint8_t* blob_b, const uint8_t* cm_b, uint8_t zb[32]) {
     kzg::host_compute_challenge_x2(za, blob_a, cm_a, zb, blob_b, cm_b);

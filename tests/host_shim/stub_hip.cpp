@@ -22,6 +22,7 @@ extern "C" int stub_hip_live_allocations() {
     return (int)g_owner.size();
 }
 
+hipError_t hipDeviceGetPCIBusId(char*, int, int) { return hipErrorInvalidValue; }      // no sysfs entry to bind the pool to: the workers float
 hipError_t hipGetDeviceCount(int* n) { *n = N_DEVICES; return hipSuccess; }
 hipError_t hipSetDevice(int d) { if (d < 0 || d >= N_DEVICES) return hipErrorInvalidDevice; tl_device = d; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = tl_device; return hipSuccess; }

@@ -318,6 +318,6 @@ def test_every_documented_option_reads_back_and_sets(product):
         assert v is not None, key
         assert ctx.set_option(key, v) == 0, key
         assert ctx.get_option(key) == v, key
-    for key in ("commit_direct_bits_effective", "fk20_bits_effective", "devices", "host_threads", "cpu_share", "tables_on_own_device"):
+    for key in ("commit_direct_bits_effective", "fk20_bits_effective", "devices", "host_threads", "cpu_share", "tables_on_own_device", "pool_node_cpus"):
         assert ctx.get_option(key) is not None, key
     ctx.close()

@@ -20,6 +20,7 @@ def shim():
     L.shim_sha256_c.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
     L.shim_challenge.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     L.shim_challenge_x2.argtypes = [C.c_char_p] * 6
+    L.shim_challenge_x16.argtypes = [C.c_char_p] * 3
     return L
 
 
@@ -75,3 +76,16 @@ def test_challenge_pairs_match_single(shim):
         for j in range(4):
             shim.shim_challenge_x2(blobs[i], cms[i], za, blobs[j], cms[j], zb)
             assert za.raw == _challenge(blobs[i], cms[i]) and zb.raw == _challenge(blobs[j], cms[j]), (i, j)
+
+
+def test_challenge_sixteen_lanes_match_single(shim):
+    """host_compute_challenge_x16 (one transcript per AVX-512 lane) against hashlib: sixteen different blobs and commitments, among them the
+    zero blob and the all-(r-1) blob"""
+    import oracle
+    blobs = [bytes(131072), (R - 1).to_bytes(32, "big") * 4096] + [oracle.rand_blob(40 + i) for i in range(14)]
+    cms = [bytes([0xC0]) + bytes(47), b"\xff" * 48] + [bytes((7 * i + j) & 0xFF for j in range(48)) for i in range(14)]
+    z = C.create_string_buffer(16 * 32)
+    if not shim.shim_challenge_x16(b"".join(blobs), b"".join(cms), z):
+        pytest.skip("no AVX-512 on this CPU")
+    for i in range(16):
+        assert z.raw[32 * i:32 * i + 32] == _challenge(blobs[i], cms[i]), i

@@ -57,6 +57,34 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < 64; i += 2) kzg::host_compute_challenge_x2(&z2[i * 32], src[i], cm, &z2[i * 32 + 32], src[i + 1], cm);
         double two = ms_since(t0) / 64;
         printf("hash per transcript: one at a time %.1f us, two interleaved %.1f us, same=%d\n", one * 1e3, two * 1e3, (int)!memcmp(z.data(), z2.data(), 64 * 32));
+        if (kzg::sha256_have_avx512()) {
+            std::vector<uint8_t> z3(64 * 32);
+            t0 = clk::now();
+            for (size_t i = 0; i < 64; i += 16) {
+                const uint8_t* bp[16];
+                const uint8_t* cp[16];
+                for (int q = 0; q < 16; q++) { bp[q] = src[i + q]; cp[q] = cm; }
+                kzg::host_compute_challenge_x16(&z3[i * 32], bp, cp);
+            }
+            printf("hash per transcript: sixteen AVX-512 lanes %.1f us, same=%d\n", ms_since(t0) / 64 * 1e3, (int)!memcmp(z.data(), z3.data(), 64 * 32));
+            for (int T : {8, TMAX, TMAX + 1}) {
+                double best = 1e9;
+                for (int rep = 0; rep < 3; rep++) {
+                    std::atomic<size_t> next{0};
+                    best = std::min(best, run_threads(T, [&](int) {
+                        for (;;) {
+                            size_t i = next.fetch_add(16);
+                            if (i + 16 > N) break;
+                            const uint8_t* bp[16];
+                            const uint8_t* cp[16];
+                            for (int q = 0; q < 16; q++) { bp[q] = src[i + q]; cp[q] = cm; }
+                            kzg::host_compute_challenge_x16(&z[i * 32], bp, cp);
+                        }
+                    }));
+                }
+                printf("hash %zu transcripts on %2d threads (sixteen lanes): %.3f ms\n", N, T, best);
+            }
+        }
         for (int T : {4, 8, TMAX}) {
             for (int x2 = 0; x2 < 2; x2++) {
                 double best = 1e9;

@@ -159,6 +159,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    numa = bind_to_gpu_node(torch, local_rank)          # before any buffer is allocated and before the library starts its host pool
     dist_on = world > 1 or bool(os.environ.get("BENCH_FORCE_DIST"))
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -376,7 +377,7 @@ def main():
                         "ms_per_step_min": round(ms_steps[0], 3), "ms_per_step_median": round(ms_steps[len(ms_steps) // 2], 3), "ms_per_step_max": round(ms_steps[-1], 3),
                         "blobs_per_s_median": round(B * world / (ms_steps[len(ms_steps) // 2] * 1e-3), 1),
                         "note": "`value` is the first region (the contract's K steps); the others repeat it back to back"},
-            "roofline": roofline, "valu": valu,
+            "roofline": roofline, "valu": valu, "numa": numa,
         }
         if multi is not None:
             out["multi_gpu"] = multi
@@ -407,6 +408,40 @@ def main():
         except Exception:      # noqa: BLE001
             pass
         print(line, flush=True)
+
+
+def bind_to_gpu_node(torch, device):
+    """What `numactl --cpunodebind` does for a rank of a multi-GPU job, done by the rank itself: bind this process (and every thread it
+    starts later: the library's host pool, the caller threads of the sustained legs) to the CPUs of the NUMA node its GPU hangs off,
+    so that the host buffers it allocates from here on are local to the pinned staging memory HIP places on that node.  *Measured* on the
+    two-socket boxes of this pool (host-pointer VerifyBlobKZGProofBatch(1024), lone call): 3.92-3.96 ms bound, 4.0-5.1 ms floating --
+    the figure then depends on which socket the process happened to allocate its blobs on.  BENCH_NO_NUMA_BIND=1 leaves the process alone.
+    Returns what was done, for the JSON line."""
+    info = {"bound": False}
+    if os.environ.get("BENCH_NO_NUMA_BIND"):
+        info["note"] = "BENCH_NO_NUMA_BIND"
+        return info
+    try:
+        p = torch.cuda.get_device_properties(device)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{getattr(p, 'pci_device_id', 0):02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as fh:
+            node = int(fh.read())
+        if node < 0:
+            return info
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
+            cpus = set()
+            for part in fh.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        mine = os.sched_getaffinity(0)
+        want = cpus & mine
+        info.update({"gpu_pci": bdf, "gpu_numa_node": node, "node_cpus": len(cpus)})
+        if want and want != mine and len(want) >= 4:
+            os.sched_setaffinity(0, want)
+            info["bound"] = True
+    except Exception as e:      # noqa: BLE001
+        info["note"] = repr(e)
+    return info
 
 
 def hw_limits(props):

@@ -442,7 +442,8 @@ static int verify_device_all(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const
 // ---------------------------------------------------------------------------------------------
 // Where the challenges of a host-pointer call are hashed.  The device hash is a latency chain of 2050 compressions per blob -- 2.7 ms
 // whether the call brings 1 blob or 1024, and only after the upload; a host core with the SHA extensions hashes a PAIR of transcripts in
-// 71 us (two chains interleaved in one instruction stream, host_sha256.hpp: 35 us each against 53 us one at a time), beside the upload.
+// 71 us (two chains interleaved in one instruction stream, host_sha256.hpp: 35 us each against 53 us one at a time) and SIXTEEN on the
+// lanes of AVX-512 registers in 380 us (24 us each), beside the upload.
 // *Measured* on the 16-CPU boxes (tools/ubench_h2d.cpp): 1024 transcripts on the pool's 15 threads in 2.7 ms; gathered with streaming
 // stores and uploaded chunk by chunk at the same time, 134 MB are on the device after 2.8-2.9 ms (3.8-4.0 with memcpy: its
 // write-allocate reads compete with the DMA engine for the memory controllers).  So a LONE call hashes on the host (pipelined: below);
@@ -461,8 +462,8 @@ static size_t device_hash_share(const mkzg_ctx* c, size_t m) {
     static const int forced = [] { const char* e = getenv("MKZG_DEV_HASH_PERCENT"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return std::min(m, m * (size_t)std::min(forced, 100) / 100);
     const double T = (double)std::max(1, c->pool->size());
-    // per transcript over the whole pool (us): 35.3 per core for a pair's half; the copies mostly hide under the upload; a chunk goes up at ~47 GB/s
-    const double hash_us = 35.3 / T, copy_us = std::max(0.6, 6.0 / T), up_us = 2.8, chain_us = 2750.0 + 200.0;
+    // per transcript over the whole pool (us): 35.3 per core for a SHA-NI pair's half, 23.7 on sixteen AVX-512 lanes; the copies mostly hide under the upload; a chunk goes up at ~47 GB/s
+    const double hash_us = (sha256_have_avx512() ? 23.7 : 35.3) / T, copy_us = std::max(0.6, 6.0 / T), up_us = 2.8, chain_us = 2750.0 + 200.0;
     const double d = ((copy_us + hash_us) * (double)m - chain_us) / (hash_us + up_us);
     if (d < 64) return 0;
     return std::min(m, (size_t)d / 64 * 64);

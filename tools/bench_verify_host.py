@@ -15,6 +15,7 @@ import bench  # noqa: E402
 def main():
     import torch
     torch.cuda.init()
+    print(json.dumps({"numa": bench.bind_to_gpu_node(torch, 0)}), flush=True)      # as bench.py does (BENCH_NO_NUMA_BIND=1: leave the process alone)
     kzg = bench.load_product()
     ctx = kzg.Context(device=0)
     argv = sys.argv[1:]

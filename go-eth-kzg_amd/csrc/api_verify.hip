@@ -535,7 +535,7 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
     }
     const int n_copy = (int)ctask_lo.size();
     const int n_hash = (int)((m - n_dev + HPT - 1) / HPT);
-    Countdown copy_left(n_copy), hash_left(n_hash);
+    Countdown copy_left(n_copy + n_hash) /* every task of the call */, hash_left(n_hash);
     const std::function<void(int)> copy_task = [&](int t) {
         const size_t k = ctask_chunk[(size_t)t], lo = ctask_lo[(size_t)t], hi = std::min(plan[k].lo + plan[k].m, lo + CPT);
         for (size_t i = lo; i < hi; i++) {
@@ -567,25 +567,51 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
     // points first: their chains are the longest thing on the side stream
     memcpy(h_pts, commitments48n, m * 48);
     memcpy(h_pts + m * 48, proofs48n, m * 48);
-    c->pool->run_async(n_copy, copy_task, &copy_left);
-    c->pool->run_async(n_hash, hash_task, &hash_left);
+    // ONE queue, interleaved: the copies of chunk k + 1 ahead of the hashes of chunk k's blobs.  The link takes a chunk every 0.3 ms and the
+    // pool gathers one in 0.1: with all copies first (the first version of this pipeline) the uploads were fed 2.5x faster than they could
+    // leave while the hashes -- the longer half of the host's work, and what the call's tail waits for -- started 1.2 ms late; interleaved,
+    // copies and hashes both end with the uploads (trace: challenges complete 3.4-3.6 -> see DESIGN.md section 4.2).
+    std::vector<int> order;                                     // >= 0: copy task; < 0: ~(hash task)
+    order.reserve((size_t)n_copy + (size_t)n_hash);
+    {
+        size_t hnext = 0, cnext = 0;
+        auto push_hash_upto = [&](size_t blob_end) { while (hnext < (size_t)n_hash && n_dev + hnext * HPT < blob_end) order.push_back(~(int)hnext++); };
+        for (size_t k = 0; k < nch; k++) {
+            while (cnext < ctask_chunk.size() && ctask_chunk[cnext] == k) order.push_back((int)cnext++);
+            if (k >= 1) push_hash_upto(plan[k - 1].lo + plan[k - 1].m);
+        }
+        push_hash_upto(m);
+    }
+    const std::function<void(int)> mixed = [&](int t) {
+        const int code = order[(size_t)t];
+        if (code >= 0) copy_task(code);
+        else { hash_task(~code); hash_left.arrive(); }
+    };
+    c->pool->run_async((int)order.size(), mixed, &copy_left);
     // every exit path below must wait for the tasks: they reference this frame
     rc = [&]() -> int {
         const bool idle = lane_fork(L, s, s2, cp);
         (void)idle;
-        HIPCHK(hipMemcpyAsync(L->d_v_raw, h_pts, m * 48, hipMemcpyHostToDevice, s2));
-        HIPCHK(hipMemcpyAsync(L->d_v_raw + cap * 48, h_pts + m * 48, m * 48, hipMemcpyHostToDevice, s2));
-        if (n_dev) HIPCHK(hipEventRecord(L->ev_decoded, s2));                  // the commitments are up: the device's share of the hash may read them
-        KT(KT_SUBGROUP, s2, g1_validate2_device(L->d_v_raw, (int)m, aff_c, st_c, L->d_v_raw + cap * 48, (int)m, aff_q, st_q, s2, MKZG_LAT_VALIDATE_MODE(m)));
         int vrc = 0;
-        if (early_msm) {
-            KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)m, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
-            const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
-            const uint32_t* pts[2] = {aff_q, aff_c};
-            const int njob[2] = {(int)m, (int)m};
-            KT(KT_VMSM, s2, vrc = vmsm_windows_device(scal, pts, njob, 2, d_parts, d_wsum, s2));
-            if (vrc) return MKZG_ERR_BAD_ARGS;
-        }
+        // the points' launches (decoding + subgroup tests 0.7 ms, the two MSMs that need nothing else 0.5 ms: done long before the last
+        // challenge) are issued right BEHIND the first chunk's upload: seven launches are 0.15 ms of this thread's time, and the link
+        // should not wait for them -- every later chunk follows the first back to back
+        auto launch_points = [&]() -> int {
+            HIPCHK(hipMemcpyAsync(L->d_v_raw, h_pts, m * 48, hipMemcpyHostToDevice, s2));
+            HIPCHK(hipMemcpyAsync(L->d_v_raw + cap * 48, h_pts + m * 48, m * 48, hipMemcpyHostToDevice, s2));
+            if (n_dev) HIPCHK(hipEventRecord(L->ev_decoded, s2));                  // the commitments are up: the device's share of the hash may read them
+            KT(KT_SUBGROUP, s2, g1_validate2_device(L->d_v_raw, (int)m, aff_c, st_c, L->d_v_raw + cap * 48, (int)m, aff_q, st_q, s2, MKZG_LAT_VALIDATE_MODE(m)));
+            if (early_msm) {
+                KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)m, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
+                const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
+                const uint32_t* pts[2] = {aff_q, aff_c};
+                const int njob[2] = {(int)m, (int)m};
+                KT(KT_VMSM, s2, vrc = vmsm_windows_device(scal, pts, njob, 2, d_parts, d_wsum, s2));
+                if (vrc) return MKZG_ERR_BAD_ARGS;
+            }
+            return MKZG_OK;
+        };
+        if (nch == 1) { const int prc = launch_points(); if (prc) return prc; }     // a call of one chunk waits for the points' 0.7 ms chain, not for the link: points first
         hipStream_t ntt_stream = ntt_on_side ? s2 : s;
         bool hash_launched = n_dev == 0;
         for (size_t k = 0; k < nch; k++) {
@@ -593,6 +619,7 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
             c->pool->wait(left[k]);
             HIPCHK(hipMemcpyAsync(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, L->h_stage + lo * MKZG_BYTES_PER_BLOB, n * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, cp));
             HIPCHK(hipEventRecord(L->ev_chunk[k & 7], cp));
+            if (k == 0 && nch > 1) { const int prc = launch_points(); if (prc) return prc; }
             if (!hash_launched && lo + n >= n_dev) {
                 // the device's share is up with this chunk: its 2.7 ms chain starts now, on the main stream
                 HIPCHK(hipStreamWaitEvent(s, L->ev_chunk[k & 7], 0));

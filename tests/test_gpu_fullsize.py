@@ -149,6 +149,37 @@ def test_verify_batch_host_pointers_1024_and_beyond(gpu_ctx, product):
         assert gpu_ctx.set_option("host_sha", -1) == 0 and gpu_ctx.set_option("verify_shape", -1) == 0
 
 
+def test_verify_host_pointers_ragged_sizes(gpu_ctx, product):
+    """the host-pointer verifier's chunk plan, task lists and hash forms at the sizes where they change: one chunk / several, a first chunk
+    of 32, tails merged into the last chunk, fewer transcripts than sixteen per pool thread (SHA-NI pairs) and more (AVX-512 lanes), an odd
+    transcript left over -- accept, and reject with the wrong proof at the LAST position (the tail of the last task of the last chunk)"""
+    import ctypes as C
+    import torch
+    L = product.lib()
+    D = 48
+    blobs = _blobs(D, 21_000)
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    d_cm = torch.zeros(D * 48, dtype=torch.uint8, device="cuda")
+    d_pr = torch.zeros(D * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(D, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert gpu_ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), D, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
+    assert gpu_ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), D, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    cm, pr = bytes(d_cm.cpu().tolist()), bytes(d_pr.cpu().tolist())
+    keep = [C.create_string_buffer(b, 131072) for b in blobs]
+    threads = gpu_ctx.get_option("host_threads")
+    sizes = sorted({1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 65, 80, 95, 96, 97, 159, 160, 161, 176, 177, 255, 256, 257, 16 * threads - 1, 16 * threads, 16 * threads + 17, 300})
+    for n in sizes:
+        arr = (C.c_char_p * n)(*[C.cast(keep[i % D], C.c_char_p) for i in range(n)])
+        cj = b"".join(cm[48 * (i % D):48 * (i % D) + 48] for i in range(n))
+        pj = b"".join(pr[48 * (i % D):48 * (i % D) + 48] for i in range(n))
+        assert L.mkzg_verify_blob_kzg_proof_batch(gpu_ctx._h, arr, cj, pj, n, n, n) == 0, n
+        o = n % D                                                     # a proof of another blob at the last position
+        bad = pj[:48 * (n - 1)] + pr[48 * o:48 * o + 48]
+        assert L.mkzg_verify_blob_kzg_proof_batch(gpu_ctx._h, arr, cj, bad, n, n, n) == 1, n
+
+
 def test_cells_and_proofs_batch_64(gpu_ctx, oracle_ctx):
     import torch
     NB = 64

@@ -122,11 +122,12 @@ static int exchange_setup(mkzg_comm* m, uint64_t n_local, uint64_t n_global, uin
     *offset = off;
     memset(r32, 0, 32);
     if (m->rank == 0) {
-        if (getrandom(r32, 32, 0) != 32) return MKZG_ERR_HIP;
-        r32[0] &= 0x3f;
+        if (getrandom(r32, 32, 0) == 32) r32[0] &= 0x3f;
+        else memset(r32, 0xff, 32);                       // no randomness: say so to every rank THROUGH the broadcast (a rank that returned here would leave the others waiting in it)
     }
     rc = comm_broadcast32(m, r32);
     if (rc) return rc;
+    if (r32[0] == 0xff) return MKZG_ERR_HIP;
     // every rank sees the same sizes, so every rank refuses the same way -- after the broadcast, so that no rank is left waiting in it
     if (sum != n_global) {
         fprintf(stderr, "[mi355kzg] rank %d: the shards hold %llu items in all, the batch was announced as %llu: the index ranges would not tile it\n", m->rank,

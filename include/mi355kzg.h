@@ -191,7 +191,7 @@ typedef struct mkzg_comm mkzg_comm;
 int mkzg_comm_unique_id(uint8_t id128[128]);
 int mkzg_comm_init(mkzg_ctx* ctx, const uint8_t id128[128], int rank, int world, mkzg_comm** out);
 int mkzg_comm_from_nccl(mkzg_ctx* ctx, void* nccl_comm, int rank, int world, mkzg_comm** out);
-void mkzg_comm_free(mkzg_comm* comm);
+void mkzg_comm_free(mkzg_comm* comm);         /* no exchange may be in flight on it; before mkzg_ctx_free of its context */
 /* microseconds this rank spent in the three collectives of its last exchange (waiting for slower ranks included) */
 double mkzg_comm_last_exchange_us(mkzg_comm* comm);
 /* Context.VerifyBlobKZGProofBatch (reference verify.go:88-143) over the ranks: host pointers as in the reference ... */

@@ -2,6 +2,7 @@
 // tests/test_host_sha256.py: both compression functions (SHA extensions when the CPU has them, portable C) and the Fiat-Shamir
 // challenge of the host-pointer verifiers.
 #include "../../go-eth-kzg_amd/csrc/host_sha256.hpp"
+#include "../../go-eth-kzg_amd/csrc/host_copy.hpp"
 
 extern "C" {
 int shim_have_sha_ni() { return kzg::sha256_have_ni() ? 1 : 0; }
@@ -22,6 +23,8 @@ void shim_sha256_c(const uint8_t* data, size_t len, uint8_t out[32]) {
     for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16); out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i]; }
 }
 void shim_challenge(const uint8_t* blob, const uint8_t* commitment48, uint8_t z32[32]) { kzg::host_compute_challenge(z32, blob, commitment48); }
+// the gather's copy into a staging area (streaming stores when the destination is 32-byte aligned and the size a multiple of 128)
+void shim_copy_to_staging(uint8_t* dst, const uint8_t* src, size_t n) { kzg::copy_to_staging(dst, src, n); }
 // sixteen transcripts, one per AVX-512 lane (returns 0 when the CPU has no AVX-512: nothing written)
 int shim_challenge_x16(const uint8_t* blobs16 /* 16 x 131072 */, const uint8_t* cms16 /* 16 x 48 */, uint8_t* z16 /* 16 x 32 */) {
 #if defined(__x86_64__)

@@ -15,7 +15,8 @@ R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 @pytest.fixture(scope="module")
 def shim():
     from conftest import build_host_shim
-    L = C.CDLL(build_host_shim("sha", ("host_sha256.hpp",)))
+    L = C.CDLL(build_host_shim("sha", ("host_sha256.hpp", "host_copy.hpp")))
+    L.shim_copy_to_staging.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.shim_sha256.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
     L.shim_sha256_c.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
     L.shim_challenge.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
@@ -89,3 +90,20 @@ def test_challenge_sixteen_lanes_match_single(shim):
         pytest.skip("no AVX-512 on this CPU")
     for i in range(16):
         assert z.raw[32 * i:32 * i + 32] == _challenge(blobs[i], cms[i]), i
+
+
+def test_copy_to_staging_every_alignment(shim):
+    """copy_to_staging (host_copy.hpp: the gathers' copy into pinned staging) for aligned destinations and sizes (the streaming-store
+    path: blobs 131072 B, cells 2048 B), unaligned sources, and the shapes that fall back to memcpy (odd sizes, unaligned destinations);
+    guard bytes around the destination stay untouched"""
+    src_buf = (C.c_ubyte * (140000 + 64))(*[(i * 37 + 11) & 0xFF for i in range(140000 + 64)])
+    for n in (0, 1, 127, 128, 129, 2048, 2049, 4096, 131072):
+        for src_off in (0, 1, 13, 32):
+            for dst_off in (0, 32, 8, 1):
+                dst = (C.c_ubyte * (n + 256))(*([0xEE] * (n + 256)))
+                base = C.addressof(dst)
+                pad = (-base) % 64 + dst_off                  # a 64-byte aligned address plus the offset under test
+                shim.shim_copy_to_staging(base + pad, C.addressof(src_buf) + src_off, n)
+                got = bytes(dst)
+                assert got[pad:pad + n] == bytes(src_buf[src_off:src_off + n]), (n, src_off, dst_off)
+                assert set(got[:pad]) <= {0xEE} and set(got[pad + n:]) <= {0xEE}, (n, src_off, dst_off)

@@ -924,14 +924,18 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
     # shared by goroutines).  Each call works in its own lane; calls that find others in flight take the throughput shape (barycentric
     # evaluation, one stream per call) and share hash launches (api_verify.hip hash_round_join).
     K = args.verify_inflight
-    if world == 1 and not dist_on and K > 1:
+    if os.environ.get("BENCH_SHARE_GPU") and world > 1:
+        K = min(K, 4)                                    # test aid: all ranks on ONE GPU
+    if K > 1:
+        # at N > 1 every rank runs this leg on ITS OWN batches at the same time (a node verifying many batches: no exchange -- the one
+        # exchange step exists only where a single batch spans the GPUs, which is `single_call` / `strong_scaling`); the rates add up
         reps = max(12, args.verify_steps)                # long enough to leave the ramp-up of the first hash rounds behind
         errs = []
         # DISTINCT inputs: `--ring` sets of N (blob, commitment, proof) triples resident in HBM (8 x 134 MB: four times the Infinity
         # Cache), caller k verifies set k mod ring -- the algorithmic bytes of this leg really stream from HBM
         sets = [(d_blobs, d_cm, d_pr, d_bad)]
         for q in range(1, max(1, args.ring)):
-            sb = torch.from_numpy(fast_blobs(N, 5000 + q).reshape(-1)).cuda()
+            sb = torch.from_numpy(fast_blobs(N, 5000 + 97 * rank + q).reshape(-1)).cuda()
             sc = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
             sp = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
             assert ctx.blob_to_kzg_commitment_batch_device(sb.data_ptr(), N, sc.data_ptr(), d_st.data_ptr(), st) == 0
@@ -958,6 +962,8 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
             for trial in range(n_trials + 1):
                 ts = [threading.Thread(target=caller, args=(k,)) for k in range(K)]
                 torch.cuda.synchronize()
+                if dist_on:
+                    dist.barrier()                       # the ranks' trials run at the same time
                 t0, c0 = time.perf_counter(), time.process_time()
                 for t in ts:
                     t.start()
@@ -971,8 +977,14 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
         def leg(res):
             med = res[len(res) // 2]
             rate = K * (reps + 1) * N / med[0]
-            return {"blobs_per_s": round(rate, 1), "blobs_per_s_each_trial": [round(K * (reps + 1) * N / r[0], 1) for r in res],
-                    "ms_per_call_amortised": round(med[0] / (K * (reps + 1)) * 1e3, 3), "host_cpus_busy": round(med[1], 1)}
+            d = {"blobs_per_s": round(rate, 1), "blobs_per_s_each_trial": [round(K * (reps + 1) * N / r[0], 1) for r in res],
+                 "ms_per_call_amortised": round(med[0] / (K * (reps + 1)) * 1e3, 3), "host_cpus_busy": round(med[1], 1)}
+            if dist_on:                                  # whole job: the ranks' median rates added up
+                t = torch.tensor([rate], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                d["blobs_per_s_this_rank"] = d["blobs_per_s"]
+                d["blobs_per_s"] = round(float(t.item()), 1)
+            return d
 
         default = trials(3)                              # library default: host_wait -1 (a crowded context asks and sleeps)
         assert ctx.set_option("host_wait", 0) == 0
@@ -980,9 +992,9 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
         assert ctx.set_option("host_wait", -1) == 0
         assert not errs, errs[0]
         sus = leg(default)
-        calls_per_s = sus["blobs_per_s"] / N
+        calls_per_s = sus.get("blobs_per_s_this_rank", sus["blobs_per_s"]) / N
         sroof, svalu = sustained_roofline(TP_KINDS, "verify_tp", algo, calls_per_s, hw, pmc_valid_for_size=(N == 1024))
-        out["sustained"] = {"callers": K, "calls": K * (reps + 1), **sus, "host_wait": int(ctx.get_option("host_wait")), "cpu_share": int(ctx.get_option("cpu_share")),
+        out["sustained"] = {"callers": K, "callers_per_rank": K, "ranks": world, "calls": K * (reps + 1) * world, **sus, "host_wait": int(ctx.get_option("host_wait")), "cpu_share": int(ctx.get_option("cpu_share")),
                             "distinct_input_sets": len(sets), "input_bytes_resident": len(sets) * N * VERIFY_BYTES_PER_BLOB,
                             "polling_waits": {**leg(polling), "note": "option host_wait 0: every waiting caller polls in hipStreamSynchronize / hipEventSynchronize"},
                             "roofline": sroof, "valu": svalu,
@@ -991,7 +1003,7 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
                                     f"{len(sets)}; one priming trial, then the MEDIAN of three timed trials"}
         del sets
     out["value"] = out.get("sustained", {}).get("blobs_per_s", out["single_call"]["blobs_per_s"])
-    out["value_is"] = (f"sustained: {K} callers on one context" if "sustained" in out else
+    out["value_is"] = ((f"sustained: {K} callers on one context" + (f" per rank, {world} ranks on their own batches at the same time, rates added up" if dist_on else "")) if "sustained" in out else
                        ("one global batch sharded over the ranks, one call at a time" if dist_on else "single calls, one at a time"))
     return out
 

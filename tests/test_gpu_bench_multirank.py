@@ -44,6 +44,9 @@ def _check(d, n=2, cell_blobs=3):
     assert m["exchange_us"] > 0 and set(m["exchange_breakdown_us"]) == {"broadcast_r_32B", "all_gather_shard_sizes", "all_gather_records_512B"}
     v = d["verify_blob_kzg_proof_batch"]
     assert v["value"] > 0 and f"sharded x{n}" in v["single_call"]["parallelism"]
+    # the sustained leg runs on every rank at once on its own batches; the whole-job rate is the sum and is the leg's (and the line's) value
+    su = v["sustained"]
+    assert su["ranks"] == n and su["blobs_per_s"] >= su["blobs_per_s_this_rank"] > 0 and v["value"] == su["blobs_per_s"] == d["verify_metric"]["value"]
     assert v["strong_scaling"]["global_batch"] == 8192 and v["strong_scaling"]["per_rank"] == 8192 // n and v["strong_scaling"]["blobs_per_s"] > 0
     e = d["eip7594"]
     assert e["compute_cells_and_kzg_proofs"]["blobs_per_s_per_gpu"] > 0

@@ -566,6 +566,7 @@ static void ctx_destroy_one(mkzg_ctx* c) {
     c->hash_prev.reset();
     c->hash_prev2.reset();
     for (auto& hs : c->hash_stream) if (hs) (void)hipStreamDestroy(hs);
+    for (auto& vs : c->val_stream) if (vs) (void)hipStreamDestroy(vs);
     if (c->init_stream) (void)hipStreamDestroy(c->init_stream);
     delete c->pool;
     delete c;

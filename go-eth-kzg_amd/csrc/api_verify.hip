@@ -101,11 +101,26 @@ int draw_rlc_scalar(uint8_t r_le32[32]) { return getrandom(r_le32, 32, 0) == 32 
 // the round and launches ONE kernel over all its jobs on one of the context's two hash streams (rounds alternate, two are in flight)
 // -- streams of the lowest priority, so that no other stream of the process shares their queues.  Everyone then waits for the round on the host (the call is synchronous anyway; a device-side wait
 // would hold the call's own queue, and with it whatever else HIP mapped there) and carries on in its own stream.
-static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, uint32_t* d_zrows, hipEvent_t ready, std::shared_ptr<HashRound>* out) {
+// points (may be all null): the call's compressed commitments and proofs and where their affine rows and statuses go -- the round then
+// validates them too, in one launch over all its calls on a stream of its own beside the hash launch (both are chains the calls only
+// wait for; as launches in every call's own stream they held that stream's hardware queue)
+struct RoundPoints { const uint8_t* proofs; uint32_t* aff_c; uint32_t* aff_q; int* st_c; int* st_q; };
+static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, uint32_t* d_zrows, hipEvent_t ready, std::shared_ptr<HashRound>* out,
+                           const RoundPoints* pts = nullptr) {
     std::shared_ptr<HashRound> r, prev;
     bool leader = false;
     {
         std::unique_lock<std::mutex> lk(c->hash_mu);
+        for (auto& hs : c->val_stream) {
+            if (hs) continue;
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+#ifndef MKZG_VAL_PRIO
+#define MKZG_VAL_PRIO 0
+#endif
+            const int vprio = MKZG_VAL_PRIO == 2 ? greatest : MKZG_VAL_PRIO == 1 ? (least + greatest) / 2 : least;
+            if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, vprio) != hipSuccess) { hs = nullptr; (void)hipGetLastError(); return MKZG_ERR_HIP; }
+        }
         for (auto& hs : c->hash_stream) {
             if (hs) continue;
             int least = 0, greatest = 0;
@@ -128,6 +143,11 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
         r->jobs.commitments[j] = d_commitments;
         r->jobs.z_out[j] = d_z;
         r->jobs.zrows_out[j] = d_zrows;
+        if (pts) {
+            const int v = r->vjobs.count++;
+            r->vjobs.in_a[v] = d_commitments; r->vjobs.n_a[v] = n; r->vjobs.aff_a[v] = pts->aff_c; r->vjobs.st_a[v] = pts->st_c;
+            r->vjobs.in_b[v] = pts->proofs; r->vjobs.n_b[v] = n; r->vjobs.aff_b[v] = pts->aff_q; r->vjobs.st_b[v] = pts->st_q;
+        }
         r->jobs.n[j] = n;
         r->ready[j] = ready;
         if (leader && prev) c->hash_cv.wait(lk, [&] { return prev->launched; });
@@ -138,18 +158,29 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
             if (wait_sleeping(c)) (void)wait_event_sleeping(prev->done);
             else (void)hipEventSynchronize(prev->done);
         }
-        hipStream_t hs;
+        hipStream_t hs, vs;
         {
             std::lock_guard<std::mutex> g(c->hash_mu);
             c->hash_forming.reset();                                           // closed: later arrivals open the next round
             c->hash_prev2 = c->hash_prev;
             c->hash_prev = r;
+            vs = c->val_stream[c->hash_rounds & 1];
             hs = c->hash_stream[c->hash_rounds++ & 1];
         }
         int rc = MKZG_OK;
         if (hipEventCreateWithFlags(&r->done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { r->done = nullptr; rc = MKZG_ERR_HIP; }
         for (int j = 0; j < r->jobs.count && !rc; j++)
             if (r->ready[j] && hipStreamWaitEvent(hs, r->ready[j], 0) != hipSuccess) rc = MKZG_ERR_HIP;
+        if (!rc && r->vjobs.count) {
+            // the same calls' points on the validation stream (its previous launch belongs to the round two back: finished, see above)
+            if (hipEventCreateWithFlags(&r->done_val, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { r->done_val = nullptr; rc = MKZG_ERR_HIP; }
+            for (int j = 0; j < r->jobs.count && !rc; j++)
+                if (r->ready[j] && hipStreamWaitEvent(vs, r->ready[j], 0) != hipSuccess) rc = MKZG_ERR_HIP;
+            if (!rc) {
+                g1_validate_jobs_device(r->vjobs, vs);
+                if (hipGetLastError() != hipSuccess || hipEventRecord(r->done_val, vs) != hipSuccess) rc = MKZG_ERR_HIP;
+            }
+        }
         if (!rc) {
             challenge_jobs_device(r->jobs, hs);
             if (hipGetLastError() != hipSuccess || hipEventRecord(r->done, hs) != hipSuccess) rc = MKZG_ERR_HIP;
@@ -291,7 +322,13 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     //    context with eight calls in flight had two of them progressing; one stream per call keeps one queue per call)
     hipStream_t s2 = tp ? s : lane_side_stream(L, s);
     const bool s_idle = lane_fork(L, s, s2);
-    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
+    // (throughput shape with the challenges still to hash: the ROUND validates the points of all its calls in one launch beside the hash)
+#ifndef MKZG_TP_ROUND_VALIDATE
+#define MKZG_TP_ROUND_VALIDATE 0            // measured and rejected (round 4, tools/ab_verify.py, one box, alternating): 1.74-1.75 M blobs/s against 1.89-1.93 M with the
+#endif                                      // validation in every call's own stream -- see DESIGN.md Appendix A; kept as a build flag
+    const bool round_validates = MKZG_TP_ROUND_VALIDATE && tp && d_blobs && !d_z32 && MKZG_TP_VALIDATE_MODE == 3;
+    if (!round_validates)
+        KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
     if (d_blobs) {
         //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
         //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions;
@@ -322,16 +359,22 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             std::shared_ptr<HashRound> round;                                // the hash of this call and of whoever else is waiting for one
             CPU_LAP(0);
             // (the round's launch also leaves what the evaluation needs of each z alone: L->d_v_zrows)
-            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->d_v_zrows, s_idle ? nullptr : L->ev_fork, &round);   // ev_fork: recorded on s before any of this call's kernels
+            const RoundPoints rp{d_proofs, aff_c, aff_q, st_c, st_q};
+            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->d_v_zrows, s_idle ? nullptr : L->ev_fork, &round, round_validates ? &rp : nullptr);   // ev_fork: recorded on s before any of this call's kernels
             CPU_LAP(1);
             if (round && round->done) {                                      // on the host: a device-side wait would hold the call's queue
                 int wr = MKZG_OK;
                 if (wait_sleeping(c)) wr = wait_event_sleeping(round->done);
                 else if (hipEventSynchronize(round->done) != hipSuccess) { (void)hipGetLastError(); wr = MKZG_ERR_HIP; }
+                if (!wr && round->done_val) {                            // ... and its points (the shorter chain: usually long finished)
+                    if (wait_sleeping(c)) wr = wait_event_sleeping(round->done_val);
+                    else if (hipEventSynchronize(round->done_val) != hipSuccess) { (void)hipGetLastError(); wr = MKZG_ERR_HIP; }
+                }
                 if (wr) {
-                    // the round's kernel may still be writing this lane's challenges: nobody gets the lane before both hash streams are idle
+                    // the round's kernels may still be writing this lane's challenges and rows: nobody gets the lane before the rounds' streams are idle
                     tl_hip_error = true;
                     for (auto& hs : c->hash_stream) if (hs) (void)hipStreamSynchronize(hs);
+                    for (auto& vs : c->val_stream) if (vs) (void)hipStreamSynchronize(vs);
                     (void)hipGetLastError();
                     return wr;
                 }

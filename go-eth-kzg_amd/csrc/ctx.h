@@ -171,11 +171,13 @@ struct Lane {
 // One launch of the Fiat-Shamir hash kernel for all the calls that were waiting for one (api_verify.hip hash_round_join)
 struct HashRound {
     kzg::ShaJobs jobs{};
+    kzg::ValJobs vjobs{};                       // the same calls' points: decoding + r-torsion test in one launch beside the hash (its own stream)
     hipEvent_t ready[kzg::SHA_MAX_JOBS] = {};   // per job: its inputs are ready on the call's stream
     hipEvent_t done = nullptr;                  // the launch has finished
+    hipEvent_t done_val = nullptr;              // the validation launch has finished
     bool launched = false;
     int rc = 0;
-    ~HashRound() { if (done) (void)hipEventDestroy(done); }
+    ~HashRound() { if (done) (void)hipEventDestroy(done); if (done_val) (void)hipEventDestroy(done_val); }
 };
 
 struct mkzg_ctx {
@@ -194,6 +196,7 @@ struct mkzg_ctx {
     std::condition_variable hash_cv;
     std::shared_ptr<HashRound> hash_forming, hash_prev, hash_prev2;   // the round being filled, the last two launched
     hipStream_t hash_stream[2] = {nullptr, nullptr};                    // rounds alternate between them: two in flight
+    hipStream_t val_stream[2] = {nullptr, nullptr};                     // the rounds' point-validation launches, beside the hash launches
     uint64_t hash_rounds = 0;
     std::mutex mu;                         // lane hand-over only
     std::condition_variable cv;

@@ -858,8 +858,9 @@ __device__ __forceinline__ bool in_subgroup_yfree_quad(const fp_t& px, const fp_
     return G1D::yfree_verdict(Q, px, rhs, rhs2, beta);
 }
 static const int VAL_PB = 16;                               // points per block of the r-torsion test (a quad of lanes each)
-__global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
-                                                     const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode) {
+// the body for one workgroup: block `blk` of one (points a, points b) job
+__device__ __forceinline__ void g1_validate_block(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
+                                                  const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode, int blk) {
     __shared__ int sub_ok[64];                              // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
     // modes: 0 decoding + quad test (128 threads), 1 decoding only, 2 quad test only, 3 decoding + one-lane test (128 threads), 4 one-lane
     // test only (64 threads: half the instructions of the quad test and a quarter of its wavefronts, a chain 1.7x as long -- for calls long
@@ -872,7 +873,7 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
     // its own (mode 1) or beside the wide test (mode 3), the block's 16 (copied four times over the wavefront) beside the quad test
     const int per_block = (mode == 1 || wide) ? 64 : VAL_PB;
     const int slot = wide ? lane : (role == 1 ? lane >> 2 : (mode == 1 ? lane : lane & (VAL_PB - 1)));
-    int i = blockIdx.x * per_block + slot;
+    int i = blk * per_block + slot;
     const bool live = i < total && (wide ? true : (role == 1 ? (lane & 3) == 0 : (mode == 1 || lane < VAL_PB)));
     if (i >= total) i %= total;
     const uint8_t* in48 = in48_a;
@@ -918,6 +919,19 @@ __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__
         if (rc == 0 && !p.inf && sub_ok[slot] == 0) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
         st[i] = rc;
     }
+}
+__global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
+                                                     const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode) {
+    g1_validate_block(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, mode, (int)blockIdx.x);
+}
+// the points of SEVERAL calls in one launch (api_verify.hip, the rounds of the throughput shape): decoding + one-lane r-torsion test (mode 3)
+// is a 1.3 ms chain on one wavefront per 64 points -- 64 wavefronts for a call of 1024 proofs -- and as a launch of its own in every
+// call's stream it held that stream's hardware queue (shared with three other callers' streams) for a third of the call's kernel time
+__global__ void __launch_bounds__(128) k_g1_validate_jobs(ValJobs jobs) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.first_block[j + 1]) j++;
+    g1_validate_block(jobs.in_a[j], jobs.n_a[j], jobs.aff_a[j], jobs.st_a[j], jobs.in_b[j], jobs.n_b[j], jobs.aff_b[j], jobs.st_b[j], 3, (int)blockIdx.x - jobs.first_block[j]);
 }
 
 
@@ -1425,6 +1439,14 @@ void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, in
     const int per_block = (mode == 1 || mode == 3 || mode == 4) ? 64 : VAL_PB;
     if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + per_block - 1) / per_block), dim3((mode == 0 || mode == 3) ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b,
                                   d_st_b, mode);
+}
+void g1_validate_jobs_device(ValJobs& jobs, hipStream_t s) {
+    int blocks = 0;
+    for (int j = 0; j < jobs.count; j++) {
+        jobs.first_block[j] = blocks;
+        blocks += (jobs.n_a[j] + jobs.n_b[j] + 63) / 64;
+    }
+    if (blocks > 0) hipLaunchKernelGGL(k_g1_validate_jobs, dim3(blocks), dim3(128), 0, s, jobs);
 }
 void rlc_scalars_device(const uint32_t* h_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         int mode, hipStream_t s) {

@@ -18,6 +18,7 @@
 #include <vector>
 #include "host_field.hpp"
 #include "host_pool.hpp"
+#include "host_cyclo_ifma.hpp"
 
 namespace kzg {
 
@@ -440,8 +441,105 @@ inline void cyclotomic_sqr(Fp12& r, const Fp12& a) {
     fp2::add(z5, t3, r5); fp2::add(z5, z5, z5); fp2::add(z5, z5, t3);       // 3 t3 + 2 z5
     r.c0.c0 = z0; r.c0.c1 = z4; r.c0.c2 = z3; r.c1.c0 = z2; r.c1.c1 = z1; r.c1.c2 = z5;
 }
-// a^|x| for a in the cyclotomic subgroup
+// a^|x| for a in the cyclotomic subgroup, scalar tower (also the reference the IFMA chain below is tested against)
+inline void exp_by_x_abs_scalar(Fp12& r, const Fp12& a) {
+    Fp12 acc = a;
+    for (int i = 62; i >= 0; i--) {
+        cyclotomic_sqr(acc, acc);
+        if ((BLS_X_ABS >> i) & 1) fp12::mul(acc, acc, a);
+    }
+    r = acc;
+}
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+// The same on AVX-512 IFMA (host_cyclo_ifma.hpp): the chain of 63 squarings on eight-lane 52-bit-limb arithmetic, the six powers
+// a^(2^k), k = 16, 48, 57, 60, 62, 63 (the set bits of |x|) handed back to the scalar tower and multiplied there.
+namespace ifma {
+// canonical 6 x 64-bit Montgomery (R = 2^384) words <-> 8 limbs of 52 bits
+static inline void to52(uint64_t out[8], const uint64_t w[6]) {
+    const uint64_t M = (1ull << 52) - 1;
+    out[0] = w[0] & M;
+    out[1] = ((w[0] >> 52) | (w[1] << 12)) & M;
+    out[2] = ((w[1] >> 40) | (w[2] << 24)) & M;
+    out[3] = ((w[2] >> 28) | (w[3] << 36)) & M;
+    out[4] = ((w[3] >> 16) | (w[4] << 48)) & M;
+    out[5] = (w[4] >> 4) & M;
+    out[6] = ((w[4] >> 56) | (w[5] << 8)) & M;
+    out[7] = w[5] >> 44;
+}
+static inline void from52(uint64_t w[6], const uint64_t l[8]) {          // value below 2^384
+    w[0] = l[0] | (l[1] << 52);
+    w[1] = (l[1] >> 12) | (l[2] << 40);
+    w[2] = (l[2] >> 24) | (l[3] << 28);
+    w[3] = (l[3] >> 36) | (l[4] << 16);
+    w[4] = (l[4] >> 48) | (l[5] << 4) | (l[6] << 56);
+    w[5] = (l[6] >> 8) | (l[7] << 44);
+}
+// the Fp4 pairs of the Granger-Scott formula: (r0, r1), (r2, r3), (r4, r5) = (c0.c0, c1.c1), (c1.c0, c0.c2), (c0.c1, c1.c2)
+static inline Fp2* pair_x(Fp12& a, int k) { return k == 0 ? &a.c0.c0 : (k == 1 ? &a.c1.c0 : &a.c0.c1); }
+static inline Fp2* pair_y(Fp12& a, int k) { return k == 0 ? &a.c1.c1 : (k == 1 ? &a.c0.c2 : &a.c1.c2); }
+__attribute__((target("avx512f,avx512ifma"))) static inline void load_state(V8 V[3], const Fp12& a_in) {
+    Fp12 a = a_in;
+    V8 c448;
+    splat(c448, C448);
+    for (int k = 0; k < 3; k++) {
+        alignas(64) uint64_t buf[8][8];
+        memset(buf, 0, sizeof buf);
+        const fe* co[4] = {&pair_x(a, k)->c0, &pair_x(a, k)->c1, &pair_y(a, k)->c0, &pair_y(a, k)->c1};
+        for (int lane = 0; lane < 4; lane++) {
+            uint64_t l[8];
+            to52(l, co[lane]->l);
+            for (int q = 0; q < 8; q++) buf[q][lane] = l[q];
+        }
+        V8 raw;
+        for (int q = 0; q < 8; q++) raw.l[q] = _mm512_load_si512((const void*)buf[q]);
+        mul8(V[k], raw, c448);                      // v 2^384 -> v 2^416 (and below 2p)
+    }
+}
+__attribute__((target("avx512f,avx512ifma"))) static inline void store_state(Fp12& out, const V8 V[3]) {
+    V8 c384;
+    splat(c384, C384);
+    for (int k = 0; k < 3; k++) {
+        V8 w;
+        mul8(w, V[k], c384);                        // v 2^416 -> v 2^384, below 2p
+        alignas(64) uint64_t buf[8][8];
+        for (int q = 0; q < 8; q++) _mm512_store_si512((void*)buf[q], w.l[q]);
+        fe* co[4] = {&pair_x(out, k)->c0, &pair_x(out, k)->c1, &pair_y(out, k)->c0, &pair_y(out, k)->c1};
+        for (int lane = 0; lane < 4; lane++) {
+            uint64_t l[8], t[6];
+            for (int q = 0; q < 8; q++) l[q] = buf[q][lane];
+            from52(t, l);
+            if (HostFp::geq_mod(t)) HostFp::sub_raw(t, t, HostFp::P::MOD);
+            memcpy(co[lane]->l, t, 48);
+        }
+    }
+}
+// n cyclotomic squarings of a (tests)
+__attribute__((target("avx512f,avx512ifma"))) static inline void cyclo_sqr_n(Fp12& r, const Fp12& a, int n) {
+    V8 V[3];
+    load_state(V, a);
+    for (int i = 0; i < n; i++) cyclo_sqr(V[0], V[1], V[2]);
+    store_state(r, V);
+}
+__attribute__((target("avx512f,avx512ifma"))) static inline void exp_by_x_abs(Fp12& r, const Fp12& a) {
+    V8 V[3];
+    load_state(V, a);
+    bool first = true;
+    for (int s = 1; s <= 63; s++) {
+        cyclo_sqr(V[0], V[1], V[2]);
+        if ((BLS_X_ABS >> s) & 1) {
+            Fp12 snap;
+            store_state(snap, V);
+            if (first) { r = snap; first = false; }
+            else fp12::mul(r, r, snap);
+        }
+    }
+}
+}  // namespace ifma
+#endif
 inline void exp_by_x_abs(Fp12& r, const Fp12& a) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    if (ifma::available()) { ifma::exp_by_x_abs(r, a); return; }
+#endif
     Fp12 acc = a;
     for (int i = 62; i >= 0; i--) {
         cyclotomic_sqr(acc, acc);

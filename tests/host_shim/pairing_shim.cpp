@@ -22,6 +22,51 @@ int shim_pairing_check(const uint8_t* p48, const uint8_t* q96, int n) {
     }
     return pairing_check_prepared(ps.data(), qp.data(), n) ? 1 : 0;
 }
+// The AVX-512 IFMA squaring chain (host_cyclo_ifma.hpp) against the scalar tower on elements of the cyclotomic subgroup: 1, 2, 3, 16, 63
+// squarings in a row (every squaring's output is the next one's loose input) and the whole a^|x|.  Returns the number of mismatches,
+// -1 on a decoding error, -2 when the CPU has no AVX-512 IFMA (nothing to compare).
+int shim_ifma_chain_check(const uint8_t* p48, const uint8_t* q96) {
+#if defined(__x86_64__)
+    if (!ifma::available()) return -2;
+    G1AffH P;
+    G2Aff Q;
+    if (!g1h_decompress(P, p48) || !g2_decompress(Q, q96)) return -1;
+    G2Prepared pr;
+    g2_prepare(pr, Q);
+    Fp12 f, t, g;
+    miller_loop_prepared(f, P, pr);
+    fp12::conj(t, f);
+    fp12::inv(g, f);
+    fp12::mul(f, t, g);
+    frobenius(t, f);
+    frobenius(t, t);
+    fp12::mul(f, t, f);                       // cyclotomic now
+    int bad = 0;
+    auto same = [](const Fp12& a, const Fp12& b) { return fp6::eq(a.c0, b.c0) && fp6::eq(a.c1, b.c1); };
+    for (int round = 0; round < 6; round++) {
+        for (int n : {1, 2, 3, 16, 63}) {
+            Fp12 a = f, b;
+            for (int i = 0; i < n; i++) cyclotomic_sqr(a, a);
+            ifma::cyclo_sqr_n(b, f, n);
+            if (!same(a, b)) bad++;
+        }
+        Fp12 a, b;
+        exp_by_x_abs_scalar(a, f);
+        ifma::exp_by_x_abs(b, f);
+        if (!same(a, b)) bad += 100;
+        cyclotomic_sqr(t, f);
+        fp12::mul(f, t, f);                   // another element of the subgroup: f^3
+    }
+    // the identity and an element with zero coefficients
+    Fp12 one, r1;
+    fp12::one(one);
+    ifma::cyclo_sqr_n(r1, one, 5);
+    if (!fp12::is_one(r1)) bad += 1000;
+    return bad;
+#else
+    return -2;
+#endif
+}
 // cyclotomic_sqr against the general squaring on an element of the cyclotomic subgroup (f^((p^6-1)(p^2+1)) of a Miller-loop
 // value) and on its powers; returns the number of mismatches.  Also checks that it is NOT a squaring outside the subgroup
 // (so the test would notice if the check were vacuous).

@@ -18,7 +18,7 @@ X = -0xD201000000010000
 @pytest.fixture(scope="module")
 def shim():
     from conftest import build_host_shim
-    return C.CDLL(build_host_shim("pairing", ("host_pairing.hpp", "host_field.hpp", "host_g1.hpp", "host_pool.hpp", "g1.hpp", "mont29.hpp", "constants29.h")))
+    return C.CDLL(build_host_shim("pairing", ("host_pairing.hpp", "host_cyclo_ifma.hpp", "host_field.hpp", "host_g1.hpp", "host_pool.hpp", "g1.hpp", "mont29.hpp", "constants29.h")))
 
 
 @pytest.fixture(scope="module")
@@ -109,3 +109,18 @@ def test_hostfp_mul_adx_matches_portable(shim):
     if bad < 0:
         pytest.skip("this CPU has no BMI2 + ADX")
     assert bad == 0
+
+
+def test_ifma_squaring_chain_matches_scalar_tower(shim, setup):
+    """the AVX-512 IFMA cyclotomic squaring chain of the final exponentiation (host_cyclo_ifma.hpp: eight 52-bit-limb Montgomery
+    multiplications per instruction stream, loose values, lane permutes for the Fp4 squarings) against the scalar Granger-Scott squaring:
+    1, 2, 3, 16 and 63 squarings in a row and the whole a^|x| on several elements of the cyclotomic subgroup, for several pairs"""
+    g1, g2 = setup
+    ran = 0
+    for i, j in ((1, 0), (5, 3), (0, 7), (9, 9)):
+        rc = shim.shim_ifma_chain_check(g1[i], g2[j])
+        if rc == -2:
+            pytest.skip("no AVX-512 IFMA on this CPU")
+        assert rc == 0, (i, j, rc)
+        ran += 1
+    assert ran == 4

@@ -137,20 +137,15 @@ __device__ __forceinline__ void sha_load_block(uint32_t w[16], int k, const uint
     }
 }
 constexpr int SHA_NBLOCKS = 2050;
-constexpr int EVT_ROWS = 14;       // what k_blob_eval_tree needs of z alone, 12-word rows: z^(2^0..2^11), z^4096 - 1, 1 / (z^4096 - 1)
-// the rows of one challenge (one lane per blob): twelve squarings, one inversion -- a 0.3-0.4 ms chain for a lone wavefront
+constexpr int EVT_ROWS = 12;       // what k_blob_eval_tree needs of z alone, 12-word rows: z^(2^0..2^11)
+// the rows of one challenge (one lane per blob): eleven squarings
 __device__ __forceinline__ void eval_prep_rows(const fr_t& z, uint32_t* __restrict__ rows, bool store) {
-    fr_t zl = z, one, rootn, inv;
+    fr_t zl = z;
 #pragma unroll 1
     for (int l = 0; l < 12; l++) {
         if (store) store_fr12(rows + l * 12, zl);
-        FrC::mul(zl, zl, zl);
+        if (l < 11) FrC::mul(zl, zl, zl);
     }
-    Fr::set_one(one);
-    FrC::sub(rootn, zl, one);
-    if (store) store_fr12(rows + 12 * 12, rootn);
-    fr_inv_n(inv, rootn);                                   // 0 -> 0: z in the domain, the evaluation kernel does not use it then
-    if (store) store_fr12(rows + 13 * 12, inv);
 }
 // The consumer splits every round over a PAIR of lanes, mirror images within a row of 16 (lane i and lane 15 - i): the "E" lane
 // (lanes 0..7 of the row: DPP banks 0, 1) holds (e, f, g, h), the "A" lane (banks 2, 3) holds (a, b, c, d), and both execute the SAME
@@ -416,20 +411,27 @@ __device__ __forceinline__ void block_sum_fr(fr_t& v, uint32_t* sh /* BT*9 words
     __syncthreads();
 }
 
-// y_b = f_b(z_b) with the batch inversion of domain.go:193-235 run DOWN THE PRODUCT TREE OF THE DOMAIN (round 3; the throughput shape
-// of the blob verifier, where this kernel was 53 % of a call's instructions).  In bit-reversed order the aligned block of 2^L positions
-// j 2^L .. (j + 1) 2^L - 1 is a coset g <zeta> of the 2^L-th roots of unity with g^(2^L) = roots_brp[j], so the product of its
-// (z - w_p) is   N(L, j) = z^(2^L) - roots_brp[j]   -- every node of the tree a subtraction, the root z^4096 - 1.  Montgomery's trick
-// pays a multiplication per element for the prefix products, an inversion per lane and two more on the way back; here the up-pass is
-// free, ONE inversion per blob (the root) serves all 4096 leaves, and the way down costs a multiplication per node:
-//   1/N(L-1, 2j) = 1/N(L, j) * N(L-1, 2j+1),   1/N(L-1, 2j+1) = 1/N(L, j) * N(L-1, 2j).
-// A lane owns the 32 leaves of one level-5 node: 7 multiplications from the root to it (redundant across lanes), 62 inside (depth
-// first, six live values), 12 squarings for the powers of z: 2.5 multiplications per element + the one with f_i, where the per-lane
-// Montgomery trick took 4 and a divsteps inversion per 32 elements.  One pass over the blob (canonical check included).
-// What depends on z alone comes from a small kernel ahead (one lane per blob): the powers z^(2^L), L = 0..11, z^4096 - 1 and its inverse
-// -- computed by every lane of the evaluation kernel they were 29 % of its instructions (the inversion alone 21 %: a wavefront pays for
-// it whether one lane needs it or all).  Rows of 12 words: EVT_ROWS per blob.
-constexpr int EVT_T = 128, EVT_LOG = 5, EVT_PER = 1 << EVT_LOG;          // 128 lanes x 32 leaves = 4096
+// y_b = f_b(z_b), EvaluateLagrangePolynomial of domain.go:193-235, as the NUMERATOR TREE of the barycentric formula -- no inversion, no
+// special case for z in the domain.  With the blob in bit-reversed order the aligned block of 2^L positions j 2^L .. (j + 1) 2^L - 1 is a
+// coset g <zeta> of the 2^L-th roots of unity with g^(2^L) = roots_brp[j], so the product of its (z - w_p) is
+//     N(L, j) = z^(2^L) - roots_brp[j]                   (and roots_brp[2j + 1] = -roots_brp[2j]).
+// The barycentric sum over one block, cleared of its denominators,
+//     S(L, j) = sum_{p in block} f_p w_p prod_{q in block, q != p} (z - w_q),
+// obeys  S(L, j) = S(L-1, 2j) N(L-1, 2j+1) + S(L-1, 2j+1) N(L-1, 2j) = S_left (Z + c) + S_right (Z - c)   with Z = z^(2^(L-1)), c = roots_brp[2j]:
+// TWO products under ONE Montgomery reduction per node (Fr::mul2), and for a pair of leaves  S(1, j) = w [ z (f_0 - f_1) + w (f_0 + f_1) ],
+// w = roots_brp[2j]: three products, two reductions.  The root gives the value directly,
+//     f(z) = (z^4096 - 1) / 4096 * sum_p f_p w_p / (z - w_p) = S(12, 0) / 4096
+// -- a polynomial identity, so z = w_k needs no branch (every term but the k-th vanishes; domain.go:204-207 is the same value).
+// 2.5 products and 1.5 reductions per element = 337 multiply-adds, against 3.5 full multiplications = 604 for the inverses run down the
+// same tree (round 3: 1 / N(L-1, 2j) = 1 / N(L, j) * N(L-1, 2j+1), then f_p / (z - w_p) per leaf) and an inversion per blob ahead of it.
+// The f_p stay PLAIN integers (no conversion: a plain value times a Montgomery one is plain), every S is plain and loose (< 1.1 r), the
+// canonical check of the blob's words rides along.  A lane owns the 2^LOG leaves of one level-LOG node (depth first, rolled: every
+// level's code exists once), the levels above go through LDS with half of the lanes leaving at each.
+// What depends on z alone comes from the hash launch (or a small kernel ahead): the powers z^(2^L), L = 0..11, rows of 12 words.
+#ifndef MKZG_EVT_LOG
+#define MKZG_EVT_LOG 5
+#endif
+constexpr int EVT_LOG = MKZG_EVT_LOG;          // leaves per lane = 2^EVT_LOG, lanes per blob = 4096 >> EVT_LOG
 __global__ void __launch_bounds__(64) k_blob_eval_prep(const uint32_t* __restrict__ z_in, int n, uint32_t* __restrict__ zrows) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n) return;
@@ -480,134 +482,108 @@ __device__ __forceinline__ void rlc_one_blob(const RlcOut& o, int b, const fr_t&
 #pragma unroll
     for (int q = 0; q < 8; q++) o.ry[(size_t)b * 8 + q] = w[q];
 }
-__global__ void __launch_bounds__(EVT_T) k_blob_eval_tree(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ zrows, const uint32_t* __restrict__ roots_brp,
-                                                         uint32_t* __restrict__ y_out, int* __restrict__ status, const RlcOut rlc) {
-    __shared__ uint32_t sh[EVT_T * 9];
-    __shared__ int sh_found;
+template <int LOG> struct EvtCfg { static constexpr int T = 4096 >> LOG; };
+struct EvtCtx {
+    const uint8_t* blob;
+    const uint32_t* roots_brp;
+    const uint32_t* rows;           // z^(2^L), uniform over the workgroup
+    bool bad;
+};
+// S(L, node) from its two children: Z = z^(2^(L-1)) (row L - 1), c = roots_brp[2 node]
+template <int L>
+__device__ __forceinline__ void evt_combine(fr_t& out, fr_t& sl, fr_t& sr, int node, const EvtCtx& cx) {
+    fr_t Z, c, zp, zm;
+    load_fr12(Z, cx.rows + (L - 1) * 12);
+    load_fr12(c, cx.roots_brp + (size_t)(2 * node) * 12);
+    Fr::add(zp, Z, c);                                      // < 2 r
+    Fr::sub<0>(zm, Z, c);                                   // Z - c + r < 2 r
+    Fr::opaque(sl);
+    Fr::opaque(sr);
+    Fr::mul2(out, sl, zp, sr, zm);                          // < (2 * 1.1 r * 2 r) / R + r < 1.1 r   (r / R = 2^-6.1)
+}
+template <int L>
+__device__ __forceinline__ void evt_subtree(fr_t& out, int node, EvtCtx& cx) {
+    if constexpr (L == 1) {
+        const int p0 = 2 * node;
+        uint32_t w0[8], w1[8];
+        load_be32_words(w0, cx.blob + (size_t)p0 * 32);
+        load_be32_words(w1, cx.blob + (size_t)p0 * 32 + 32);
+        // canonical check: the top word decides for all but 2^-31 of the canonical values
+        if (w0[7] >= FrParams::MOD32[7]) cx.bad |= Fr::words32_geq_mod(w0);
+        if (w1[7] >= FrParams::MOD32[7]) cx.bad |= Fr::words32_geq_mod(w1);
+        fr_t f0, f1, em, ep, w, z, tt;
+        Fr::from_words32(f0, w0);                           // plain; a non-canonical word fails the call, whatever it adds here
+        Fr::from_words32(f1, w1);
+        Fr::sub<0>(em, f0, f1);                             // f_0 - f_1 + r
+        Fr::add(ep, f0, f1);
+        load_fr12(w, cx.roots_brp + (size_t)p0 * 12);
+        load_fr12(z, cx.rows);
+        Fr::mul2(tt, em, z, ep, w);                         // z (f_0 - f_1) + w (f_0 + f_1), plain, < 1.1 r
+        Fr::mul(out, tt, w);
+    } else {
+        fr_t sl, sr;
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            fr_t v;
+            evt_subtree<L - 1>(v, 2 * node + c, cx);
+            if (c == 0) sl = v;
+            else sr = v;
+        }
+        evt_combine<L>(out, sl, sr, node, cx);
+    }
+}
+template <int LOG>
+__global__ void __launch_bounds__(4096 >> LOG) k_blob_eval_tree(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ zrows, const uint32_t* __restrict__ roots_brp,
+                                                               uint32_t* __restrict__ y_out, int* __restrict__ status, const RlcOut rlc) {
+    constexpr int T = 4096 >> LOG;
+    __shared__ uint32_t sh[T * 9];
     __shared__ int sh_bad;
     const int b = blockIdx.x, t = threadIdx.x;
-    const uint8_t* blob = blobs + (size_t)b * 131072;
-    if (t == 0) { sh_found = -1; sh_bad = 0; }
+    if (t == 0) sh_bad = 0;
+    EvtCtx cx;
+    cx.blob = blobs + (size_t)b * 131072;
+    cx.roots_brp = roots_brp;
+    cx.rows = zrows + (size_t)b * EVT_ROWS * 12;
+    cx.bad = false;
+    fr_t s;
+    evt_subtree<LOG>(s, t, cx);
+    __syncthreads();                                        // sh_bad = 0 is out
+    if (cx.bad) sh_bad = 1;
+    // the levels above the lanes: after the step of level L the lanes whose low L - LOG bits are zero hold S(L, t >> (L - LOG))
+#pragma unroll
+    for (int q = 0; q < 9; q++) sh[q * T + t] = s.l[q];
     __syncthreads();
-    const uint32_t* rows = zrows + (size_t)b * EVT_ROWS * 12;
-    fr_t zp[EVT_LOG];                                       // z^(2^L) for the levels inside a lane's subtree
-#pragma unroll
-    for (int l = 0; l < EVT_LOG; l++) load_fr12(zp[l], rows + l * 12);
-    // the levels above: the product of this lane's siblings from level 5 up to level 11 (its way down from the root, in any order)
-    fr_t sibs, rootn;
-    Fr::set_one(sibs);
 #pragma unroll 1
-    for (int l = EVT_LOG; l < 12; l++) {
-        const int js = (t >> (l - EVT_LOG)) ^ 1;            // the sibling of this lane's node at level l
-        fr_t r, zl, nsib;
-        load_fr12(r, roots_brp + (size_t)js * 12);
-        load_fr12(zl, rows + l * 12);
-        FrC::sub(nsib, zl, r);
-        FrC::mul(sibs, sibs, nsib);
-    }
-    load_fr12(rootn, rows + 12 * 12);                       // z^4096 - 1
-    if (Fr::limbs_all_zero(rootn)) {
-        // z is a point of the domain (uniform over the block): the value is the corresponding evaluation (domain.go:204-207), once the
-        // blob has passed the canonical check
-        bool bad = false;
-        int found = -1;
-        for (int q = 0; q < EVT_PER; q++) {
-            const int p = t * EVT_PER + q;
-            uint32_t w[8];
-            load_be32_words(w, blob + (size_t)p * 32);
-            bad |= Fr::words32_geq_mod(w);
-            fr_t wi, d;
-            load_fr12(wi, roots_brp + (size_t)p * 12);
-            FrC::sub(d, zp[0], wi);
-            if (Fr::limbs_all_zero(d)) found = p;
+    for (int L = LOG + 1; L <= 12; L++) {
+        const int step = 1 << (L - 1 - LOG);
+        if ((t & (2 * step - 1)) == 0) {
+            fr_t sr, Z, c, zp, zm;
+#pragma unroll
+            for (int q = 0; q < 9; q++) sr.l[q] = sh[q * T + t + step];
+            load_fr12(Z, cx.rows + (L - 1) * 12);
+            load_fr12(c, roots_brp + (size_t)(2 * (t >> (L - LOG))) * 12);
+            Fr::add(zp, Z, c);
+            Fr::sub<0>(zm, Z, c);
+            Fr::opaque(s);
+            Fr::mul2(s, s, zp, sr, zm);
+#pragma unroll
+            for (int q = 0; q < 9; q++) sh[q * T + t] = s.l[q];
         }
-        if (bad) sh_bad = 1;
-        if (found >= 0) sh_found = found;
         __syncthreads();
-        if (t == 0) {
-            status[b] = sh_bad ? MKZG_ERR_NON_CANONICAL_SCALAR : 0;
-            if (!sh_bad && sh_found >= 0) {
-                uint32_t w[8];
-                load_be32_words(w, blob + (size_t)sh_found * 32);
-                fr_t f;
-                fr_from_words(f, w);
-                store_fr12(y_out + (size_t)b * 12, f);
-                if (rlc.s1) rlc_one_blob(rlc, b, zp[0], f);
-            }
-        }
-        return;
     }
-    // 1 / N(5, t) = the root's inverse times the siblings on the way down
-    fr_t inv[EVT_LOG + 1];
-    load_fr12(inv[EVT_LOG], rows + 13 * 12);
-    FrC::mul(inv[EVT_LOG], inv[EVT_LOG], sibs);
-    // depth first over the lane's 32 leaves: five nested two-way loops, one multiplication by the sibling's node value per step down
-    // (rolled: every level's code exists once, the six live inverses keep their registers)
-    fr_t s1, s2;
-    Fr::set_zero(s1);
-    Fr::set_zero(s2);
-    bool bad = false;
-    auto down = [&](fr_t& child, const fr_t& parent, int level, int node) {     // 1/N(level, node) from its parent's inverse
-        fr_t r, nsib;
-        load_fr12(r, roots_brp + (size_t)(node ^ 1) * 12);
-        FrC::sub(nsib, zp[level], r);
-        FrC::mul(child, parent, nsib);
-    };
-    const int n5 = t;
-#pragma unroll 1
-    for (int a = 0; a < 2; a++) {
-        const int n4 = 2 * n5 + a;
-        down(inv[4], inv[5], 4, n4);
-#pragma unroll 1
-        for (int c3 = 0; c3 < 2; c3++) {
-            const int n3 = 2 * n4 + c3;
-            down(inv[3], inv[4], 3, n3);
-#pragma unroll 1
-            for (int c2 = 0; c2 < 2; c2++) {
-                const int n2 = 2 * n3 + c2;
-                down(inv[2], inv[3], 2, n2);
-#pragma unroll 1
-                for (int c1 = 0; c1 < 2; c1++) {
-                    const int n1 = 2 * n2 + c1;
-                    down(inv[1], inv[2], 1, n1);
-#pragma unroll
-                    for (int c0 = 0; c0 < 2; c0++) {
-                        const int p = 2 * n1 + c0;
-                        down(inv[0], inv[1], 0, p);
-                        uint32_t w[8];
-                        load_be32_words(w, blob + (size_t)p * 32);
-                        bad |= Fr::words32_geq_mod(w);
-                        fr_t f, term;
-                        Fr::from_words32(f, w);             // plain; a non-canonical word fails the call below, whatever it adds here
-                        FrC::mul(term, f, inv[0]);          // plain f_p / (z - w_p): Montgomery product of a plain value with a Montgomery one
-                        FrC::add(s1, s1, term);
-                        FrC::add(s2, s2, f);
-                    }
-                }
-            }
-        }
-    }
-    if (bad) sh_bad = 1;
-    // sum_p f_p w_p / (z - w_p) = z sum_p f_p / (z - w_p) - sum_p f_p
-    fr_t part, s1m, s2m;
-    Fr::from_plain(s1m, s1);
-    Fr::reduce_once(s1m, s1m);
-    Fr::from_plain(s2m, s2);
-    Fr::reduce_once(s2m, s2m);
-    FrC::mul(part, s1m, zp[0]);
-    FrC::sub(part, part, s2m);
-    block_sum_fr<EVT_T>(part, sh);                          // (its barriers also publish sh_bad)
     if (t == 0) {
         if (sh_bad) {
             status[b] = MKZG_ERR_NON_CANONICAL_SCALAR;
         } else {
-            fr_t c, y;
+            fr_t c, r2, y, z;
             Fr::set(c, FR_INV_4096);
-            FrC::mul(c, rootn, c);                          // (z^4096 - 1) / 4096
-            FrC::mul(y, c, part);
+            Fr::set(r2, FrParams::R2);
+            Fr::mul(c, c, r2);                              // R^2 / 4096: plain S -> Montgomery S / 4096
+            FrC::mul(y, s, c);
             store_fr12(y_out + (size_t)b * 12, y);
             status[b] = 0;
-            if (rlc.s1) rlc_one_blob(rlc, b, zp[0], y);
+            load_fr12(z, cx.rows);
+            if (rlc.s1) rlc_one_blob(rlc, b, z, y);
         }
     }
 }
@@ -1422,7 +1398,7 @@ void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_
         rlc.exp_offset = exp_offset;
         for (int i = 0; i < 8; i++) rlc.r.w[i] = h_r8 ? h_r8[i] : 0;
         if (!rows_ready) hipLaunchKernelGGL(k_blob_eval_prep, dim3((n + 63) / 64), dim3(64), 0, s, d_z, n, d_zrows);
-        hipLaunchKernelGGL(k_blob_eval_tree, dim3(n), dim3(EVT_T), 0, s, d_blobs, d_zrows, d_roots, d_y, d_status, rlc);
+        hipLaunchKernelGGL((k_blob_eval_tree<EVT_LOG>), dim3(n), dim3(4096 >> EVT_LOG), 0, s, d_blobs, d_zrows, d_roots, d_y, d_status, rlc);
     }
 #endif
 }

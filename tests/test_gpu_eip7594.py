@@ -205,6 +205,43 @@ def test_sharded_cell_verifier_records(gpu_ctx, oracle_ctx):
     assert rc == 0 and gpu_ctx.verify_cell_batch_finish([g[0][1], g[1][1], rec]) == 0
 
 
+@pytest.mark.parametrize("verify_shape", [0, 1])
+def test_sharded_cell_verifier_records_256(gpu_ctx, oracle_ctx, verify_shape):
+    """all 256 cells of two blobs in two shards (200 + 56; more than 16 points per MSM, so the bucket kernels run, not the few-point one):
+    records equal the oracle's byte for byte whichever shape the context is forced into; a swapped proof is rejected under both"""
+    tuples = []
+    for seed in (71, 72):
+        blob = rand_blob(seed)
+        rc, cm = gpu_ctx.BlobToKZGCommitment(blob)
+        rc2, cells, proofs = gpu_ctx.ComputeCellsAndKZGProofs(blob)
+        assert rc == 0 and rc2 == 0
+        tuples += [(cm, ci, cells[ci], proofs[ci]) for ci in range(128)]
+    r32 = bytes(range(11, 43))
+    cut = 200
+
+    def records(eng, tups):
+        recs = []
+        for lo, hi in ((0, cut), (cut, len(tups))):
+            sh = tups[lo:hi]
+            recs.append(eng.verify_cell_batch_partial([t[0] for t in sh], [t[1] for t in sh], [t[2] for t in sh], [t[3] for t in sh], lo, r32))
+        return recs
+
+    o = records(oracle_ctx, tuples)
+    assert oracle_ctx.verify_cell_batch_finish([x[1] for x in o]) == 0
+    prev = gpu_ctx.get_option("verify_shape")
+    gpu_ctx.set_option("verify_shape", verify_shape)
+    try:
+        g = records(gpu_ctx, tuples)
+        assert [x[0] for x in g] == [0, 0] and g == o
+        assert gpu_ctx.verify_cell_batch_finish([x[1] for x in g]) == 0
+        cms, idx, cells, prs = map(list, zip(*tuples))
+        assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs) == 0
+        prs[40], prs[41] = prs[41], prs[40]
+        assert gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs) == 1
+    finally:
+        gpu_ctx.set_option("verify_shape", prev)
+
+
 def test_recover_batch(gpu_ctx, oracle_ctx):
     """mkzg_recover_cells_and_kzg_proofs_batch: ragged jobs (different erasure patterns per blob, one invalid job in the middle) give the
     same bytes as the single-blob call and the oracle"""

@@ -825,9 +825,9 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
     srt_each = sorted(each)
     kern = {k: round(v[0], 4) for k, v in prof.items() if v[1]}
     algo = (131072 + 48 + 48) * N          # bytes read per blob
-    # the latency shape brackets two launches under k_vmsm_window (two jobs beside the hash, the late one on quads of lanes) and two under k_rlc_scalars
+    # the latency shape brackets two launches under k_vmsm_window (two jobs beside the hash, the late one on quads of lanes)
     tp_forced = args.verify_shape == 1
-    kinds = TP_KINDS if tp_forced else (None if dist_on else {"k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_window_quad": 1, "k_vmsm_combine": 2}, "k_rlc_scalars": {"k_rlc_scalars": 2}})
+    kinds = TP_KINDS if tp_forced else (None if dist_on else {"k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_window_quad": 1, "k_vmsm_combine": 2}})
     roof, valu = leg_roofline(kern, algo, hw, pmc_valid_for_size=(N == 1024), leg="verify_tp" if tp_forced else "verify", kinds=kinds)
     out = {"metric": "blobs/sec VerifyBlobKZGProofBatch", "batch_per_gpu": N, "unit": "blobs/s",
            "single_call": {"blobs_per_s": round(N * world / dt * args.verify_steps, 2), "ms_per_call": round(ms, 3), "host_finish_ms": round(host_us / args.verify_steps / 1e3, 3), "ms_each_call": each,

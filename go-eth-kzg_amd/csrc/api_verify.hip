@@ -289,17 +289,6 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     CpuMark cpu_mark;
     g_cpu_calls++;
 #endif
-    if (d_blobs && !tp) {
-        // coefficient rows of the blobs (inverse NTT beside the challenge hash) and the NTT twiddles they need
-        rc = ensure_twiddles(c);
-        if (rc) return rc;
-        if (n > L->v_coeff_cap) {
-            L->v_coeff_cap = 0;
-            rc = dev_realloc(L->d_v_coeffs, n * 4096 * 48);
-            if (rc) return rc;
-            L->v_coeff_cap = n;
-        }
-    }
     const size_t cap = L->v_cap;
     uint32_t* aff_c = L->d_v_aff;
     uint32_t* aff_q = L->d_v_aff + cap * 32;
@@ -330,17 +319,15 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     if (!round_validates)
         KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
     if (d_blobs) {
-        //    ... and, for blobs, their canonicity check and inverse NTT (DeserializeBlob, serialization.go:134-146): the claimed value
-        //    y = f(z) is then a 4096-term polynomial evaluation once z is known, instead of the barycentric formula with its inversions;
-        //    the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
+        //    ... and, for blobs, the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
         //    (throughput shape: none of that -- the three MSMs go out as ONE launch after the challenge, see below)
-        //    (challenges hashed on the host: there is no hash to run beside -- the points' chains on the side stream, the NTT and the
-        //    evaluation on the main one, and the three MSMs as one launch after both)
+        //    (challenges hashed on the host: there is no hash to run beside -- the points' chains on the side stream, the evaluation on the
+        //    main one, and the three MSMs as one launch after both)
+        //    The blobs themselves wait for their challenge: y = f(z) is ONE pass over the blob once z is known (k_blob_eval_tree, with the
+        //    canonicity check of DeserializeBlob, serialization.go:134-146) -- up to round 4 the latency shape ran an inverse NTT of every blob
+        //    beside the hash (5x the instructions, 201 MB of coefficient rows per lane) to make that pass a Horner evaluation of the same length.
         const bool host_z = d_z32 != nullptr;
-        if (!tp && host_z) {
-            KT(KT_CELLS_NTT, s, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s));
-        } else if (!tp) {
-            KT(KT_CELLS_NTT, s2, cells_from_blobs_device(d_blobs, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs, nullptr, st_b, s2));
+        if (!tp && !host_z) {
             KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
             const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
             const uint32_t* pts[2] = {aff_q, aff_c};
@@ -383,7 +370,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             if (rc) return rc;
         } else {
             if (c->opt_debug_serial.load(std::memory_order_relaxed)) HIPCHK(hipStreamSynchronize(s2));
-            KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, L->d_v_z, s));
+            KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, L->d_v_z, s, L->d_v_zrows));     // (leaves the evaluation's z-only rows too)
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
         if (tp) {
@@ -399,16 +386,20 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             const int njob[3] = {(int)n, (int)n, (int)n};
             KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
         } else if (d_z32) {
-            KT(KT_POLY_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
-            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
+            // challenges from the host: the rows of z by a small kernel ahead, then as above
+            KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s, false, r_words, exp_offset, L->d_v_s1, L->d_v_s3,
+                                                 L->d_v_ry));
+            tp_ry = true;
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
             const int njob[3] = {(int)n, (int)n, (int)n};
             KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s, 512, 1));       // 3 jobs x 32 windows x 2 slices at 1024 proofs: still a quad per bucket
         } else {
-            KT(KT_POLY_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)n, L->d_v_y, st_b, s));
-            // 3. what depends on the challenges: r^i z_i, sum r^i y_i, and the MSM sum r^i z_i Q_i (kzg_verify.go:179)
-            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)n, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
+            // 3. what depends on the challenges: y = f(z) with r^i z_i and r^i y_i from the lane that finishes each blob (the host adds the
+            //    latter up), and the MSM sum r^i z_i Q_i (kzg_verify.go:179)
+            KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s, true, r_words, exp_offset, L->d_v_s1, L->d_v_s3,
+                                                 L->d_v_ry));
+            tp_ry = true;
             const uint32_t* scal[1] = {L->d_v_s3};
             const uint32_t* pts[1] = {aff_q};
             const int njob[1] = {(int)n};
@@ -527,14 +518,7 @@ static size_t device_hash_share(const mkzg_ctx* c, size_t m) {
 static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t m, uint32_t exp_offset,
                                const uint8_t* r_le32, VerifyFold* out) {
     hipStream_t s = L->stream, s2 = L->side, cp = L->side2;
-    int rc = ensure_twiddles(c);
-    if (rc) return rc;
-    if (m > L->v_coeff_cap) {
-        L->v_coeff_cap = 0;
-        rc = dev_realloc(L->d_v_coeffs, m * 4096 * 48);
-        if (rc) return rc;
-        L->v_coeff_cap = m;
-    }
+    int rc = MKZG_OK;
     const size_t cap = L->v_cap;
     uint32_t* aff_c = L->d_v_aff;
     uint32_t* aff_q = L->d_v_aff + cap * 32;
@@ -552,7 +536,6 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
     uint8_t* d_z = L->d_blobs + m * MKZG_BYTES_PER_BLOB;
     const size_t n_dev = device_hash_share(c, m);                      // transcripts [0, n_dev) are hashed by the device
     const bool early_msm = m >= 256;                                   // below that the three MSMs leave as one launch at the end
-    const bool ntt_on_side = n_dev > 0;
     // chunk plan: a small first chunk starts the link early, then chunks of 128
     struct Chunk { size_t lo, m; };
     std::vector<Chunk> plan;
@@ -655,7 +638,6 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
             return MKZG_OK;
         };
         if (nch == 1) { const int prc = launch_points(); if (prc) return prc; }     // a call of one chunk waits for the points' 0.7 ms chain, not for the link: points first
-        hipStream_t ntt_stream = ntt_on_side ? s2 : s;
         bool hash_launched = n_dev == 0;
         for (size_t k = 0; k < nch; k++) {
             const size_t lo = plan[k].lo, n = plan[k].m;
@@ -670,8 +652,7 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
                 KT(KT_SHA256, s, challenge_device(L->d_blobs, L->d_v_raw, (int)n_dev, L->d_v_z, s));
                 hash_launched = true;
             }
-            HIPCHK(hipStreamWaitEvent(ntt_stream, L->ev_chunk[k & 7], 0));
-            KT(KT_CELLS_NTT, ntt_stream, cells_from_blobs_device(L->d_blobs + lo * MKZG_BYTES_PER_BLOB, (int)n, c->d_tw_fwd, c->d_tw_inv, L->d_v_coeffs + lo * 4096 * 12, nullptr, st_b + lo, ntt_stream));
+            if (k + 1 == nch) HIPCHK(hipStreamWaitEvent(s, L->ev_chunk[k & 7], 0));          // the copy stream is in order: the last chunk's event covers them all
         }
         HIPCHK(hipEventRecord(L->ev_join, s2));
         // the host's share of the challenges: what the call waits for from here on, so this thread hashes too
@@ -681,15 +662,15 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
             scalars_to_fr_device(d_z + n_dev * 32, (int)(m - n_dev), L->d_v_z + n_dev * 12, st_x + n_dev, s);       // canonical by construction
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
-        KT(KT_POLY_EVAL, s, poly_eval_device(L->d_v_coeffs, L->d_v_z, (int)m, L->d_v_y, st_b, s));
+        // y = f(z) in one pass over the blobs (canonicity check included), r^i z_i and r^i y_i from the lane that finishes each blob
+        KT(KT_EVAL_TREE, s, blob_eval_device(L->d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)m, L->d_v_y, st_b, L->d_v_zrows, s, false, r_words, exp_offset, L->d_v_s1, L->d_v_s3,
+                                             L->d_v_ry));
         if (early_msm) {
-            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)m, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 2, s));
             const uint32_t* scal[1] = {L->d_v_s3};
             const uint32_t* pts[1] = {aff_q};
             const int njob[1] = {(int)m};
             KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 1, d_parts + 2 * parts_per_job, d_wsum + 2 * wsum_per_job, s, 256, 1));
         } else {
-            KT(KT_RLC, s, rlc_scalars_device(r_words, L->d_v_z, L->d_v_y, (int)m, exp_offset, L->d_v_s1, L->d_v_s3, L->d_v_misc + 8, 0, s));
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
             const int njob[3] = {(int)m, (int)m, (int)m};
@@ -705,8 +686,8 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
         L->failed = true;
         return rc;
     }
-    // the copy stream's last chunk was waited for by the NTT stream, and that one was joined into s
-    return verify_fold_tail(c, L, m, true, 0, s, out);
+    // (the main stream waited for the copy stream's last chunk and joined the side stream)
+    return verify_fold_tail(c, L, m, true, 0, s, out, true);
 }
 
 static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t m, uint32_t exp_offset,

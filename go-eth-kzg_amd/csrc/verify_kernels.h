@@ -8,7 +8,8 @@
 namespace kzg {
 
 // Fr rows are 12 words (9 limbs + padding), affine G1 rows 32 words, as in msm_kernels.hip.
-void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s);
+void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s,
+                      uint32_t* d_zrows = nullptr /* blob_eval_scratch_words() per blob: also leave the rows blob_eval_device needs of every z (rows_ready) */);
 // the same for up to SHA_MAX_JOBS (blobs, commitments, n, z) jobs -- one per call in flight -- in ONE launch; every n > 0
 #ifndef MKZG_NLANE
 #define MKZG_NLANE 32

@@ -370,8 +370,9 @@ __device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ 
     if (a_side) store_fr12(z_out + (size_t)b * 12, z);
     if (zrows_out) eval_prep_rows(z, zrows_out + (size_t)b * EVT_ROWS * 12, a_side);
 }
-__global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out) {
-    sha_challenge_block(blobs, commitments48, n, z_out, (int)blockIdx.x);
+__global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out,
+                                                          uint32_t* __restrict__ zrows_out) {
+    sha_challenge_block(blobs, commitments48, n, z_out, (int)blockIdx.x, zrows_out);
 }
 // the challenges of SEVERAL calls in one launch (api_verify.hip, the hash rounds of the throughput shape): the chain is 2.7 ms long
 // whatever the number of blobs, and a launch holds its hardware queue for that long -- calls that arrive together share one
@@ -1372,8 +1373,8 @@ __global__ void __launch_bounds__(64) k_fr_to_scalars(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(256), 0, s, d_blobs, d_commitments, n, d_z);
+void challenge_device(const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, hipStream_t s, uint32_t* d_zrows) {
+    if (n > 0) hipLaunchKernelGGL(k_challenge_sha256, dim3((n + 63) / 64), dim3(256), 0, s, d_blobs, d_commitments, n, d_z, d_zrows);
 }
 void challenge_jobs_device(ShaJobs& jobs, hipStream_t s) {
     int blocks = 0;

@@ -114,10 +114,12 @@ void mkzg_ctx_free(mkzg_ctx* ctx);
  *                         the first transcripts of very large pieces -- up to 160 blobs per pool thread; with other calls in flight 20,
  *                         then 8 per thread, and the device's shared hash rounds above that);
  *                         ComputeBlobKZGProof follows the same switch
- *   "verify_shape"        VerifyBlobKZGProofBatch: 0 = latency shape (inverse NTT of the blobs beside the challenge hash, then a short
- *                         Horner pass; a quad of lanes per point in the subgroup tests), 1 = throughput shape (barycentric evaluation
- *                         straight from the blobs, one lane per point: half the instructions, longer dependent chains), -1 (default)
- *                         = throughput shape when at least two other calls are in flight on the context.  Same results either way. */
+ *   "verify_shape"        VerifyBlobKZGProofBatch: 0 = latency shape (the call's own hash launch with the points' chains and the two
+ *                         challenge-free MSMs beside it on side streams; a quad of lanes per point in the subgroup tests), 1 =
+ *                         throughput shape (one stream per call, hash launches shared between the calls in flight, one lane per point:
+ *                         half the instructions, longer dependent chains), -1 (default) = throughput shape when at least two other
+ *                         calls are in flight on the context.  Either way y = f(z) is one pass over the blob once its challenge is
+ *                         known (the numerator tree of the barycentric formula).  Same results either way. */
 int mkzg_ctx_set_option(mkzg_ctx* ctx, const char* key, long value);
 /* reads an option back; also "commit_direct_bits_effective", "fk20_bits_effective", "devices", "host_threads" (threads of one device's
  * host pool including the caller: the CPUs the cgroup grants divided by LOCAL_WORLD_SIZE or the context's devices; the environment
@@ -208,8 +210,8 @@ int mkzg_verify_cell_kzg_proof_batch_exchange(mkzg_comm* comm, const uint8_t* co
  * serialization.go:134-146): y_i = f_i(z_i) for n device-resident blobs and n caller-chosen evaluation points (host memory, n x 32 B
  * big-endian, canonical), points of the domain included (domain.go:163-171, :199-203).  The verifiers derive z from a hash and the
  * proof path returns y beside its proof; this entry point evaluates alone, through each of the three kernels the library has for it:
- *   form 0  inverse NTT + Horner on the coefficients (the batch verifier's latency shape),
- *   form 1  barycentric formula down the product tree of the domain, one inversion per blob (the throughput shape),
+ *   form 0  inverse NTT + Horner on the coefficients (the EIP-7594 transform; no verifier uses it for this any more: a cross-check),
+ *   form 1  the numerator tree of the barycentric formula over the product tree of the domain, no inversion (the batch verifier's),
  *   form 2  barycentric formula with one batch inversion per lane (the proof path's kernel, whose quotient is discarded here).
  * All forms must return the same bytes.  y32n / status: host memory (n x 32 B, n ints); status[i] is the blob's code, else z's.
  * Returns the first non-zero status.  n <= 4096.  Synchronises `stream`. */

@@ -486,7 +486,7 @@ int sd_cell_verify_finish(mkzg_ctx* c, const CellFold& f) {
     g1h_to_affine(ps[0], f.sums[0]);
     g1h_to_affine(ps[1], rl);
     const G2Prepared* qs[2] = {&c->g2_alpha64, &c->g2_neg_gen};
-    return pairing_check_prepared_2mt(ps, qs, c->pool) ? MKZG_OK : MKZG_VERIFY_FAILED;
+    return pairing_check_prepared_2mt(ps, qs, c->pool, miller_segments(c)) ? MKZG_OK : MKZG_VERIFY_FAILED;
 }
 
 // shared front end of RecoverCells / RecoverCellsAndComputeKZGProofs (reference api_eip7594.go:93-142) for n_blobs independent

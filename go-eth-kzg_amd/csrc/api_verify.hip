@@ -442,7 +442,7 @@ int sd_verify_finish(mkzg_ctx* c, const VerifyFold& f) {
     g1h_to_affine(ps[0], Fsum);
     g1h_to_affine(ps[1], negA);
     const G2Prepared* qs[2] = {&c->g2_gen, &c->g2_alpha};
-    return pairing_check_prepared_2mt(ps, qs, c->pool) ? MKZG_OK : MKZG_VERIFY_FAILED;
+    return pairing_check_prepared_2mt(ps, qs, c->pool, miller_segments(c)) ? MKZG_OK : MKZG_VERIFY_FAILED;
 }
 static int timed_finish(mkzg_ctx* c, Lane* L, const VerifyFold& f) {
     auto t0 = std::chrono::steady_clock::now();

@@ -310,6 +310,18 @@ int lane_sync(mkzg_ctx* c, Lane* L, hipStream_t s);
         if (kt_on__) L->timer.end(kind, s);                       \
     } while (0)
 
+// The verifiers' last step is two Miller loops + one final exponentiation on the host (host_pairing.hpp).  A call that is alone on the
+// context waits for exactly that, and the pool's other threads are idle: it cuts every loop into three (two) segments on a thread each
+// (0.51 -> ~0.40 ms for the whole check on an EPYC 9575F); with more calls in flight the threads are needed elsewhere: one loop per thread.
+static inline int miller_segments(const mkzg_ctx* c) {
+    static const int forced = [] { const char* e = getenv("MKZG_MILLER_SEGMENTS"); return e ? atoi(e) : 0; }();      // A/B aid
+    if (forced) return forced;
+    const int busy = c->lanes_busy.load(std::memory_order_relaxed), threads = c->pool ? c->pool->size() + 1 : 1;
+    if (busy <= 1 && threads >= 6) return 3;
+    if (busy <= 2 && threads >= 4) return 2;
+    return 1;
+}
+
 // ---- shared tables, built once (api.hip, api_cells.hip)
 int ensure_commit_table(mkzg_ctx* c);
 int ensure_direct(mkzg_ctx* c);             // MKZG_OK also when the table cannot be had: direct_bits_built then says what is in use

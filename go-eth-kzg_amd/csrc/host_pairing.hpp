@@ -592,9 +592,27 @@ inline void miller_loop_prepared(Fp12& f, const G1AffH& P, const G2Prepared& Q) 
         if ((BLS_X_ABS >> i) & 1) mul_by_line(f, P.y, P.x, Q.lines[idx++]);
     }
 }
-// e(P_0, Q_0) e(P_1, Q_1) == 1 with the two Miller loops on two host threads (the shared-squaring loop below does 63 squarings +
-// 136 line products in sequence; two threads do 63 + 68 each and one extra product)
-inline bool pairing_check_prepared_2mt(const G1AffH* Ps, const G2Prepared* const* Qs, HostPool* pool = nullptr);
+// A SEGMENT of the Miller loop of one pair: the steps of bits hi..lo of |x| started from f = 1, then squared lo more times -- with the
+// prepared lines every step's line value is independent of f, so  f_loop = prod_segments segment(hi_j, lo_j)  and the segments of a
+// loop can run on different threads (each pays its trailing squarings: 1.8 us each against 3.7 us for a step).
+inline void miller_segment_prepared(Fp12& f, const G1AffH& P, const G2Prepared& Q, int hi, int lo) {
+    fp12::one(f);
+    size_t idx = (size_t)(62 - hi);
+    for (int i = 62; i > hi; i--) idx += (BLS_X_ABS >> i) & 1;
+    bool started = false;
+    for (int i = hi; i >= lo; i--) {
+        if (started) fp12::sqr(f, f);
+        mul_by_line(f, P.y, P.x, Q.lines[idx++]);
+        if ((BLS_X_ABS >> i) & 1) mul_by_line(f, P.y, P.x, Q.lines[idx++]);
+        started = true;
+    }
+    for (int i = 0; i < lo; i++) fp12::sqr(f, f);
+}
+// e(P_0, Q_0) e(P_1, Q_1) == 1 with the Miller loops on host threads: one loop per thread (the shared-squaring loop below does 63
+// squarings + 136 line products in sequence; two threads do 63 + 68 each and one extra product), or, when the pool has threads to spare
+// (`segments` 2 or 3: a lone caller waits for this), every loop cut into segments of equal duration on a thread each
+// (240 us -> ~155 / ~130 us per loop on an EPYC 9575F for 60 % / 100 % more CPU time)
+inline bool pairing_check_prepared_2mt(const G1AffH* Ps, const G2Prepared* const* Qs, HostPool* pool = nullptr, int segments = 1);
 
 // prod_i e(P_i, Q_i) == 1 for prepared Q_i; pairs with an infinity member contribute 1
 inline bool pairing_check_prepared(const G1AffH* Ps, const G2Prepared* const* Qs, int n) {
@@ -620,18 +638,26 @@ inline bool pairing_check_prepared(const G1AffH* Ps, const G2Prepared* const* Qs
     return fp12::is_one(e);
 }
 
-inline bool pairing_check_prepared_2mt(const G1AffH* Ps, const G2Prepared* const* Qs, HostPool* pool) {
+inline bool pairing_check_prepared_2mt(const G1AffH* Ps, const G2Prepared* const* Qs, HostPool* pool, int segments) {
     if (Ps[0].inf || Qs[0]->inf || Ps[1].inf || Qs[1]->inf) return pairing_check_prepared(Ps, Qs, 2);
-    Fp12 fs[2], f, e;
-    Fp12 &f0 = fs[0], &f1 = fs[1];
-    if (pool) {
+    Fp12 fs[6], f, e;
+    int nf = 2;
+    if (pool && segments >= 2) {
+        // segment bounds (bits of |x|, 62..0) that equalise  3.7 us x steps + 1.8 us x trailing squarings
+        static const int B2[3] = {62, 40, -1}, B3[4] = {62, 53, 36, -1};
+        const int K = segments >= 3 ? 3 : 2;
+        const int* B = K == 3 ? B3 : B2;
+        nf = 2 * K;
+        pool->parallel(nf, [&](int t) { const int pair = t / K, j = t % K; miller_segment_prepared(fs[t], Ps[pair], *Qs[pair], B[j], B[j + 1] + 1); });
+    } else if (pool) {
         pool->parallel(2, [&](int i) { miller_loop_prepared(fs[i], Ps[i], *Qs[i]); });
     } else {
-        std::thread t([&] { miller_loop_prepared(f1, Ps[1], *Qs[1]); });
-        miller_loop_prepared(f0, Ps[0], *Qs[0]);
+        std::thread t([&] { miller_loop_prepared(fs[1], Ps[1], *Qs[1]); });
+        miller_loop_prepared(fs[0], Ps[0], *Qs[0]);
         t.join();
     }
-    fp12::mul(f, f0, f1);
+    f = fs[0];
+    for (int i = 1; i < nf; i++) fp12::mul(f, f, fs[i]);
     fp12::conj(f, f);   // x < 0
     final_exponentiation(e, f);
     return fp12::is_one(e);

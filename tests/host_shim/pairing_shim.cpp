@@ -18,9 +18,38 @@ int shim_pairing_check(const uint8_t* p48, const uint8_t* q96, int n) {
     if (n == 2) {                    // the two-thread variant must agree with the shared-squaring loop
         const bool a = pairing_check_prepared(ps.data(), qp.data(), 2), b = pairing_check_prepared_2mt(ps.data(), qp.data());
         if (a != b) return -3;
+        static HostPool pool(6);     // the segmented loops (two and three segments per loop on pool threads) must agree as well
+        if (pairing_check_prepared_2mt(ps.data(), qp.data(), &pool, 1) != a || pairing_check_prepared_2mt(ps.data(), qp.data(), &pool, 2) != a ||
+            pairing_check_prepared_2mt(ps.data(), qp.data(), &pool, 3) != a)
+            return -4;
         return a ? 1 : 0;
     }
     return pairing_check_prepared(ps.data(), qp.data(), n) ? 1 : 0;
+}
+// miller_segment_prepared: the product of the segments of a loop, for several cuts (every bit position of |x| that is set lies inside,
+// at the start and at the end of some segment), equals miller_loop_prepared's value exactly.  Returns the number of mismatches.
+int shim_miller_segments_check(const uint8_t* p48, const uint8_t* q96) {
+    G1AffH P;
+    G2Aff Q;
+    if (!g1h_decompress(P, p48) || !g2_decompress(Q, q96)) return -1;
+    G2Prepared pr;
+    g2_prepare(pr, Q);
+    Fp12 whole;
+    miller_loop_prepared(whole, P, pr);
+    auto same = [](const Fp12& a, const Fp12& b) { return fp6::eq(a.c0, b.c0) && fp6::eq(a.c1, b.c1); };
+    static const int cuts[][5] = {{62, -1, -1, -1, -1}, {62, 40, -1, -1, -1}, {62, 53, 36, -1, -1}, {62, 61, 48, 16, -1}, {62, 60, 57, 47, 15}, {62, 0, -1, -1, -1}};
+    int bad = 0;
+    for (const auto& cut : cuts) {
+        Fp12 acc, seg;
+        fp12::one(acc);
+        for (int j = 0; j < 5 && (j == 0 || cut[j] >= 0); j++) {
+            const int hi = cut[j], lo = (j + 1 < 5 && cut[j + 1] >= 0) ? cut[j + 1] + 1 : 0;
+            miller_segment_prepared(seg, P, pr, hi, lo);
+            fp12::mul(acc, acc, seg);
+        }
+        if (!same(acc, whole)) bad++;
+    }
+    return bad;
 }
 // The AVX-512 IFMA squaring chain (host_cyclo_ifma.hpp) against the scalar tower on elements of the cyclotomic subgroup: 1, 2, 3, 16, 63
 // squarings in a row (every squaring's output is the next one's loose input) and the whole a^|x|.  Returns the number of mismatches,

@@ -124,3 +124,12 @@ def test_ifma_squaring_chain_matches_scalar_tower(shim, setup):
         assert rc == 0, (i, j, rc)
         ran += 1
     assert ran == 4
+
+
+def test_miller_loop_segments_multiply_to_the_whole_loop(shim, setup):
+    """host_pairing.hpp miller_segment_prepared: a Miller loop cut into segments that start from 1 and carry their trailing squarings
+    (what a lone verifier call spreads over pool threads) multiplies back to the value of the whole loop, for cuts at, before and
+    after every set bit of |x|; the pairing checks built on two and three segments agree with the plain ones (shim_pairing_check)"""
+    g1, g2 = setup
+    for i, j in ((1, 0), (5, 3), (0, 7), (9, 9)):
+        assert shim.shim_miller_segments_check(g1[i], g2[j]) == 0, (i, j)

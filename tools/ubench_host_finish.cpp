@@ -46,6 +46,11 @@ int main() {
     printf("2-pairing check   %8.1f us (one thread)\n", time_us(100, [&] { sink += pairing_check_prepared(ps, qs, 2); }));
     HostPool pool(4);
     printf("2-pairing check   %8.1f us (Miller loops on two pool threads)\n", time_us(100, [&] { sink += pairing_check_prepared_2mt(ps, qs, &pool); }));
+    {
+        HostPool pool8(8);
+        printf("2-pairing check   %8.1f us (every loop in two segments, four threads)\n", time_us(100, [&] { sink += pairing_check_prepared_2mt(ps, qs, &pool8, 2); }));
+        printf("2-pairing check   %8.1f us (every loop in three segments, six threads)\n", time_us(100, [&] { sink += pairing_check_prepared_2mt(ps, qs, &pool8, 3); }));
+    }
     // G1 side: Horner over 32 window sums of 8 bits, the fixed-base multiplication, the conversion to affine
     uint32_t wsum[32 * 48];
     {

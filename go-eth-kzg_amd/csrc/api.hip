@@ -107,7 +107,7 @@ void free_lane(Lane* L) {
     L->q_cap = 0; L->quot_cap = 0;
     dev_free(L->d_coeffs); dev_free(L->d_cells); dev_free(L->d_cell_st);
     L->cell_cap = 0;
-    dev_free(L->d_cv_cells); dev_free(L->d_cv_cell_idx); dev_free(L->d_cv_row_idx); dev_free(L->d_cv_rp); dev_free(L->d_cv_weights); dev_free(L->d_cv_partials);
+    dev_free(L->d_cv_cells); dev_free(L->d_cv_in); dev_free(L->d_cv_rp); dev_free(L->d_cv_weights); dev_free(L->d_cv_partials);
     dev_free(L->d_cv_interp); dev_free(L->d_cv_st);
     L->cv_cap = 0;
     L->cv_cells_cap = 0;

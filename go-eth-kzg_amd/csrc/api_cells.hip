@@ -177,8 +177,7 @@ static int ensure_cv_ws(Lane* L, size_t n_cells, size_t n) {
     if (n <= L->cv_cap) return MKZG_OK;
     L->cv_cap = 0;
     const size_t cap = std::max<size_t>(n, 128);
-    int rc = dev_realloc(L->d_cv_cell_idx, cap * 8);
-    if (!rc) rc = dev_realloc(L->d_cv_row_idx, cap * 4);
+    int rc = dev_realloc(L->d_cv_in, cap * (48 + 48 + 8 + 4));
     if (!rc) rc = dev_realloc(L->d_cv_rp, cap * 48);
     if (!rc) rc = dev_realloc(L->d_cv_weights, cap * 32);
     if (!rc) rc = dev_realloc(L->d_cv_partials, (size_t)CELL_INTERP_BLOCKS * 64 * 48);
@@ -345,8 +344,12 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     memcpy(h_proofs, proofs48n, n * 48);
     memcpy(h_cidx, cell_indices, n * 8);
     memcpy(h_ridx, row_idx.data(), n * 4);
-    HIPCHK(hipMemcpyAsync(L->d_v_raw, h_rows, n_rows * 48, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(L->d_v_raw + cap * 48, h_proofs, n * 48, hipMemcpyHostToDevice, s));
+    // ONE upload for the four small arrays (every copy is a launch in the call's hardware queue, which it shares with other calls: ~0.09 ms each under load)
+    uint8_t* d_rows = L->d_cv_in;
+    uint8_t* d_proofs = d_rows + n_rows * 48;
+    const uint64_t* d_cidx = (const uint64_t*)(d_proofs + n * 48);
+    const uint32_t* d_ridx = (const uint32_t*)(d_proofs + n * 48 + n * 8);
+    HIPCHK(hipMemcpyAsync(d_rows, h_rows, n_rows * 48 + n * (48 + 8 + 4), hipMemcpyHostToDevice, s));
     // points
     uint32_t* aff_rows = L->d_v_aff;
     uint32_t* aff_q = L->d_v_aff + cap * 32;
@@ -360,13 +363,13 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     int* sub_rows = L->d_cv_st + L->cv_cap;
     int* sub_q = L->d_cv_st + 2 * L->cv_cap;
     lane_fork(L, s, s2, s3);
-    KT(KT_DECOMPRESS, s2, g1_validate2_device(L->d_v_raw, (int)n_rows, aff_rows, st_rows, L->d_v_raw + cap * 48, (int)n, aff_q, st_q, s2, 1));
+    KT(KT_DECOMPRESS, s2, g1_validate2_device(d_rows, (int)n_rows, aff_rows, st_rows, d_proofs, (int)n, aff_q, st_q, s2, 1));
     HIPCHK(hipEventRecord(L->ev_decoded, s2));
     // the r-torsion test: a quad of lanes per point for calls of few cells (its 0.75 ms chain is what such a call waits for); one lane per
     // point when the uploads, the interpolation and the MSMs take longer than the 1.3 ms chain anyway (half the instructions, and the
     // other kernels' workgroups find free SIMDs: see k_g1_validate)
     const int sub_mode = MKZG_CV_SUBGROUP_WIDE_FROM > 0 && n + n_rows >= (size_t)MKZG_CV_SUBGROUP_WIDE_FROM ? 4 : 2;
-    KT(KT_SUBGROUP, s3, g1_validate2_device(L->d_v_raw, (int)n_rows, nullptr, sub_rows, L->d_v_raw + cap * 48, (int)n, nullptr, sub_q, s3, sub_mode));
+    KT(KT_SUBGROUP, s3, g1_validate2_device(d_rows, (int)n_rows, nullptr, sub_rows, d_proofs, (int)n, nullptr, sub_q, s3, sub_mode));
     HIPCHK(hipEventRecord(L->ev_join, s3));
     // uploads, part 2: the cells (n x 2 KiB, scattered host pointers) are gathered into the pinned staging area by the host pool running
     // AHEAD of this thread -- all chunks' tasks queued at once -- while the GPU validates the points; this thread waits for chunk k only
@@ -398,10 +401,8 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
         c->pool->wait(all_left);                  // the tasks reference this frame
         if (urc) return urc;
     }
-    HIPCHK(hipMemcpyAsync(L->d_cv_cell_idx, h_cidx, n * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(L->d_cv_row_idx, h_ridx, n * 4, hipMemcpyHostToDevice, s));
     // scalars
-    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, L->d_cv_cell_idx, L->d_cv_row_idx, d_cells ? d_cells : L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,
+    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, d_cidx, d_ridx, d_cells ? d_cells : L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,
                                                        L->d_v_s1, L->d_v_s3, L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s));
     HIPCHK(hipStreamWaitEvent(s, L->ev_decoded, 0));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
@@ -414,12 +415,16 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     int* h_st = (int*)L->h_v;
-    std::vector<int> st_cells(n), h_sub_rows(n_rows), h_sub_q(n);
+    // every verdict array lands in the lane's PINNED area (behind the window sums, where the blob verifier keeps its r^i y_i words: cap x 8
+    // words for 2 n + n_rows here): a device-to-host copy into pageable memory is a blocking copy that polls inside the runtime until the
+    // stream gets there -- with twelve callers that was twelve CPUs spinning beside the pool (tools/bench_cellverify_inflight.py), whatever
+    // `host_wait` said
+    int* st_cells = (int*)(h_misc + V_MISC_WORDS_C + 16);
+    int* h_sub_rows = st_cells + L->cv_cap;
+    int* h_sub_q = st_cells + 2 * L->cv_cap;
     HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));               // the subgroup verdicts
     HIPCHK(hipMemcpyAsync(h_st, L->d_v_st, 2 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(st_cells.data(), L->d_cv_st, n * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_sub_rows.data(), sub_rows, n_rows * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_sub_q.data(), sub_q, n * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(st_cells, L->d_cv_st, (2 * L->cv_cap + n) * sizeof(int), hipMemcpyDeviceToHost, s));     // cell statuses | subgroup verdicts of the rows | of the proofs: one copy
     HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS_C * 4, hipMemcpyDeviceToHost, s));
     LANE_SYNC(c, L, s);
     L->drained = true;

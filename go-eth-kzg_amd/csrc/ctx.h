@@ -144,8 +144,7 @@ struct Lane {
     size_t cv_cap = 0;                     // VerifyCellKZGProofBatch workspace, cv_cap cells
     size_t cv_cells_cap = 0;               // cells the lane can stage itself (host-pointer calls; device-pointer calls bring theirs)
     uint8_t* d_cv_cells = nullptr;         // cv_cells_cap x 2048 B
-    uint64_t* d_cv_cell_idx = nullptr;
-    uint32_t* d_cv_row_idx = nullptr;
+    uint8_t* d_cv_in = nullptr;            // one upload per call: commitment rows | proofs | cell indices (u64) | row indices (u32), packed by the call's counts
     uint32_t* d_cv_rp = nullptr;           // cv_cap Fr rows
     uint32_t* d_cv_weights = nullptr;      // cv_cap x 8 words
     uint32_t* d_cv_partials = nullptr;     // CELL_INTERP_BLOCKS x 64 Fr rows

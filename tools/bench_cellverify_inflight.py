@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """VerifyCellKZGProofBatch over 64 x 128 = 8192 cells (host pointers, arguments marshalled once as a cgo caller holds them): sustained
-cells/s against the number of caller threads on one shared context."""
+cells/s against the number of caller threads on one shared context, with the host CPUs the process keeps busy.
+CV_DEVICE=1: the cells stay in HBM (mkzg_verify_cell_kzg_proof_batch_device) -- the same calls without gather and upload."""
 import ctypes
 import os
 import sys
@@ -17,6 +18,8 @@ def main():
     torch.cuda.init()
     kzg = load_product()
     ctx = kzg.Context(device=0)
+    if os.environ.get("CV_HOST_WAIT"):
+        assert ctx.set_option("host_wait", int(os.environ["CV_HOST_WAIT"])) == 0
     NB = int(os.environ.get("CV_BLOBS", "64"))
     blobs = [rand_blob(s) for s in range(NB)]
     d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
@@ -37,6 +40,8 @@ def main():
     bad[0:48] = proofs[48:96]
     bad = bytes(bad)
     L = kzg.lib()
+    dev = os.environ.get("CV_DEVICE") == "1"
+    d_all = torch.frombuffer(bytearray(cells), dtype=torch.uint8).cuda() if dev else None
     ks = [int(x) for x in os.environ["CV_CALLERS"].split(",")] if os.environ.get("CV_CALLERS") else (1, 2, 3, 4, 6, 8, 12, 16)
     for K in ks:
         reps = 5
@@ -44,6 +49,12 @@ def main():
 
         def caller(k):
             try:
+                if dev:
+                    st = torch.cuda.Stream()
+                    for _ in range(reps):
+                        assert L.mkzg_verify_cell_kzg_proof_batch_device(ctx._h, cj, ctypes.cast(idx, ctypes.c_void_p), ctypes.c_void_p(d_all.data_ptr()), proofs, n, ctypes.c_void_p(st.cuda_stream)) == 0
+                    assert L.mkzg_verify_cell_kzg_proof_batch_device(ctx._h, cj, ctypes.cast(idx, ctypes.c_void_p), ctypes.c_void_p(d_all.data_ptr()), bad, n, ctypes.c_void_p(st.cuda_stream)) == 1
+                    return
                 for _ in range(reps):
                     assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, proofs, n) == 0
                 assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, bad, n) == 1
@@ -52,14 +63,14 @@ def main():
 
         for trial in range(2):
             ts = [threading.Thread(target=caller, args=(k,)) for k in range(K)]
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.process_time()
             for t in ts:
                 t.start()
             for t in ts:
                 t.join()
-            dt = time.perf_counter() - t0
+            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
         assert not errs, errs[0]
-        print(f"{K} callers: {K * (reps + 1) * n / dt / 1e6:.2f} M cells/s, {1e3 * dt / (K * (reps + 1)):.3f} ms per call amortised", flush=True)
+        print(f"{K} callers{' (cells in HBM)' if dev else ''}: {K * (reps + 1) * n / dt / 1e6:.2f} M cells/s, {1e3 * dt / (K * (reps + 1)):.3f} ms per call amortised, {cpu / dt:.1f} host CPUs busy", flush=True)
     ctx.close()
 
 

@@ -1238,7 +1238,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
         badp = bytearray(proofs)
         badp[0:48] = proofs[48:96]
         badp = bytes(badp)
-        KV, reps = 12, 4                                 # measured (tools/bench_cellverify_inflight.py, one box): 6 callers 5.9, 8: 7.1, 12: 8.3, 16: 7.6, 24: 5.8 M cells/s
+        KV, reps = 12, 9                                 # measured (tools/bench_cellverify_inflight.py, one box, verdicts into pinned memory): 4 callers 8.5-9.5, 8: 7.4-9.8, 12: 8.9, 16: 8.3, 24: 8.4 M cells/s
         errs = []
         # every caller its own NB x 128 (commitment, index, cell, proof) tuples in host memory (12 x 17.6 MB)
         vsets = [(cj, arr, proofs, badp, keep)]
@@ -1267,16 +1267,17 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
             except Exception as e:      # noqa: BLE001
                 errs.append(repr(e))
 
-        dts = []
+        dts, cpus = [], []
         for trial in range(4):                           # the first trial primes the lanes' workspaces; the MEDIAN of the other three counts
             ts = [threading.Thread(target=cv_caller, args=(k,)) for k in range(KV)]
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.process_time()
             for t in ts:
                 t.start()
             for t in ts:
                 t.join()
             if trial:
                 dts.append(time.perf_counter() - t0)
+                cpus.append((time.process_time() - c0) / dts[-1])
         dts.sort()
         dtk = dts[len(dts) // 2]
         assert not errs, errs[0]
@@ -1284,7 +1285,8 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
         sroof, svalu = sustained_roofline(vkinds, "eip7594", 2152 * n, KV * (reps + 1) / dtk, hw, pmc_valid_for_size=full_size)
         out["verify_cell_kzg_proof_batch"]["sustained"] = {"callers": KV, "calls": KV * (reps + 1), "cells_per_s": round(KV * (reps + 1) * n / dtk, 1),
                                                            "cells_per_s_each_trial": [round(KV * (reps + 1) * n / d, 1) for d in dts],
-                                                           "ms_per_call_amortised": round(dtk / (KV * (reps + 1)) * 1e3, 3), "roofline": sroof, "valu": svalu,
+                                                           "ms_per_call_amortised": round(dtk / (KV * (reps + 1)) * 1e3, 3), "host_cpus_busy": round(sorted(cpus)[len(cpus) // 2], 1),
+                                                           "roofline": sroof, "valu": svalu,
                                                            "pcie": {"achieved_GBps": round(KV * (reps + 1) * n * 2152 / dtk / 1e9, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s",
                                                                     "frac": round(KV * (reps + 1) * n * 2152 / dtk / 1e9 / PCIE_PEAK_GBS, 4)},
                                                            "note": "host pointers in; every caller its own cells; one priming trial, then the median of three"}

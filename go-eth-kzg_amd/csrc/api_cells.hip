@@ -371,6 +371,10 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     const int sub_mode = MKZG_CV_SUBGROUP_WIDE_FROM > 0 && n + n_rows >= (size_t)MKZG_CV_SUBGROUP_WIDE_FROM ? 4 : 2;
     KT(KT_SUBGROUP, s3, g1_validate2_device(d_rows, (int)n_rows, nullptr, sub_rows, d_proofs, (int)n, nullptr, sub_q, s3, sub_mode));
     HIPCHK(hipEventRecord(L->ev_join, s3));
+    // scalars, first part: r^k, r^k h_k^64 and the rows' weights need the indices only -- in the call's queue AHEAD of the cells' upload, where
+    // they run while the host still gathers (A/B with twelve callers: 9.4 against 8.6-9.3 M cells/s)
+    KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, d_cidx, d_ridx, nullptr, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp, L->d_v_s1, L->d_v_s3,
+                                                       L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s, 1));
     // uploads, part 2: the cells (n x 2 KiB, scattered host pointers) are gathered into the pinned staging area by the host pool running
     // AHEAD of this thread -- all chunks' tasks queued at once -- while the GPU validates the points; this thread waits for chunk k only
     // and puts its copy in flight
@@ -401,9 +405,9 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
         c->pool->wait(all_left);                  // the tasks reference this frame
         if (urc) return urc;
     }
-    // scalars
+    // scalars, second part: the interpolation reads the cells
     KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, d_cidx, d_ridx, d_cells ? d_cells : L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,
-                                                       L->d_v_s1, L->d_v_s3, L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s));
+                                                       L->d_v_s1, L->d_v_s3, L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s, 2));
     HIPCHK(hipStreamWaitEvent(s, L->ev_decoded, 0));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
     const uint32_t* scal[4] = {L->d_v_s1, L->d_cv_weights, L->d_cv_interp, L->d_v_s3};

@@ -23,6 +23,7 @@ constexpr int CELL_INTERP_BLOCKS = 2048;
 // h_r8: HOST pointer to the eight words of r (it travels in the kernel arguments)
 void cell_verify_scalars_device(const uint32_t* h_r8, uint32_t exp_offset, const uint64_t* d_cell_idx, const uint32_t* d_row_idx, const uint8_t* d_cells, int n, int n_rows,
                                 const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint32_t* d_rp_rows, uint32_t* d_s1, uint32_t* d_s4, uint32_t* d_weights8,
-                                uint32_t* d_partials, uint32_t* d_interp8, int* d_cell_status, hipStream_t s);
+                                uint32_t* d_partials, uint32_t* d_interp8, int* d_cell_status, hipStream_t s,
+                                int phase = 0 /* 1: the launches that need the indices and r only; 2: those that read the cells; 0: all */);
 
 }  // namespace kzg

@@ -544,15 +544,19 @@ void fk20_scalars_device(const uint32_t* d_coeffs, int n, const uint32_t* d_tw_f
 
 void cell_verify_scalars_device(const uint32_t* h_r8, uint32_t exp_offset, const uint64_t* d_cell_idx, const uint32_t* d_row_idx, const uint8_t* d_cells, int n, int n_rows,
                                 const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint32_t* d_rp_rows, uint32_t* d_s1, uint32_t* d_s4, uint32_t* d_weights8,
-                                uint32_t* d_partials, uint32_t* d_interp8, int* d_cell_status, hipStream_t s) {
+                                uint32_t* d_partials, uint32_t* d_interp8, int* d_cell_status, hipStream_t s, int phase) {
     if (n <= 0) return;
-    RWords r;                                  // by value: see rlc_scalars_device
-    for (int i = 0; i < 8; i++) r.w[i] = h_r8[i];
-    hipLaunchKernelGGL(k_cell_rpowers, dim3((n + 255) / 256), dim3(256), 0, s, r, exp_offset, d_cell_idx, n, d_tw_fwd, d_rp_rows, d_s1, d_s4);
-    hipLaunchKernelGGL(k_cell_weights, dim3(n_rows), dim3(256), 0, s, d_rp_rows, d_row_idx, n, n_rows, d_weights8);
-    const int nb = n < CELL_INTERP_BLOCKS ? n : CELL_INTERP_BLOCKS;
-    hipLaunchKernelGGL(k_cell_interp, dim3(nb), dim3(64), 0, s, d_cells, d_cell_idx, d_rp_rows, n, d_tw_inv, d_partials, d_cell_status);
-    hipLaunchKernelGGL(k_cell_interp_reduce, dim3(1), dim3(1024), 0, s, d_partials, nb, d_interp8);
+    if (phase != 2) {                          // what needs the indices and r only: the caller issues it ahead of the cells' upload
+        RWords r;                              // by value: see rlc_scalars_device
+        for (int i = 0; i < 8; i++) r.w[i] = h_r8[i];
+        hipLaunchKernelGGL(k_cell_rpowers, dim3((n + 255) / 256), dim3(256), 0, s, r, exp_offset, d_cell_idx, n, d_tw_fwd, d_rp_rows, d_s1, d_s4);
+        hipLaunchKernelGGL(k_cell_weights, dim3(n_rows), dim3(256), 0, s, d_rp_rows, d_row_idx, n, n_rows, d_weights8);
+    }
+    if (phase != 1) {                          // what reads the cells
+        const int nb = n < CELL_INTERP_BLOCKS ? n : CELL_INTERP_BLOCKS;
+        hipLaunchKernelGGL(k_cell_interp, dim3(nb), dim3(64), 0, s, d_cells, d_cell_idx, d_rp_rows, n, d_tw_inv, d_partials, d_cell_status);
+        hipLaunchKernelGGL(k_cell_interp_reduce, dim3(1), dim3(1024), 0, s, d_partials, nb, d_interp8);
+    }
 }
 
 }  // namespace kzg

@@ -102,7 +102,7 @@ def parse_args():
                          "0 = bucket method (10.5 MB table), 12..15 = that width")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the first is `value`, all are reported (min / median / max)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling legs of the two batch verifiers (8192 blobs / 65,536 cells in all)")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the steps alternate over (1 = strictly serial steps)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the steps alternate over (1 = strictly serial steps; 2 until the second session of round 4: 4 streams measure 3-4 % more on the same box, 6 and 8 no more than 4)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with hipEvents (roofline section is then empty)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-drop-in", action="store_true")
@@ -214,8 +214,8 @@ def main():
         if args.direct_bits > 0 and eff != args.direct_bits:
             print(f"bench.py: direct table with {args.direct_bits} bits unavailable on this box, the library degraded to {eff or 'the bucket method'}", file=sys.stderr)
         args.direct_bits = eff
-    # consecutive steps alternate between two HIP streams (each with its own output buffers): every call works in its own lane of the
-    # context, so the latency-bound finish of step i overlaps the accumulation of step i+1
+    # consecutive steps alternate between HIP streams (each with its own output buffers): every call works in its own lane of the
+    # context, so the latency-bound finish of step i overlaps the accumulation of the steps behind it
     NS = max(1, args.streams)
     # distinct priorities -> distinct hardware queues (two default-priority torch streams can share one queue)
     streams = [torch.cuda.Stream(priority=(-1 if i % 2 == 0 else 0)) for i in range(NS)]
@@ -223,9 +223,10 @@ def main():
     d_stats = [torch.zeros(B, dtype=torch.int32, device="cuda") for _ in range(NS)]
     torch.cuda.synchronize()
     counter = [0]
+    ns_active = [NS]
 
     def step(batch=None):
-        i = counter[0] % NS
+        i = counter[0] % ns_active[0]
         src = ring[counter[0] % len(ring)] if batch is None else batch
         counter[0] += 1
         rc = ctx.blob_to_kzg_commitment_batch_device(src.data_ptr(), B, d_outs[i].data_ptr(), d_stats[i].data_ptr(), streams[i].cuda_stream)
@@ -269,6 +270,14 @@ def main():
     region_s = [elapsed] + [timed_region() for _ in range(max(0, args.repeats - 1))]
     prof_repeats = ctx.profile_read(reset=True)               # the same kernels over the repeated regions (what a profiler's average mixes in)
     ctx.profile_enable(False)
+    # the same region over fewer streams, for the record (not `value`): how much of the figure is overlap between consecutive steps
+    streams_sweep = {}
+    for m in sorted({1, 2, NS}):
+        if m < NS:
+            ns_active[0] = m
+            timed_region()
+            streams_sweep[str(m)] = round(B * world * args.steps / timed_region(), 1)
+    ns_active[0] = NS
     assert all(int(t.abs().sum().item()) == 0 for t in d_stats), "some blobs were rejected"
     # untimed check pass: the cross-check batch through every stream of the timed loop
     for _ in range(NS):
@@ -336,9 +345,14 @@ def main():
             roofline["achieved_one_stream"] = round(ALGO_BYTES_PER_BLOB * B / (iso_ms_r * 1e-3) / 1e9, 3)
             roofline["frac_one_stream"] = round(ALGO_BYTES_PER_BLOB * B / (iso_ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
         roofline["input_ring"] = {"batches": len(ring), "bytes": len(ring) * B * BLOB, "note": "the timed steps cycle through this many distinct input batches resident in HBM"}
+        step_ms = elapsed / args.steps * 1e3
+        roofline["achieved_per_step"] = round(ALGO_BYTES_PER_BLOB * B / (step_ms * 1e-3) / 1e9, 3)
+        roofline["frac_per_step"] = round(ALGO_BYTES_PER_BLOB * B / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
         if NS > 1:
-            roofline["note"] = (f"{NS} streams: avg_kernel_ms is a launch's duration while it shares the GPU with the other stream's kernels (it can exceed ms_per_step); "
-                                "avg_kernel_ms_one_stream is the same launch alone on the GPU (three untimed single-stream steps)")
+            roofline["note"] = (f"{NS} streams: `achieved` / `frac` divide a launch's algorithmic bytes by ITS duration, and avg_kernel_ms is a launch's duration while it shares "
+                                f"the GPU with the launches of the other {NS - 1} streams (it exceeds ms_per_step; with 2 streams it was ~3.2 ms and frac 0.0013 for the same kernel); "
+                                "avg_kernel_ms_one_stream / frac_one_stream: the same launch alone on the GPU (three untimed single-stream steps); achieved_per_step / frac_per_step: "
+                                "a launch's bytes over ms_per_step, what the overlapped pipeline streams per unit of wall time")
         # what actually bounds this path: integer VALU issue.  Wave-instructions of the dominant kernel (rocprofv3 SQ_INSTS_VALU,
         # profiles/*_traffic.json, valid only for the kernel sources they were collected on) over its duration, against the hardware
         # limit -- one VALU instruction per SIMD per 4 cycles at the device's maximum clock -- and against the rate this particular GPU
@@ -377,6 +391,8 @@ def main():
                         "ms_per_step_min": round(ms_steps[0], 3), "ms_per_step_median": round(ms_steps[len(ms_steps) // 2], 3), "ms_per_step_max": round(ms_steps[-1], 3),
                         "blobs_per_s_median": round(B * world / (ms_steps[len(ms_steps) // 2] * 1e-3), 1),
                         "note": "`value` is the first region (the contract's K steps); the others repeat it back to back"},
+            "streams_sweep": {"blobs_per_s_by_streams": streams_sweep, "note": "one more timed region of the same K steps over fewer streams (after an untimed one), for the record: "
+                              "what the overlap between consecutive steps is worth; `value` is the region over config.streams streams"},
             "roofline": roofline, "valu": valu, "numa": numa,
         }
         if multi is not None:

@@ -121,7 +121,7 @@ struct Lane {
     int* d_v_st = nullptr;                 // 3 v_cap ints (commitments | proofs | blobs)
     uint32_t* d_v_z = nullptr;             // v_cap Fr rows
     uint32_t* d_v_y = nullptr;
-    uint32_t* d_v_zrows = nullptr;          // v_cap x 14 rows of 12 words: what the evaluation needs of z alone (verify_kernels.hip k_blob_eval_prep)
+    uint32_t* d_v_zrows = nullptr;          // v_cap x 12 rows of 12 words: z^(2^L), L = 0..11 -- what the evaluation needs of z alone (the hash launch or k_blob_eval_prep writes them)
     uint32_t* d_v_s1 = nullptr;            // v_cap x 8 words
     uint32_t* d_v_s3 = nullptr;
     uint32_t* d_v_ry = nullptr;            // v_cap x 8 words: r^i y_i per blob (throughput shape: the evaluation kernel writes them, the host adds them up)

@@ -40,7 +40,7 @@ struct ValJobs {
 void g1_validate_jobs_device(ValJobs& jobs, hipStream_t s);
 // d_zrows: n x blob_eval_scratch_words() words of scratch (what depends on z alone, from a one-lane-per-blob kernel ahead of the evaluation)
 size_t blob_eval_scratch_words();
-// rows_ready: d_zrows were written by the challenge launch already (ShaJobs::zrows_out).  h_r8 (HOST pointer to the eight words of r, may be
+// rows_ready: d_zrows were written by the challenge launch already (ShaJobs::zrows_out, challenge_device's d_zrows).  h_r8 (HOST pointer to the eight words of r, may be
 // null): the evaluation kernel's last lane also leaves the blob's share of the random linear combination -- d_s1[b] = r^(exp_offset + b),
 // d_s3[b] = r^i z_b (8 plain words each, the MSM scalars), d_ry[b] = r^i y_b (8 plain words: the host adds them up) -- instead of a
 // k_rlc_scalars launch behind it

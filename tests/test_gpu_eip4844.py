@@ -211,8 +211,8 @@ def test_batch_64_device_generated(gpu_ctx, oracle_ctx):
 
 @pytest.fixture(params=[0, 1], ids=["latency_shape", "throughput_shape"])
 def verify_shape(request, gpu_ctx):
-    """both shapes of the blob verifier (api_verify.hip): 0 = inverse NTT + Horner, quad-lane subgroup tests, side streams;
-    1 = product-tree barycentric evaluation (k_blob_eval_tree), one lane per point, shared hash rounds -- forced, then put back"""
+    """both shapes of the blob verifier (api_verify.hip): 0 = the call's own hash launch, quad-lane subgroup tests, side streams;
+    1 = one stream per call, one lane per point, shared hash rounds -- forced, then put back; both evaluate with k_blob_eval_tree"""
     assert gpu_ctx.set_option("verify_shape", request.param) == 0
     yield request.param
     assert gpu_ctx.set_option("verify_shape", -1) == 0
@@ -596,7 +596,7 @@ def _domain_roots_brp():
 
 def test_evaluation_kernels_agree_with_oracle(gpu_ctx, oracle_ctx):
     """Domain.EvaluateLagrangePolynomial (reference internal/domain/domain.go:163-235) through each of the library's three evaluation
-    kernels -- inverse NTT + Horner, the product-tree barycentric form that carries the throughput shape (k_blob_eval_tree), the proof
+    kernels -- inverse NTT + Horner (a cross-check only since round 4), the numerator tree of the barycentric formula that both verifier shapes run (k_blob_eval_tree), the proof
     path's per-lane batch inversion -- at caller-chosen points: random z, z = 0, z = r - 1, and POINTS OF THE DOMAIN (stored index 0 = the root
     1, an odd index, index 4095, a middle one), where the barycentric formula divides by zero and the value is the stored scalar itself.
     Each branch also with a non-canonical blob (status, no value) and a non-canonical z.  Byte-exact against the oracle."""

@@ -572,8 +572,10 @@ static int recover_front(mkzg_ctx* c, Lane* L, size_t n_blobs, const uint64_t* c
     }
     HIPCHK(hipGetLastError());
     // device-side statuses (non-canonical field elements in the cells) join the host-side ones
-    std::vector<int> dst(n_blobs);
-    HIPCHK(hipMemcpyAsync(dst.data(), L->d_cell_st, n_blobs * sizeof(int), hipMemcpyDeviceToHost, s));
+    // (into pinned memory -- the positions' staging words, whose upload is ahead of this copy in stream order: a copy into pageable memory
+    // blocks and polls inside the runtime until the stream gets there)
+    int* dst = pos;
+    HIPCHK(hipMemcpyAsync(dst, L->d_cell_st, n_blobs * sizeof(int), hipMemcpyDeviceToHost, s));
     LANE_SYNC(c, L, s);
     for (size_t b = 0; b < n_blobs; b++) if (!status[b]) status[b] = dst[b];
     return MKZG_OK;

@@ -895,13 +895,15 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
         // merge statuses: blob error first, then commitment error (prove.go:49-62)
         HIPCHK(hipGetLastError());
-        std::vector<int> stb(slice), stc(slice);
-        HIPCHK(hipMemcpyAsync(stb.data(), st_blob, slice * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(stc.data(), st_cm, slice * sizeof(int), hipMemcpyDeviceToHost, s));
+        // (into the lane's pinned area: a copy into pageable memory blocks and polls inside the runtime until the stream gets there)
+        int* stb = (int*)L->h_v;
+        int* stc = stb + L->v_cap;
+        HIPCHK(hipMemcpyAsync(stb, st_blob, slice * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(stc, st_cm, slice * sizeof(int), hipMemcpyDeviceToHost, s));
         LANE_SYNC(c, L, s);
         bool any = false;
         for (size_t i = 0; i < slice; i++) { stb[i] = stb[i] ? stb[i] : stc[i]; any = any || stb[i]; }
-        if (any) HIPCHK(hipMemcpyAsync(d_status + done, stb.data(), slice * sizeof(int), hipMemcpyHostToDevice, s));
+        if (any) HIPCHK(hipMemcpyAsync(d_status + done, stb, slice * sizeof(int), hipMemcpyHostToDevice, s));
         if (any) LANE_SYNC(c, L, s);
         done += slice;
     }

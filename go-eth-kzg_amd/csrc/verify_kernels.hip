@@ -897,9 +897,11 @@ __device__ __forceinline__ void g1_validate_block(const uint8_t* __restrict__ in
         st[i] = rc;
     }
 }
+// (one instantiation per mode: a kernel's registers are the maximum over every path it contains)
+template <int MODE>
 __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
-                                                     const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int mode) {
-    g1_validate_block(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, mode, (int)blockIdx.x);
+                                                     const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
+    g1_validate_block(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, MODE, (int)blockIdx.x);
 }
 // the points of SEVERAL calls in one launch (api_verify.hip, the rounds of the throughput shape): decoding + one-lane r-torsion test (mode 3)
 // is a 1.3 ms chain on one wavefront per 64 points -- 64 wavefronts for a call of 1024 proofs -- and as a launch of its own in every
@@ -1414,8 +1416,15 @@ void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, in
                          int mode) {
     const int n = n_a + n_b;
     const int per_block = (mode == 1 || mode == 3 || mode == 4) ? 64 : VAL_PB;
-    if (n > 0) hipLaunchKernelGGL(k_g1_validate, dim3((n + per_block - 1) / per_block), dim3((mode == 0 || mode == 3) ? 128 : 64), 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b,
-                                  d_st_b, mode);
+    if (n <= 0) return;
+    const dim3 grid((n + per_block - 1) / per_block), block((mode == 0 || mode == 3) ? 128 : 64);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((k_g1_validate<0>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
+        case 1: hipLaunchKernelGGL((k_g1_validate<1>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
+        case 2: hipLaunchKernelGGL((k_g1_validate<2>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
+        case 3: hipLaunchKernelGGL((k_g1_validate<3>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
+        default: hipLaunchKernelGGL((k_g1_validate<4>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
+    }
 }
 void g1_validate_jobs_device(ValJobs& jobs, hipStream_t s) {
     int blocks = 0;

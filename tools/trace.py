@@ -79,6 +79,8 @@ def wl_verify_host(args):
     BLOB, load_product, rand_blob = _product()
 
     import torch
+    import bench
+    print("numa:", bench.bind_to_gpu_node(torch, 0), flush=True)      # as bench.py does: the caller's blobs then live on the GPU's NUMA node
     torch.cuda.init()
     kzg = load_product()
     ctx = kzg.Context(device=0)

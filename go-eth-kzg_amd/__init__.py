@@ -46,7 +46,7 @@ EXPORTED_SYMBOLS = [
     "mkzg_recover_cells_and_kzg_proofs_batch_device",
     "mkzg_evaluate_blobs_device", "mkzg_verify_cell_kzg_proof_batch_device", "mkzg_verify_cell_kzg_proof_batch_partial_device",
     "mkzg_comm_unique_id", "mkzg_comm_init", "mkzg_comm_from_nccl", "mkzg_comm_free", "mkzg_comm_last_exchange_us",
-    "mkzg_verify_blob_kzg_proof_batch_exchange", "mkzg_verify_blob_kzg_proof_batch_exchange_device", "mkzg_verify_cell_kzg_proof_batch_exchange",
+    "mkzg_verify_blob_kzg_proof_batch_exchange", "mkzg_verify_blob_kzg_proof_batch_exchange_device", "mkzg_verify_cell_kzg_proof_batch_exchange", "mkzg_verify_cell_kzg_proof_batch_exchange_device",
 ]
 
 
@@ -104,6 +104,7 @@ def lib():
         L.mkzg_verify_blob_kzg_proof_batch_exchange.argtypes = [vp, vp, C.c_char_p, C.c_char_p, sz, C.c_uint64]
         L.mkzg_verify_blob_kzg_proof_batch_exchange_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, vp]
         L.mkzg_verify_cell_kzg_proof_batch_exchange.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64]
+        L.mkzg_verify_cell_kzg_proof_batch_exchange_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64, vp]
         L.mkzg_verify_cell_kzg_proof_batch_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, vp]
         L.mkzg_verify_cell_kzg_proof_batch_partial_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
         L.mkzg_recover_cells_and_kzg_proofs_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]

@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
                 if rc.returncode != 0:
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), (rc.stderr or "")[-4000:]))
     if force or jobs or _stale(OUT, objs):
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"])      # api_exchange.hip dlopens librccl
     return OUT
 
 

@@ -566,7 +566,6 @@ static void ctx_destroy_one(mkzg_ctx* c) {
     c->hash_prev.reset();
     c->hash_prev2.reset();
     for (auto& hs : c->hash_stream) if (hs) (void)hipStreamDestroy(hs);
-    for (auto& vs : c->val_stream) if (vs) (void)hipStreamDestroy(vs);
     if (c->init_stream) (void)hipStreamDestroy(c->init_stream);
     delete c->pool;
     delete c;
@@ -644,7 +643,8 @@ static cpu_set_t device_node_cpus(int device, int need) {
     CPU_ZERO(&mine);
     if (sched_getaffinity(0, sizeof mine, &mine) != 0) return out;
     int n_all = CPU_COUNT(&mine);
-    for (char* tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+    char* save = nullptr;                                 // strtok_r: contexts are created concurrently, one thread per device
+    for (char* tok = strtok_r(list, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {
         int a = 0, b = 0;
         const int k = sscanf(tok, "%d-%d", &a, &b);
         if (k == 1) b = a;

@@ -180,7 +180,7 @@ static int ensure_cv_ws(Lane* L, size_t n_cells, size_t n) {
     int rc = dev_realloc(L->d_cv_in, cap * (48 + 48 + 8 + 4));
     if (!rc) rc = dev_realloc(L->d_cv_rp, cap * 48);
     if (!rc) rc = dev_realloc(L->d_cv_weights, cap * 32);
-    if (!rc) rc = dev_realloc(L->d_cv_partials, (size_t)CELL_INTERP_BLOCKS * 64 * 48);
+    if (!rc) rc = dev_realloc_zero(L->d_cv_partials, CELL_INTERP_SCRATCH_BYTES);      // the tickets at its end
     if (!rc) rc = dev_realloc(L->d_cv_interp, 64 * 32);
     if (!rc) rc = dev_realloc(L->d_cv_st, 3 * cap * sizeof(int));
     if (rc) return rc;
@@ -309,7 +309,7 @@ static const size_t CELL_PIECE = VMSM_MAX_N;       // cells per fold (the variab
 // cells: host pointers (the reference's []*Cell), or d_cells: the piece's n x 2048 B contiguous in HBM (no gather, no upload; s is then the
 // caller's stream)
 static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, const uint64_t* cell_indices, const uint8_t* const* cells, const uint8_t* d_cells,
-                           const uint8_t* proofs48n, size_t n, uint32_t exp_offset, const uint32_t r_words[8], hipStream_t s, CellFold* out) {
+                           const uint8_t* proofs48n, size_t n, uint32_t exp_offset, const uint32_t r_words_in[8], hipStream_t s, CellFold* out, RlcLate* late = nullptr) {
     // deduplicateKZGCommitments (api_eip7594.go:238-265); per piece -- the sum over rows is linear, so pieces need not agree on the rows
     std::unordered_map<std::string, uint32_t> seen;
     std::vector<uint32_t> row_idx(n);
@@ -373,6 +373,18 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     HIPCHK(hipEventRecord(L->ev_join, s3));
     // scalars, first part: r^k, r^k h_k^64 and the rows' weights need the indices only -- in the call's queue AHEAD of the cells' upload, where
     // they run while the host still gathers (A/B with twelve callers: 9.4 against 8.6-9.3 M cells/s)
+    // (r still on its way from a collective, RlcLate: the points' chains are running by now; the cells' gather below does not overlap the
+    // wait -- a rank of a multi-process job that brings host pointers pays the slowest rank's lateness there)
+    uint32_t r_words[8];
+    if (late) {
+        const int lrc = late->get();
+        if (lrc) return lrc;
+        if (late->offset + exp_offset + n > 0xffffffffull) return MKZG_ERR_BAD_ARGS;
+        memcpy(r_words, late->r_words, 32);
+        exp_offset += (uint32_t)late->offset;
+    } else {
+        memcpy(r_words, r_words_in, 32);
+    }
     KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, d_cidx, d_ridx, nullptr, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp, L->d_v_s1, L->d_v_s3,
                                                        L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s, 1));
     // uploads, part 2: the cells (n x 2 KiB, scattered host pointers) are gathered into the pinned staging area by the host pool running
@@ -454,7 +466,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
 // pieces are folded in order, so among several invalid inputs the error reported is the one of the earliest piece -- the vectors and
 // the reference's tests pin error-vs-failure only.
 int sd_cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells, size_t n_cells,
-                        const uint8_t* proofs48n, size_t n_p, uint64_t exp_offset, const uint8_t* r_be32, CellFold* out, const uint8_t* d_cells, hipStream_t user_stream) {
+                        const uint8_t* proofs48n, size_t n_p, uint64_t exp_offset, const uint8_t* r_be32, CellFold* out, const uint8_t* d_cells, hipStream_t user_stream, RlcLate* late) {
     for (int m = 0; m < 4; m++) G1H::set_inf(out->sums[m]);
     if (!c) return MKZG_ERR_BAD_ARGS;
     const size_t n = n_c;
@@ -467,8 +479,10 @@ int sd_cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, 
     int rc = ensure_twiddles(c);
     if (!rc) rc = ensure_monomial(c);
     if (rc) return rc;
-    uint32_t r_words[8];
-    if (r_be32) {
+    uint32_t r_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (late) {
+        // (asked for inside the first piece, behind the points' launches)
+    } else if (r_be32) {
         for (int i = 0; i < 8; i++) r_words[i] = ((uint32_t)r_be32[28 - 4 * i] << 24) | ((uint32_t)r_be32[29 - 4 * i] << 16) | ((uint32_t)r_be32[30 - 4 * i] << 8) | r_be32[31 - 4 * i];
     } else if (getrandom(r_words, 32, 0) != 32) {
         return MKZG_ERR_HIP;
@@ -479,7 +493,7 @@ int sd_cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, 
     for (size_t off = 0; off < n; off += CELL_PIECE) {
         const size_t m = std::min(CELL_PIECE, n - off);
         rc = cell_fold_piece(c, G.L, commitments48n + off * 48, cell_indices + off, d_cells ? nullptr : cells + off, d_cells ? d_cells + off * 2048 : nullptr, proofs48n + off * 48, m,
-                             (uint32_t)(exp_offset + off), r_words, G.s, &f);
+                             (uint32_t)(exp_offset + off), r_words, G.s, &f, late);
         if (rc) return G.fail(rc);
         for (int q = 0; q < 4; q++) G1H::add(out->sums[q], out->sums[q], f.sums[q]);
     }
@@ -611,6 +625,19 @@ int mkzg_verify_cell_kzg_proof_batch_device(mkzg_ctx* c, const uint8_t* commitme
     return sd_cell_verify_finish(c, f);
 }
 // Sharded form (see CellFold): record = status@0 (int32), compressed sums[0..3] at 16, 64, 112, 160.
+}   // extern "C"
+void cell_fold_record(uint8_t record512[512], int rc, const CellFold& f) {
+    memset(record512, 0, 512);
+    const int32_t st = rc;
+    memcpy(record512, &st, 4);
+    if (rc != MKZG_OK) return;
+    for (int m = 0; m < 4; m++) {
+        G1AffH a;
+        g1h_to_affine(a, f.sums[m]);
+        g1h_compress(record512 + 16 + 48 * m, a);
+    }
+}
+extern "C" {
 int mkzg_verify_cell_kzg_proof_batch_partial(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells,
                                              size_t n_cells, const uint8_t* proofs48n, size_t n_p, uint64_t offset, const uint8_t r32[32], uint8_t record512[512]) {
     if (!c || !r32 || !record512) return MKZG_ERR_BAD_ARGS;
@@ -618,34 +645,20 @@ int mkzg_verify_cell_kzg_proof_batch_partial(mkzg_ctx* c, const uint8_t* commitm
     memset(record512, 0, 512);
     CellFold f;
     int rc = sd_cell_verify_fold(c, commitments48n, n_c, cell_indices, n_i, cells, n_cells, proofs48n, n_p, offset, r32, &f);
-    int32_t st = rc;
-    memcpy(record512, &st, 4);
-    if (rc == MKZG_OK) {
-        for (int m = 0; m < 4; m++) {
-            G1AffH a;
-            g1h_to_affine(a, f.sums[m]);
-            g1h_compress(record512 + 16 + 48 * m, a);
-        }
-    }
+    cell_fold_record(record512, rc, f);
     return rc;
 }
 // sharded form over device-resident cells (this rank's shard)
 int mkzg_verify_cell_kzg_proof_batch_partial_device(mkzg_ctx* c, const uint8_t* commitments48n, const uint64_t* cell_indices, const void* d_cells, const uint8_t* proofs48n, size_t n,
                                                     uint64_t offset, const uint8_t r32[32], uint8_t record512[512], void* stream) {
-    if (!c || !r32 || !record512 || (n && !d_cells)) return MKZG_ERR_BAD_ARGS;
-    if (!c->peers.empty() && n && !(c = ctx_for_pointer(c, d_cells))) return MKZG_ERR_BAD_ARGS;
+    if (!c || !r32 || !record512) return MKZG_ERR_BAD_ARGS;
     memset(record512, 0, 512);
     CellFold f;
-    int rc = sd_cell_verify_fold(c, commitments48n, n, cell_indices, n, nullptr, n, proofs48n, n, offset, r32, &f, (const uint8_t*)d_cells, (hipStream_t)stream);
-    int32_t st = rc;
-    memcpy(record512, &st, 4);
-    if (rc == MKZG_OK) {
-        for (int m = 0; m < 4; m++) {
-            G1AffH a;
-            g1h_to_affine(a, f.sums[m]);
-            g1h_compress(record512 + 16 + 48 * m, a);
-        }
-    }
+    int rc;
+    if (n && !d_cells) rc = MKZG_ERR_BAD_ARGS;
+    else if (!c->peers.empty() && n && !(c = ctx_for_pointer(c, d_cells))) rc = MKZG_ERR_BAD_ARGS;
+    else rc = sd_cell_verify_fold(c, commitments48n, n, cell_indices, n, nullptr, n, proofs48n, n, offset, r32, &f, (const uint8_t*)d_cells, (hipStream_t)stream);
+    cell_fold_record(record512, rc, f);                       // whatever the outcome, the record says so: it is what travels
     return rc;
 }
 int mkzg_verify_cell_kzg_proof_batch_finish(mkzg_ctx* c, const uint8_t* records512, size_t n_records) {

@@ -14,8 +14,12 @@ void verify_fold_clear(VerifyFold& f);
 void verify_fold_add(VerifyFold& acc, const VerifyFold& f);
 // host-pointer fold of n items with global exponents r^(exp_offset + i); r_le32: the batch-wide scalar as 32 little-endian bytes.
 // first_nil (may be null) receives the index of the first nil blob or n; statuses are resolved inside (reference verify.go:102-123 order).
+// late (may be null): r and the offset still on their way (RlcLate, ctx.h) -- exponents are then r^(late->offset + exp_offset + i)
 int sd_verify_blob_fold_host(mkzg_ctx* c, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n, uint64_t exp_offset,
-                             const uint8_t r_le32[32], VerifyFold* out);
+                             const uint8_t r_le32[32], VerifyFold* out, RlcLate* late = nullptr);
+int sd_verify_blob_fold_device(mkzg_ctx* c, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n, uint64_t exp_offset, const uint8_t* r_le32,
+                               hipStream_t stream, VerifyFold* out, RlcLate* late = nullptr);
+void verify_fold_record(uint8_t record512[512], int rc, const VerifyFold& total);
 int sd_verify_finish(mkzg_ctx* c, const VerifyFold& f);
 int draw_rlc_scalar(uint8_t r_le32[32]);
 
@@ -23,7 +27,9 @@ int draw_rlc_scalar(uint8_t r_le32[32]);
 struct CellFold { G1HX sums[4]; };
 int sd_cell_verify_fold(mkzg_ctx* c, const uint8_t* commitments48n, size_t n_c, const uint64_t* cell_indices, size_t n_i, const uint8_t* const* cells, size_t n_cells,
                         const uint8_t* proofs48n, size_t n_p, uint64_t exp_offset, const uint8_t* r_be32 /* null: draw */, CellFold* out,
-                        const uint8_t* d_cells = nullptr /* the cells contiguous in HBM instead of host pointers */, hipStream_t user_stream = nullptr);
+                        const uint8_t* d_cells = nullptr /* the cells contiguous in HBM instead of host pointers */, hipStream_t user_stream = nullptr,
+                        RlcLate* late = nullptr /* r and the offset still on their way: r_be32 unused, exponents r^(late->offset + exp_offset + k) */);
+void cell_fold_record(uint8_t record512[512], int rc, const CellFold& f);
 int sd_cell_verify_finish(mkzg_ctx* c, const CellFold& f);
 
 // ---- multi-device fronts (c->peers non-empty)

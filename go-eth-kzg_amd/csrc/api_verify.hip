@@ -36,7 +36,9 @@ int ensure_verify_ws(Lane* L, size_t n) {
     if (!rc) rc = dev_realloc(L->d_v_s1, cap * 32);
     if (!rc) rc = dev_realloc(L->d_v_s3, cap * 32);
     if (!rc) rc = dev_realloc(L->d_v_ry, cap * 32);
-    if (!rc) rc = dev_realloc(L->d_v_misc, (V_MISC_WORDS + VMSM_PART_WORDS) * 4);      // window sums for the host + slice sums (device only)
+    // window sums for the host + slice sums (device only); k_vmsm_window keeps a ticket per (job, window) in the spare words of its slice
+    // records: zero here, reset by the kernel itself
+    if (!rc) rc = dev_realloc_zero(L->d_v_misc, (V_MISC_WORDS + VMSM_PART_WORDS) * 4);
     L->h_v_bytes = 0;
     if (!rc) rc = pinned_realloc(L->h_v, 3 * cap * sizeof(int) + V_MISC_WORDS * 4 + 64 + cap * 32);      // statuses | misc | r^i y_i words (throughput shape)
     if (rc) return rc;
@@ -101,26 +103,13 @@ int draw_rlc_scalar(uint8_t r_le32[32]) { return getrandom(r_le32, 32, 0) == 32 
 // the round and launches ONE kernel over all its jobs on one of the context's two hash streams (rounds alternate, two are in flight)
 // -- streams of the lowest priority, so that no other stream of the process shares their queues.  Everyone then waits for the round on the host (the call is synchronous anyway; a device-side wait
 // would hold the call's own queue, and with it whatever else HIP mapped there) and carries on in its own stream.
-// points (may be all null): the call's compressed commitments and proofs and where their affine rows and statuses go -- the round then
-// validates them too, in one launch over all its calls on a stream of its own beside the hash launch (both are chains the calls only
-// wait for; as launches in every call's own stream they held that stream's hardware queue)
-struct RoundPoints { const uint8_t* proofs; uint32_t* aff_c; uint32_t* aff_q; int* st_c; int* st_q; };
-static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, uint32_t* d_zrows, hipEvent_t ready, std::shared_ptr<HashRound>* out,
-                           const RoundPoints* pts = nullptr) {
+// (A round that also validated its calls' points in one launch on a stream of its own was measured in round 4 and dropped -- DESIGN.md
+// Appendix A: the 1.3 ms chain runs in every call's own stream while the call waits for its round anyway.)
+static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, uint32_t* d_zrows, hipEvent_t ready, std::shared_ptr<HashRound>* out) {
     std::shared_ptr<HashRound> r, prev;
     bool leader = false;
     {
         std::unique_lock<std::mutex> lk(c->hash_mu);
-        for (auto& hs : c->val_stream) {
-            if (hs) continue;
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-#ifndef MKZG_VAL_PRIO
-#define MKZG_VAL_PRIO 0
-#endif
-            const int vprio = MKZG_VAL_PRIO == 2 ? greatest : MKZG_VAL_PRIO == 1 ? (least + greatest) / 2 : least;
-            if (hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, vprio) != hipSuccess) { hs = nullptr; (void)hipGetLastError(); return MKZG_ERR_HIP; }
-        }
         for (auto& hs : c->hash_stream) {
             if (hs) continue;
             int least = 0, greatest = 0;
@@ -143,11 +132,6 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
         r->jobs.commitments[j] = d_commitments;
         r->jobs.z_out[j] = d_z;
         r->jobs.zrows_out[j] = d_zrows;
-        if (pts) {
-            const int v = r->vjobs.count++;
-            r->vjobs.in_a[v] = d_commitments; r->vjobs.n_a[v] = n; r->vjobs.aff_a[v] = pts->aff_c; r->vjobs.st_a[v] = pts->st_c;
-            r->vjobs.in_b[v] = pts->proofs; r->vjobs.n_b[v] = n; r->vjobs.aff_b[v] = pts->aff_q; r->vjobs.st_b[v] = pts->st_q;
-        }
         r->jobs.n[j] = n;
         r->ready[j] = ready;
         if (leader && prev) c->hash_cv.wait(lk, [&] { return prev->launched; });
@@ -158,29 +142,18 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
             if (wait_sleeping(c)) (void)wait_event_sleeping(prev->done);
             else (void)hipEventSynchronize(prev->done);
         }
-        hipStream_t hs, vs;
+        hipStream_t hs;
         {
             std::lock_guard<std::mutex> g(c->hash_mu);
             c->hash_forming.reset();                                           // closed: later arrivals open the next round
             c->hash_prev2 = c->hash_prev;
             c->hash_prev = r;
-            vs = c->val_stream[c->hash_rounds & 1];
             hs = c->hash_stream[c->hash_rounds++ & 1];
         }
         int rc = MKZG_OK;
         if (hipEventCreateWithFlags(&r->done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { r->done = nullptr; rc = MKZG_ERR_HIP; }
         for (int j = 0; j < r->jobs.count && !rc; j++)
             if (r->ready[j] && hipStreamWaitEvent(hs, r->ready[j], 0) != hipSuccess) rc = MKZG_ERR_HIP;
-        if (!rc && r->vjobs.count) {
-            // the same calls' points on the validation stream (its previous launch belongs to the round two back: finished, see above)
-            if (hipEventCreateWithFlags(&r->done_val, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { r->done_val = nullptr; rc = MKZG_ERR_HIP; }
-            for (int j = 0; j < r->jobs.count && !rc; j++)
-                if (r->ready[j] && hipStreamWaitEvent(vs, r->ready[j], 0) != hipSuccess) rc = MKZG_ERR_HIP;
-            if (!rc) {
-                g1_validate_jobs_device(r->vjobs, vs);
-                if (hipGetLastError() != hipSuccess || hipEventRecord(r->done_val, vs) != hipSuccess) rc = MKZG_ERR_HIP;
-            }
-        }
         if (!rc) {
             challenge_jobs_device(r->jobs, hs);
             if (hipGetLastError() != hipSuccess || hipEventRecord(r->done, hs) != hipSuccess) rc = MKZG_ERR_HIP;
@@ -276,7 +249,7 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
     return MKZG_OK;
 }
 static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
-                       uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out) {
+                       uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out, RlcLate* late = nullptr) {
     if (n == 0 || n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
     int rc = ensure_verify_ws(L, n);
     if (rc) return rc;
@@ -298,7 +271,18 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     int* st_x = L->d_v_st + 3 * cap;        // scratch: status of a second scalar array
     // 0. everything that needs r but not the challenges runs beside the challenge hash
     uint32_t r_words[8];                        // r travels in the kernel arguments (rwords.h), not through a 32-byte upload
-    memcpy(r_words, r_le32, 32);
+    if (!late) memcpy(r_words, r_le32, 32);
+    // r and the exponents' offset out of a collective still in flight (RlcLate, ctx.h): asked for where they are first used
+    auto need_r = [&]() -> int {
+        if (!late) return MKZG_OK;
+        const int lrc = late->get();
+        if (lrc) return lrc;
+        if (late->offset + exp_offset + n > 0xffffffffull) return MKZG_ERR_BAD_ARGS;
+        memcpy(r_words, late->r_words, 32);
+        exp_offset += (uint32_t)late->offset;
+        late = nullptr;
+        return MKZG_OK;
+    };
     uint32_t* d_parts = L->d_v_misc + V_MISC_WORDS;
     uint32_t* d_wsum = L->d_v_misc + 16;
     const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
@@ -311,13 +295,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     //    context with eight calls in flight had two of them progressing; one stream per call keeps one queue per call)
     hipStream_t s2 = tp ? s : lane_side_stream(L, s);
     const bool s_idle = lane_fork(L, s, s2);
-    // (throughput shape with the challenges still to hash: the ROUND validates the points of all its calls in one launch beside the hash)
-#ifndef MKZG_TP_ROUND_VALIDATE
-#define MKZG_TP_ROUND_VALIDATE 0            // measured and rejected (round 4, tools/ab_verify.py, one box, alternating): 1.74-1.75 M blobs/s against 1.89-1.93 M with the
-#endif                                      // validation in every call's own stream -- see DESIGN.md Appendix A; kept as a build flag
-    const bool round_validates = MKZG_TP_ROUND_VALIDATE && tp && d_blobs && !d_z32 && MKZG_TP_VALIDATE_MODE == 3;
-    if (!round_validates)
-        KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
+    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
     if (d_blobs) {
         //    ... and, for blobs, the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
         //    (throughput shape: none of that -- the three MSMs go out as ONE launch after the challenge, see below)
@@ -326,17 +304,19 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         //    The blobs themselves wait for their challenge: y = f(z) is ONE pass over the blob once z is known (k_blob_eval_tree, with the
         //    canonicity check of DeserializeBlob, serialization.go:134-146) -- up to round 4 the latency shape ran an inverse NTT of every blob
         //    beside the hash (5x the instructions, 201 MB of coefficient rows per lane) to make that pass a Horner evaluation of the same length.
-        const bool host_z = d_z32 != nullptr;
-        if (!tp && !host_z) {
-            KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
-            const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
-            const uint32_t* pts[2] = {aff_q, aff_c};
-            const int njob[2] = {(int)n, (int)n};
-            KT(KT_VMSM, s2, vrc = vmsm_windows_device(scal, pts, njob, 2, d_parts, d_wsum, s2));
-            if (vrc) return MKZG_ERR_BAD_ARGS;
-        }
     }
-    HIPCHK(hipEventRecord(L->ev_join, s2));
+    const bool early_msms = d_blobs && !tp && !d_z32;
+    auto step0 = [&]() -> int {
+        KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)n, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
+        const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
+        const uint32_t* pts[2] = {aff_q, aff_c};
+        const int njob[2] = {(int)n, (int)n};
+        KT(KT_VMSM, s2, vrc = vmsm_windows_device(scal, pts, njob, 2, d_parts, d_wsum, s2));
+        return vrc ? MKZG_ERR_BAD_ARGS : MKZG_OK;
+    };
+    const bool step0_late = early_msms && late != nullptr;    // r still on its way: the hash goes out first, these behind it (beside it on the device all the same)
+    if (early_msms && !step0_late) { rc = step0(); if (rc) return rc; }
+    if (!step0_late) HIPCHK(hipEventRecord(L->ev_join, s2));
     // 2. challenge and claimed value per blob, or caller-supplied z / y
     int y_bad = 0;
     if (d_blobs) {
@@ -346,22 +326,16 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             std::shared_ptr<HashRound> round;                                // the hash of this call and of whoever else is waiting for one
             CPU_LAP(0);
             // (the round's launch also leaves what the evaluation needs of each z alone: L->d_v_zrows)
-            const RoundPoints rp{d_proofs, aff_c, aff_q, st_c, st_q};
-            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->d_v_zrows, s_idle ? nullptr : L->ev_fork, &round, round_validates ? &rp : nullptr);   // ev_fork: recorded on s before any of this call's kernels
+            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->d_v_zrows, s_idle ? nullptr : L->ev_fork, &round);   // ev_fork: recorded on s before any of this call's kernels
             CPU_LAP(1);
             if (round && round->done) {                                      // on the host: a device-side wait would hold the call's queue
                 int wr = MKZG_OK;
                 if (wait_sleeping(c)) wr = wait_event_sleeping(round->done);
                 else if (hipEventSynchronize(round->done) != hipSuccess) { (void)hipGetLastError(); wr = MKZG_ERR_HIP; }
-                if (!wr && round->done_val) {                            // ... and its points (the shorter chain: usually long finished)
-                    if (wait_sleeping(c)) wr = wait_event_sleeping(round->done_val);
-                    else if (hipEventSynchronize(round->done_val) != hipSuccess) { (void)hipGetLastError(); wr = MKZG_ERR_HIP; }
-                }
                 if (wr) {
                     // the round's kernels may still be writing this lane's challenges and rows: nobody gets the lane before the rounds' streams are idle
                     tl_hip_error = true;
                     for (auto& hs : c->hash_stream) if (hs) (void)hipStreamSynchronize(hs);
-                    for (auto& vs : c->val_stream) if (vs) (void)hipStreamSynchronize(vs);
                     (void)hipGetLastError();
                     return wr;
                 }
@@ -371,6 +345,11 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         } else {
             if (c->opt_debug_serial.load(std::memory_order_relaxed)) HIPCHK(hipStreamSynchronize(s2));
             KT(KT_SHA256, s, challenge_device(d_blobs, d_commitments, (int)n, L->d_v_z, s, L->d_v_zrows));     // (leaves the evaluation's z-only rows too)
+        }
+        if ((rc = need_r())) return rc;                                      // (a late r: the hash, the decoding and the subgroup tests are running by now)
+        if (step0_late) {
+            if ((rc = step0())) return rc;
+            HIPCHK(hipEventRecord(L->ev_join, s2));
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
         if (tp) {
@@ -492,12 +471,19 @@ static bool use_host_sha(const mkzg_ctx* c, size_t m) {
 // Of a lone call's m transcripts, how many the DEVICE hashes (the first ones: they are uploaded first).  The host finishes its share at
 // about m x t_copy + (m - d) x t_hash, the device at t_launch + d x t_upload + 2.75 ms; d balances the two (nothing up to ~1100 blobs on 15
 // pool threads: *measured* at 1024 blobs 4.41 ms with none, 4.41 with 12 %, 4.74 with 25 %; 600 of a 2048-blob piece).  MKZG_DEV_HASH_PERCENT overrides (A/B).
+// the host's share takes the sixteen-lane AVX-512 form when it gives every pool thread and the caller at least one task of sixteen
+static bool host_sha_wide(const mkzg_ctx* c, size_t host_share) {
+    static const bool no_wide = getenv("MKZG_NO_WIDE_SHA") != nullptr;          // A/B aid
+    return !no_wide && sha256_have_avx512() && host_share >= 16 * (size_t)(c->pool->size() + 1);
+}
 static size_t device_hash_share(const mkzg_ctx* c, size_t m) {
     static const int forced = [] { const char* e = getenv("MKZG_DEV_HASH_PERCENT"); return e ? atoi(e) : -1; }();
     if (forced >= 0) return std::min(m, m * (size_t)std::min(forced, 100) / 100);
     const double T = (double)std::max(1, c->pool->size());
-    // per transcript over the whole pool (us): 35.3 per core for a SHA-NI pair's half, 23.7 on sixteen AVX-512 lanes; the copies mostly hide under the upload; a chunk goes up at ~47 GB/s
-    const double hash_us = (sha256_have_avx512() ? 23.7 : 35.3) / T, copy_us = std::max(0.6, 6.0 / T), up_us = 2.8, chain_us = 2750.0 + 200.0;
+    // per transcript over the whole pool (us): 35.3 per core for a SHA-NI pair's half, 23.7 on sixteen AVX-512 lanes -- priced by the form the
+    // host will really take (host_sha_wide; the device's share only shrinks the host's, and a share that large is far above the
+    // threshold); the copies mostly hide under the upload; a chunk goes up at ~47 GB/s
+    const double hash_us = (host_sha_wide(c, m) ? 23.7 : 35.3) / T, copy_us = std::max(0.6, 6.0 / T), up_us = 2.8, chain_us = 2750.0 + 200.0;
     const double d = ((copy_us + hash_us) * (double)m - chain_us) / (hash_us + up_us);
     if (d < 64) return 0;
     return std::min(m, (size_t)d / 64 * 64);
@@ -516,7 +502,7 @@ static size_t device_hash_share(const mkzg_ctx* c, size_t m) {
 // *Measured* (bench.py -> drop_in.verify_blob_kzg_proof_batch, N = 1024): 7.6-7.8 ms per call before (gather, upload, THEN the device
 // pipeline) -> see DESIGN.md section 4.2 for the current figure.
 static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t m, uint32_t exp_offset,
-                               const uint8_t* r_le32, VerifyFold* out) {
+                               const uint8_t* r_le32, VerifyFold* out, RlcLate* late = nullptr) {
     hipStream_t s = L->stream, s2 = L->side, cp = L->side2;
     int rc = MKZG_OK;
     const size_t cap = L->v_cap;
@@ -527,7 +513,7 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
     int* st_b = L->d_v_st + 2 * cap;
     int* st_x = L->d_v_st + 3 * cap;
     uint32_t r_words[8];
-    memcpy(r_words, r_le32, 32);
+    if (!late) memcpy(r_words, r_le32, 32);
     uint32_t* d_parts = L->d_v_misc + V_MISC_WORDS;
     uint32_t* d_wsum = L->d_v_misc + 16;
     const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
@@ -535,7 +521,9 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
     uint8_t* h_pts = h_z + m * 32;                                     // m x 48 B commitments | m x 48 B proofs
     uint8_t* d_z = L->d_blobs + m * MKZG_BYTES_PER_BLOB;
     const size_t n_dev = device_hash_share(c, m);                      // transcripts [0, n_dev) are hashed by the device
-    const bool early_msm = m >= 256;                                   // below that the three MSMs leave as one launch at the end
+    // below 256 blobs the three MSMs leave as one launch at the end -- and so they do when r is still on its way (RlcLate: nothing here
+    // needs it before the evaluation, and this thread must not stop feeding the link to wait for another rank)
+    const bool early_msm = m >= 256 && !late;
     // chunk plan: a small first chunk starts the link early, then chunks of 128
     struct Chunk { size_t lo, m; };
     std::vector<Chunk> plan;
@@ -549,8 +537,7 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
     const size_t nch = plan.size();
     // copy tasks: 8 blobs each; hash tasks: 4 transcripts (two SHA-NI pairs) each -- or 16, one per AVX-512 lane, when the host's share
     // gives every pool thread (and this one) at least one such task
-    static const bool no_wide = getenv("MKZG_NO_WIDE_SHA") != nullptr;          // A/B aid
-    const bool wide_sha = !no_wide && sha256_have_avx512() && m - n_dev >= 16 * (size_t)(c->pool->size() + 1);
+    const bool wide_sha = host_sha_wide(c, m - n_dev);
     const size_t CPT = 8, HPT = wide_sha ? 16 : 4;
     std::vector<size_t> ctask_chunk, ctask_lo;
     std::vector<Countdown> left(nch);
@@ -662,6 +649,13 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
             scalars_to_fr_device(d_z + n_dev * 32, (int)(m - n_dev), L->d_v_z + n_dev * 12, st_x + n_dev, s);       // canonical by construction
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
+        if (late) {
+            const int lrc = late->get();
+            if (lrc) return lrc;
+            if (late->offset + exp_offset + m > 0xffffffffull) return MKZG_ERR_BAD_ARGS;
+            memcpy(r_words, late->r_words, 32);
+            exp_offset += (uint32_t)late->offset;
+        }
         // y = f(z) in one pass over the blobs (canonicity check included), r^i z_i and r^i y_i from the lane that finishes each blob
         KT(KT_EVAL_TREE, s, blob_eval_device(L->d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)m, L->d_v_y, st_b, L->d_v_zrows, s, false, r_words, exp_offset, L->d_v_s1, L->d_v_s3,
                                              L->d_v_ry));
@@ -691,7 +685,7 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
 }
 
 static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t m, uint32_t exp_offset,
-                           const uint8_t* r_le32, VerifyFold* out, int* rc_nil /* out: MKZG_ERR_NIL_INPUT precedence result, or 0 */) {
+                           const uint8_t* r_le32, VerifyFold* out, int* rc_nil /* out: MKZG_ERR_NIL_INPUT precedence result, or 0 */, RlcLate* late = nullptr) {
     *rc_nil = 0;
     hipStream_t s = L->stream;
     const bool hsha = use_host_sha(c, m);
@@ -701,7 +695,7 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
     size_t first_nil = m;
     for (size_t i = 0; i < m; i++) if (!blobs[i]) { first_nil = i; break; }
     if (hsha && !throughput_shape(c)) {
-        rc = fold_host_pipelined(c, L, blobs, commitments48n, proofs48n, m, exp_offset, r_le32, out);
+        rc = fold_host_pipelined(c, L, blobs, commitments48n, proofs48n, m, exp_offset, r_le32, out, late);
     } else {
         uint8_t* h_z = L->h_stage + m * MKZG_BYTES_PER_BLOB;              // m x 32 B
         uint8_t* h_pts = h_z + m * 32;                                     // m x 48 B commitments | m x 48 B proofs
@@ -740,7 +734,7 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
         c->pool->wait(all_left);                      // the tasks reference this frame
         if (rc) return rc;
         if (hsha) HIPCHK(hipMemcpyAsync(d_z, h_z, m * 32, hipMemcpyHostToDevice, s));
-        rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out);
+        rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out, late);
     }
     if (first_nil < m) {
         // the reference deserialises commitment i and proof i before blob i, so a nil blob only surfaces after their checks: an error
@@ -760,13 +754,13 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
 }
 // n items with host pointers in one lane: pieces of HOST_PIECE blobs share r and carry global exponents
 static int fold_host_all(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n, uint64_t exp_offset,
-                         const uint8_t* r_le32, VerifyFold* total) {
+                         const uint8_t* r_le32, VerifyFold* total, RlcLate* late = nullptr) {
     verify_fold_clear(*total);
     VerifyFold f;
     for (size_t off = 0; off < n; off += HOST_PIECE) {
         const size_t m = std::min<size_t>(HOST_PIECE, n - off);
         int rc_nil = 0;
-        int rc = fold_host_piece(c, L, blobs + off, commitments48n + off * 48, proofs48n + off * 48, m, (uint32_t)(exp_offset + off), r_le32, &f, &rc_nil);
+        int rc = fold_host_piece(c, L, blobs + off, commitments48n + off * 48, proofs48n + off * 48, m, (uint32_t)(exp_offset + off), r_le32, &f, &rc_nil, late);
         if (rc_nil) return rc_nil;
         if (rc) return rc;
         verify_fold_add(*total, f);
@@ -774,12 +768,50 @@ static int fold_host_all(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, cons
     return MKZG_OK;
 }
 int sd_verify_blob_fold_host(mkzg_ctx* c, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n, uint64_t exp_offset,
-                             const uint8_t r_le32[32], VerifyFold* out) {
+                             const uint8_t r_le32[32], VerifyFold* out, RlcLate* late) {
     verify_fold_clear(*out);
     if (n == 0) return MKZG_OK;
     LaneGuard G(c);
     G.L->last_host_finish_us = 0;
-    return G.fail(fold_host_all(c, G.L, blobs, commitments48n, proofs48n, n, exp_offset, r_le32, out));
+    return G.fail(fold_host_all(c, G.L, blobs, commitments48n, proofs48n, n, exp_offset, r_le32, out, late));
+}
+// a shard contiguous in HBM: pieces of VMSM_MAX_N items with the global exponents r^(exp_offset + i) (with `late`: r^(late->offset + i),
+// r_le32 unused); the caller's stream is synchronised (the sums come back to the host)
+int sd_verify_blob_fold_device(mkzg_ctx* c, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n, uint64_t exp_offset, const uint8_t* r_le32,
+                               hipStream_t stream, VerifyFold* out, RlcLate* late) {
+    verify_fold_clear(*out);
+    if (n == 0) return MKZG_OK;
+    if (exp_offset + n > 0xffffffffull) return MKZG_ERR_BAD_ARGS;
+    LaneGuard G(c, stream);
+    G.L->last_host_finish_us = 0;
+    VerifyFold f;
+    int rc = MKZG_OK;
+    for (size_t off = 0; off < n && !rc; off += VMSM_MAX_N) {
+        const size_t m = std::min<size_t>(VMSM_MAX_N, n - off);
+        rc = verify_fold(c, G.L, (const uint8_t*)d_blobs + off * MKZG_BYTES_PER_BLOB, nullptr, nullptr, (const uint8_t*)d_commitments48 + off * 48, (const uint8_t*)d_proofs48 + off * 48, m,
+                         (uint32_t)(exp_offset + off), r_le32, G.s, &f, late);
+        if (!rc) verify_fold_add(*out, f);
+    }
+    c->last_host_finish_us.store(G.L->last_host_finish_us);
+    return G.fail(rc);
+}
+// the verifiers' 512-byte record of a fold: status | A | Cc | D | e (include/mi355kzg.h)
+void verify_fold_record(uint8_t record512[512], int rc, const VerifyFold& total) {
+    memset(record512, 0, 512);
+    const int32_t st = rc;
+    memcpy(record512, &st, 4);
+    if (rc != MKZG_OK) return;
+    G1AffH a;
+    g1h_to_affine(a, total.A);
+    g1h_compress(record512 + 16, a);
+    g1h_to_affine(a, total.Cc);
+    g1h_compress(record512 + 64, a);
+    g1h_to_affine(a, total.D);
+    g1h_compress(record512 + 112, a);
+    for (int i = 0; i < 8; i++) {
+        const uint32_t w = total.e[7 - i];
+        record512[160 + 4 * i] = (uint8_t)(w >> 24); record512[161 + 4 * i] = (uint8_t)(w >> 16); record512[162 + 4 * i] = (uint8_t)(w >> 8); record512[163 + 4 * i] = (uint8_t)w;
+    }
 }
 
 extern "C" {
@@ -1078,42 +1110,19 @@ int mkzg_msm_g1(mkzg_ctx* c, const uint64_t* scalars_mont4, const uint64_t* poin
 // Record: [0..4) status (LE int) | [16..64) A | [64..112) Cc | [112..160) D (compressed G1) | [160..192) e (32 B big-endian) | zero padding
 int mkzg_verify_blob_kzg_proof_batch_partial_device(mkzg_ctx* c, const void* d_blobs, const void* d_commitments48, const void* d_proofs48, size_t n_local, uint64_t offset,
                                                     const uint8_t r32[32], uint8_t record512[512], void* stream) {
-    if (!c || !r32 || !record512 || (n_local && (!d_blobs || !d_commitments48 || !d_proofs48))) return MKZG_ERR_BAD_ARGS;
-    if (!c->peers.empty() && !(c = ctx_for_pointer(c, d_blobs))) return MKZG_ERR_BAD_ARGS;
-    if (offset + n_local > 0xffffffffull) return MKZG_ERR_BAD_ARGS;
+    if (!c || !r32 || !record512) return MKZG_ERR_BAD_ARGS;
     memset(record512, 0, 512);
-    uint8_t r_le[32];
-    for (int i = 0; i < 32; i++) r_le[i] = r32[31 - i];              // big-endian bytes -> little-endian words
-    VerifyFold total, f;
-    verify_fold_clear(total);
     int rc = MKZG_OK;
-    if (n_local) {
-        LaneGuard G(c, (hipStream_t)stream);
-        G.L->last_host_finish_us = 0;
-        for (size_t off = 0; off < n_local && !rc; off += VMSM_MAX_N) {
-            const size_t m = std::min<size_t>(VMSM_MAX_N, n_local - off);
-            rc = verify_fold(c, G.L, (const uint8_t*)d_blobs + off * MKZG_BYTES_PER_BLOB, nullptr, nullptr, (const uint8_t*)d_commitments48 + off * 48,
-                             (const uint8_t*)d_proofs48 + off * 48, m, (uint32_t)(offset + off), r_le, G.s, &f);
-            if (!rc) verify_fold_add(total, f);
-        }
-        G.fail(rc);
-        c->last_host_finish_us.store(G.L->last_host_finish_us);
+    VerifyFold total;
+    verify_fold_clear(total);
+    if (n_local && (!d_blobs || !d_commitments48 || !d_proofs48)) rc = MKZG_ERR_BAD_ARGS;
+    else if (!c->peers.empty() && n_local && !(c = ctx_for_pointer(c, d_blobs))) rc = MKZG_ERR_BAD_ARGS;
+    else {
+        uint8_t r_le[32];
+        for (int i = 0; i < 32; i++) r_le[i] = r32[31 - i];              // big-endian bytes -> little-endian words
+        rc = sd_verify_blob_fold_device(c, d_blobs, d_commitments48, d_proofs48, n_local, offset, r_le, (hipStream_t)stream, &total, nullptr);
     }
-    int32_t st = rc;
-    memcpy(record512, &st, 4);
-    if (rc == MKZG_OK) {
-        G1AffH a;
-        g1h_to_affine(a, total.A);
-        g1h_compress(record512 + 16, a);
-        g1h_to_affine(a, total.Cc);
-        g1h_compress(record512 + 64, a);
-        g1h_to_affine(a, total.D);
-        g1h_compress(record512 + 112, a);
-        for (int i = 0; i < 8; i++) {
-            uint32_t w = total.e[7 - i];
-            record512[160 + 4 * i] = (uint8_t)(w >> 24); record512[161 + 4 * i] = (uint8_t)(w >> 16); record512[162 + 4 * i] = (uint8_t)(w >> 8); record512[163 + 4 * i] = (uint8_t)w;
-        }
-    }
+    verify_fold_record(record512, rc, total);                           // whatever the outcome, the record says so: it is what travels
     return rc;
 }
 int mkzg_verify_blob_kzg_proof_batch_finish(mkzg_ctx* c, const uint8_t* records512, size_t n_records) {

@@ -20,6 +20,8 @@ void fk20_scalars_device(const uint32_t* d_coeffs, int n, const uint32_t* d_tw_f
 // VerifyCellKZGProofBatch scalar work: r -> r^k rows, s1 (r^k), s4 (r^k h^64), per-row weights, interpolation
 // polynomial (64 plain scalars); d_partials: CELL_INTERP_BLOCKS x 64 Fr rows of scratch
 constexpr int CELL_INTERP_BLOCKS = 2048;
+// ... followed by one row set per group of 64 workgroups and the tickets of k_cell_interp's own final sum (ZERO when allocated; the kernel resets them)
+constexpr size_t CELL_INTERP_SCRATCH_BYTES = ((size_t)CELL_INTERP_BLOCKS * 64 + (size_t)(CELL_INTERP_BLOCKS / 64) * 64) * 48 + 64 * 4;
 // h_r8: HOST pointer to the eight words of r (it travels in the kernel arguments)
 void cell_verify_scalars_device(const uint32_t* h_r8, uint32_t exp_offset, const uint64_t* d_cell_idx, const uint32_t* d_row_idx, const uint8_t* d_cells, int n, int n_rows,
                                 const uint32_t* d_tw_fwd, const uint32_t* d_tw_inv, uint32_t* d_rp_rows, uint32_t* d_s1, uint32_t* d_s4, uint32_t* d_weights8,

@@ -366,10 +366,30 @@ __device__ __forceinline__ void fr_store_plain8(uint32_t* dst, const fr_t& m) {
     for (int q = 0; q < 8; q++) dst[q] = w[q];
 }
 // r^k rows, s1_k = r^k, s4_k = r^k * h_{cell_k}^64   (kzg_verify.go:28, 73-79; srs.go:75-78)
-__global__ void __launch_bounds__(256) k_cell_rpowers(const RWords r_words8, uint32_t exp_offset, const uint64_t* __restrict__ cell_idx, int n, const uint32_t* __restrict__ tw_fwd,
-                                                      uint32_t* __restrict__ rp_rows, uint32_t* __restrict__ s1, uint32_t* __restrict__ s4) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
+// r^(k + exp_offset) in Montgomery form (canonical): the exponent is the GLOBAL index of the cell (sharded batches: exp_offset = first
+// cell of this rank)
+__device__ __forceinline__ void cell_rpower(fr_t& rp, const fr_t& r, uint32_t e) {
+    fr_t base = r;
+    Fr::set_one(rp);
+    for (; e; e >>= 1) {
+        if (e & 1) c_fr_mul(rp, rp, base);
+        c_fr_mul(base, base, base);
+    }
+    Fr::reduce_once(rp, rp);
+}
+// ONE launch for everything that needs the indices and r only (round 5: two launches until then, and every launch is time in a
+// hardware queue the call shares with other calls):
+//   blocks [0, nb_cells)            per cell k: r^k (Montgomery row for the interpolation, plain words for the MSM sum r^k pi_k) and
+//                                   r^k h_c^64 (the MSM sum r^k h_k^64 pi_k, kzg_verify.go:68-80)
+//   blocks [nb_cells, + n_rows)     weights[row] = sum of r^k over the cells k that belong to commitment `row` (kzg_verify.go:35-41): a
+//                                   strided scan of the row indices, the power computed HERE for every match (a row of a block has 128
+//                                   cells: half a power per thread) -- so the two halves of the grid do not depend on each other --
+//                                   then an LDS tree over the Fr partial sums
+__global__ void __launch_bounds__(256) k_cell_rpowers(const RWords r_words8, uint32_t exp_offset, const uint64_t* __restrict__ cell_idx, const uint32_t* __restrict__ row_idx, int n,
+                                                      int n_rows, int nb_cells, const uint32_t* __restrict__ tw_fwd, uint32_t* __restrict__ rp_rows, uint32_t* __restrict__ s1,
+                                                      uint32_t* __restrict__ s4, uint32_t* __restrict__ weights8) {
+    __shared__ uint32_t sh[9 * 256];
+    const int t = threadIdx.x;
     uint32_t rw[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) rw[i] = r_words8.w[i];
@@ -378,32 +398,27 @@ __global__ void __launch_bounds__(256) k_cell_rpowers(const RWords r_words8, uin
     Fr::from_words32(pl, rw);
     Fr::from_plain(r, pl);
     Fr::reduce_once(r, r);
-    fr_t rp, base = r;
-    Fr::set_one(rp);
-    for (uint32_t e = (uint32_t)k + exp_offset; e; e >>= 1) {      // global exponent (sharded batches: exp_offset = first cell of this rank)
-        if (e & 1) c_fr_mul(rp, rp, base);
-        c_fr_mul(base, base, base);
+    if ((int)blockIdx.x < nb_cells) {
+        const int k = blockIdx.x * 256 + t;
+        if (k >= n) return;
+        fr_t rp;
+        cell_rpower(rp, r, (uint32_t)k + exp_offset);
+        c_store_fr12(rp_rows + (size_t)k * 12, rp);
+        fr_store_plain8(s1 + (size_t)k * 8, rp);
+        const uint32_t c = (uint32_t)cell_idx[k] & 127u;
+        fr_t hp, v;
+        tw_any(hp, tw_fwd, 64u * (__brev(c) >> 25));                 // h_c^64 = w_8192^(64 brev7(c))
+        c_fr_mul(v, rp, hp);
+        fr_store_plain8(s4 + (size_t)k * 8, v);
+        return;
     }
-    Fr::reduce_once(rp, rp);
-    c_store_fr12(rp_rows + (size_t)k * 12, rp);
-    fr_store_plain8(s1 + (size_t)k * 8, rp);
-    const uint32_t c = (uint32_t)cell_idx[k] & 127u;
-    fr_t hp, v;
-    tw_any(hp, tw_fwd, 64u * (__brev(c) >> 25));                 // h_c^64 = w_8192^(64 brev7(c))
-    c_fr_mul(v, rp, hp);
-    fr_store_plain8(s4 + (size_t)k * 8, v);
-}
-// weights[row] = sum of r^k over the cells k that belong to commitment `row` (kzg_verify.go:35-41).  One 256-thread
-// workgroup per row: strided scan of the row indices, LDS tree over the Fr partial sums.
-__global__ void __launch_bounds__(256) k_cell_weights(const uint32_t* __restrict__ rp_rows, const uint32_t* __restrict__ row_idx, int n, int n_rows, uint32_t* __restrict__ weights8) {
-    __shared__ uint32_t sh[9 * 256];
-    const int row = blockIdx.x, t = threadIdx.x;
+    const int row = (int)blockIdx.x - nb_cells;
     fr_t acc;
     Fr::set_zero(acc);
     for (int k = t; k < n; k += 256) {
         if ((int)row_idx[k] == row) {
             fr_t v;
-            c_load_fr12(v, rp_rows + (size_t)k * 12);
+            cell_rpower(v, r, (uint32_t)k + exp_offset);
             FrC::add(acc, acc, v);
         }
     }
@@ -430,7 +445,7 @@ __global__ void __launch_bounds__(256) k_cell_weights(const uint32_t* __restrict
 // per cell: canonical check, coset IFFT-64 on the bit-reversed evaluations, times r^k, summed per
 // workgroup into partials[block][64]   (kzg_verify.go:50-66, coset_fft.go:55-70)
 __global__ void __launch_bounds__(64) k_cell_interp(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_idx, const uint32_t* __restrict__ rp_rows, int n,
-                                                    const uint32_t* __restrict__ tw_inv, uint32_t* __restrict__ partials, int* __restrict__ cell_status) {
+                                                    const uint32_t* __restrict__ tw_inv, uint32_t* __restrict__ partials, int* __restrict__ cell_status, uint32_t* __restrict__ interp8) {
     __shared__ uint32_t sh[9 * 64];
     const int lane = threadIdx.x;
     fr_t acc, inv64;
@@ -485,32 +500,49 @@ __global__ void __launch_bounds__(64) k_cell_interp(const uint8_t* __restrict__ 
         __syncthreads();
     }
     c_store_fr12(partials + ((size_t)blockIdx.x * 64 + lane) * 12, acc);
-}
-// interp[i] = sum over the workgroups' partial sums; 16 wavefronts each add a strided share of the partials, then an LDS tree
-__global__ void __launch_bounds__(1024) k_cell_interp_reduce(const uint32_t* __restrict__ partials, int n_blocks, uint32_t* __restrict__ interp8) {
-    __shared__ uint32_t sh[16 * 64 * 9];
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    fr_t acc;
+    // interp[i] = the sum of all workgroups' partial sums, by whoever finishes last -- a launch of its own until round 5.  Two levels of
+    // tickets (behind the partial rows: zero when the workspace is allocated, reset by the taker of the last one): the last workgroup of
+    // every GROUP of 64 adds its group's rows, the last group to finish adds the <= 32 group rows and writes the 64 plain scalars.
+    __shared__ int is_last;
+    uint32_t* gpart = partials + (size_t)CELL_INTERP_BLOCKS * 64 * 12;         // [CELL_INTERP_BLOCKS / 64][64] Fr rows
+    uint32_t* tick = gpart + (size_t)(CELL_INTERP_BLOCKS / 64) * 64 * 12;      // [groups] + 1
+    const int g = (int)blockIdx.x >> 6, n_groups = ((int)gridDim.x + 63) >> 6;
+    const int g_size = min(64, (int)gridDim.x - (g << 6));
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) {
+        const uint32_t got = atomicAdd(&tick[g], 1u);
+        is_last = got == (uint32_t)(g_size - 1);
+        if (is_last) tick[g] = 0;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
     Fr::set_zero(acc);
-    for (int b = grp; b < n_blocks; b += 16) {
+    for (int b = 0; b < g_size; b++) {
         fr_t v;
-        c_load_fr12(v, partials + ((size_t)b * 64 + lane) * 12);
+        c_load_fr12(v, partials + ((size_t)((g << 6) + b) * 64 + lane) * 12);
         FrC::add(acc, acc, v);
     }
-#pragma unroll
-    for (int q = 0; q < 9; q++) sh[(grp * 9 + q) * 64 + lane] = acc.l[q];
+    c_store_fr12(gpart + ((size_t)g * 64 + lane) * 12, acc);
+    __threadfence();
     __syncthreads();
-    if (grp == 0) {
-        for (int g = 1; g < 16; g++) {
-            fr_t v;
-#pragma unroll
-            for (int q = 0; q < 9; q++) v.l[q] = sh[(g * 9 + q) * 64 + lane];
-            FrC::add(acc, acc, v);
-        }
-        fr_store_plain8(interp8 + (size_t)lane * 8, acc);
+    if (lane == 0) {
+        const uint32_t got = atomicAdd(&tick[CELL_INTERP_BLOCKS / 64], 1u);
+        is_last = got == (uint32_t)(n_groups - 1);
+        if (is_last) tick[CELL_INTERP_BLOCKS / 64] = 0;
     }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    Fr::set_zero(acc);
+    for (int b = 0; b < n_groups; b++) {
+        fr_t v;
+        c_load_fr12(v, gpart + ((size_t)b * 64 + lane) * 12);
+        FrC::add(acc, acc, v);
+    }
+    fr_store_plain8(interp8 + (size_t)lane * 8, acc);
 }
-
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
@@ -549,13 +581,12 @@ void cell_verify_scalars_device(const uint32_t* h_r8, uint32_t exp_offset, const
     if (phase != 2) {                          // what needs the indices and r only: the caller issues it ahead of the cells' upload
         RWords r;                              // by value: see rlc_scalars_device
         for (int i = 0; i < 8; i++) r.w[i] = h_r8[i];
-        hipLaunchKernelGGL(k_cell_rpowers, dim3((n + 255) / 256), dim3(256), 0, s, r, exp_offset, d_cell_idx, n, d_tw_fwd, d_rp_rows, d_s1, d_s4);
-        hipLaunchKernelGGL(k_cell_weights, dim3(n_rows), dim3(256), 0, s, d_rp_rows, d_row_idx, n, n_rows, d_weights8);
+        const int nb_cells = (n + 255) / 256;
+        hipLaunchKernelGGL(k_cell_rpowers, dim3(nb_cells + n_rows), dim3(256), 0, s, r, exp_offset, d_cell_idx, d_row_idx, n, n_rows, nb_cells, d_tw_fwd, d_rp_rows, d_s1, d_s4, d_weights8);
     }
     if (phase != 1) {                          // what reads the cells
         const int nb = n < CELL_INTERP_BLOCKS ? n : CELL_INTERP_BLOCKS;
-        hipLaunchKernelGGL(k_cell_interp, dim3(nb), dim3(64), 0, s, d_cells, d_cell_idx, d_rp_rows, n, d_tw_inv, d_partials, d_cell_status);
-        hipLaunchKernelGGL(k_cell_interp_reduce, dim3(1), dim3(1024), 0, s, d_partials, nb, d_interp8);
+        hipLaunchKernelGGL(k_cell_interp, dim3(nb), dim3(64), 0, s, d_cells, d_cell_idx, d_rp_rows, n, d_tw_inv, d_partials, d_cell_status, d_interp8);     // (sums its partials itself)
     }
 }
 

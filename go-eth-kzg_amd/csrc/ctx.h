@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <memory>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -50,6 +51,29 @@ template <class T>
 static inline int dev_realloc(T*& p, size_t bytes) {
     if (p) { (void)hipFree(p); p = nullptr; }
     HIPCHK(hipMalloc(&p, bytes ? bytes : 16));
+    return MKZG_OK;
+}
+// The batch-wide scalar r and a shard's first global index arriving LATE (api_exchange.hip: both come out of a collective that waits
+// for the slowest rank of the job).  A fold handed one of these launches what needs neither -- hashing, decoding, subgroup tests,
+// gathers and uploads -- and calls get() where r is first used; exponents are then (offset + the fold's own index).
+struct RlcLate {
+    std::function<int(uint32_t r_words[8], uint64_t* offset)> wait;   // blocks; fills r (eight little-endian words, reduced) and the offset
+    bool done = false;
+    int rc = 0;
+    uint32_t r_words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t offset = 0;
+    int get() {
+        if (!done) { rc = wait(r_words, &offset); done = true; }
+        return rc;
+    }
+};
+// ... zero-filled and complete before it returns (ticket words of the kernels that fold their own last step: k_vmsm_window, k_cell_interp)
+template <class T>
+static inline int dev_realloc_zero(T*& p, size_t bytes) {
+    int rc = dev_realloc(p, bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemset(p, 0, bytes ? bytes : 16));
+    HIPCHK(hipStreamSynchronize(nullptr));
     return MKZG_OK;
 }
 template <class T>
@@ -170,13 +194,11 @@ struct Lane {
 // One launch of the Fiat-Shamir hash kernel for all the calls that were waiting for one (api_verify.hip hash_round_join)
 struct HashRound {
     kzg::ShaJobs jobs{};
-    kzg::ValJobs vjobs{};                       // the same calls' points: decoding + r-torsion test in one launch beside the hash (its own stream)
     hipEvent_t ready[kzg::SHA_MAX_JOBS] = {};   // per job: its inputs are ready on the call's stream
     hipEvent_t done = nullptr;                  // the launch has finished
-    hipEvent_t done_val = nullptr;              // the validation launch has finished
     bool launched = false;
     int rc = 0;
-    ~HashRound() { if (done) (void)hipEventDestroy(done); if (done_val) (void)hipEventDestroy(done_val); }
+    ~HashRound() { if (done) (void)hipEventDestroy(done); }
 };
 
 struct mkzg_ctx {
@@ -195,7 +217,6 @@ struct mkzg_ctx {
     std::condition_variable hash_cv;
     std::shared_ptr<HashRound> hash_forming, hash_prev, hash_prev2;   // the round being filled, the last two launched
     hipStream_t hash_stream[2] = {nullptr, nullptr};                    // rounds alternate between them: two in flight
-    hipStream_t val_stream[2] = {nullptr, nullptr};                     // the rounds' point-validation launches, beside the hash launches
     uint64_t hash_rounds = 0;
     std::mutex mu;                         // lane hand-over only
     std::condition_variable cv;

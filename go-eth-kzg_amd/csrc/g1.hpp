@@ -173,6 +173,61 @@ struct G1T {
         select(res, a_inf, b, res);
         r = res;
     }
+    // acc += b with b read THROUGH AN ACCESSOR (B::get(fe&, coordinate 0..3 = X, Y, ZZ, ZZZ): an LDS snapshot in k_vmsm_window), each
+    // coordinate fetched where it is used, ZZ and ZZZ twice -- so that the second operand never occupies 56 registers beside the
+    // first (round 5: the suffix network of the window sums held 344 registers + 688 B of scratch with add() on two register
+    // operands).  Exact like add(): identity operands and P + P / P - P are resolved by (divergent) branches that touch limbs only.
+    template <class B>
+    static KZ_HD void add_from(XYZZ& acc, const B& b) {
+        fe bzz, t;
+        b.get(bzz, 2);
+        if (F::limbs_all_zero(bzz)) return;                   // b is the identity
+        if (is_inf(acc)) {                                    // acc is: the sum is b
+            b.get(acc.x, 0);
+            b.get(acc.y, 1);
+            b.get(acc.zz, 2);
+            b.get(acc.zzz, 3);
+            return;
+        }
+        opaque(acc);
+        F::opaque(bzz);
+        fe U1, S1, Pd, Rd;
+        F::mul(U1, acc.x, bzz);                               // X1 ZZ2
+        b.get(t, 0);
+        F::mul(Pd, t, acc.zz);                                // X2 ZZ1
+        F::template sub<1>(Pd, Pd, U1);
+        b.get(t, 3);
+        F::mul(S1, acc.y, t);                                 // Y1 ZZZ2
+        b.get(t, 1);
+        F::mul(Rd, t, acc.zzz);                               // Y2 ZZZ1
+        F::template sub<1>(Rd, Rd, S1);
+        if (F::template is_zero_mod<16>(Pd)) {
+            if (F::template is_zero_mod<16>(Rd)) dbl(acc, acc);
+            else set_inf(acc);
+            return;
+        }
+        opaque(acc);
+        F::opaque(Pd);
+        F::opaque(Rd);
+        F::opaque(U1);
+        F::opaque(S1);
+        fe PP, PPP, Q, X3;
+        F::sqr(PP, Pd);
+        F::mul(PPP, Pd, PP);
+        F::mul(Q, U1, PP);
+        F::mul(t, acc.zz, PP);
+        b.get(bzz, 2);
+        F::mul(acc.zz, t, bzz);                               // ZZ1 ZZ2 PP
+        F::mul(t, acc.zzz, PPP);
+        b.get(bzz, 3);
+        F::mul(acc.zzz, t, bzz);                              // ZZZ1 ZZZ2 PPP
+        F::sqr(X3, Rd);
+        F::template sub_b_2c<2>(X3, X3, PPP, Q);
+        F::template sub<3>(t, Q, X3);
+        F::template neg<1>(S1, S1);                           // 2p - S1
+        F::mul2(acc.y, Rd, t, S1, PPP);                       // R (Q - X3) - S1 PPP   (< 1.01p)
+        acc.x = X3;
+    }
     static KZ_HD void select(XYZZ& r, bool c, const XYZZ& a, const XYZZ& b) {   // r = c ? a : b, limb by limb
         F::select(r.x, c, a.x, b.x);
         F::select(r.y, c, a.y, b.y);
@@ -499,6 +554,113 @@ struct G1T {
         }
         return yfree_verdict(Q, px, rhs, rhs2, beta);
     }
+
+    // ------------------------------------------------------------------------------------------
+    // The y-free test a third time, for a SMALL REGISTER FOOTPRINT (round 5: k_g1_validate held 474-497 registers, one wavefront per
+    // SIMD and nothing beside it).  Same verdict as in_subgroup() for every finite point of the curve; what changes is how it is
+    // carried:
+    //   * the group law on y^2 = x^3 + b never reads b, so the chain may run on ANY curve isomorphic to E.  (x, y) -> (x l^2, y l^3)
+    //     maps E to E_l: y^2 = x^3 + 4 l^6.  With l = y the image of P is P' = (x rhs, rhs^2), rhs = y^2 = x^3 + 4: an AFFINE point
+    //     free of y, and every multiple of it computed with the ordinary Jacobian formulas is free of y -- the form above reached
+    //     the same representation but paid for it inside its addition (17 products where a mixed addition takes 10);
+    //   * pass 0 leaves T' = [|x|]P' = (X, Y, Z) on E_y.  One more isomorphism, l = Z, makes (X, Y) an AFFINE point of E_{yZ}:
+    //     pass 1 is the same loop from another start, no Jacobian operand with cached powers (six field elements above), no inversion.
+    //     Q' = [|x|](X, Y) = (X', Y', Z') on E_{yZ} is the Jacobian point (X', Y', Z' Z y) of E, so phi(P) = (beta x, y) == -Q reads
+    //     X' == Z'^2 (beta x rhs Z^2) and -Y' == Z'^3 (rhs^2 Z^3): both constants are formed between the passes;
+    //   * the addition is INCOMPLETE on purpose.  Its exceptional cases are [k]B = +-B or [k]B = identity for some 0 < k < 2^64 with
+    //     B = P' or T'; either makes the order of P a divisor of a number below r (gcd(|x|, r) = 1: T has the order of P whenever
+    //     that order is r), so P is not in the r-torsion -- and in each of them the formulas yield Z3 = Z1 H = 0 (mod p), which
+    //     every later doubling (Z3 = 2 Y Z) and addition keeps.  The verdict of an exceptional chain is therefore "Z = 0 at the end"
+    //     = not in the subgroup, with no branch, no select and no copy of the operands in the loop;
+    //   * what the ten additions read -- the start point of the pass -- and the two constants of the verdict live in a STASH the
+    //     caller provides (S::put / S::get: LDS on the device, 14 KB per wavefront; plain members on the host), so that the 126
+    //     doublings run with the running point alone in registers.
+    // Bounds (F = Fp): after jdbl X < 17.01p, Y < 5.01p, Z < 1.01p; after the addition X < 5.01p, Y, Z < 1.01p.
+    // ------------------------------------------------------------------------------------------
+    template <class S>
+    static KZ_HD void jmadd_incomplete(Jac& r, const Jac& a_, S& st) {   // r = a + (stash 2, stash 3)
+        Jac a = a_;
+        opaque(a);
+        fe Z1Z1, U2, H, t, S2, Rd, Z3, HH, HHH, V, X3, Y3, x2, y2;
+        F::sqr(Z1Z1, a.z);
+        st.get(x2, 2);
+        F::mul(U2, x2, Z1Z1);
+        F::template sub<5>(H, U2, a.x);               // U2 - X1 + 32p        (< 33.01p)
+        F::mul(t, a.z, Z1Z1);
+        st.get(y2, 3);
+        F::mul(S2, y2, t);
+        F::template sub<3>(Rd, S2, a.y);              // S2 - Y1 + 8p         (< 9.01p)
+        F::mul(Z3, a.z, H);                           // 0 (mod p) in every exceptional case, see above
+        F::sqr(HH, H);
+        F::mul(HHH, H, HH);
+        F::mul(V, a.x, HH);
+        F::sqr(X3, Rd);
+        F::template sub_b_2c<2>(X3, X3, HHH, V);      // R^2 - H^3 - 2V + 4p  (< 5.01p)
+        F::template sub<3>(t, V, X3);                 // V - X3 + 8p          (< 9.01p)
+        F::template neg<3>(S2, a.y);                  // 8p - Y1
+        F::mul2(Y3, Rd, t, S2, HHH);                  // R (V - X3) - Y1 H^3  (< 1.01p)
+        r.x = X3;
+        r.y = Y3;
+        r.z = Z3;
+    }
+    template <class S>
+    static KZ_HD bool in_subgroup_yfree_lean(const fe& px, const fe& rhs, const fe& beta, S& st) {
+        Jac Q;
+        {
+            fe t;
+            F::mul(Q.x, px, rhs);                     // P' = (x y^2, y^4) on E_y
+            F::sqr(Q.y, rhs);
+            F::set_one(Q.z);
+            st.put(2, Q.x);
+            st.put(3, Q.y);
+            F::mul(t, beta, Q.x);
+            st.put(0, t);                             // beta x rhs
+        }
+        bool bad = false;
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+        for (int pass = 0; pass < 2; pass++) {
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+            for (int bit = 62; bit >= 0; bit--) {
+                jdbl(Q, Q);
+                if ((BLS_X_ABS >> bit) & 1) jmadd_incomplete(Q, Q, st);
+            }
+            if (pass == 0) {                          // T' = Q: the verdict's constants, then (X, Y) as the affine start of pass 1
+                fe zz, zzz, c;
+                bad = F::template is_zero_mod<16>(Q.z);
+                F::sqr(zz, Q.z);
+                F::mul(zzz, zz, Q.z);
+                st.get(c, 0);
+                F::mul(c, c, zz);
+                st.put(0, c);                         // beta x rhs Z^2
+                st.get(c, 3);
+                F::mul(c, c, zzz);
+                st.put(1, c);                         // rhs^2 Z^3
+                st.put(2, Q.x);
+                st.put(3, Q.y);
+                F::set_one(Q.z);
+            }
+        }
+        if (bad || F::template is_zero_mod<16>(Q.z)) return false;
+        fe zz, l, c;
+        F::sqr(zz, Q.z);
+        st.get(c, 0);
+        F::mul(l, zz, c);
+        bool ok = F::eq_mod(l, Q.x);
+        F::mul(l, zz, Q.z);
+        st.get(c, 1);
+        F::mul(l, l, c);
+        F::template neg<3>(c, Q.y);
+        return ok && F::eq_mod(l, c);
+    }
+    struct MemberStash {   // the stash as plain members: host tests, and device callers that can afford the registers
+        fe s[4];
+        KZ_HD void put(int i, const fe& v) { s[i] = v; }
+        KZ_HD void get(fe& v, int i) const { v = s[i]; }
+    };
 };
 
 // ---- device / radix-2^29 instantiation, under the names the kernels use

@@ -25,19 +25,6 @@ struct ShaJobs {
     int count;
 };
 void challenge_jobs_device(ShaJobs& jobs, hipStream_t s);
-// the point validation (decoding + one-lane r-torsion test: g1_validate2_device mode 3) of up to SHA_MAX_JOBS calls in ONE launch
-struct ValJobs {
-    const uint8_t* in_a[SHA_MAX_JOBS];
-    const uint8_t* in_b[SHA_MAX_JOBS];
-    uint32_t* aff_a[SHA_MAX_JOBS];
-    uint32_t* aff_b[SHA_MAX_JOBS];
-    int* st_a[SHA_MAX_JOBS];
-    int* st_b[SHA_MAX_JOBS];
-    int n_a[SHA_MAX_JOBS], n_b[SHA_MAX_JOBS];
-    int first_block[SHA_MAX_JOBS];
-    int count;
-};
-void g1_validate_jobs_device(ValJobs& jobs, hipStream_t s);
 // d_zrows: n x blob_eval_scratch_words() words of scratch (what depends on z alone, from a one-lane-per-blob kernel ahead of the evaluation)
 size_t blob_eval_scratch_words();
 // rows_ready: d_zrows were written by the challenge launch already (ShaJobs::zrows_out, challenge_device's d_zrows).  h_r8 (HOST pointer to the eight words of r, may be

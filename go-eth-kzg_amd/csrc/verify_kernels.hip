@@ -897,22 +897,92 @@ __device__ __forceinline__ void g1_validate_block(const uint8_t* __restrict__ in
         st[i] = rc;
     }
 }
+// ---- modes 3 and 4 since round 5: the register-lean chain (g1.hpp in_subgroup_yfree_lean)
+// What the chain's ten additions read lives in LDS, one column of 4 x 14 words per lane (conflict-free 32-bit accesses); the loads
+// are volatile so that the compiler cannot carry the values through the doubling loops in registers -- which is the whole point:
+// mode 3 / 4 held 487 / 474 registers (256 + AGPRs as spill space), one wavefront per SIMD with nothing beside it, for chains that
+// issue at ~60 % of a SIMD's rate.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+struct LdsStash {
+    uint32_t* col;                                          // &mem[lane]; word (slot * 14 + limb) at col[(slot * 14 + limb) * 64]
+    __device__ __forceinline__ void put(int slot, const fp_t& v) {
+#pragma unroll
+        for (int q = 0; q < 14; q++) col[(slot * 14 + q) * 64] = v.l[q];
+    }
+    __device__ __forceinline__ void get(fp_t& v, int slot) const {
+        const volatile lds_u32* c = (const volatile lds_u32*)col;     // (the address space spelled out: through the struct it decays to flat loads)
+#pragma unroll
+        for (int q = 0; q < 14; q++) v.l[q] = c[(slot * 14 + q) * 64];
+    }
+};
+// MODE 3: wavefront 0 decodes 64 points, writes their affine rows, leaves (return code, identity flag) in LDS and EXITS -- it used
+// to idle at a barrier for two thirds of the launch holding its SIMD's registers; wavefront 1 runs the test on the same 64 points,
+// then picks the decoding's verdicts up (long there) and writes the statuses.  MODE 4: the test alone, statuses of its own.
+template <int MODE>
+__device__ __forceinline__ void g1_validate_wide_block(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
+                                                       const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b, int blk) {
+    __shared__ uint32_t stash_mem[4 * 14 * 64];
+    __shared__ int dec[64];
+    constexpr int DEC_READY = 1 << 30;
+    const int lane = threadIdx.x & 63, role = MODE == 3 ? (int)(threadIdx.x >> 6) : 1;
+    const int total = n_a + n_b;
+    int i = blk * 64 + lane;
+    const bool live = i < total;
+    if (i >= total) i %= total;
+    const uint8_t* in48 = in48_a;
+    uint32_t* aff = aff_a;
+    int* st = st_a;
+    if (i >= n_a) { i -= n_a; in48 = in48_b; aff = aff_b; st = st_b; }
+    if (MODE == 3) {
+        if (role == 0) dec[lane] = 0;
+        __syncthreads();
+        if (role == 0) {
+            G1Aff p;
+            p.inf = 1;
+            const int rc = g1_decode_lane(p, in48 + (size_t)i * 48);
+            if (live) {
+                uint32_t w[32];
+#pragma unroll
+                for (int q = 0; q < 14; q++) { w[q] = p.x.l[q]; w[14 + q] = p.y.l[q]; }
+                w[28] = p.inf; w[29] = 0; w[30] = 0; w[31] = 0;
+                uint4* o = reinterpret_cast<uint4*>(aff + (size_t)i * 32);
+#pragma unroll
+                for (int q = 0; q < 8; q++) o[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+            }
+            *(volatile int*)&dec[lane] = DEC_READY | (rc & 0xff) | (p.inf ? 0x100 : 0);
+            return;
+        }
+    }
+    int v = 2;                                              // 1 in the subgroup, 0 not, 2 no verdict (identity or undecodable x)
+    {
+        fp_t x, rhs, beta;
+        uint32_t flags;
+        if (g1_parse_lane(x, flags, in48 + (size_t)i * 48) == 0) {
+            g1_curve_rhs(rhs, x);
+            Fp::set(beta, FP_BETA);
+            LdsStash stash{stash_mem + lane};
+            v = G1D::in_subgroup_yfree_lean(x, rhs, beta, stash) ? 1 : 0;
+        }
+    }
+    if (MODE == 4) {
+        if (live) st[i] = v == 0 ? MKZG_ERR_G1_NOT_IN_SUBGROUP : 0;
+        return;
+    }
+    int d;
+    do { d = *(volatile int*)&dec[lane]; } while (!(d & DEC_READY));
+    if (live) {
+        int rc = d & 0xff;
+        if (rc == 0 && !(d & 0x100) && v == 0) rc = MKZG_ERR_G1_NOT_IN_SUBGROUP;
+        st[i] = rc;
+    }
+}
 // (one instantiation per mode: a kernel's registers are the maximum over every path it contains)
 template <int MODE>
 __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
                                                      const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
-    g1_validate_block(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, MODE, (int)blockIdx.x);
+    if (MODE == 3 || MODE == 4) g1_validate_wide_block<MODE>(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, (int)blockIdx.x);
+    else g1_validate_block(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, MODE, (int)blockIdx.x);
 }
-// the points of SEVERAL calls in one launch (api_verify.hip, the rounds of the throughput shape): decoding + one-lane r-torsion test (mode 3)
-// is a 1.3 ms chain on one wavefront per 64 points -- 64 wavefronts for a call of 1024 proofs -- and as a launch of its own in every
-// call's stream it held that stream's hardware queue (shared with three other callers' streams) for a third of the call's kernel time
-__global__ void __launch_bounds__(128) k_g1_validate_jobs(ValJobs jobs) {
-    int j = 0;
-#pragma unroll 1
-    while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.first_block[j + 1]) j++;
-    g1_validate_block(jobs.in_a[j], jobs.n_a[j], jobs.aff_a[j], jobs.st_a[j], jobs.in_b[j], jobs.n_b[j], jobs.aff_b[j], jobs.st_b[j], 3, (int)blockIdx.x - jobs.first_block[j]);
-}
-
 
 // ------------------------------------------------------------------------------------------
 // RLC scalars (single workgroup): r -> r^i ; s1_i = r^i ; s3_i = r^i z_i ; e = sum r^i y_i
@@ -1015,11 +1085,12 @@ struct VmsmJobs { VmsmJob j[4]; int k[4]; };    // k: point-range slices per (jo
 // grid (window, job, slice): a (job, window) pair with many points is cut into up to VMSM_KMAX slices of the point range, each
 // with its own 128 buckets -- the bucket walk is a serial chain of mixed additions per lane, so 8192 points in one workgroup
 // are 64 additions deep where eight slices are 8 deep; k_vmsm_combine adds the slices' window sums.
-__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __restrict__ parts /* [msm][VNWIN][VMSM_KMAX][64] XYZZ */) {
+__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __restrict__ parts /* [msm][VNWIN][VMSM_KMAX][64] XYZZ */, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
     __shared__ uint32_t ent[VMAXN];
     __shared__ uint32_t hist[VNB + 1];
     __shared__ uint32_t cursor[VNB];
     __shared__ uint32_t xchg[2 * 56];
+    __shared__ int last_flag;
     const int w = blockIdx.x, m = blockIdx.y, t = threadIdx.x, z = blockIdx.z;
     if (z >= jobs.k[m]) return;
     const int n_all = jobs.j[m].n, lo = (int)((long long)n_all * z / jobs.k[m]), hi = (int)((long long)n_all * (z + 1) / jobs.k[m]);
@@ -1079,44 +1150,96 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
     // window sum = sum_k (k+1) B_k = sum over all 128 buckets of the SUFFIX sums  suffix_k = sum_{j >= k} B_j:
     //   rounds 0-5   suffix scan inside each wavefront (64 buckets)
     //   round  6     wavefront 0 adds wavefront 1's total to every one of its suffixes (one parallel addition, through LDS)
-    //   rounds 7-12  tree sum of the 64 suffixes of each wavefront;  then one addition of the two wavefronts' sums
+    //   rounds 7-12  tree sum of the 64 suffixes of each wavefront
+    //   round  13    thread 0 adds wavefront 1's sum: the slice's window sum
+    //   rounds 14..  (slices > 1, the LAST workgroup of this (job, window) to get here) thread 0 adds the other slices' sums
     // -- 14 additions deep; the weights never appear, so there is no 64 S_1 = six serial doublings as a (S, Q) formulation has.
-    // The additions are inlined (one copy, rolled loop): the points stay in registers between rounds.
-    const int lane = t & 63, wave = t >> 6;
-    G1X Pf = acc, o;
-    auto put_x = [&](const G1X& v) {
+    // ONE inlined copy of the addition in a rolled loop, its second operand read from an LDS snapshot where it is used
+    // (G1D::add_from) -- until round 5 the operand came by 56 wavefront shuffles into registers and the kernel held 344 of them plus
+    // 688 B of scratch, one wavefront per SIMD; the snapshot reuses ent[], dead after the bucket walk.  The slice combination and
+    // the export as canonical plain coordinates used to be a launch of their own (k_vmsm_combine): an atomic ticket per (job,
+    // window) in the spare words of slice 0's record -- zero when the workspace is allocated, reset by whoever takes the last one.
+    struct LdsXyzz {
+        const uint32_t* p;
+        int stride;
+        __device__ __forceinline__ void get(fp_t& v, int c) const {
+            const volatile lds_u32* q = (const volatile lds_u32*)p + c * 14 * stride;
 #pragma unroll
-        for (int i = 0; i < 14; i++) { xchg[i] = v.x.l[i]; xchg[14 + i] = v.y.l[i]; xchg[28 + i] = v.zz.l[i]; xchg[42 + i] = v.zzz.l[i]; }
+            for (int i = 0; i < 14; i++) v.l[i] = q[i * stride];
+        }
     };
-    auto get_x = [&](G1X& v) {
-#pragma unroll
-        for (int i = 0; i < 14; i++) { v.x.l[i] = xchg[i]; v.y.l[i] = xchg[14 + i]; v.zz.l[i] = xchg[28 + i]; v.zzz.l[i] = xchg[42 + i]; }
-    };
+    const int lane = t & 63, wave = t >> 6, K = jobs.k[m];
+    G1X Pf = acc;
+    __syncthreads();                                        // every lane is through with ent[]
+    uint32_t* snap = ent;                                   // [56][VNB]
+    uint32_t* mine = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + z) * 64;
+    uint32_t* ticket = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX) * 64 + 56;
+    int rounds = 14;
 #pragma unroll 1
-    for (int round = 0; round < 13; round++) {
+    for (int round = 0; round < rounds; round++) {
+        LdsXyzz src;
         bool take;
-        if (round == 6) {
-            if (wave == 1 && lane == 0) put_x(Pf);
+        if (round == 6 || round >= 13) {
+            uint32_t* x = xchg + (round & 1) * 56;          // round 6 and the odd rounds from 13 on never overlap in time: barriers below
+            if (round <= 13) {
+                if (wave == 1 && lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < 14; i++) { x[i] = Pf.x.l[i]; x[14 + i] = Pf.y.l[i]; x[28 + i] = Pf.zz.l[i]; x[42 + i] = Pf.zzz.l[i]; }
+                }
+            } else if (t == 0) {                            // another slice's sum, from HBM (its writer's release precedes the ticket we took)
+                const int zz = round - 14 < z ? round - 14 : round - 13;
+                const uint32_t* o = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + zz) * 64;
+#pragma unroll
+                for (int i = 0; i < 56; i++) x[i] = __builtin_nontemporal_load(o + i);
+            }
             __syncthreads();
-            get_x(o);
-            take = wave == 0;
+            src.p = x;
+            src.stride = 1;
+            take = round == 6 ? wave == 0 : t == 0;
         } else {
             const int d = round < 6 ? (1 << round) : (32 >> (round - 7));
-            shfl_down_xyzz_v(o, Pf, d);
+#pragma unroll
+            for (int i = 0; i < 14; i++) {
+                snap[i * VNB + t] = Pf.x.l[i];
+                snap[(14 + i) * VNB + t] = Pf.y.l[i];
+                snap[(28 + i) * VNB + t] = Pf.zz.l[i];
+                snap[(42 + i) * VNB + t] = Pf.zzz.l[i];
+            }
+            src.p = snap + ((t + d) & (VNB - 1));
+            src.stride = VNB;
             take = round < 6 ? (lane + d < 64) : (lane < d);
         }
-        if (take) g1x_add(Pf, Pf, o);
-    }
-    __syncthreads();
-    if (wave == 1 && lane == 0) put_x(Pf);
-    __syncthreads();
-    if (t == 0) {
-        G1X Q1, tot;
-        get_x(Q1);
-        g1x_add_nv(tot, Pf, Q1);
-        uint32_t* dst = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + z) * 64;
+        if (take) G1D::add_from(Pf, src);
+        if (round == 13 && K > 1) {                         // publish the slice's sum and take a ticket; the last one carries on
+            if (t == 0) {
 #pragma unroll
-        for (int i = 0; i < 14; i++) { dst[i] = tot.x.l[i]; dst[14 + i] = tot.y.l[i]; dst[28 + i] = tot.zz.l[i]; dst[42 + i] = tot.zzz.l[i]; }
+                for (int i = 0; i < 14; i++) { mine[i] = Pf.x.l[i]; mine[14 + i] = Pf.y.l[i]; mine[28 + i] = Pf.zz.l[i]; mine[42 + i] = Pf.zzz.l[i]; }
+                __threadfence();
+                const uint32_t got = atomicAdd(ticket, 1u);
+                last_flag = got == (uint32_t)(K - 1);
+                if (got == (uint32_t)(K - 1)) { *ticket = 0; __threadfence(); }
+            }
+            __syncthreads();
+            if (!last_flag) return;
+            rounds = 14 + K - 1;
+        }
+        if (round >= 13) __syncthreads();                   // xchg is rewritten by the next round
+    }
+    if (t == 0) {                                           // canonical plain coordinates (all-zero = identity) for the host's Horner step
+        uint32_t* dst = out + ((size_t)m * VNWIN + w) * 48;
+        const bool inf = g1x_is_inf(Pf);
+        fp_t c;
+        uint32_t ww[12];
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            fp_t f;                                         // limb selects, not a reference picked at run time (that would pin Pf to scratch)
+#pragma unroll
+            for (int i = 0; i < 14; i++) f.l[i] = k == 0 ? Pf.x.l[i] : k == 1 ? Pf.y.l[i] : k == 2 ? Pf.zz.l[i] : Pf.zzz.l[i];
+            Fp::to_plain(c, f);
+            Fp::to_words32(ww, c);
+#pragma unroll
+            for (int qq = 0; qq < 12; qq++) dst[12 * k + qq] = inf ? 0u : ww[qq];
+        }
     }
 }
 // The same, a QUAD of lanes per bucket (g1_quad.hpp): for the MSM a lone caller WAITS for -- sum r^i z_i Q_i of the blob batch verifier
@@ -1418,6 +1541,12 @@ void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, in
     const int per_block = (mode == 1 || mode == 3 || mode == 4) ? 64 : VAL_PB;
     if (n <= 0) return;
     const dim3 grid((n + per_block - 1) / per_block), block((mode == 0 || mode == 3) ? 128 : 64);
+    static const int lds_pad = getenv("MKZG_VAL_LDS_PAD") ? atoi(getenv("MKZG_VAL_LDS_PAD")) : 0;     // experiment knob: dynamic LDS per workgroup caps the workgroups per CU
+    if (lds_pad > 0 && (mode == 3 || mode == 4)) {
+        if (mode == 3) hipLaunchKernelGGL((k_g1_validate<3>), grid, block, lds_pad, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
+        else hipLaunchKernelGGL((k_g1_validate<4>), grid, block, lds_pad, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
+        return;
+    }
     switch (mode) {
         case 0: hipLaunchKernelGGL((k_g1_validate<0>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
         case 1: hipLaunchKernelGGL((k_g1_validate<1>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
@@ -1425,14 +1554,6 @@ void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, in
         case 3: hipLaunchKernelGGL((k_g1_validate<3>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
         default: hipLaunchKernelGGL((k_g1_validate<4>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
     }
-}
-void g1_validate_jobs_device(ValJobs& jobs, hipStream_t s) {
-    int blocks = 0;
-    for (int j = 0; j < jobs.count; j++) {
-        jobs.first_block[j] = blocks;
-        blocks += (jobs.n_a[j] + jobs.n_b[j] + 63) / 64;
-    }
-    if (blocks > 0) hipLaunchKernelGGL(k_g1_validate_jobs, dim3(blocks), dim3(128), 0, s, jobs);
 }
 void rlc_scalars_device(const uint32_t* h_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,
                         int mode, hipStream_t s) {
@@ -1471,7 +1592,7 @@ int vmsm_windows_device(const uint32_t* const* d_scalars, const uint32_t* const*
     bool quad = latency != 0 && VNWIN * n_msm * kmax <= 256;                      // somebody waits for this launch and it leaves the chip mostly empty: a quad per bucket
     for (int m = 0; m < n_msm; m++) quad = quad && (n_per_job[m] + jobs.k[m] - 1) / jobs.k[m] <= VQ_MAXN;
     if (quad) hipLaunchKernelGGL(k_vmsm_window_quad, dim3(VNWIN, n_msm, kmax), dim3(VQT), 0, s, jobs, d_parts);
-    else hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts);
+    else { hipLaunchKernelGGL(k_vmsm_window, dim3(VNWIN, n_msm, kmax), dim3(VNB), 0, s, jobs, d_parts, d_out); return 0; }   // combines its slices itself (tickets)
     hipLaunchKernelGGL(k_vmsm_combine, dim3((n_msm * VNWIN + 63) / 64), dim3(64), 0, s, jobs, n_msm, d_parts, d_out);
     return 0;
 }

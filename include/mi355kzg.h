@@ -175,9 +175,10 @@ int mkzg_verify_blob_kzg_proof_batch_finish(mkzg_ctx* ctx, const uint8_t* record
 /* ---- multi-process jobs: the batch verifiers' exchange step inside the library ------------------------------------------------
  * One process per GPU.  Commitments, proofs, cells and recovery shard by blob and need nothing below.  The two batch
  * verifiers fold a random linear combination over the WHOLE batch (reference internal/kzg/kzg_verify.go:111-202,
- * internal/kzg_multi/kzg_verify.go:16-105), so the ranks meet once: all-gather of the shard sizes (offset = prefix sum: the shards
- * must tile the announced batch), broadcast of r from rank 0, all-gather of one 512-byte record per rank; every rank then adds the
- * partial sums and runs the one pairing check.  The collectives are RCCL's, issued by the library: the host program (Go over cgo)
+ * internal/kzg_multi/kzg_verify.go:16-105), so the ranks meet once: ONE all-gather of 48 bytes per rank -- the shard sizes (offset =
+ * prefix sum: the shards must tile the announced batch) and, from rank 0, the random scalar r -- put in flight while the rank already
+ * hashes, decodes and uploads its shard (none of that needs r), then the all-gather of one 512-byte record per rank; every rank adds
+ * the partial sums and runs the one pairing check.  The collectives are RCCL's, issued by the library: the host program (Go over cgo)
  * needs no RCCL binding of its own, and librccl is dlopen'ed by the first call below -- single-GPU users need no RCCL installed
  * (MKZG_RCCL_LIB overrides the library name).  The `_partial` / `_finish` pairs above remain for hosts that move the records
  * themselves (go-eth-kzg_amd/distributed.py does, through torch.distributed).
@@ -194,7 +195,8 @@ int mkzg_comm_unique_id(uint8_t id128[128]);
 int mkzg_comm_init(mkzg_ctx* ctx, const uint8_t id128[128], int rank, int world, mkzg_comm** out);
 int mkzg_comm_from_nccl(mkzg_ctx* ctx, void* nccl_comm, int rank, int world, mkzg_comm** out);
 void mkzg_comm_free(mkzg_comm* comm);         /* no exchange may be in flight on it; before mkzg_ctx_free of its context */
-/* microseconds this rank spent in the three collectives of its last exchange (waiting for slower ranks included) */
+/* microseconds this rank WAITED in the two collectives of its last exchange (slower ranks' lateness included; the part of the first
+ * collective that ran beside the rank's own hashing / decoding / uploads is not) */
 double mkzg_comm_last_exchange_us(mkzg_comm* comm);
 /* Context.VerifyBlobKZGProofBatch (reference verify.go:88-143) over the ranks: host pointers as in the reference ... */
 int mkzg_verify_blob_kzg_proof_batch_exchange(mkzg_comm* comm, const uint8_t* const* blobs, const uint8_t* commitments48n, const uint8_t* proofs48n, size_t n_local,
@@ -205,6 +207,10 @@ int mkzg_verify_blob_kzg_proof_batch_exchange_device(mkzg_comm* comm, const void
 /* Context.VerifyCellKZGProofBatch (reference api_eip7594.go:163-214) over the ranks: this rank's (commitment, index, cell, proof) tuples */
 int mkzg_verify_cell_kzg_proof_batch_exchange(mkzg_comm* comm, const uint8_t* commitments48n, const uint64_t* cell_indices, const uint8_t* const* cells,
                                               const uint8_t* proofs48n, size_t n_local, uint64_t n_global);
+/* ... or this rank's cells contiguous in HBM (n_local x 2048 B, in the order of the other three arrays, which stay host arrays as in
+ * the reference): no gather and no upload of 2 KiB per cell */
+int mkzg_verify_cell_kzg_proof_batch_exchange_device(mkzg_comm* comm, const uint8_t* commitments48n, const uint64_t* cell_indices, const void* d_cells,
+                                                     const uint8_t* proofs48n, size_t n_local, uint64_t n_global, void* stream);
 
 /* Domain.EvaluateLagrangePolynomial (reference internal/domain/domain.go:193-235, with DeserializeBlob's canonicity check,
  * serialization.go:134-146): y_i = f_i(z_i) for n device-resident blobs and n caller-chosen evaluation points (host memory, n x 32 B

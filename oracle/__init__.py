@@ -56,6 +56,7 @@ def lib():
         L.kzgo_blob_to_kzg_commitment_batch_threads.argtypes = [vp, u8p, sz, u8p, vp, i32]
         L.kzgo_compute_kzg_proof.argtypes = [vp, u8p, u8p, u8p, u8p]
         L.kzgo_compute_blob_kzg_proof.argtypes = [vp, u8p, u8p, u8p]
+        L.kzgo_compute_blob_kzg_proof_batch_threads.argtypes = [vp, u8p, u8p, sz, u8p, vp, i32]
         L.kzgo_verify_kzg_proof.argtypes = [vp, u8p, u8p, u8p, u8p]
         L.kzgo_verify_blob_kzg_proof.argtypes = [vp, u8p, u8p, u8p]
         L.kzgo_verify_blob_kzg_proof_batch.argtypes = [vp, u8p, sz, u8p, sz, u8p, sz]
@@ -150,6 +151,13 @@ class OracleContext:
         p = _buf(48)
         rc = self._L.kzgo_compute_blob_kzg_proof(self._h, bytes(blob), bytes(commitment), p)
         return rc, (p.raw if rc == 0 else None)
+
+    def compute_blob_kzg_proof_batch(self, blobs_concat, commitments_concat, n, threads=0):
+        """OpenMP over (blob, commitment) pairs; threads = 0: the OpenMP default"""
+        out = _buf(48 * n)
+        st = (C.c_int * n)()
+        rc = self._L.kzgo_compute_blob_kzg_proof_batch_threads(self._h, blobs_concat, commitments_concat, n, out, C.cast(st, C.c_void_p), int(threads))
+        return rc, out.raw, list(st)
 
     def verify_kzg_proof(self, commitment, z, y, proof):
         if len(commitment) != 48 or len(z) != 32 or len(y) != 32 or len(proof) != 48:

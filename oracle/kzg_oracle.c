@@ -400,6 +400,19 @@ KZGO_EXPORT int kzgo_compute_blob_kzg_proof(const kzgo_ctx *c, const uint8_t *bl
     if (!rc) { compute_challenge(&z, blob, commitment48); open_at(c, poly, &z, &pr, &y); serialize_g1j(proof48, &pr); }
     free(poly); return rc;
 }
+/* test helper: the same over independent (blob, commitment) pairs on `threads` OpenMP threads (0: the OpenMP default) -- so that the
+ * full-size GPU tests can hold many proofs of a 1024-blob batch against this restatement in seconds */
+KZGO_EXPORT int kzgo_compute_blob_kzg_proof_batch_threads(const kzgo_ctx *c, const uint8_t *blobs, const uint8_t *commitments48, size_t n, uint8_t *proofs48, int *status, int threads) {
+    int any = 0;
+    if (threads <= 0) threads = omp_get_max_threads();
+    #pragma omp parallel for schedule(dynamic) reduction(|:any) num_threads(threads)
+    for (size_t i = 0; i < n; i++) {
+        int rc = kzgo_compute_blob_kzg_proof(c, blobs + i * BLOB_BYTES, commitments48 + 48 * i, proofs48 + 48 * i);
+        if (status) status[i] = rc;
+        any |= rc;
+    }
+    return any ? KZG_ERR_BAD_ARGS : KZG_OK;
+}
 
 /* reference internal/kzg/kzg_verify.go:35-100 */
 static int verify_single(const kzgo_ctx *c, const g1a_t *commitment, const g1a_t *proof, const fr_t *z, const fr_t *y) {

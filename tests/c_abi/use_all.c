@@ -22,7 +22,7 @@ static any_fn all_symbols[] = {
     (any_fn)mkzg_recover_cells_and_kzg_proofs, (any_fn)mkzg_recover_cells_and_kzg_proofs_batch, (any_fn)mkzg_recover_cells, (any_fn)mkzg_profile_enable, (any_fn)mkzg_profile_read,
     (any_fn)mkzg_last_host_finish_us, (any_fn)mkzg_valu_calibrate, (any_fn)mkzg_msm_g1, (any_fn)mkzg_version, (any_fn)mkzg_evaluate_blobs_device, (any_fn)mkzg_recover_cells_and_kzg_proofs_batch_device, (any_fn)mkzg_verify_cell_kzg_proof_batch_device, (any_fn)mkzg_verify_cell_kzg_proof_batch_partial_device, (any_fn)mkzg_comm_unique_id, (any_fn)mkzg_comm_init, (any_fn)mkzg_comm_from_nccl, (any_fn)mkzg_comm_free,
     (any_fn)mkzg_comm_last_exchange_us, (any_fn)mkzg_verify_blob_kzg_proof_batch_exchange, (any_fn)mkzg_verify_blob_kzg_proof_batch_exchange_device,
-    (any_fn)mkzg_verify_cell_kzg_proof_batch_exchange,
+    (any_fn)mkzg_verify_cell_kzg_proof_batch_exchange, (any_fn)mkzg_verify_cell_kzg_proof_batch_exchange_device,
 };
 
 static char* slurp(const char* path, long* len) {

@@ -36,6 +36,9 @@ void shim_fr_sub(const uint32_t* a, const uint32_t* b, uint32_t* o) { fr_t x, y,
 // points: acc = 4 x 14 limbs (x, y, zz, zzz)
 void shim_g1_madd(uint32_t* acc, const uint32_t* x, const uint32_t* y) { G1X a; memcpy(&a, acc, 224); fp_t px, py; Fp::set(px, x); Fp::set(py, y); g1x_madd(a, px, py); memcpy(acc, &a, 224); }
 void shim_g1_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { G1X x, y, r; memcpy(&x, a, 224); memcpy(&y, b, 224); g1x_add(r, x, y); memcpy(o, &r, 224); }
+// the same through the accessor form (g1.hpp add_from: the second operand fetched coordinate by coordinate, as k_vmsm_window reads its LDS snapshot)
+struct XyzzRef { const G1X* p; void get(fp_t& v, int c) const { v = c == 0 ? p->x : c == 1 ? p->y : c == 2 ? p->zz : p->zzz; } };
+void shim_g1_add_from(const uint32_t* a, const uint32_t* b, uint32_t* o) { G1X x, y; memcpy(&x, a, 224); memcpy(&y, b, 224); XyzzRef r{&y}; G1D::add_from(x, r); memcpy(o, &x, 224); }
 void shim_g1_dbl(const uint32_t* a, uint32_t* o) { G1X x, r; memcpy(&x, a, 224); g1x_dbl(r, x); memcpy(o, &r, 224); }
 void shim_g1_set_inf(uint32_t* o) { G1X r; g1x_set_inf(r); memcpy(o, &r, 224); }
 // Jacobian accumulators: 3 x 14 limbs (x, y, z)
@@ -49,12 +52,14 @@ void shim_g1j_add(const uint32_t* a, const uint32_t* b, uint32_t* o) {   // b: a
 void shim_g1j_add_affine(const uint32_t* a, const uint32_t* px, const uint32_t* py, uint32_t* o) {
     G1J x, r; memcpy(&x, a, 168); fp_t fx, fy; Fp::set(fx, px); Fp::set(fy, py); G1JC c; G1D::jac_cache_affine(c, fx, fy); G1D::jadd(r, x, c); memcpy(o, &r, 168);
 }
-// r-torsion test of the affine point (x, y) (Montgomery limbs): bit 0 = with y, bit 1 = from x and y^2 alone
+// r-torsion test of the affine point (x, y) (Montgomery limbs): bit 0 = with y, bit 1 = from x and y^2 alone, bit 2 = the register-lean
+// form of the latter (isomorphic curves, incomplete additions, stash)
 int shim_g1_in_subgroup(const uint32_t* x, const uint32_t* y) {
     fp_t fx, fy, beta, rhs;
     Fp::set(fx, x); Fp::set(fy, y); Fp::set(beta, FP_BETA);
     Fp::sqr(rhs, fy);
-    return (G1D::in_subgroup(fx, fy, beta) ? 1 : 0) | (G1D::in_subgroup_yfree(fx, rhs, beta) ? 2 : 0);
+    G1D::MemberStash st;
+    return (G1D::in_subgroup(fx, fy, beta) ? 1 : 0) | (G1D::in_subgroup_yfree(fx, rhs, beta) ? 2 : 0) | (G1D::in_subgroup_yfree_lean(fx, rhs, beta, st) ? 4 : 0);
 }
 // returns compressed 48 bytes
 void shim_g1_compress(const uint32_t* a, uint8_t* out48) {

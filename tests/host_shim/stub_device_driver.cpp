@@ -110,7 +110,7 @@ static void run(const std::string& js, const std::vector<int>& devices, int thre
 static void exchange_scenario(const std::string& js, int world) {
     uint8_t id[128];
     CHECK(mkzg_comm_unique_id(id) == MKZG_OK);
-    std::vector<int> got(5 * (size_t)world, -1);
+    std::vector<int> got(8 * (size_t)world, -1);
     std::vector<std::thread> th;
     for (int rank = 0; rank < world; rank++) th.emplace_back([&, rank] {
         CHECK(hipSetDevice((rank + 1) % world) == hipSuccess);                  // the caller sits on another device than its context's
@@ -127,7 +127,7 @@ static void exchange_scenario(const std::string& js, int world) {
         for (size_t b = 0; b < NB; b++) { cms[48 * b] = 0xc0; prs[48 * b] = 0xc0; }
         uint64_t total = 0;
         for (int k = 0; k < world; k++) total += 3 + (uint64_t)k;
-        int* g = &got[5 * (size_t)rank];
+        int* g = &got[8 * (size_t)rank];
         g[0] = mkzg_verify_blob_kzg_proof_batch_exchange(cm, bp.data(), cms.data(), prs.data(), NB, total);
         g[1] = mkzg_verify_blob_kzg_proof_batch_exchange(cm, bp.data(), cms.data(), prs.data(), NB, total + 1);        // announced size is wrong
         if (rank == world - 1) bp[1] = nullptr;                                                                          // a nil blob in the LAST shard
@@ -144,6 +144,18 @@ static void exchange_scenario(const std::string& js, int world) {
         if (rank == 1) cp[5] = nullptr;
         g[4] = mkzg_verify_cell_kzg_proof_batch_exchange(cm, ccm.data(), idx.data(), cp.data(), cpr.data(), NC, 8 * (uint64_t)(world - 1));
         CHECK(mkzg_comm_last_exchange_us(cm) >= 0.0);
+        cp[5] = cellv[5].data();
+        // a rank-local ARGUMENT error (the last rank passes no proofs): it travels through the collectives instead of leaving the other
+        // ranks waiting in them, and every rank returns it
+        g[5] = mkzg_verify_cell_kzg_proof_batch_exchange(cm, ccm.data(), idx.data(), cp.data(), (rank == world - 1 && NC) ? nullptr : cpr.data(), NC, 8 * (uint64_t)(world - 1));
+        g[6] = mkzg_verify_blob_kzg_proof_batch_exchange(cm, rank == world - 1 ? nullptr : bp.data(), cms.data(), prs.data(), NB, total);
+        // the cells of this rank contiguous in "HBM" (stub device memory)
+        void* d_cells = nullptr;
+        CHECK(hipSetDevice(dev) == hipSuccess);
+        CHECK(hipMalloc(&d_cells, 8 * 2048) == hipSuccess);
+        CHECK(hipSetDevice((rank + 1) % world) == hipSuccess);
+        g[7] = mkzg_verify_cell_kzg_proof_batch_exchange_device(cm, ccm.data(), idx.data(), d_cells, cpr.data(), NC, 8 * (uint64_t)(world - 1), nullptr);
+        CHECK(hipFree(d_cells) == hipSuccess);
         int d = -1;
         CHECK(hipGetDevice(&d) == hipSuccess && d == (rank + 1) % world);
         mkzg_comm_free(cm);
@@ -151,12 +163,15 @@ static void exchange_scenario(const std::string& js, int world) {
     });
     for (auto& t : th) t.join();
     for (int rank = 1; rank < world; rank++)
-        for (int q = 0; q < 5; q++) CHECK(got[5 * (size_t)rank + q] == got[q]);           // every rank the same verdict
+        for (int q = 0; q < 8; q++) CHECK(got[8 * (size_t)rank + q] == got[q]);           // every rank the same verdict
     CHECK(soft(got[0]));
     CHECK(got[1] == MKZG_ERR_BATCH_LENGTH);
     CHECK(got[2] == MKZG_ERR_NIL_INPUT);
     CHECK(soft(got[3]));
     CHECK(world < 2 || got[4] == MKZG_ERR_NIL_INPUT);
+    CHECK(world < 2 ? soft(got[5]) : got[5] == MKZG_ERR_BAD_ARGS);
+    CHECK(got[6] == MKZG_ERR_BAD_ARGS);
+    CHECK(soft(got[7]));
 }
 
 // An eight-device context (api_multi.hip): one full context per device behind the front, host-pointer batches cut into contiguous

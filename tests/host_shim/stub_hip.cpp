@@ -59,6 +59,7 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
     a->device = it->second;
     return hipSuccess;
 }
+hipError_t hipMemset(void* dst, int v, size_t n) { if (n) memset(dst, v, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(dst, src, n); return hipSuccess; }
 
 hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned int, int priority) { *s = (hipStream_t) new StubStream{priority}; return hipSuccess; }

@@ -28,12 +28,11 @@ def test_commitment_batch_256(gpu_ctx, oracle_ctx):
     assert int(d_st.abs().sum().item()) == 0
     out = bytes(d_out.cpu().tolist())
     cms = [out[48 * i:48 * i + 48] for i in range(B)]
-    # oracle on every 8th blob (seeds 0, 8, ...), all of them through the OpenMP batch helper
-    idx = list(range(0, B, 8))
-    rc, exp, stl = oracle_ctx.blob_to_kzg_commitment_batch(b"".join(blobs[i] for i in idx), len(idx))
+    # the oracle on ALL 256 blobs (SURVEY 8d cfg 2: seeds 0..255) through its OpenMP batch helper
+    rc, exp, stl = oracle_ctx.blob_to_kzg_commitment_batch(b"".join(blobs), B)
     assert rc == 0
-    for k, i in enumerate(idx):
-        assert cms[i] == exp[48 * k:48 * k + 48], i
+    for i in range(B):
+        assert cms[i] == exp[48 * i:48 * i + 48], i
     # order independence + batch == single: the reversed batch gives the reversed outputs
     rev = torch.frombuffer(bytearray(b"".join(reversed(blobs))), dtype=torch.uint8).cuda()
     d_out2 = torch.zeros(B * 48, dtype=torch.uint8, device="cuda")
@@ -50,7 +49,7 @@ def test_commitment_batch_256(gpu_ctx, oracle_ctx):
 def test_verify_batch_1024(gpu_ctx, oracle_ctx):
     import torch
     N = 1024
-    blobs = _blobs(N, 10_000)
+    blobs = _blobs(N, 0)                          # SURVEY 8d cfg 3, literally: seeds 0..1023, commitment_i / proof_i as bench_test.go:55-66
     d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
     d_cm = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
     d_pr = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
@@ -60,18 +59,28 @@ def test_verify_batch_1024(gpu_ctx, oracle_ctx):
     assert gpu_ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), N, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
     torch.cuda.synchronize()
     assert int(d_st.abs().sum().item()) == 0
-    # spot parity of the generated proofs
+    # parity of the generated inputs: every 16th commitment + proof (64 of each, first and last included) against the oracle
     cm = bytes(d_cm.cpu().tolist())
     pr = bytes(d_pr.cpu().tolist())
-    for i in (0, 513, 1023):
-        assert pr[48 * i:48 * i + 48] == oracle_ctx.compute_blob_kzg_proof(blobs[i], cm[48 * i:48 * i + 48])[1]
+    idx = list(range(0, N, 16))[:-1] + [N - 1]
+    sub_b = b"".join(blobs[i] for i in idx)
+    rc, exp_cm, _ = oracle_ctx.blob_to_kzg_commitment_batch(sub_b, len(idx))
+    assert rc == 0
+    rc, exp_pr, _ = oracle_ctx.compute_blob_kzg_proof_batch(sub_b, exp_cm, len(idx))
+    assert rc == 0
+    for k, i in enumerate(idx):
+        assert cm[48 * i:48 * i + 48] == exp_cm[48 * k:48 * k + 48], i
+        assert pr[48 * i:48 * i + 48] == exp_pr[48 * k:48 * k + 48], i
     badb = d_blobs.clone()
     badb[131072 * 900 + 32 * 17:131072 * 900 + 32 * 18] = 0xff           # blob 900 holds a non-canonical field element
     try:
         for shape in (0, 1):                 # the lone-call shape and the shape calls take when they share the chip (option verify_shape)
             assert gpu_ctx.set_option("verify_shape", shape) == 0
             assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, st) == 0
-            for victim in (0, 700, 1023):        # one corrupted proof anywhere must reject the whole batch
+            bad = d_pr.clone()                   # cfg 3's negative run: proof_0 replaced by proof_1
+            bad[0:48] = d_pr[48:96]
+            assert gpu_ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), bad.data_ptr(), N, st) == 1
+            for victim in (700, 1023):           # one corrupted proof anywhere must reject the whole batch
                 bad = d_pr.clone()
                 other = (victim + 1) % N
                 bad[48 * victim:48 * victim + 48] = d_pr[48 * other:48 * other + 48]
@@ -93,10 +102,15 @@ def test_verify_batch_host_pointers_1024_and_beyond(gpu_ctx, product):
     undecodable commitment; nil blobs with the reference's precedence (an error at a lower index wins)."""
     import ctypes as C
     import torch
+    import numpy as np
     L = product.lib()
-    D = 64
-    blobs = _blobs(D, 20_000)
-    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).cuda()
+    D = 2100                                      # EVERY item of the 1024- and the 2100-blob batches is its own blob (64 until round 5: a
+    #                                               bug that permutes items within a residue class was invisible); numpy Philox instead of
+    #                                               4096 SHA-256 calls per blob, uniform below 2^254 < r
+    raw = np.random.Generator(np.random.Philox(20_000)).integers(0, 256, size=(D, 4096, 32), dtype=np.uint8)
+    raw[:, :, 0] &= 0x3F
+    blobs = [raw[i].tobytes() for i in range(D)]
+    d_blobs = torch.from_numpy(raw.reshape(-1)).cuda()
     d_cm = torch.zeros(D * 48, dtype=torch.uint8, device="cuda")
     d_pr = torch.zeros(D * 48, dtype=torch.uint8, device="cuda")
     d_st = torch.zeros(D, dtype=torch.int32, device="cuda")
@@ -194,9 +208,11 @@ def test_cells_and_proofs_batch_64(gpu_ctx, oracle_ctx):
     assert int(d_st.abs().sum().item()) == 0
     cells = d_cells.cpu().numpy().tobytes()
     proofs = d_proofs.cpu().numpy().tobytes()
-    for b in (0, 42, 63):
+    for b in range(0, NB, 4):                     # every 4th blob (0.4 s each on the oracle) and the last
         rc, ec, ep = oracle_ctx.compute_cells_and_kzg_proofs(blobs[b])
-        assert rc == 0 and cells[b * 262144:(b + 1) * 262144] == ec and proofs[b * 6144:(b + 1) * 6144] == ep
+        assert rc == 0 and cells[b * 262144:(b + 1) * 262144] == ec and proofs[b * 6144:(b + 1) * 6144] == ep, b
+    rc, ec, ep = oracle_ctx.compute_cells_and_kzg_proofs(blobs[NB - 1])
+    assert rc == 0 and cells[(NB - 1) * 262144:] == ec and proofs[(NB - 1) * 6144:] == ep
     # systematic code: the first 64 cells of every blob are the blob itself
     for b in range(NB):
         assert cells[b * 262144:b * 262144 + 131072] == blobs[b]

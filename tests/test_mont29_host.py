@@ -266,6 +266,17 @@ def test_g1_ops(shim):
     assert shim_compress(shim, o) == compress(ec_add(pts[0], pts[1]))
     shim.shim_g1_add(inf, a, o)
     assert shim_compress(shim, o) == compress(ec_add(pts[0], pts[1]))
+    # the accessor form of the addition (add_from, what k_vmsm_window's suffix network runs): general, P + P, P - P, identity on
+    # either side, identity + identity -- same group element as add() every time
+    neg_a = (C.c_uint32 * 56)(*a)
+    for i in range(14):
+        neg_a[14 + i] = limbs((4 * P - sum(int(a[14 + k]) << (29 * k) for k in range(14))))[i]
+    for x_, y_, want in ((a, b, r_ab), (a, a, ec_mul(2, ec_add(pts[0], pts[1]))), (a, neg_a, None), (a, inf, ec_add(pts[0], pts[1])),
+                         (inf, a, ec_add(pts[0], pts[1])), (inf, inf, None), (b, a, r_ab)):
+        shim.shim_g1_add_from(x_, y_, o)
+        assert shim_compress(shim, o) == compress(want)
+        shim.shim_g1_add(x_, y_, o)
+        assert shim_compress(shim, o) == compress(want)
     # long chain: bounds stay valid over many operations
     acc = (C.c_uint32 * 56)()
     shim.shim_g1_set_inf(acc)
@@ -278,7 +289,7 @@ def test_g1_ops(shim):
             shim.shim_g1_dbl(acc, acc)
             ref = ec_add(ref, ref)
         if i % 5 == 4:
-            shim.shim_g1_add(acc, a, acc)
+            (shim.shim_g1_add if i % 10 == 4 else shim.shim_g1_add_from)(acc, a, acc)
             ref = ec_add(ref, ec_add(pts[0], pts[1]))
     assert shim_compress(shim, acc) == compress(ref)
 
@@ -371,7 +382,7 @@ def test_g1_subgroup_tests(shim):
     aff = lambda pt: (limbs(pt[0] * RP % P), limbs(pt[1] * RP % P))
     for _ in range(4):
         pt = ec_mul(rng.randrange(1, R), G)
-        assert shim.shim_g1_in_subgroup(*aff(pt)) == 3
+        assert shim.shim_g1_in_subgroup(*aff(pt)) == 7
     outside = [(0, 2), (0, P - 2)]
     while len(outside) < 6:                                     # random points of the curve: in G1 with probability 1/cofactor
         x = rng.randrange(P)
@@ -386,7 +397,27 @@ def test_g1_subgroup_tests(shim):
     H_COF = 0x396c8c005555e1568c00aaab0000aaab
     q = ec_mul(H_COF, outside[3])
     assert q is not None and ec_mul(R, q) is None
-    assert shim.shim_g1_in_subgroup(*aff(q)) == 3
+    assert shim.shim_g1_in_subgroup(*aff(q)) == 7
+    # points of SMALL order (h = 3 * 11^2 * 10177^2 * 859267^2 * 52437899^2): the chains of all three forms meet [k]B = +-B and
+    # [k]B = identity inside their loops -- the register-lean form has no branch for these, its additions return Z = 0 (mod p)
+    # and the verdict reads that as "not in the subgroup" (g1.hpp in_subgroup_yfree_lean)
+    assert H_COF == 3 * 11 ** 2 * 10177 ** 2 * 859267 ** 2 * 52437899 ** 2
+    small = []
+    for base in outside[2:]:
+        for f, e in ((3, 1), (11, 2), (10177, 2), (859267, 2), (52437899, 2)):
+            pt = ec_mul(H_COF * R // f ** e, base)              # order divides f^e
+            while pt is not None:
+                small.append(pt)
+                pt = ec_mul(f, pt)
+    small += [ec_add(a, b) for a, b in zip(small, small[1:]) if ec_add(a, b) is not None]      # mixed small orders (33, 3 * 10177, ...)
+    seen = set(small)
+    assert len(seen) >= 20, len(seen)
+    for pt in seen:
+        assert ec_mul(R, pt) is not None
+        assert shim.shim_g1_in_subgroup(*aff(pt)) == 0, pt
+    # a point of G1 plus a point of order 3: outside, and the three forms agree
+    mixed = ec_add(ec_mul(12345, G), (0, 2))
+    assert shim.shim_g1_in_subgroup(*aff(mixed)) == 0
 
 
 def test_g1_matches_oracle(shim):

@@ -10,5 +10,5 @@ objs=""
 for f in api api_verify api_cells api_multi api_exchange msm_kernels verify_kernels cells_kernels fk20_kernels recover_kernels; do
   if [ "$f.hip" == "$src" ]; then objs="$objs /tmp/variant_$name.o"; else objs="$objs $f.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/build_ab/libmi355kzg_$name.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/build_ab/libmi355kzg_$name.so $objs -ldl
 echo built $name

@@ -14,6 +14,8 @@ Workloads (run under the profiler on the GPU box; the program itself goes after 
         same FK20 launches behind different predecessors (the sparse-wavefront finding of DESIGN.md section 7)
     rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/t -- python3 tools/trace.py cells_batch [N=128] [R=3]
         R device-resident ComputeCellsAndKZGProofs calls of N blobs, one caller: the launches of one piece and the gaps between them
+    rocprofv3 --kernel-trace --stats -d gpurun_out/t -- python3 tools/trace.py lone [R=5]
+        R lone device-resident blob-verifier calls under each shape + R lone cell-verifier calls (cells in HBM): isolated kernel durations
 Readers (anywhere):
     python3 tools/trace.py timeline DIR [t_from_ms t_to_ms]   kernel + copy records merged into one time-ordered listing
     python3 tools/trace.py busy DIR [gap_ms]                  last burst of kernels: wall time, time with a kernel running, kernels in flight
@@ -171,6 +173,52 @@ def wl_verify_inflight(args):
     ctx.close()
 
 
+def wl_lone(args):
+    """isolated kernel durations: R lone device-resident VerifyBlobKZGProofBatch(1024) calls under each verifier shape, then R lone
+    VerifyCellKZGProofBatch(8192) calls with the cells in HBM -- read with `rocprofv3 --kernel-trace --stats`"""
+    BLOB, load_product, rand_blob = _product()
+
+    import torch
+    torch.cuda.init()
+    R = int(args[0]) if args else 5
+    kzg = load_product()
+    ctx = kzg.Context(device=0)
+    N, NB = 1024, 64
+    base = [rand_blob(s) for s in range(NB)]
+    d_blobs = torch.frombuffer(bytearray(b"".join(base[i % NB] for i in range(N))), dtype=torch.uint8).cuda()
+    d_cm = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
+    d_pr = torch.zeros(N * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(N, dtype=torch.int32, device="cuda")
+    assert ctx.blob_to_kzg_commitment_batch_device(d_blobs.data_ptr(), N, d_cm.data_ptr(), d_st.data_ptr(), 0) == 0
+    assert ctx.compute_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), N, d_pr.data_ptr(), d_st.data_ptr(), 0) == 0
+    torch.cuda.synchronize()
+    for shape in (0, 1):
+        assert ctx.set_option("verify_shape", shape) == 0
+        ts = []
+        for i in range(R + 1):
+            t0 = time.perf_counter()
+            assert ctx.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_cm.data_ptr(), d_pr.data_ptr(), N, 0) == 0
+            ts.append(1e3 * (time.perf_counter() - t0))
+        print(f"verify_shape {shape}: lone VerifyBlobKZGProofBatch(1024) ms " + " ".join(f"{t:.3f}" for t in ts[1:]), flush=True)
+    assert ctx.set_option("verify_shape", -1) == 0
+    d_cells = torch.zeros(NB * 262144, dtype=torch.uint8, device="cuda")
+    d_proofs = torch.zeros(NB * 128 * 48, dtype=torch.uint8, device="cuda")
+    assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), 0) == 0
+    torch.cuda.synchronize()
+    cms, proofs = d_cm.cpu().numpy().tobytes(), d_proofs.cpu().numpy().tobytes()
+    n = NB * 128
+    idx = (ctypes.c_uint64 * n)(*[i % 128 for i in range(n)])
+    cj = b"".join(cms[48 * (i // 128):48 * (i // 128) + 48] for i in range(n))
+    L = kzg.lib()
+    ts = []
+    for i in range(R + 1):
+        t0 = time.perf_counter()
+        assert L.mkzg_verify_cell_kzg_proof_batch_device(ctx._h, cj, ctypes.cast(idx, ctypes.c_void_p), ctypes.c_void_p(d_cells.data_ptr()), proofs, n, ctypes.c_void_p(0)) == 0
+        ts.append(1e3 * (time.perf_counter() - t0))
+    print("lone VerifyCellKZGProofBatch(8192, cells in HBM) ms " + " ".join(f"{t:.3f}" for t in ts[1:]), flush=True)
+    ctx.close()
+
+
 def wl_msm_paths(args):
     BLOB, load_product, rand_blob = _product()
 
@@ -314,7 +362,7 @@ def rd_summary(args):
         print(f"  grid {grid} queue {q}: n={len(ds)} mean={sum(ds) / len(ds):.3f} min={min(ds):.3f} max={max(ds):.3f}   [{' '.join(f'{d:.2f}' for d in ds)}]")
 
 
-COMMANDS = {"single": wl_single, "verify_host": wl_verify_host, "verify_inflight": wl_verify_inflight, "msm_paths": wl_msm_paths, "cells_batch": wl_cells_batch,
+COMMANDS = {"single": wl_single, "lone": wl_lone, "verify_host": wl_verify_host, "verify_inflight": wl_verify_inflight, "msm_paths": wl_msm_paths, "cells_batch": wl_cells_batch,
             "busy": rd_busy, "timeline": rd_timeline, "summary": rd_summary}
 
 if __name__ == "__main__":

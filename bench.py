@@ -319,6 +319,30 @@ def main():
     if args.cell_blobs > 0:
         eip7594 = bench_eip7594(ctx, kzg, torch, dist, dist_on, dist_dev, world, rank, args, hw)
 
+    single = None
+    if rank == 0 and world == 1 and not dist_on and not args.no_drop_in and args.verify_batch > 0 and args.cell_blobs > 0:
+        single = bench_single_blob_callers(ctx, kzg, torch)
+        # ratios to the batch entry points of the same run: host-pointer commitments (one caller), cells with proofs (64 device-resident
+        # blobs per call, eight callers if measured), host-pointer VerifyBlobKZGProofBatch (most callers measured)
+        ref = {}
+        dk = next((k for k in drop_in if k.startswith(("default_options", "direct_table"))), None)
+        if dk:
+            ref["blob_to_kzg_commitment"] = ("drop_in.%s.blobs_per_s_two_callers" % dk, drop_in[dk]["blobs_per_s_two_callers"])
+        if eip7594:
+            cc = eip7594.get("compute_cells_and_kzg_proofs", {})
+            ref["compute_cells_and_kzg_proofs"] = (("eip7594.compute_cells_and_kzg_proofs.sustained.blobs_per_s", cc["sustained"]["blobs_per_s"]) if "sustained" in cc
+                                                   else ("eip7594.compute_cells_and_kzg_proofs.blobs_per_s", cc.get("blobs_per_s")))
+        hv = drop_in.get("verify_blob_kzg_proof_batch", {})
+        ks = sorted(int(k.split("_")[1]) for k in hv if k.startswith("callers_"))
+        if ks:
+            ref["verify_blob_kzg_proof"] = ("drop_in.verify_blob_kzg_proof_batch.callers_%d.blobs_per_s" % ks[-1], hv[f"callers_{ks[-1]}"]["blobs_per_s"])
+        for kind, (what, v) in ref.items():
+            if v:
+                best = max(single[kind].values(), key=lambda d: d["blobs_per_s"])["blobs_per_s"]
+                single[kind]["batch_entry_point"] = {"what": what, "blobs_per_s": v}
+                single[kind]["ratio_to_batch"] = round(best / v, 3)
+        drop_in["single_blob_callers"] = single
+
     if rank == 0:
         total_blobs = B * world * args.steps
         value = total_blobs / elapsed
@@ -329,10 +353,16 @@ def main():
         avg_ms = dom_ms / max(1, dom_n)
         achieved = ALGO_BYTES_PER_BLOB * B / (avg_ms * 1e-3) / 1e9
         pmc = pmc_profile(dom)
+        # `achieved` / `frac` / `avg_kernel_ms`: ONE launch alone on the GPU (three untimed single-stream steps of this run) -- the figure
+        # that is comparable from round to round and across --streams settings; the same launch while it shares the chip with the other
+        # streams' launches of the timed region is `*_overlapped` (it was the headline until round 4 and moved with the stream count:
+        # 0.0013 over two streams, 0.00077 over four, same kernel)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic_bytes"),
                     "avg_kernel_ms": round(avg_ms, 4), "launches": dom_n,
                     "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if v[1]}}
+        roofline["achieved_overlapped"], roofline["frac_overlapped"], roofline["avg_kernel_ms_overlapped"] = roofline["achieved"], roofline["frac"], roofline["avg_kernel_ms"]
+        roofline["measured"] = "timed region (no isolated launches in this run)"
         if not args.no_profile and prof_repeats.get(dom, (0, 0))[1]:
             rep_ms, rep_n = prof_repeats[dom]
             roofline["avg_kernel_ms_all_regions"] = round((dom_ms + rep_ms) / (dom_n + rep_n), 4)
@@ -344,14 +374,15 @@ def main():
             roofline["avg_kernel_ms_one_stream"] = round(iso_ms_r, 4)
             roofline["achieved_one_stream"] = round(ALGO_BYTES_PER_BLOB * B / (iso_ms_r * 1e-3) / 1e9, 3)
             roofline["frac_one_stream"] = round(ALGO_BYTES_PER_BLOB * B / (iso_ms_r * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
+            roofline["achieved"], roofline["frac"], roofline["avg_kernel_ms"] = roofline["achieved_one_stream"], roofline["frac_one_stream"], roofline["avg_kernel_ms_one_stream"]
+            roofline["measured"] = "one launch alone on the GPU, HIP events on its launch stream (three untimed single-stream steps); the timed region's overlapped launches: *_overlapped"
         roofline["input_ring"] = {"batches": len(ring), "bytes": len(ring) * B * BLOB, "note": "the timed steps cycle through this many distinct input batches resident in HBM"}
         step_ms = elapsed / args.steps * 1e3
         roofline["achieved_per_step"] = round(ALGO_BYTES_PER_BLOB * B / (step_ms * 1e-3) / 1e9, 3)
         roofline["frac_per_step"] = round(ALGO_BYTES_PER_BLOB * B / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
         if NS > 1:
-            roofline["note"] = (f"{NS} streams: `achieved` / `frac` divide a launch's algorithmic bytes by ITS duration, and avg_kernel_ms is a launch's duration while it shares "
-                                f"the GPU with the launches of the other {NS - 1} streams (it exceeds ms_per_step; with 2 streams it was ~3.2 ms and frac 0.0013 for the same kernel); "
-                                "avg_kernel_ms_one_stream / frac_one_stream: the same launch alone on the GPU (three untimed single-stream steps); achieved_per_step / frac_per_step: "
+            roofline["note"] = (f"{NS} streams: *_overlapped divide a launch's algorithmic bytes by ITS duration while it shares the GPU with the launches of the other {NS - 1} "
+                                "streams (that duration exceeds ms_per_step); achieved / frac / avg_kernel_ms: the same launch alone on the GPU; achieved_per_step / frac_per_step: "
                                 "a launch's bytes over ms_per_step, what the overlapped pipeline streams per unit of wall time")
         # what actually bounds this path: integer VALU issue.  Wave-instructions of the dominant kernel (rocprofv3 SQ_INSTS_VALU,
         # profiles/*_traffic.json, valid only for the kernel sources they were collected on) over its duration, against the hardware
@@ -375,9 +406,14 @@ def main():
                         "achieved_timed_region": round(rate_timed / 1e9, 2),
                         "peak_hw": round(peak_hw / 1e9, 1), "peak_hw_note": hw["note"],
                         "frac_hw_isolated": round(rate_iso / peak_hw, 4), "frac_hw_timed_region": round(rate_timed / peak_hw, 4),
-                        "calibrated_mad_rate": round(calib / 1e9, 2) if calib else None,
-                        "calibration_note": "v_mad_u64_u32 only, 2 wavefronts per SIMD, measured in this run: what this GPU's clock under load allows for the slowest-issuing instruction of the mix; not a ceiling",
+                        "calibrated_mix_rate": round(calib / 1e9, 2) if calib else None,
+                        "calibration_note": "measured in this run: four wavefronts per SIMD issuing the multiplier's mix (eight v_mad_u64_u32, one v_lshl_add_u64, one v_and_b32 per ten instructions) on independent accumulators -- what this GPU's clock under load sustains for the kernels' instruction mix",
                         "pmc_source": pmc.get("source_file")}
+        if valu is not None:
+            # the ceiling that binds, inside the object the driver parses: wave-instructions per second over the hardware issue limit
+            roofline["valu_frac"] = valu["frac_hw_timed_region"]
+            roofline["valu_frac_one_stream"] = valu["frac_hw_isolated"]
+            roofline["valu_note"] = "integer VALU issue is what bounds this kernel: SQ_INSTS_VALU per launch (committed PMC pass) x launches/s of the timed region (valu_frac) or over the isolated launch (valu_frac_one_stream), against 256 CUs x 4 SIMDs x f_max / 4"
         ms_steps = sorted(r / args.steps * 1e3 for r in region_s)
         out = {
             "metric": "blobs/sec BlobToKZGCommitment (batch=256 per GPU)", "value": round(value, 2), "unit": "blobs/s",
@@ -402,8 +438,14 @@ def main():
         if verify is not None:
             out["verify_blob_kzg_proof_batch"] = verify
             # the second half of BASELINE.json's metric at the top level too: whole-job blobs/s of VerifyBlobKZGProofBatch over all ranks
-            out["verify_metric"] = {"metric": "blobs/sec VerifyBlobKZGProofBatch (batch=%d per GPU)" % args.verify_batch, "value": verify["value"], "unit": "blobs/s", "n_gpus": world,
+            shape = (f"{verify['sustained']['callers']} device-resident callers on one context" if "sustained" in verify else "single device-resident calls")
+            out["verify_metric"] = {"metric": "blobs/sec VerifyBlobKZGProofBatch (batch=%d per GPU; %s)" % (args.verify_batch, shape), "value": verify["value"], "unit": "blobs/s", "n_gpus": world,
                                     "what": verify["value_is"]}
+            hostv = drop_in.get("verify_blob_kzg_proof_batch", {}) if drop_in else {}
+            ks = sorted(int(k.split("_")[1]) for k in hostv if k.startswith("callers_"))
+            if ks:
+                out["verify_metric"]["reference_shaped"] = {"metric": "blobs/sec VerifyBlobKZGProofBatch (batch=%d; host pointers as verify.go:88 hands them over, %d callers)" % (args.verify_batch, ks[-1]),
+                                                            "value": hostv[f"callers_{ks[-1]}"].get("blobs_per_s"), "bound": "PCIe", "see": "drop_in.verify_blob_kzg_proof_batch"}
         if eip7594 is not None:
             out["eip7594"] = eip7594
         if not args.no_cpu_baseline and world == 1:        # reported baseline: rank 0 at N = 1 only
@@ -413,8 +455,20 @@ def main():
         line = None
     if dist_on:
         dist.barrier()
-        dist.destroy_process_group()
     ctx.close()
+    # the OTHER multi-GPU form, one process over all the job's devices (api_multi.hip): after every rank has given its HBM back
+    if dist_on:
+        dist.barrier()
+    if rank == 0 and not args.no_drop_in:
+        try:
+            in_proc = bench_multi_in_process(kzg, torch, min(torch.cuda.device_count(), 1 if shared_gpu else world))
+        except Exception as e:      # noqa: BLE001  (a leg that has never met real hardware must not cost the line)
+            in_proc = {"error": repr(e)[:300]}
+        out.setdefault("multi_gpu", {})["in_process"] = in_proc
+        line = json.dumps(out)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
     if line is not None:
         # the JSON line is the LAST thing on stdout: RCCL and gloo write banners to the C-level stdout (RCCL's version block sits in the
         # stdio buffer until the process exits), so that buffer goes out first
@@ -672,6 +726,141 @@ def bench_drop_in(ctx, kzg, host_blobs, d_expect):
             "device_resident_one_synchronous_caller": {"ms_per_call": round(dtd * 1e3, 3), "blobs_per_s": round(n / dtd, 1)},
             "one_caller_over_device_resident": round(dtd / dt1, 3), "two_callers_over_device_resident": round(dtd / dt2, 3),
             "note": "PCIe inclusive: pageable host blobs in (gathered into pinned staging chunk by chunk), host bytes out"}
+
+
+def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, seconds=0.35):
+    """What an UNMODIFIED caller of the reference gets: BlobToKZGCommitment, ComputeCellsAndKZGProofs and VerifyBlobKZGProof take ONE blob
+    (prove.go:13-33, api_eip7594.go:28-52, verify.go:48-83) and clients call them from many goroutines on one shared context
+    (verify.go:152-169, examples_test.go:11).  K threads on one context, each looping the single-blob host-pointer entry point of the C
+    ABI over its own blobs (arguments marshalled once, as a cgo caller holds them); blobs/s over all threads, host CPUs busy; the caller
+    of this function puts the ratio to the batch entry point of the same box beside it.  ctypes releases the GIL around every call."""
+    L = kzg.lib()
+    K_max = max(callers)
+    n = K_max * per_thread
+    hb = fast_blobs(n, 8800)
+    d_b = torch.from_numpy(hb.reshape(-1)).cuda()
+    d_cm = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    d_pr = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
+    d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert ctx.blob_to_kzg_commitment_batch_device(d_b.data_ptr(), n, d_cm.data_ptr(), d_st.data_ptr(), st) == 0
+    assert ctx.compute_blob_kzg_proof_batch_device(d_b.data_ptr(), d_cm.data_ptr(), n, d_pr.data_ptr(), d_st.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    cms, prs = d_cm.cpu().numpy().tobytes(), d_pr.cpu().numpy().tobytes()
+    blobs = [ctypes.create_string_buffer(hb[i].tobytes(), BLOB) for i in range(n)]
+    cm = [cms[48 * i:48 * i + 48] for i in range(n)]
+    pr = [prs[48 * i:48 * i + 48] for i in range(n)]
+
+    def run(kind, K):
+        errs, counts = [], [0] * K
+        stop = threading.Event()
+
+        def caller(k):
+            try:
+                out48 = ctypes.create_string_buffer(48)
+                cells = ctypes.create_string_buffer(128 * 2048)
+                proofs = ctypes.create_string_buffer(128 * 48)
+                i = 0
+                while not stop.is_set():
+                    j = k * per_thread + i % per_thread
+                    if kind == "blob_to_kzg_commitment":
+                        rc = L.mkzg_blob_to_kzg_commitment(ctx._h, blobs[j], 0, out48)
+                        ok = rc == 0 and (i >= per_thread or out48.raw == cm[j])
+                    elif kind == "compute_cells_and_kzg_proofs":
+                        rc = L.mkzg_compute_cells_and_kzg_proofs(ctx._h, blobs[j], 0, cells, proofs)
+                        ok = rc == 0
+                    else:
+                        wrong = i % 7 == 3                                     # every seventh call brings another blob's proof: must be rejected
+                        rc = L.mkzg_verify_blob_kzg_proof(ctx._h, blobs[j], cm[j], pr[(j + 1) % n] if wrong else pr[j])
+                        ok = rc == (1 if wrong else 0)
+                    if not ok:
+                        errs.append((kind, k, i, rc))
+                        return
+                    i += 1
+                    counts[k] = i
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+
+        rates, cpus = [], []
+        for trial in range(3):                                                  # one priming trial, then two timed
+            stop.clear()
+            counts[:] = [0] * K
+            ts = [threading.Thread(target=caller, args=(k,)) for k in range(K)]
+            t0, c0 = time.perf_counter(), time.process_time()
+            for t in ts:
+                t.start()
+            time.sleep(seconds if trial else 0.1)
+            stop.set()
+            for t in ts:
+                t.join()
+            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+            assert not errs, errs[0]
+            if trial:
+                rates.append(sum(counts) / dt)
+                cpus.append(cpu / dt)
+        return {"blobs_per_s": round(max(rates), 1), "blobs_per_s_each": [round(r, 1) for r in rates], "host_cpus_busy": round(max(cpus), 1), "us_per_call_per_thread": round(K / max(rates) * 1e6, 1)}
+
+    out = {"blobs_per_thread": per_thread, "seconds_per_trial": seconds}
+    for kind in ("blob_to_kzg_commitment", "compute_cells_and_kzg_proofs", "verify_blob_kzg_proof"):
+        out[kind] = {f"callers_{K}": run(kind, K) for K in callers}
+    return out
+
+
+def bench_multi_in_process(kzg, torch, n_dev, B=256, N=1024, reps=4):
+    """The form ONE Go process on a multi-GPU node would use (verify.go:152-169: one shared Context, many goroutines): a single context
+    over n_dev devices (mkzg_ctx_new with n_dev ids, api_multi.hip), host-pointer batches cut into contiguous shards inside the library,
+    the batch verifiers' per-device sums added in process -- no RCCL, no ranks.  Runs on rank 0 after every rank's own context is closed
+    (the tables of both forms do not fit one GPU's HBM together).  Host-pointer batches of n_dev x the per-GPU sizes of the headline legs."""
+    if n_dev < 2:
+        return {"skipped": "one device (--gpus 1, or one device visible): the in-process multi-device context is the single-device context"}
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count()))                    # this leg spans sockets: each peer's pool goes to its own GPU's node instead
+    except OSError:
+        pass
+    os.environ["MKZG_POOL_AFFINITY"] = "1"
+    L = kzg.lib()
+    ctx = kzg.Context(devices=list(range(n_dev)))
+    out = {"devices": n_dev, "host_threads": int(ctx.get_option("host_threads") or 0)}
+    try:
+        torch.cuda.set_device(0)
+        nb, nv = B * n_dev, N * n_dev
+        hb = fast_blobs(nv, 9900)
+        keep = [ctypes.create_string_buffer(hb[i].tobytes(), BLOB) for i in range(nv)]
+        arr = (ctypes.c_char_p * nv)(*[ctypes.cast(k, ctypes.c_char_p) for k in keep])
+        # commitments + proofs of all nv blobs through the context itself (host pointers in: sharded over the devices)
+        cms = ctypes.create_string_buffer(48 * nv)
+        st = (ctypes.c_int * nv)()
+        assert L.mkzg_blob_to_kzg_commitment_batch(ctx._h, arr, nv, cms, st) == 0
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            assert L.mkzg_blob_to_kzg_commitment_batch(ctx._h, arr, nb, cms, st) == 0
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[len(ts) // 2]
+        out["blob_to_kzg_commitment_batch"] = {"blobs": nb, "ms_per_call": round(med * 1e3, 3), "blobs_per_s": round(nb / med, 1)}
+        assert L.mkzg_blob_to_kzg_commitment_batch(ctx._h, arr, nv, cms, st) == 0
+        d_b = torch.from_numpy(hb.reshape(-1)).cuda()
+        d_cm = torch.frombuffer(bytearray(cms.raw), dtype=torch.uint8).cuda()
+        d_pr = torch.zeros(nv * 48, dtype=torch.uint8, device="cuda")
+        d_st = torch.zeros(nv, dtype=torch.int32, device="cuda")
+        assert ctx.compute_blob_kzg_proof_batch_device(d_b.data_ptr(), d_cm.data_ptr(), nv, d_pr.data_ptr(), d_st.data_ptr(), 0) == 0      # runs where the pointers live: device 0
+        torch.cuda.synchronize()
+        prs = d_pr.cpu().numpy().tobytes()
+        bad = prs[:48 * (nv - 1)] + prs[:48]                               # the LAST shard's last proof is another blob's
+        assert L.mkzg_verify_blob_kzg_proof_batch(ctx._h, arr, cms.raw, prs, nv, nv, nv) == 0
+        assert L.mkzg_verify_blob_kzg_proof_batch(ctx._h, arr, cms.raw, bad, nv, nv, nv) == 1
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            assert L.mkzg_verify_blob_kzg_proof_batch(ctx._h, arr, cms.raw, prs, nv, nv, nv) == 0
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts)[len(ts) // 2]
+        out["verify_blob_kzg_proof_batch"] = {"blobs": nv, "ms_per_call": round(med * 1e3, 3), "blobs_per_s": round(nv / med, 1),
+                                              "pcie_GBps_all_links": round(nv * VERIFY_BYTES_PER_BLOB / med / 1e9, 2)}
+        out["tables_on_own_device"] = int(ctx.get_option("tables_on_own_device") or 0)
+    finally:
+        ctx.close()
+    return out
 
 
 PCIE_PEAK_GBS = 63.0                       # PCIe 5.0 x16, one direction: 32 GT/s x 16 lanes x 128/130 = 63.0 GB/s before packet overheads
@@ -1192,22 +1381,39 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
         def verify_once():
             return L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, proofs, n)
     assert verify_once() == 0
+    assert verify_once() == 0
     ctx.profile_read(reset=True)
     if dist_on:
         dist.barrier()
+    # every call timed on its own (round 5: the mean of `steps` calls could not tell an outlier from a slow path -- the driver's box
+    # once reported 3.0 ms where the same library measured 1.97 elsewhere): min / median / max, the host finish, the link's rate
+    n_calls = max(steps, 12)
+    each, fin = [], []
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(n_calls):
+        t1 = time.perf_counter()
         assert verify_once() == 0
+        each.append((time.perf_counter() - t1) * 1e3)
+        fin.append(ctx.last_host_finish_us() / 1e3)
     if dist_on:
         dist.barrier()
-    dt = maxed((time.perf_counter() - t0) / steps)
+    dt_mean = maxed((time.perf_counter() - t0) / n_calls)
     prof = ctx.profile_read(reset=True)
-    kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
+    kern = {k: round(v[0] / n_calls, 3) for k, v in prof.items() if v[1]}
     roof, valu = leg_roofline(kern, 2152 * n, hw, pmc_valid_for_size=full_size, leg="eip7594")
+    srt = sorted(each)
+    med = srt[len(srt) // 2]
+    dt = dt_mean if dist_on else med * 1e-3                    # several ranks: the slowest rank's mean between barriers; one rank: the median call
     out["verify_cell_kzg_proof_batch"] = {"cells_per_gpu": n, "cells_total": n * world, "ms_per_call": round(dt * 1e3, 3), "cells_per_s": round(n * world / dt, 1),
-                                          "parallelism": "one call" if not dist_on else f"one global batch sharded x{world}; broadcast(r) + all_gather(512 B records)",
+                                          "calls": n_calls, "ms_per_call_min": round(srt[0], 3), "ms_per_call_median": round(med, 3), "ms_per_call_max": round(srt[-1], 3),
+                                          "ms_per_call_mean": round(dt_mean * 1e3, 3), "ms_per_call_each": [round(x, 3) for x in each],
+                                          "host_finish_ms": round(sorted(fin)[len(fin) // 2], 3),
+                                          "pcie": {"bytes_per_call": 2152 * n, "achieved_GBps": round(2152 * n / (med * 1e-3) / 1e9, 2), "peak_GBps": PCIE_PEAK_GBS,
+                                                   "frac": round(2152 * n / (med * 1e-3) / 1e9 / PCIE_PEAK_GBS, 4),
+                                                   "note": "a lone call is a chain (gather + upload, interpolation, MSM, host finish), not a stream: the link is busy for a quarter of it"},
+                                          "parallelism": "one call" if not dist_on else f"one global batch sharded x{world}; all_gather(sizes, r) + all_gather(512 B records)",
                                           "kernels_ms": kern, "roofline": roof, "valu": valu,
-                                          "note": "host pointers in (16 MiB of cells per 8192 gathered and uploaded inside the call)"}
+                                          "note": "host pointers in (16 MiB of cells per 8192 gathered and uploaded inside the call); ms_per_call = the median of `calls` calls timed one by one"}
     if solo:
         # the cells already in HBM (mkzg_verify_cell_kzg_proof_batch_device: commitments, indices and proofs stay host arrays): no gather, no 16 MiB upload
         assert L.mkzg_verify_cell_kzg_proof_batch_device(ctx._h, cj, idx, d_cells.data_ptr(), proofs, n, st) == 0

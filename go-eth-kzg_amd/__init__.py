@@ -104,7 +104,8 @@ def lib():
         L.mkzg_verify_blob_kzg_proof_batch_exchange.argtypes = [vp, vp, C.c_char_p, C.c_char_p, sz, C.c_uint64]
         L.mkzg_verify_blob_kzg_proof_batch_exchange_device.argtypes = [vp, vp, vp, vp, sz, C.c_uint64, vp]
         L.mkzg_verify_cell_kzg_proof_batch_exchange.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64]
-        L.mkzg_verify_cell_kzg_proof_batch_exchange_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64, vp]
+        if hasattr(L, "mkzg_verify_cell_kzg_proof_batch_exchange_device") or "MI355KZG_LIB" not in os.environ:      # (an older build named for an A/B run may lack it)
+            L.mkzg_verify_cell_kzg_proof_batch_exchange_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64, vp]
         L.mkzg_verify_cell_kzg_proof_batch_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, vp]
         L.mkzg_verify_cell_kzg_proof_batch_partial_device.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.c_uint64, C.c_char_p, C.c_char_p, vp]
         L.mkzg_recover_cells_and_kzg_proofs_batch_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]

@@ -858,6 +858,11 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         c->opt_verify_shape = (int)value;
         return MKZG_OK;
     }
+    if (!strcmp(key, "combine_single_calls")) {
+        if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_combine = (int)value;
+        return MKZG_OK;
+    }
     return MKZG_ERR_BAD_ARGS;
 }
 int mkzg_ctx_set_option(mkzg_ctx* c, const char* key, long value) {
@@ -883,6 +888,12 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "host_gather_tasks")) *value = q->opt_host_gather_tasks;
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
     else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
+    else if (!strcmp(key, "combine_single_calls")) *value = q->opt_combine;
+    else if (!strcmp(key, "combined_calls")) {                                                  // single-item calls served as members of a group of two or more so far
+        *value = 0;
+        const std::vector<mkzg_ctx*> all = c->peers.empty() ? std::vector<mkzg_ctx*>{c} : c->peers;
+        for (mkzg_ctx* p : all) *value += (long)(p->comb_commit.combined_items() + p->comb_cells.combined_items() + p->comb_verify.combined_items());
+    }
     else if (!strcmp(key, "host_wait")) *value = q->opt_host_wait;
     else if (!strcmp(key, "fk20_segments")) *value = q->opt_fk20_segments;
     else if (!strcmp(key, "debug_serial")) *value = q->opt_debug_serial;
@@ -942,10 +953,35 @@ int mkzg_blob_to_kzg_commitment(mkzg_ctx* c, const uint8_t* blob, int num_thread
     if (!c || !out48) return MKZG_ERR_BAD_ARGS;
     if (!blob) return MKZG_ERR_NIL_INPUT;
     if (!c->peers.empty()) c = c->peers[c->rr++ % c->peers.size()];
-    const uint8_t* one[1] = {blob};
-    int st = 0;
-    int rc = mkzg_blob_to_kzg_commitment_batch(c, one, 1, out48, &st);
-    if (rc) return rc;
+    // calls that find others in flight leave as one batch (host_combine.hpp); a caller that is alone is a group of one: the path it always took
+    mkzg_ctx::CommitCall call{blob, out48, MKZG_OK};
+    auto process = [c](std::vector<mkzg_ctx::CommitCall*>& items) {
+        const size_t n = items.size();
+        if (n == 1) {
+            const uint8_t* one[1] = {items[0]->blob};
+            int st = 0;
+            items[0]->rc = mkzg_blob_to_kzg_commitment_batch(c, one, 1, items[0]->out48, &st);
+            return;
+        }
+        c->comb_commit.count_combined(n);
+        std::vector<const uint8_t*> ptrs(n);
+        std::vector<uint8_t> out(48 * n);
+        std::vector<int> st(n, 0);
+        for (size_t i = 0; i < n; i++) ptrs[i] = items[i]->blob;
+        const int rc = mkzg_blob_to_kzg_commitment_batch(c, ptrs.data(), n, out.data(), st.data());
+        const bool broken = rc == MKZG_ERR_HIP || rc == MKZG_ERR_BAD_ARGS;           // not an item's status: nobody got a result
+        for (size_t i = 0; i < n; i++) {
+            items[i]->rc = broken ? rc : st[i];
+            if (!items[i]->rc) memcpy(items[i]->out48, out.data() + 48 * i, 48);
+        }
+    };
+    if (c->opt_combine.load(std::memory_order_relaxed)) {
+        c->comb_commit.run(&call, process);
+    } else {
+        std::vector<mkzg_ctx::CommitCall*> one{&call};
+        process(one);
+    }
+    if (call.rc) return call.rc;
     if (num_threads >= 1024) return MKZG_ERR_TOO_MANY_GOROUTINES;                  // multiexp.go:45-50
     return MKZG_OK;
 }

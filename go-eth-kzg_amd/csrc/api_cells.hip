@@ -270,28 +270,57 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* c, const void* d_bl
     return G.fail(cells_and_proofs_device(c, G.L, (const uint8_t*)d_blobs, n, (uint8_t*)d_cells, (uint8_t*)d_proofs, d_status, G.s));
 }
 
+}   // extern "C"
+// the cells and proofs of n blobs given as host pointers, in one lane: the blobs staged side by side, ONE pass of the batch kernels,
+// every item's 262,144 + 6,144 bytes straight into its caller's buffers.  rcs[i]: the item's own status.
+static int cells_and_proofs_host(mkzg_ctx* c, size_t n, const uint8_t* const* blobs, uint8_t* const* cells_out, uint8_t* const* proofs_out, int* rcs) {
+    LaneGuard G(c);
+    Lane* L = G.L;
+    int rc = ensure_fk20_tables(c);
+    if (!rc) rc = ensure_fk20_ws(L, n);
+    if (!rc) rc = ensure_staging(L, n, MKZG_BYTES_PER_BLOB + 64);
+    if (rc) return G.fail(rc);
+    for (size_t i = 0; i < n; i++) memcpy(L->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB);
+    HIPCHK(hipMemcpyAsync(L->d_blobs, L->h_stage, n * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, G.s));
+    rc = cells_and_proofs_device(c, L, L->d_blobs, n, L->d_cells, L->d_fk_proofs, L->d_cell_st, G.s);
+    if (rc) return G.fail(rc);
+    int* h_st = (int*)(L->h_stage + n * MKZG_BYTES_PER_BLOB);           // pinned: a copy into pageable memory polls inside the runtime
+    HIPCHK(hipMemcpyAsync(h_st, L->d_cell_st, n * sizeof(int), hipMemcpyDeviceToHost, G.s));
+    for (size_t i = 0; i < n; i++) {
+        HIPCHK(hipMemcpyAsync(cells_out[i], L->d_cells + i * 262144, 262144, hipMemcpyDeviceToHost, G.s));
+        HIPCHK(hipMemcpyAsync(proofs_out[i], L->d_fk_proofs + i * 128 * 48, 128 * 48, hipMemcpyDeviceToHost, G.s));
+    }
+    LANE_SYNC(c, G.L, G.s);
+    G.L->drained = true;
+    for (size_t i = 0; i < n; i++) rcs[i] = h_st[i];
+    return MKZG_OK;
+}
+extern "C" {
+// Context.ComputeCellsAndKZGProofs (reference api_eip7594.go:28-52).  Calls that find other such calls in flight share one pass of the
+// batch kernels (host_combine.hpp): the FK20 stage takes 2.0 ms for one blob and 4.8 ms for sixty-four.
 int mkzg_compute_cells_and_kzg_proofs(mkzg_ctx* c, const uint8_t* blob, int num_threads, uint8_t* cells_out, uint8_t* proofs_out) {
     (void)num_threads;
     if (!c || !cells_out || !proofs_out) return MKZG_ERR_BAD_ARGS;
     if (!blob) return MKZG_ERR_NIL_INPUT;
     c = md_pick(c);
-    LaneGuard G(c);
-    Lane* L = G.L;
-    int rc = ensure_fk20_tables(c);
-    if (!rc) rc = ensure_fk20_ws(L, 1);
-    if (!rc) rc = ensure_staging(L, 1, MKZG_BYTES_PER_BLOB);
-    if (rc) return G.fail(rc);
-    memcpy(L->h_stage, blob, MKZG_BYTES_PER_BLOB);
-    HIPCHK(hipMemcpyAsync(L->d_blobs, L->h_stage, MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, G.s));
-    rc = cells_and_proofs_device(c, L, L->d_blobs, 1, L->d_cells, L->d_fk_proofs, L->d_cell_st, G.s);
-    if (rc) return G.fail(rc);
-    int st = 0;
-    HIPCHK(hipMemcpyAsync(&st, L->d_cell_st, sizeof(int), hipMemcpyDeviceToHost, G.s));
-    HIPCHK(hipMemcpyAsync(cells_out, L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
-    HIPCHK(hipMemcpyAsync(proofs_out, L->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, G.s));
-    LANE_SYNC(c, G.L, G.s);
-    G.L->drained = true;
-    return st;
+    mkzg_ctx::CellsCall call{blob, cells_out, proofs_out, MKZG_OK};
+    auto process = [c](std::vector<mkzg_ctx::CellsCall*>& items) {
+        const size_t n = items.size();
+        if (n > 1) c->comb_cells.count_combined(n);
+        std::vector<const uint8_t*> in(n);
+        std::vector<uint8_t*> oc(n), op(n);
+        std::vector<int> rcs(n, MKZG_OK);
+        for (size_t i = 0; i < n; i++) { in[i] = items[i]->blob; oc[i] = items[i]->cells_out; op[i] = items[i]->proofs_out; }
+        const int rc = cells_and_proofs_host(c, n, in.data(), oc.data(), op.data(), rcs.data());
+        for (size_t i = 0; i < n; i++) items[i]->rc = rc ? rc : rcs[i];
+    };
+    if (c->opt_combine.load(std::memory_order_relaxed)) {
+        c->comb_cells.run(&call, process);
+    } else {
+        std::vector<mkzg_ctx::CellsCall*> one{&call};
+        process(one);
+    }
+    return call.rc;
 }
 
 }  // extern "C"

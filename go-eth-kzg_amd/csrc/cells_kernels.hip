@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include "mont29.hpp"
 #include "cells_kernels.h"
+#include "pub_ticket.hpp"
 
 namespace kzg {
 
@@ -499,46 +500,53 @@ __global__ void __launch_bounds__(64) k_cell_interp(const uint8_t* __restrict__ 
         FrC::add(acc, acc, v);
         __syncthreads();
     }
-    c_store_fr12(partials + ((size_t)blockIdx.x * 64 + lane) * 12, acc);
     // interp[i] = the sum of all workgroups' partial sums, by whoever finishes last -- a launch of its own until round 5.  Two levels of
     // tickets (behind the partial rows: zero when the workspace is allocated, reset by the taker of the last one): the last workgroup of
     // every GROUP of 64 adds its group's rows, the last group to finish adds the <= 32 group rows and writes the 64 plain scalars.
+    // Rows travel as agent-scope stores / loads (pub_ticket.hpp), nine words each.
     __shared__ int is_last;
     uint32_t* gpart = partials + (size_t)CELL_INTERP_BLOCKS * 64 * 12;         // [CELL_INTERP_BLOCKS / 64][64] Fr rows
     uint32_t* tick = gpart + (size_t)(CELL_INTERP_BLOCKS / 64) * 64 * 12;      // [groups] + 1
     const int g = (int)blockIdx.x >> 6, n_groups = ((int)gridDim.x + 63) >> 6;
     const int g_size = min(64, (int)gridDim.x - (g << 6));
-    __threadfence();
+    auto put_row = [&](uint32_t* row, const fr_t& v) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) pub_store(row + q, v.l[q]);
+    };
+    auto get_row = [&](fr_t& v, const uint32_t* row) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) v.l[q] = pub_load(row + q);
+    };
+    put_row(partials + ((size_t)blockIdx.x * 64 + lane) * 12, acc);
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (lane == 0) {
-        const uint32_t got = atomicAdd(&tick[g], 1u);
+        const uint32_t got = pub_ticket(&tick[g]);
         is_last = got == (uint32_t)(g_size - 1);
-        if (is_last) tick[g] = 0;
+        if (is_last) pub_store(&tick[g], 0u);
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
     Fr::set_zero(acc);
     for (int b = 0; b < g_size; b++) {
         fr_t v;
-        c_load_fr12(v, partials + ((size_t)((g << 6) + b) * 64 + lane) * 12);
+        get_row(v, partials + ((size_t)((g << 6) + b) * 64 + lane) * 12);
         FrC::add(acc, acc, v);
     }
-    c_store_fr12(gpart + ((size_t)g * 64 + lane) * 12, acc);
-    __threadfence();
+    put_row(gpart + ((size_t)g * 64 + lane) * 12, acc);
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (lane == 0) {
-        const uint32_t got = atomicAdd(&tick[CELL_INTERP_BLOCKS / 64], 1u);
+        const uint32_t got = pub_ticket(&tick[CELL_INTERP_BLOCKS / 64]);
         is_last = got == (uint32_t)(n_groups - 1);
-        if (is_last) tick[CELL_INTERP_BLOCKS / 64] = 0;
+        if (is_last) pub_store(&tick[CELL_INTERP_BLOCKS / 64], 0u);
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
     Fr::set_zero(acc);
     for (int b = 0; b < n_groups; b++) {
         fr_t v;
-        c_load_fr12(v, gpart + ((size_t)b * 64 + lane) * 12);
+        get_row(v, gpart + ((size_t)b * 64 + lane) * 12);
         FrC::add(acc, acc, v);
     }
     fr_store_plain8(interp8 + (size_t)lane * 8, acc);

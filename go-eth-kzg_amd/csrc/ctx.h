@@ -29,6 +29,7 @@
 #include "host_g1.hpp"
 #include "host_pool.hpp"
 #include "host_copy.hpp"
+#include "host_combine.hpp"
 
 using namespace kzg;
 
@@ -233,6 +234,14 @@ struct mkzg_ctx {
     std::atomic<int> opt_host_chunk{128};              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
     std::atomic<int> opt_host_gather_tasks{16};        // gather tasks per chunk of the host-pointer commitment pipeline (measured, tools/sweep_host_commit.py: 3.37 ms per 256 blobs with 16, 3.55 with 4)
     std::atomic<int> opt_host_zero_copy{1};            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
+    // single-item calls of the reference API served in groups through the batch paths when several are in flight (host_combine.hpp)
+    struct CommitCall { const uint8_t* blob; uint8_t* out48; int rc; };
+    struct CellsCall { const uint8_t* blob; uint8_t* cells_out; uint8_t* proofs_out; int rc; };
+    struct VerifyCall { const uint8_t* blob; const uint8_t* commitment48; const uint8_t* proof48; int rc; bool again; };
+    kzg::Combiner<CommitCall> comb_commit;
+    kzg::Combiner<CellsCall> comb_cells;
+    kzg::Combiner<VerifyCall> comb_verify;
+    std::atomic<int> opt_combine{1};                   // "combine_single_calls": 1 (default) groups concurrent single-blob calls, 0 every call on its own
     std::atomic<int> opt_verify_shape{-1};             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
     int opt_cells_chunk = 256;             // most blobs per launch set of a ComputeCellsAndKZGProofs batch (a lane's FK20 workspace grows to the pieces it has seen: 1.6 MB per blob)
     int opt_lanes = NLANE;                 // lanes calls may occupy at once (each keeps its workspaces and pinned staging until trimmed or destroyed)

@@ -928,28 +928,34 @@ __global__ void __launch_bounds__(256) k_commit_direct_fin_quad(const uint32_t* 
 }
 
 // ------------------------------------------------------------------------------------------
-// VALU calibration: what this particular GPU sustains on v_mad_u64_u32 (the instruction ~70% of every kernel
-// here consists of), two wavefronts per SIMD, eight independent accumulators per lane.  Boxes of one pool differ
-// by up to 1.5x on this number (power management), so efficiency is quoted against it, not against a data sheet.
+// VALU calibration: what this particular GPU sustains on the multiplier's instruction mix -- eight v_mad_u64_u32 (80 % of an Fp
+// multiplication's instructions), one v_lshl_add_u64 and one v_and_b32 per ten -- with FOUR wavefronts per SIMD on independent
+// accumulators (round 5; two wavefronts of multiply-adds only until then, which the commitment kernel's timed region out-ran: not
+// a ceiling).  Boxes of one pool differ by up to 1.5x on this number (power management).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_valu_calibrate(uint32_t* out, int iters, uint32_t seed) {
     uint32_t a0 = seed + threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;
     uint64_t c0 = a0, c1 = a1, c2 = a2, c3 = a3, c4 = a0 + 9, c5 = a1 + 9, c6 = a2 + 9, c7 = a3 + 9;
+    uint64_t s0 = a2 + 17, s1 = a3 + 19;
+    uint32_t m0 = ~a1;
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 0; r < 8; r++)
-            asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n v_mad_u64_u32 %1, vcc, %8, %10, %1\n v_mad_u64_u32 %2, vcc, %9, %10, %2\n v_mad_u64_u32 %3, vcc, %8, %11, %3\n"
-                         "v_mad_u64_u32 %4, vcc, %9, %11, %4\n v_mad_u64_u32 %5, vcc, %10, %11, %5\n v_mad_u64_u32 %6, vcc, %8, %8, %6\n v_mad_u64_u32 %7, vcc, %9, %9, %7\n"
-                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "vcc");
+            asm volatile("v_mad_u64_u32 %[c0], vcc, %[a0], %[a1], %[c0]\n v_mad_u64_u32 %[c1], vcc, %[a0], %[a2], %[c1]\n v_mad_u64_u32 %[c2], vcc, %[a1], %[a2], %[c2]\n"
+                         "v_mad_u64_u32 %[c3], vcc, %[a0], %[a3], %[c3]\n v_mad_u64_u32 %[c4], vcc, %[a1], %[a3], %[c4]\n v_mad_u64_u32 %[c5], vcc, %[a2], %[a3], %[c5]\n"
+                         "v_mad_u64_u32 %[c6], vcc, %[a0], %[a0], %[c6]\n v_mad_u64_u32 %[c7], vcc, %[a1], %[a1], %[c7]\n"
+                         "v_lshl_add_u64 %[s0], %[s0], 3, %[s1]\n v_and_b32 %[m0], %[m0], %[a0]\n"
+                         : [c0] "+v"(c0), [c1] "+v"(c1), [c2] "+v"(c2), [c3] "+v"(c3), [c4] "+v"(c4), [c5] "+v"(c5), [c6] "+v"(c6), [c7] "+v"(c7), [s0] "+v"(s0), [s1] "+v"(s1), [m0] "+v"(m0)
+                         : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3) : "vcc");
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7 ^ s0 ^ s1) ^ m0;
 }
 // returns wave-instructions per second (0 on failure)
 double valu_calibrate_device(hipStream_t s) {
     int cus = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0.0;
-    const int blocks = cus * 2, iters = 20000;         // 4 wavefronts per workgroup -> 2 per SIMD
+    const int blocks = cus * 4, iters = 10000;         // 4 wavefronts per workgroup -> 4 per SIMD
     uint32_t* d = nullptr;
     if (hipMalloc(&d, (size_t)blocks * 256 * sizeof(uint32_t)) != hipSuccess) return 0.0;
     hipEvent_t e0, e1;
@@ -962,7 +968,7 @@ double valu_calibrate_device(hipStream_t s) {
     float ms = 0.f;
     double rate = 0.0;
     if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f)
-        rate = (double)blocks * 4 * iters * 64 / (ms * 1e-3);
+        rate = (double)blocks * 4 * iters * 80 / (ms * 1e-3);              // 8 x (8 mads + 2) instructions per iteration and wavefront
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(d);

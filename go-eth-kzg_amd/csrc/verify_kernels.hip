@@ -28,6 +28,7 @@
 #include "g1_quad.hpp"
 #include "verify_kernels.h"
 #include "g1_decode.hpp"
+#include "pub_ticket.hpp"
 
 namespace kzg {
 
@@ -980,8 +981,29 @@ __device__ __forceinline__ void g1_validate_wide_block(const uint8_t* __restrict
 template <int MODE>
 __global__ void __launch_bounds__(128) k_g1_validate(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
                                                      const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
-    if (MODE == 3 || MODE == 4) g1_validate_wide_block<MODE>(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, (int)blockIdx.x);
-    else g1_validate_block(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, MODE, (int)blockIdx.x);
+    g1_validate_block(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, MODE, (int)blockIdx.x);
+}
+// Modes 3 and 4 with the register-lean chain.  ONE WAVEFRONT PER SIMD ALL THE SAME (amdgpu_waves_per_eu(1, 1): the compiler pads the
+// allocation): *measured* (round 5, tools/ab_r05_3.sh) this GPU's dispatcher does not look for an idle SIMD -- concurrent launches
+// start filling the same compute units, and a chain wavefront that CAN share its SIMD with another launch's chain wavefront does:
+// at 221 / 226 registers and two wavefronts per SIMD the test alone ran in 0.95 ms (1.07-1.10 with the old chain), but beside the
+// cell verifier's decoding launch both took 1.2-1.3 ms (decoding: 0.45 -> 1.16 ms), the lone 8192-cell call went from 1.8 to 2.9 ms
+// and 32 callers of the blob verifier from 2.2 to 1.3 M blobs/s.  What the lean chain buys is therefore its instructions (10 products
+// per addition instead of 17, no select / copy code in the loop, a loop body that fits the instruction cache) and the decoding
+// wavefronts that EXIT instead of idling at a barrier -- not a second chain on the same SIMD.
+#ifndef MKZG_VAL_LEAN_ATTR
+#define MKZG_VAL_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(128) MKZG_VAL_LEAN_ATTR k_g1_validate_lean(const uint8_t* __restrict__ in48_a, int n_a, uint32_t* __restrict__ aff_a, int* __restrict__ st_a,
+                                                                            const uint8_t* __restrict__ in48_b, int n_b, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
+#ifndef MKZG_VAL_LEAN_SHARED
+    // The WHOLE register file of the SIMD (256 + 256), as the old chain's 474-497 registers had in effect: with the allocation the
+    // compiler pads to for one wavefront per SIMD (~380) the 108-register evaluation wavefronts of other calls still moved in beside
+    // the chain -- 32 callers 1.43 M blobs/s, 1.85 M with this line, tools/ab_r05_4.sh.  -DMKZG_VAL_LEAN_SHARED builds without it.
+    asm volatile("" ::: "v255", "a255");
+#endif
+    g1_validate_wide_block<MODE>(in48_a, n_a, aff_a, st_a, in48_b, n_b, aff_b, st_b, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1085,12 +1107,18 @@ struct VmsmJobs { VmsmJob j[4]; int k[4]; };    // k: point-range slices per (jo
 // grid (window, job, slice): a (job, window) pair with many points is cut into up to VMSM_KMAX slices of the point range, each
 // with its own 128 buckets -- the bucket walk is a serial chain of mixed additions per lane, so 8192 points in one workgroup
 // are 64 additions deep where eight slices are 8 deep; k_vmsm_combine adds the slices' window sums.
+// (one wavefront per SIMD by declaration, like k_g1_validate_lean and for the same measured reason: at 255 registers two of these chains
+// -- or one of these and a subgroup test -- would share a SIMD whenever two launches meet on a compute unit)
+#ifndef MKZG_VMSM_RESERVE
+#define MKZG_VMSM_RESERVE "a89"             // 256 + 90 registers: what the kernel held before round 5 (344) -- a challenge-hash wavefront (153) still fits beside it, a second chain does not
+#endif
 __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __restrict__ parts /* [msm][VNWIN][VMSM_KMAX][64] XYZZ */, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
     __shared__ uint32_t ent[VMAXN];
     __shared__ uint32_t hist[VNB + 1];
     __shared__ uint32_t cursor[VNB];
     __shared__ uint32_t xchg[2 * 56];
     __shared__ int last_flag;
+    asm volatile("" ::: MKZG_VMSM_RESERVE);
     const int w = blockIdx.x, m = blockIdx.y, t = threadIdx.x, z = blockIdx.z;
     if (z >= jobs.k[m]) return;
     const int n_all = jobs.j[m].n, lo = (int)((long long)n_all * z / jobs.k[m]), hi = (int)((long long)n_all * (z + 1) / jobs.k[m]);
@@ -1186,11 +1214,11 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
 #pragma unroll
                     for (int i = 0; i < 14; i++) { x[i] = Pf.x.l[i]; x[14 + i] = Pf.y.l[i]; x[28 + i] = Pf.zz.l[i]; x[42 + i] = Pf.zzz.l[i]; }
                 }
-            } else if (t == 0) {                            // another slice's sum, from HBM (its writer's release precedes the ticket we took)
+            } else if (t == 0) {                            // another slice's sum (published before the ticket we took: pub_ticket.hpp)
                 const int zz = round - 14 < z ? round - 14 : round - 13;
                 const uint32_t* o = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + zz) * 64;
 #pragma unroll
-                for (int i = 0; i < 56; i++) x[i] = __builtin_nontemporal_load(o + i);
+                for (int i = 0; i < 56; i++) x[i] = pub_load(o + i);
             }
             __syncthreads();
             src.p = x;
@@ -1213,11 +1241,10 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
         if (round == 13 && K > 1) {                         // publish the slice's sum and take a ticket; the last one carries on
             if (t == 0) {
 #pragma unroll
-                for (int i = 0; i < 14; i++) { mine[i] = Pf.x.l[i]; mine[14 + i] = Pf.y.l[i]; mine[28 + i] = Pf.zz.l[i]; mine[42 + i] = Pf.zzz.l[i]; }
-                __threadfence();
-                const uint32_t got = atomicAdd(ticket, 1u);
+                for (int i = 0; i < 14; i++) { pub_store(mine + i, Pf.x.l[i]); pub_store(mine + 14 + i, Pf.y.l[i]); pub_store(mine + 28 + i, Pf.zz.l[i]); pub_store(mine + 42 + i, Pf.zzz.l[i]); }
+                const uint32_t got = pub_ticket(ticket);
                 last_flag = got == (uint32_t)(K - 1);
-                if (got == (uint32_t)(K - 1)) { *ticket = 0; __threadfence(); }
+                if (got == (uint32_t)(K - 1)) pub_store(ticket, 0u);
             }
             __syncthreads();
             if (!last_flag) return;
@@ -1541,18 +1568,12 @@ void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, in
     const int per_block = (mode == 1 || mode == 3 || mode == 4) ? 64 : VAL_PB;
     if (n <= 0) return;
     const dim3 grid((n + per_block - 1) / per_block), block((mode == 0 || mode == 3) ? 128 : 64);
-    static const int lds_pad = getenv("MKZG_VAL_LDS_PAD") ? atoi(getenv("MKZG_VAL_LDS_PAD")) : 0;     // experiment knob: dynamic LDS per workgroup caps the workgroups per CU
-    if (lds_pad > 0 && (mode == 3 || mode == 4)) {
-        if (mode == 3) hipLaunchKernelGGL((k_g1_validate<3>), grid, block, lds_pad, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
-        else hipLaunchKernelGGL((k_g1_validate<4>), grid, block, lds_pad, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b);
-        return;
-    }
     switch (mode) {
         case 0: hipLaunchKernelGGL((k_g1_validate<0>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
         case 1: hipLaunchKernelGGL((k_g1_validate<1>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
         case 2: hipLaunchKernelGGL((k_g1_validate<2>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
-        case 3: hipLaunchKernelGGL((k_g1_validate<3>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
-        default: hipLaunchKernelGGL((k_g1_validate<4>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
+        case 3: hipLaunchKernelGGL((k_g1_validate_lean<3>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
+        default: hipLaunchKernelGGL((k_g1_validate_lean<4>), grid, block, 0, s, d_in48_a, n_a, d_aff_a, d_st_a, d_in48_b, n_b, d_aff_b, d_st_b); break;
     }
 }
 void rlc_scalars_device(const uint32_t* h_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,

@@ -322,6 +322,11 @@ def main():
     single = None
     if rank == 0 and world == 1 and not dist_on and not args.no_drop_in and args.verify_batch > 0 and args.cell_blobs > 0:
         single = bench_single_blob_callers(ctx, kzg, torch)
+        assert ctx.set_option("combine_single_calls", 0) == 0            # for the record: every call on its own, as until round 5
+        alone = bench_single_blob_callers(ctx, kzg, torch, callers=(32,))
+        assert ctx.set_option("combine_single_calls", 1) == 0
+        for kind in ("blob_to_kzg_commitment", "compute_cells_and_kzg_proofs", "verify_blob_kzg_proof"):
+            single[kind]["callers_32_uncombined"] = alone[kind]["callers_32"]
         # ratios to the batch entry points of the same run: host-pointer commitments (one caller), cells with proofs (64 device-resident
         # blobs per call, eight callers if measured), host-pointer VerifyBlobKZGProofBatch (most callers measured)
         ref = {}
@@ -728,7 +733,7 @@ def bench_drop_in(ctx, kzg, host_blobs, d_expect):
             "note": "PCIe inclusive: pageable host blobs in (gathered into pinned staging chunk by chunk), host bytes out"}
 
 
-def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, seconds=0.35):
+def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, seconds=0.35, kinds=None, wrong_every=0):
     """What an UNMODIFIED caller of the reference gets: BlobToKZGCommitment, ComputeCellsAndKZGProofs and VerifyBlobKZGProof take ONE blob
     (prove.go:13-33, api_eip7594.go:28-52, verify.go:48-83) and clients call them from many goroutines on one shared context
     (verify.go:152-169, examples_test.go:11).  K threads on one context, each looping the single-blob host-pointer entry point of the C
@@ -751,6 +756,8 @@ def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, se
     cm = [cms[48 * i:48 * i + 48] for i in range(n)]
     pr = [prs[48 * i:48 * i + 48] for i in range(n)]
 
+    timed = [False]
+
     def run(kind, K):
         errs, counts = [], [0] * K
         stop = threading.Event()
@@ -770,7 +777,9 @@ def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, se
                         rc = L.mkzg_compute_cells_and_kzg_proofs(ctx._h, blobs[j], 0, cells, proofs)
                         ok = rc == 0
                     else:
-                        wrong = i % 7 == 3                                     # every seventh call brings another blob's proof: must be rejected
+                        # (wrong_every = m: every m-th call brings another blob's proof and must be rejected -- a group that holds one
+                        # verifies member by member; the timed trials of bench.py run clean, a wrong proof per thread in the priming trial)
+                        wrong = (wrong_every > 0 and i % wrong_every == wrong_every - 1) or (not timed[0] and i == 1)
                         rc = L.mkzg_verify_blob_kzg_proof(ctx._h, blobs[j], cm[j], pr[(j + 1) % n] if wrong else pr[j])
                         ok = rc == (1 if wrong else 0)
                     if not ok:
@@ -783,6 +792,7 @@ def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, se
 
         rates, cpus = [], []
         for trial in range(3):                                                  # one priming trial, then two timed
+            timed[0] = trial > 0
             stop.clear()
             counts[:] = [0] * K
             ts = [threading.Thread(target=caller, args=(k,)) for k in range(K)]
@@ -800,9 +810,11 @@ def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, se
                 cpus.append(cpu / dt)
         return {"blobs_per_s": round(max(rates), 1), "blobs_per_s_each": [round(r, 1) for r in rates], "host_cpus_busy": round(max(cpus), 1), "us_per_call_per_thread": round(K / max(rates) * 1e6, 1)}
 
-    out = {"blobs_per_thread": per_thread, "seconds_per_trial": seconds}
-    for kind in ("blob_to_kzg_commitment", "compute_cells_and_kzg_proofs", "verify_blob_kzg_proof"):
+    out = {"blobs_per_thread": per_thread, "seconds_per_trial": seconds, "combine_single_calls": int(ctx.get_option("combine_single_calls") or 0)}
+    before = ctx.get_option("combined_calls") or 0
+    for kind in kinds or ("blob_to_kzg_commitment", "compute_cells_and_kzg_proofs", "verify_blob_kzg_proof"):
         out[kind] = {f"callers_{K}": run(kind, K) for K in callers}
+    out["calls_served_in_groups"] = int((ctx.get_option("combined_calls") or 0) - before)
     return out
 
 

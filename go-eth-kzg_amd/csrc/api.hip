@@ -100,15 +100,16 @@ void free_lane(Lane* L) {
     L->h_stage_bytes = 0; L->h_out_items = 0; L->h_v_bytes = 0;
     dev_free(L->d_blobs); dev_free(L->d_out); dev_free(L->d_status);
     L->d_blobs_bytes = 0; L->d_out_items = 0;
-    dev_free(L->d_v_raw); dev_free(L->d_v_aff); dev_free(L->d_v_st); dev_free(L->d_v_z); dev_free(L->d_v_y); dev_free(L->d_v_zrows); dev_free(L->d_v_s1); dev_free(L->d_v_s3); dev_free(L->d_v_ry);
-    dev_free(L->d_v_misc); dev_free(L->d_v_coeffs);
+    dev_free(L->d_v_raw); dev_free(L->d_v_aff); dev_free(L->d_v_block); dev_free(L->d_v_z); dev_free(L->d_v_y); dev_free(L->d_v_zrows); dev_free(L->d_v_s1); dev_free(L->d_v_s3);
+    L->d_v_st = nullptr; L->d_v_stx = nullptr; L->d_v_ry = nullptr; L->d_v_misc = nullptr; L->d_v_parts = nullptr;
+    dev_free(L->d_v_coeffs);
     L->v_cap = 0; L->v_coeff_cap = 0;
     dev_free(L->d_quot); dev_free(L->d_q_z); dev_free(L->d_q_y); dev_free(L->d_q_st);
     L->q_cap = 0; L->quot_cap = 0;
     dev_free(L->d_coeffs); dev_free(L->d_cells); dev_free(L->d_cell_st);
     L->cell_cap = 0;
     dev_free(L->d_cv_cells); dev_free(L->d_cv_in); dev_free(L->d_cv_rp); dev_free(L->d_cv_weights); dev_free(L->d_cv_partials);
-    dev_free(L->d_cv_interp); dev_free(L->d_cv_st);
+    dev_free(L->d_cv_interp);
     L->cv_cap = 0;
     L->cv_cells_cap = 0;
     dev_free(L->d_rec_scratch); dev_free(L->d_rec_pos);

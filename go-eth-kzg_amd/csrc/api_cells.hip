@@ -182,7 +182,6 @@ static int ensure_cv_ws(Lane* L, size_t n_cells, size_t n) {
     if (!rc) rc = dev_realloc(L->d_cv_weights, cap * 32);
     if (!rc) rc = dev_realloc_zero(L->d_cv_partials, CELL_INTERP_SCRATCH_BYTES);      // the tickets at its end
     if (!rc) rc = dev_realloc(L->d_cv_interp, 64 * 32);
-    if (!rc) rc = dev_realloc(L->d_cv_st, 3 * cap * sizeof(int));
     if (rc) return rc;
     L->cv_cap = cap;
     return MKZG_OK;
@@ -276,22 +275,35 @@ int mkzg_compute_cells_and_kzg_proofs_batch_device(mkzg_ctx* c, const void* d_bl
 static int cells_and_proofs_host(mkzg_ctx* c, size_t n, const uint8_t* const* blobs, uint8_t* const* cells_out, uint8_t* const* proofs_out, int* rcs) {
     LaneGuard G(c);
     Lane* L = G.L;
+    const size_t per_item = MKZG_BYTES_PER_BLOB + 262144 + 128 * 48 + 64;    // staged: the blob in, its cells and proofs out (pinned both ways)
     int rc = ensure_fk20_tables(c);
     if (!rc) rc = ensure_fk20_ws(L, n);
-    if (!rc) rc = ensure_staging(L, n, MKZG_BYTES_PER_BLOB + 64);
+    if (!rc) rc = ensure_staging(L, n, per_item);
     if (rc) return G.fail(rc);
-    for (size_t i = 0; i < n; i++) memcpy(L->h_stage + i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB);
+    uint8_t* h_cells = L->h_stage + n * MKZG_BYTES_PER_BLOB;
+    uint8_t* h_proofs = h_cells + n * 262144;
+    int* h_st = (int*)(h_proofs + n * 128 * 48);
+    if (n == 1) memcpy(L->h_stage, blobs[0], MKZG_BYTES_PER_BLOB);
+    else c->pool->parallel((int)n, [&](int i) { copy_to_staging(L->h_stage + (size_t)i * MKZG_BYTES_PER_BLOB, blobs[i], MKZG_BYTES_PER_BLOB); });
     HIPCHK(hipMemcpyAsync(L->d_blobs, L->h_stage, n * MKZG_BYTES_PER_BLOB, hipMemcpyHostToDevice, G.s));
     rc = cells_and_proofs_device(c, L, L->d_blobs, n, L->d_cells, L->d_fk_proofs, L->d_cell_st, G.s);
     if (rc) return G.fail(rc);
-    int* h_st = (int*)(L->h_stage + n * MKZG_BYTES_PER_BLOB);           // pinned: a copy into pageable memory polls inside the runtime
     HIPCHK(hipMemcpyAsync(h_st, L->d_cell_st, n * sizeof(int), hipMemcpyDeviceToHost, G.s));
-    for (size_t i = 0; i < n; i++) {
-        HIPCHK(hipMemcpyAsync(cells_out[i], L->d_cells + i * 262144, 262144, hipMemcpyDeviceToHost, G.s));
-        HIPCHK(hipMemcpyAsync(proofs_out[i], L->d_fk_proofs + i * 128 * 48, 128 * 48, hipMemcpyDeviceToHost, G.s));
+    if (n == 1) {                                                            // a lone call: straight into the caller's buffers, as before
+        HIPCHK(hipMemcpyAsync(cells_out[0], L->d_cells, 262144, hipMemcpyDeviceToHost, G.s));
+        HIPCHK(hipMemcpyAsync(proofs_out[0], L->d_fk_proofs, 128 * 48, hipMemcpyDeviceToHost, G.s));
+    } else {                                                                 // a group: two copies into pinned memory, then the pool hands them out
+        HIPCHK(hipMemcpyAsync(h_cells, L->d_cells, n * 262144, hipMemcpyDeviceToHost, G.s));
+        HIPCHK(hipMemcpyAsync(h_proofs, L->d_fk_proofs, n * 128 * 48, hipMemcpyDeviceToHost, G.s));
     }
     LANE_SYNC(c, G.L, G.s);
     G.L->drained = true;
+    if (n > 1)
+        c->pool->parallel((int)n, [&](int i) {
+            if (h_st[i]) return;
+            memcpy(cells_out[i], h_cells + (size_t)i * 262144, 262144);
+            memcpy(proofs_out[i], h_proofs + (size_t)i * 128 * 48, 128 * 48);
+        });
     for (size_t i = 0; i < n; i++) rcs[i] = h_st[i];
     return MKZG_OK;
 }
@@ -389,8 +401,12 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     // only, so they start as soon as the scalars are ready instead of after the longer chain.  A point outside the subgroup is still a
     // point of the curve (the group law is total there), and its verdict makes the call fail before any sum is looked at.
     hipStream_t s2 = lane_side_stream(L, s), s3 = L->side2;
-    int* sub_rows = L->d_cv_st + L->cv_cap;
-    int* sub_q = L->d_cv_st + 2 * L->cv_cap;
+    // the call's three verdict arrays (cell statuses, subgroup verdicts of the rows, of the proofs: cap ints each) sit in the aux region of
+    // the lane's verdict block (ctx.h: 8 cap words, where the blob verifier keeps its r^i y_i), behind the decoding statuses and the window
+    // sums: everything the call brings back is ONE copy of a prefix of that block
+    int* d_cv_st = (int*)L->d_v_ry;
+    int* sub_rows = d_cv_st + cap;
+    int* sub_q = d_cv_st + 2 * cap;
     lane_fork(L, s, s2, s3);
     KT(KT_DECOMPRESS, s2, g1_validate2_device(d_rows, (int)n_rows, aff_rows, st_rows, d_proofs, (int)n, aff_q, st_q, s2, 1));
     HIPCHK(hipEventRecord(L->ev_decoded, s2));
@@ -415,7 +431,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
         memcpy(r_words, r_words_in, 32);
     }
     KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, d_cidx, d_ridx, nullptr, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp, L->d_v_s1, L->d_v_s3,
-                                                       L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s, 1));
+                                                       L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, d_cv_st, s, 1));
     // uploads, part 2: the cells (n x 2 KiB, scattered host pointers) are gathered into the pinned staging area by the host pool running
     // AHEAD of this thread -- all chunks' tasks queued at once -- while the GPU validates the points; this thread waits for chunk k only
     // and puts its copy in flight
@@ -448,7 +464,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     }
     // scalars, second part: the interpolation reads the cells
     KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, d_cidx, d_ridx, d_cells ? d_cells : L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,
-                                                       L->d_v_s1, L->d_v_s3, L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, L->d_cv_st, s, 2));
+                                                       L->d_v_s1, L->d_v_s3, L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, d_cv_st, s, 2));
     HIPCHK(hipStreamWaitEvent(s, L->ev_decoded, 0));
     // MSMs (kzg_verify.go:32,41,68,80): sum r^k pi_k ; sum w_row C_row ; sum interp_i [tau^i]G1 ; sum r^k h^64 pi_k
     const uint32_t* scal[4] = {L->d_v_s1, L->d_cv_weights, L->d_cv_interp, L->d_v_s3};
@@ -456,21 +472,18 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     const int njob[4] = {(int)n, (int)n_rows, 64, (int)n};
     int vrc = 0;
     // (a quad of lanes per bucket when the launch leaves the chip mostly empty: one blob's 128 cells, not a block's 8192)
-    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 4, L->d_v_misc + V_MISC_WORDS_C, L->d_v_misc + 16, s, 2048, 1));
+    KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 4, L->d_v_parts, L->d_v_misc + 16, s, 2048, 1));
     if (vrc) return MKZG_ERR_BAD_ARGS;
     HIPCHK(hipGetLastError());
     int* h_st = (int*)L->h_v;
-    // every verdict array lands in the lane's PINNED area (behind the window sums, where the blob verifier keeps its r^i y_i words: cap x 8
-    // words for 2 n + n_rows here): a device-to-host copy into pageable memory is a blocking copy that polls inside the runtime until the
-    // stream gets there -- with twelve callers that was twelve CPUs spinning beside the pool (tools/bench_cellverify_inflight.py), whatever
-    // `host_wait` said
+    // every verdict array lands in the lane's PINNED mirror of the verdict block: a device-to-host copy into pageable memory is a
+    // blocking copy that polls inside the runtime until the stream gets there -- with twelve callers that was twelve CPUs spinning beside
+    // the pool (tools/bench_cellverify_inflight.py), whatever `host_wait` said.  One copy since round 5 (three until then).
     int* st_cells = (int*)(h_misc + V_MISC_WORDS_C + 16);
-    int* h_sub_rows = st_cells + L->cv_cap;
-    int* h_sub_q = st_cells + 2 * L->cv_cap;
+    int* h_sub_rows = st_cells + cap;
+    int* h_sub_q = st_cells + 2 * cap;
     HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));               // the subgroup verdicts
-    HIPCHK(hipMemcpyAsync(h_st, L->d_v_st, 2 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(st_cells, L->d_cv_st, (2 * L->cv_cap + n) * sizeof(int), hipMemcpyDeviceToHost, s));     // cell statuses | subgroup verdicts of the rows | of the proofs: one copy
-    HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS_C * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_st, L->d_v_block, verdict_block_bytes(cap, (3 * cap * sizeof(int) + 31) / 32), hipMemcpyDeviceToHost, s));
     LANE_SYNC(c, L, s);
     L->drained = true;
     // error precedence of api_eip7594.go:190-213: all commitments, then all proofs, then all cells

@@ -21,6 +21,8 @@
 // workspaces
 // ---------------------------------------------------------------------------------------------
 static const size_t V_MISC_WORDS = 16 + 4 * VMSM_WINDOWS * 48;
+// bytes of the verdict block up to and including `aux_items` of its aux region's 32-byte items (ctx.h Lane::d_v_block)
+size_t verdict_block_bytes(size_t cap, size_t aux_items) { return 3 * cap * sizeof(int) + (V_MISC_WORDS + 16) * 4 + aux_items * 32; }
 static const size_t HOST_PIECE = 2048;      // blobs staged at once by the host-pointer verifier (256 MiB pinned + device)
 
 int ensure_verify_ws(Lane* L, size_t n) {
@@ -29,20 +31,28 @@ int ensure_verify_ws(Lane* L, size_t n) {
     L->v_cap = 0;
     int rc = dev_realloc(L->d_v_raw, 2 * cap * 48);
     if (!rc) rc = dev_realloc(L->d_v_aff, 2 * cap * 128);
-    if (!rc) rc = dev_realloc(L->d_v_st, 4 * cap * sizeof(int));        // commitments | proofs | blobs | scratch
     if (!rc) rc = dev_realloc(L->d_v_z, cap * 48);
     if (!rc) rc = dev_realloc(L->d_v_y, cap * 48);
     if (!rc) rc = dev_realloc(L->d_v_zrows, cap * blob_eval_scratch_words() * 4);
     if (!rc) rc = dev_realloc(L->d_v_s1, cap * 32);
     if (!rc) rc = dev_realloc(L->d_v_s3, cap * 32);
-    if (!rc) rc = dev_realloc(L->d_v_ry, cap * 32);
-    // window sums for the host + slice sums (device only); k_vmsm_window keeps a ticket per (job, window) in the spare words of its slice
-    // records: zero here, reset by the kernel itself
-    if (!rc) rc = dev_realloc_zero(L->d_v_misc, (V_MISC_WORDS + VMSM_PART_WORDS) * 4);
+    if (!rc) {
+        // the verdict block (ctx.h): what comes back in one copy first, device-only scratch behind; zero-filled -- k_vmsm_window keeps a
+        // ticket per (job, window) in the spare words of its slice records and resets it itself
+        const size_t head = verdict_block_bytes(cap, cap);
+        rc = dev_realloc_zero(L->d_v_block, head + cap * sizeof(int) + VMSM_PART_WORDS * 4);
+        if (!rc) {
+            L->d_v_st = (int*)L->d_v_block;
+            L->d_v_misc = (uint32_t*)(L->d_v_block + 3 * cap * sizeof(int));
+            L->d_v_ry = L->d_v_misc + V_MISC_WORDS + 16;
+            L->d_v_stx = (int*)(L->d_v_block + head);
+            L->d_v_parts = (uint32_t*)(L->d_v_block + head + cap * sizeof(int));
+        }
+    }
     L->h_v_bytes = 0;
-    if (!rc) rc = pinned_realloc(L->h_v, 3 * cap * sizeof(int) + V_MISC_WORDS * 4 + 64 + cap * 32);      // statuses | misc | r^i y_i words (throughput shape)
+    if (!rc) rc = pinned_realloc(L->h_v, verdict_block_bytes(cap, cap));      // the same layout: statuses | misc | 64 B | aux
     if (rc) return rc;
-    L->h_v_bytes = 3 * cap * sizeof(int) + V_MISC_WORDS * 4 + 64 + cap * 32;
+    L->h_v_bytes = verdict_block_bytes(cap, cap);
     L->v_cap = cap;
     return MKZG_OK;
 }
@@ -210,10 +220,8 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
     HIPCHK(hipGetLastError());
     // 5. one round trip: statuses, e, window sums
     int* h_st = (int*)L->h_v;
-    HIPCHK(hipMemcpyAsync(h_st, L->d_v_st, 3 * cap * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, V_MISC_WORDS * 4, hipMemcpyDeviceToHost, s));
     uint32_t* h_ry = h_misc + V_MISC_WORDS + 16;
-    if (sum_ry_on_host) HIPCHK(hipMemcpyAsync(h_ry, L->d_v_ry, n * 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_st, L->d_v_block, verdict_block_bytes(cap, sum_ry_on_host ? n : 0), hipMemcpyDeviceToHost, s));      // statuses, misc (and the r^i y_i words): ONE copy
     LANE_SYNC(c, L, s);                     // polls for a lone caller, asks and sleeps when the context is crowded (ctx.h)
     L->drained = true;                      // the side streams were joined into s by the caller; nothing of this call is left on the device
     if (with_blobs) {
@@ -268,7 +276,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     int* st_c = L->d_v_st;
     int* st_q = L->d_v_st + cap;
     int* st_b = L->d_v_st + 2 * cap;
-    int* st_x = L->d_v_st + 3 * cap;        // scratch: status of a second scalar array
+    int* st_x = L->d_v_stx;                 // scratch: status of a second scalar array
     // 0. everything that needs r but not the challenges runs beside the challenge hash
     uint32_t r_words[8];                        // r travels in the kernel arguments (rwords.h), not through a 32-byte upload
     if (!late) memcpy(r_words, r_le32, 32);
@@ -283,7 +291,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         late = nullptr;
         return MKZG_OK;
     };
-    uint32_t* d_parts = L->d_v_misc + V_MISC_WORDS;
+    uint32_t* d_parts = L->d_v_parts;
     uint32_t* d_wsum = L->d_v_misc + 16;
     const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
     int vrc = 0;
@@ -511,10 +519,10 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
     int* st_c = L->d_v_st;
     int* st_q = L->d_v_st + cap;
     int* st_b = L->d_v_st + 2 * cap;
-    int* st_x = L->d_v_st + 3 * cap;
+    int* st_x = L->d_v_stx;
     uint32_t r_words[8];
     if (!late) memcpy(r_words, r_le32, 32);
-    uint32_t* d_parts = L->d_v_misc + V_MISC_WORDS;
+    uint32_t* d_parts = L->d_v_parts;
     uint32_t* d_wsum = L->d_v_misc + 16;
     const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
     uint8_t* h_z = L->h_stage + m * MKZG_BYTES_PER_BLOB;              // m x 32 B
@@ -949,7 +957,7 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         lane_fork(L, s, s2);
         g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, s2);
         HIPCHK(hipEventRecord(L->ev_join, s2));
-        if (d_z32) scalars_to_fr_device(d_z32 + done * 32, (int)slice, L->d_q_z, L->d_v_st + 3 * L->v_cap, s);
+        if (d_z32) scalars_to_fr_device(d_z32 + done * 32, (int)slice, L->d_q_z, L->d_v_stx, s);
         else KT(KT_SHA256, s, challenge_device(blobs, cms, (int)slice, L->d_q_z, s));
         for (size_t off = 0; off < slice; off += (size_t)c->opt_max_batch) {
             const size_t chunk = std::min<size_t>(slice - off, (size_t)c->opt_max_batch);
@@ -1069,7 +1077,7 @@ int mkzg_evaluate_blobs_device(mkzg_ctx* c, const void* d_blobs, const uint8_t* 
     if (rc) return G.fail(rc);
     const size_t cap = L->v_cap;
     int* st_b = L->d_v_st + 2 * cap;
-    int* st_z = L->d_v_st + 3 * cap;
+    int* st_z = L->d_v_stx;
     const uint8_t* blobs = (const uint8_t*)d_blobs;
     HIPCHK(hipMemcpyAsync(L->d_v_s3, z32n, n * 32, hipMemcpyHostToDevice, s));
     scalars_to_fr_device((const uint8_t*)L->d_v_s3, (int)n, L->d_v_z, st_z, s);
@@ -1119,7 +1127,7 @@ int mkzg_msm_g1(mkzg_ctx* c, const uint64_t* scalars_mont4, const uint64_t* poin
         const uint32_t* scal[1] = {L->d_v_s1};
         const uint32_t* pts[1] = {L->d_v_aff};
         const int nj[1] = {(int)m};
-        if (vmsm_windows_device(scal, pts, nj, 1, L->d_v_misc + V_MISC_WORDS, L->d_v_misc + 16, s, 2048, 1)) return G.fail(MKZG_ERR_BAD_ARGS);
+        if (vmsm_windows_device(scal, pts, nj, 1, L->d_v_parts, L->d_v_misc + 16, s, 2048, 1)) return G.fail(MKZG_ERR_BAD_ARGS);
         HIPCHK(hipGetLastError());
         uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * L->v_cap * sizeof(int));
         HIPCHK(hipMemcpyAsync(h_misc, L->d_v_misc, (16 + VMSM_WINDOWS * 48) * 4, hipMemcpyDeviceToHost, s));

@@ -143,14 +143,22 @@ struct Lane {
     size_t v_cap = 0;
     uint8_t* d_v_raw = nullptr;            // 2 v_cap x 48 B   (commitments | proofs)
     uint32_t* d_v_aff = nullptr;           // 2 v_cap affine rows
-    int* d_v_st = nullptr;                 // 3 v_cap ints (commitments | proofs | blobs)
+    // ONE device block for everything a verifier call brings back (round 5: three copies per call until then, each a packet in a hardware
+    // queue the call shares): [statuses 3 v_cap ints (commitments | proofs | blobs)] [misc: r, e, window sums] [16 words] [aux v_cap x 8
+    // words: the blob verifier's r^i y_i, or the cell verifier's three verdict arrays of v_cap ints each] -- the pinned mirror h_v has the
+    // same layout, so ONE copy of a prefix of the block serves both verifiers; behind it, device only: a scratch status array and the
+    // slice sums of the MSMs (with the tickets of k_vmsm_window: zero when allocated)
+    uint8_t* d_v_block = nullptr;
+    int* d_v_st = nullptr;                 // -> block
+    int* d_v_stx = nullptr;                // -> block: v_cap ints of scratch (status of a second scalar array)
+    uint32_t* d_v_parts = nullptr;         // -> block: VMSM_PART_WORDS
     uint32_t* d_v_z = nullptr;             // v_cap Fr rows
     uint32_t* d_v_y = nullptr;
     uint32_t* d_v_zrows = nullptr;          // v_cap x 12 rows of 12 words: z^(2^L), L = 0..11 -- what the evaluation needs of z alone (the hash launch or k_blob_eval_prep writes them)
     uint32_t* d_v_s1 = nullptr;            // v_cap x 8 words
     uint32_t* d_v_s3 = nullptr;
-    uint32_t* d_v_ry = nullptr;            // v_cap x 8 words: r^i y_i per blob (throughput shape: the evaluation kernel writes them, the host adds them up)
-    uint32_t* d_v_misc = nullptr;          // [0..8) r, [8..16) e, [16 .. 16+4*32*48) window sums, then the slice sums of the MSMs
+    uint32_t* d_v_ry = nullptr;            // -> block (aux): v_cap x 8 words: r^i y_i per blob (throughput shape: the evaluation kernel writes them, the host adds them up)
+    uint32_t* d_v_misc = nullptr;          // -> block: [0..8) r, [8..16) e, [16 .. 16+4*32*48) window sums
     uint8_t* h_v = nullptr;                // pinned: statuses + misc
     size_t h_v_bytes = 0;
     uint32_t* d_v_coeffs = nullptr;        // coefficient rows of the blobs (v_coeff_cap x 4096 x 12 words)
@@ -174,7 +182,6 @@ struct Lane {
     uint32_t* d_cv_weights = nullptr;      // cv_cap x 8 words
     uint32_t* d_cv_partials = nullptr;     // CELL_INTERP_BLOCKS x 64 Fr rows
     uint32_t* d_cv_interp = nullptr;       // 64 x 8 words
-    int* d_cv_st = nullptr;                // 3 x cv_cap: cell statuses, subgroup verdicts of the commitment rows, of the proofs
     size_t rec_cap = 0;                    // blobs the recovery scratch / position arrays hold
     uint32_t* d_rec_scratch = nullptr;
     int* d_rec_pos = nullptr;              // per blob 128 positions + 64 missing ids, then one count per blob
@@ -361,6 +368,7 @@ int ensure_rec_tables(mkzg_ctx* c);
 // ---- per-lane workspaces
 int ensure_staging(Lane* L, size_t n_items, size_t in_bytes_per_item);
 int ensure_verify_ws(Lane* L, size_t n);
+size_t verdict_block_bytes(size_t cap, size_t aux_items);      // api_verify.hip: bytes of Lane::d_v_block that come back in one copy
 int ensure_quot_ws(Lane* L, size_t n, size_t n_quot);
 int ensure_cells_ws(Lane* L, size_t n);
 int ensure_fk20_ws(Lane* L, size_t n);

@@ -145,7 +145,16 @@ __device__ __noinline__ void f_mul_glv(G1X& r, const G1X& p, const uint32_t* kk)
 // FK20_TOOM_WNAF), so control flow is uniform, an addition happens only at the ~1/6 of the bit positions with a non-zero digit
 // (43 additions on average against 52 with per-lane fixed windows) and the table holds the 8 odd multiples instead of 16.
 // Same Jacobian accumulator and cached-Z table entries as f_mul_glv.
+#ifndef MKZG_FK20_COZ
+#define MKZG_FK20_COZ 1                           // round 5: co-Z table + mixed incomplete additions (g1.hpp mul_wnaf_coz); 0 builds the form below
+#endif
 __device__ __noinline__ void f_mul_wnaf(G1X& r, const G1X& p, const uint32_t* __restrict__ row) {
+#if MKZG_FK20_COZ
+    fp_t beta_c;
+    Fp::set(beta_c, FP_BETA);
+    G1D::mul_wnaf_coz(r, p, row, beta_c);
+    return;
+#endif
     G1JC tbl[8];                                  // (2j + 1) p
     {
         G1J run, two;

@@ -656,6 +656,151 @@ struct G1T {
         F::template neg<3>(c, Q.y);
         return ok && F::eq_mod(l, c);
     }
+    // ------------------------------------------------------------------------------------------
+    // [k]P for a wavefront-uniform k given as the width-5 NAF strings of its GLV halves (fk20_toom.h FK20_TOOM_WNAF: digit codes d1 |
+    // d2 << 8 per bit position, two positions per word; k P = k1 P + k2 (-phi(P)), phi(x, y) = (beta x, y)) -- the FK20 transform
+    // stage's 686 fixed-scalar products, round 5 form:
+    //   * the eight odd multiples P, 3P, ..., 15P by CO-Z arithmetic (Meloni): one doubling that leaves P with 2P's Z, then seven
+    //     additions R = D + T_j of two points with the SAME Z (5M + 2S, no Z^2 / Z^3 of either operand) that also re-express D = 2P
+    //     with R's Z.  Z_{j+1} = Z_j (X_D - X_Tj), so T_j is brought to the last Z by the suffix products of those seven factors;
+    //   * all eight then share one Z: on the isomorphic curve E_Z (see in_subgroup_yfree_lean) they are AFFINE, the 43 additions of
+    //     the chain are mixed additions (10 products instead of 16 with a cached-Z Jacobian operand, two coordinates per table entry
+    //     instead of five: 896 B of scratch per lane instead of 2240), and the result's Z is multiplied by the common Z at the end;
+    //   * the additions are incomplete.  P has order r or is the identity (every input of this stage is a sum of SRS multiples), the
+    //     scalars are 686 constants, and gen_fk20_toom.py walks every chain modulo r and asserts that no addition meets acc = +-operand
+    //     or acc = identity after the first one; the identity as INPUT makes every Z product exactly zero, which is the identity out.
+    // Cost 90 + 131 x 7 + 43 x 10.5 ~ 1460 field multiplications against 1740.
+    // ------------------------------------------------------------------------------------------
+    static KZ_HD void jmadd_inc(Jac& r, const Jac& a_, const fe& x2, const fe& y2) {   // r = a + (x2, y2); as jmadd_incomplete, operands in registers
+        Jac a = a_;
+        opaque(a);
+        fe Z1Z1, U2, H, t, S2, Rd, Z3, HH, HHH, V, X3, Y3;
+        F::sqr(Z1Z1, a.z);
+        F::mul(U2, x2, Z1Z1);
+        F::template sub<5>(H, U2, a.x);
+        F::mul(t, a.z, Z1Z1);
+        F::mul(S2, y2, t);
+        F::template sub<3>(Rd, S2, a.y);
+        F::mul(Z3, a.z, H);
+        F::sqr(HH, H);
+        F::mul(HHH, H, HH);
+        F::mul(V, a.x, HH);
+        F::sqr(X3, Rd);
+        F::template sub_b_2c<2>(X3, X3, HHH, V);
+        F::template sub<3>(t, V, X3);
+        F::template neg<3>(S2, a.y);
+        F::mul2(Y3, Rd, t, S2, HHH);
+        r.x = X3;
+        r.y = Y3;
+        r.z = Z3;
+    }
+    static KZ_HD void mul_wnaf_coz(XYZZ& r, const XYZZ& p_, const uint32_t* row, const fe& beta) {
+        fe tx[8], ty[8], lam[7], zc;
+        {
+            XYZZ p = p_;
+            opaque(p);
+            fe X, Y, Z, A, B2, C4, t, D, E, dx, dy, Dx, Dy;
+            F::mul(X, p.x, p.zz);                       // Jacobian (X ZZ, Y ZZZ, ZZ)
+            F::mul(Y, p.y, p.zzz);
+            Z = p.zz;
+            // DBLU: (Dx, Dy) = 2P and P re-expressed with its Z (jdbl's values: 4 X Y^2 and 8 Y^4)
+            F::sqr(A, X);
+            F::sqr(B2, Y);
+            F::dbl(B2, B2);
+            F::sqr(C4, B2);
+            F::add(t, X, B2);
+            F::sqr(t, t);
+            F::template sub_b_c<2>(D, t, A, C4);        // 4 X Y^2  (< 5.01p)
+            F::triple(E, A);
+            F::sqr(Dx, E);
+            F::template sub_2c<4>(Dx, Dx, D);           // < 17.01p
+            F::template sub<5>(t, D, Dx);
+            F::mul(Dy, E, t);
+            F::template sub_2c<2>(Dy, Dy, C4);          // < 5.01p
+            F::dbl(t, Y);
+            F::mul(zc, t, Z);                           // Z of both
+            tx[0] = D;
+            F::dbl(ty[0], C4);                          // 8 Y^4   (< 2.02p)
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+            for (int j = 0; j < 7; j++) {               // ZADDU: T_{j+1} = D + T_j, D re-expressed with the new Z
+                fe X2 = tx[j], Y2 = ty[j], Cq, W1, W2, A1, Dq, X3, Y3;
+                F::opaque(Dx);
+                F::opaque(Dy);
+                F::opaque(X2);
+                F::opaque(Y2);
+                F::opaque(zc);
+                F::template sub<3>(dx, Dx, X2);          // X2 < 5.01p <= 8p
+                F::template sub<2>(dy, Dy, Y2);          // Y2 < 3.01p <= 4p
+                F::sqr(Cq, dx);
+                F::mul(W1, Dx, Cq);
+                F::mul(W2, X2, Cq);
+                F::sqr(Dq, dy);
+                F::template sub<1>(t, W1, W2);
+                F::mul(A1, Dy, t);
+                F::template sub_b_c<2>(X3, Dq, W1, W2);  // < 5.01p
+                F::template sub<3>(t, W1, X3);
+                F::mul(Y3, dy, t);
+                F::template sub<1>(Y3, Y3, A1);          // < 3.01p
+                F::mul(zc, zc, dx);
+                lam[j] = dx;
+                tx[j + 1] = X3;
+                ty[j + 1] = Y3;
+                Dx = W1;
+                Dy = A1;
+            }
+            // every T_j to the last Z: times (prod_{i >= j} lam_i)^2 and ^3
+            fe f = lam[6], f2, f3;
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+            for (int j = 6; j >= 0; j--) {
+                F::opaque(f);
+                if (j < 6) F::mul(f, f, lam[j]);
+                F::sqr(f2, f);
+                F::mul(f3, f2, f);
+                F::mul(tx[j], tx[j], f2);
+                F::mul(ty[j], ty[j], f3);
+            }
+        }
+        Jac acc;
+        F::set_zero(acc.x);
+        F::set_zero(acc.y);
+        F::set_zero(acc.z);
+        bool started = false;
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+        for (int i = 130; i >= 0; i--) {
+            if (started) jdbl(acc, acc);
+            const uint32_t code = (row[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            if (code == 0) continue;
+#ifdef __HIP_DEVICE_COMPILE__
+#pragma unroll 1
+#endif
+            for (int half = 0; half < 2; half++) {
+                const int d = (int)(int8_t)(half ? code >> 8 : code & 0xffu);
+                if (d) {
+                    const int e = ((d < 0 ? -d : d) - 1) >> 1;
+                    fe qx = tx[e], qy = ty[e];
+                    // second half: -phi(.) = (beta X, -Y); a negative digit flips the sign once more
+                    if (half) F::mul(qx, qx, beta);
+                    if ((d < 0) != (half != 0)) F::template neg<2>(qy, qy);      // 4p - y  (y < 3.01p: the last entry is not rescaled)
+                    if (started) {
+                        jmadd_inc(acc, acc, qx, qy);
+                    } else {
+                        acc.x = qx;
+                        acc.y = qy;
+                        F::set_one(acc.z);
+                        started = true;
+                    }
+                }
+            }
+        }
+        F::mul(acc.z, acc.z, zc);                       // back from E_Z: (X', Y', Z' Z)
+        jac_to_xyzz(r, acc);
+    }
     struct MemberStash {   // the stash as plain members: host tests, and device callers that can afford the registers
         fe s[4];
         KZ_HD void put(int i, const fe& v) { s[i] = v; }

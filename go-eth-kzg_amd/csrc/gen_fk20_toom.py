@@ -128,9 +128,30 @@ def wnaf5(k):
     return ds
 
 
+def check_incomplete_chain(k, d1, d2):
+    """g1.hpp mul_wnaf_coz adds with INCOMPLETE formulas: for a point P of order r the chain acc = 2 acc; acc += d1 P; acc += d2 [x^2] P
+    must never add an operand equal to +-acc, nor add to the identity after the first addition.  k is a constant, so this is decided
+    here, once, for every one of the 686 chains (acc = [m] P with m known modulo r)."""
+    m, started = 0, False
+    for i in range(max(len(d1), len(d2)) - 1, -1, -1):
+        if started:
+            m = 2 * m % R
+        for d, unit in ((d1[i] if i < len(d1) else 0, 1), (d2[i] if i < len(d2) else 0, X2)):
+            if d == 0:
+                continue
+            t = d * unit % R
+            if started:
+                assert m % R != 0 and m != t and m != (R - t) % R, ("exceptional addition in the chain of", hex(k), i)
+                m = (m + t) % R
+            else:
+                m, started = t, True
+    assert m == k % R
+
+
 def wnaf_row(k):
     d1, d2 = wnaf5(k % X2), wnaf5(k // X2)
     assert k // X2 < (1 << 128) and len(d1) <= 131 and len(d2) <= 131
+    check_incomplete_chain(k, d1, d2)
     d1 += [0] * (132 - len(d1))
     d2 += [0] * (132 - len(d2))
     codes = [(a & 0xFF) | ((b & 0xFF) << 8) for a, b in zip(d1, d2)]

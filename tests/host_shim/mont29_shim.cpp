@@ -39,6 +39,10 @@ void shim_g1_add(const uint32_t* a, const uint32_t* b, uint32_t* o) { G1X x, y, 
 // the same through the accessor form (g1.hpp add_from: the second operand fetched coordinate by coordinate, as k_vmsm_window reads its LDS snapshot)
 struct XyzzRef { const G1X* p; void get(fp_t& v, int c) const { v = c == 0 ? p->x : c == 1 ? p->y : c == 2 ? p->zz : p->zzz; } };
 void shim_g1_add_from(const uint32_t* a, const uint32_t* b, uint32_t* o) { G1X x, y; memcpy(&x, a, 224); memcpy(&y, b, 224); XyzzRef r{&y}; G1D::add_from(x, r); memcpy(o, &x, 224); }
+// [k]P by the co-Z table / mixed-addition chain of the FK20 transform stage (g1.hpp mul_wnaf_coz); row: 66 words of digit codes
+void shim_g1_mul_wnaf_coz(const uint32_t* a, const uint32_t* row66, uint32_t* o) {
+    G1X x, r; memcpy(&x, a, 224); fp_t beta; Fp::set(beta, FP_BETA); G1D::mul_wnaf_coz(r, x, row66, beta); memcpy(o, &r, 224);
+}
 void shim_g1_dbl(const uint32_t* a, uint32_t* o) { G1X x, r; memcpy(&x, a, 224); g1x_dbl(r, x); memcpy(o, &r, 224); }
 void shim_g1_set_inf(uint32_t* o) { G1X r; g1x_set_inf(r); memcpy(o, &r, 224); }
 // Jacobian accumulators: 3 x 14 limbs (x, y, z)

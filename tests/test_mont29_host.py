@@ -420,6 +420,60 @@ def test_g1_subgroup_tests(shim):
     assert shim.shim_g1_in_subgroup(*aff(mixed)) == 0
 
 
+def test_g1_fixed_scalar_products_by_coz_table(shim):
+    """g1.hpp mul_wnaf_coz (the FK20 transform stage's 686 fixed-scalar products): co-Z table of the odd multiples, mixed additions on
+    the isomorphic curve, incomplete by design -- against big-integer scalar multiplication for random scalars in the generator's digit
+    format (gen_fk20_toom.py wnaf_row: k = k1 + k2 x^2, k P = k1 P + k2 (-phi(P))), for affine and non-trivially scaled inputs, the
+    identity, and with the accumulator bounds checked at the output"""
+    X2 = 0xD201000000010000 ** 2
+    G = (G1X, G1Y)
+    rng = random.Random(77)
+
+    def wnaf5(k):
+        ds = []
+        while k:
+            if k & 1:
+                d = k & 31
+                if d >= 16:
+                    d -= 32
+                k -= d
+            else:
+                d = 0
+            ds.append(d)
+            k >>= 1
+        return ds
+
+    def row(k):
+        d1, d2 = wnaf5(k % X2), wnaf5(k // X2)
+        assert len(d1) <= 131 and len(d2) <= 131
+        d1 += [0] * (132 - len(d1))
+        d2 += [0] * (132 - len(d2))
+        codes = [(a & 0xFF) | ((b & 0xFF) << 8) for a, b in zip(d1, d2)]
+        return (C.c_uint32 * 66)(*[codes[2 * i] | codes[2 * i + 1] << 16 for i in range(66)])
+
+    o = (C.c_uint32 * 56)()
+    for trial in range(12):
+        pt = ec_mul(rng.randrange(1, R), G)
+        a = xyzz_from_affine(pt)
+        if trial % 2:                                    # a non-trivial ZZ / ZZZ on the input: p0 + p1 through the mixed addition
+            other = ec_mul(rng.randrange(1, R), G)
+            shim.shim_g1_madd(a, limbs(other[0] * RP % P), limbs(other[1] * RP % P))
+            pt = ec_add(pt, other)
+        k = rng.randrange(1, R) if trial else 1
+        if trial == 3:
+            k = R - 1
+        if trial == 5:
+            k = X2                                       # k1 = 0: the chain starts in the second half
+        shim.shim_g1_mul_wnaf_coz(a, row(k), o)
+        assert shim_compress(shim, o) == compress(ec_mul(k % R, pt)), (trial, k)
+        v = [sum(int(o[14 * q + i]) << (29 * i) for i in range(14)) for q in range(4)]
+        assert v[0] < 8 * P and v[1] < 4 * P and v[2] < 1.01 * P and v[3] < 1.01 * P
+    inf = (C.c_uint32 * 56)()
+    shim.shim_g1_set_inf(inf)
+    shim.shim_g1_mul_wnaf_coz(inf, row(rng.randrange(1, R)), o)
+    assert shim_compress(shim, o) == compress(None)
+
+
 def test_g1_matches_oracle(shim):
     """cross-check with the CPU oracle on k*G"""
     import oracle

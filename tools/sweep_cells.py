@@ -17,6 +17,8 @@ def main():
     ctx = kzg.Context(device=0)
     if os.environ.get("FK20_BITS"):
         assert ctx.set_option("fk20_bits", int(os.environ["FK20_BITS"])) == 0
+    if os.environ.get("FK20_SEGMENTS") is not None:
+        assert ctx.set_option("fk20_segments", int(os.environ["FK20_SEGMENTS"])) == 0
     NB = int(os.environ.get("SWEEP_NB", "128"))
     if os.environ.get("CELLS_CHUNK"):
         assert ctx.set_option("cells_chunk", int(os.environ["CELLS_CHUNK"])) == 0

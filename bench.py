@@ -530,8 +530,9 @@ def hw_limits(props):
 KIND_KERNELS = {
     "k_fk20_ffts": {"k_fk20_pre": 3, "k_fk20_toom_mul": 1, "k_fk20_post": 3, "k_fk20_finish": 1},
     "k_fk20_msm": {"k_fk20_msm": 1, "k_fk20_msm_reduce": 1},
-    "k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_combine": 1},
-    "k_cell_verify_scalars": {"k_cell_rpowers": 1, "k_cell_weights": 1, "k_cell_interp": 1, "k_cell_interp_reduce": 1},
+    "k_vmsm_window": {"k_vmsm_window": 1},                                           # combines its slices itself since round 5 (k_vmsm_combine: the quad path only)
+    "k_cell_verify_scalars": {"k_cell_rpowers": 1, "k_cell_interp": 1},              # weights ride in k_cell_rpowers, the final sum in k_cell_interp (round 5)
+    "k_g1_decompress": {"k_g1_validate": 1},                                         # the cell verifier's decoding launch (mode 1)
     "k_recover_*": {"k_recover_vanishing": 1, "k_recover_stage_a": 1, "k_recover_stage_b1": 1, "k_recover_stage_c": 1, "k_recover_stage_d": 1},
 }
 
@@ -580,8 +581,10 @@ def leg_roofline(kern_ms, algo_bytes, hw, pmc_valid_for_size=True, leg="verify",
 
 # the kernels of ONE VerifyBlobKZGProofBatch call in the throughput shape (api_verify.hip): profile kind -> kernels x launches
 # (the evaluation's z-only rows ride in the hash launch and the scalars of the linear combination in the evaluation kernel's tail)
-TP_KINDS = {"k_g1_validate": {"k_g1_validate": 1}, "k_challenge_sha256": {"k_challenge_sha256_jobs": 1}, "k_blob_eval_tree": {"k_blob_eval_tree": 1},
-            "k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_combine": 1}}
+TP_KINDS = {"k_g1_validate": {"k_g1_validate_lean": 1}, "k_challenge_sha256": {"k_challenge_sha256_jobs": 1}, "k_blob_eval_tree": {"k_blob_eval_tree": 1},
+            "k_vmsm_window": {"k_vmsm_window": 1}}
+# the cell verifier's kinds (EIP-7594 leg): the r-torsion test of 8192 proofs is the register-lean one-lane form
+CELL_KINDS = dict(KIND_KERNELS, k_g1_validate={"k_g1_validate_lean": 1})
 
 
 def sustained_roofline(kinds, leg, algo_bytes_per_call, calls_per_s, hw, pmc_valid_for_size=True):
@@ -652,8 +655,8 @@ def source_hash(files):
 
 
 PMC_SOURCES = {"commit": ["msm_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "modinv30.hpp"],
-               "verify": ["verify_kernels.hip", "cells_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp"],
-               "eip7594": ["fk20_kernels.hip", "recover_kernels.hip", "cells_kernels.hip", "verify_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp"]}
+               "verify": ["verify_kernels.hip", "cells_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp", "pub_ticket.hpp"],
+               "eip7594": ["fk20_kernels.hip", "recover_kernels.hip", "cells_kernels.hip", "verify_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp", "pub_ticket.hpp"]}
 
 
 def pmc_profile(kernel, leg="commit"):
@@ -1044,7 +1047,7 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
     algo = (131072 + 48 + 48) * N          # bytes read per blob
     # the latency shape brackets two launches under k_vmsm_window (two jobs beside the hash, the late one on quads of lanes)
     tp_forced = args.verify_shape == 1
-    kinds = TP_KINDS if tp_forced else (None if dist_on else {"k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_window_quad": 1, "k_vmsm_combine": 2}})
+    kinds = TP_KINDS if tp_forced else (None if dist_on else {"k_vmsm_window": {"k_vmsm_window": 1, "k_vmsm_window_quad": 1, "k_vmsm_combine": 1}})
     roof, valu = leg_roofline(kern, algo, hw, pmc_valid_for_size=(N == 1024), leg="verify_tp" if tp_forced else "verify", kinds=kinds)
     out = {"metric": "blobs/sec VerifyBlobKZGProofBatch", "batch_per_gpu": N, "unit": "blobs/s",
            "single_call": {"blobs_per_s": round(N * world / dt * args.verify_steps, 2), "ms_per_call": round(ms, 3), "host_finish_ms": round(host_us / args.verify_steps / 1e3, 3), "ms_each_call": each,
@@ -1412,7 +1415,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
     dt_mean = maxed((time.perf_counter() - t0) / n_calls)
     prof = ctx.profile_read(reset=True)
     kern = {k: round(v[0] / n_calls, 3) for k, v in prof.items() if v[1]}
-    roof, valu = leg_roofline(kern, 2152 * n, hw, pmc_valid_for_size=full_size, leg="eip7594")
+    roof, valu = leg_roofline(kern, 2152 * n, hw, pmc_valid_for_size=full_size, leg="eip7594", kinds=CELL_KINDS)
     srt = sorted(each)
     med = srt[len(srt) // 2]
     dt = dt_mean if dist_on else med * 1e-3                    # several ranks: the slowest rank's mean between barriers; one rank: the median call
@@ -1515,7 +1518,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
         dts.sort()
         dtk = dts[len(dts) // 2]
         assert not errs, errs[0]
-        vkinds = {kind: KIND_KERNELS.get(kind, {kind: 1}) for kind in kern}
+        vkinds = {kind: CELL_KINDS.get(kind, {kind: 1}) for kind in kern}
         sroof, svalu = sustained_roofline(vkinds, "eip7594", 2152 * n, KV * (reps + 1) / dtk, hw, pmc_valid_for_size=full_size)
         out["verify_cell_kzg_proof_batch"]["sustained"] = {"callers": KV, "calls": KV * (reps + 1), "cells_per_s": round(KV * (reps + 1) * n / dtk, 1),
                                                            "cells_per_s_each_trial": [round(KV * (reps + 1) * n / d, 1) for d in dts],

@@ -619,27 +619,35 @@ __global__ void __launch_bounds__(64) k_fk20_toom_mul(const uint32_t* __restrict
 // doubling and additions -- the K x units pieces go out as launches of at most 1024 single-wavefront workgroups (one per SIMD),
 // segment-major: piece (unit, s) lies units >= 1024 places after (unit, s - 1), hence in a later launch, and the launch boundary is
 // the only synchronisation.  The accumulator and the table of a unit live in global memory between launches (fk20_seg_bytes).
-constexpr int FK_SEG_ENTRY_Q = 18;                        // uint4 per table entry and lane (70 words)
+constexpr int FK_SEG_ENTRY_Q = 7;                         // uint4 per table entry and lane: an affine point of the co-Z table (28 words)
+constexpr int FK_SEG_ZC_Q = 4;                            // the table's common Z (14 words)
 constexpr int FK_SEG_ACC_Q = 11;                          // uint4 per accumulator and lane (42 words)
-constexpr int FK_SEG_UNIT_Q = 8 * FK_SEG_ENTRY_Q + FK_SEG_ACC_Q;
+constexpr int FK_SEG_UNIT_Q = 8 * FK_SEG_ENTRY_Q + FK_SEG_ZC_Q + FK_SEG_ACC_Q;
 size_t fk20_seg_bytes(int n) { return (size_t)686 * ((n + 63) / 64) * FK_SEG_UNIT_Q * 64 * sizeof(uint4); }
-__device__ __forceinline__ void seg_store_jc(uint4* unit, int entry, int lane, const G1JC& e) {
-    uint32_t w[72];
+template <int NQ, int NF>
+__device__ __forceinline__ void seg_store_fes(uint4* base, int lane, const fp_t* const* f) {      // NF field elements as NQ uint4, stride 64 lanes
+    uint32_t w[4 * NQ];
 #pragma unroll
-    for (int i = 0; i < 14; i++) { w[i] = e.x.l[i]; w[14 + i] = e.y.l[i]; w[28 + i] = e.z.l[i]; w[42 + i] = e.zz.l[i]; w[56 + i] = e.zzz.l[i]; }
-    w[70] = 0; w[71] = 0;
+    for (int k = 0; k < NF; k++)
 #pragma unroll
-    for (int q = 0; q < FK_SEG_ENTRY_Q; q++) unit[(size_t)(entry * FK_SEG_ENTRY_Q + q) * 64 + lane] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+        for (int i = 0; i < 14; i++) w[14 * k + i] = f[k]->l[i];
+#pragma unroll
+    for (int i = 14 * NF; i < 4 * NQ; i++) w[i] = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) base[(size_t)q * 64 + lane] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
-__device__ __forceinline__ void seg_load_jc(G1JC& e, const uint4* unit, int entry, int lane) {
-    uint32_t w[72];
+template <int NQ, int NF>
+__device__ __forceinline__ void seg_load_fes(fp_t* const* f, const uint4* base, int lane) {
+    uint32_t w[4 * NQ];
 #pragma unroll
-    for (int q = 0; q < FK_SEG_ENTRY_Q; q++) {
-        const uint4 v = unit[(size_t)(entry * FK_SEG_ENTRY_Q + q) * 64 + lane];
+    for (int q = 0; q < NQ; q++) {
+        const uint4 v = base[(size_t)q * 64 + lane];
         w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
     }
 #pragma unroll
-    for (int i = 0; i < 14; i++) { e.x.l[i] = w[i]; e.y.l[i] = w[14 + i]; e.z.l[i] = w[28 + i]; e.zz.l[i] = w[42 + i]; e.zzz.l[i] = w[56 + i]; }
+    for (int k = 0; k < NF; k++)
+#pragma unroll
+        for (int i = 0; i < 14; i++) f[k]->l[i] = w[14 * k + i];
 }
 __device__ __forceinline__ void seg_store_acc(uint4* unit, int lane, const G1J& a) {
     uint32_t w[44];
@@ -647,20 +655,21 @@ __device__ __forceinline__ void seg_store_acc(uint4* unit, int lane, const G1J& 
     for (int i = 0; i < 14; i++) { w[i] = a.x.l[i]; w[14 + i] = a.y.l[i]; w[28 + i] = a.z.l[i]; }
     w[42] = 0; w[43] = 0;
 #pragma unroll
-    for (int q = 0; q < FK_SEG_ACC_Q; q++) unit[(size_t)(8 * FK_SEG_ENTRY_Q + q) * 64 + lane] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    for (int q = 0; q < FK_SEG_ACC_Q; q++) unit[(size_t)(8 * FK_SEG_ENTRY_Q + FK_SEG_ZC_Q + q) * 64 + lane] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 __device__ __forceinline__ void seg_load_acc(G1J& a, const uint4* unit, int lane) {
     uint32_t w[44];
 #pragma unroll
     for (int q = 0; q < FK_SEG_ACC_Q; q++) {
-        const uint4 v = unit[(size_t)(8 * FK_SEG_ENTRY_Q + q) * 64 + lane];
+        const uint4 v = unit[(size_t)(8 * FK_SEG_ENTRY_Q + FK_SEG_ZC_Q + q) * 64 + lane];
         w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
     }
 #pragma unroll
     for (int i = 0; i < 14; i++) { a.x.l[i] = w[i]; a.y.l[i] = w[14 + i]; a.z.l[i] = w[28 + i]; }
 }
-// costs in field multiplications: a doubling 7, an addition 16, the table (one doubling, seven additions, eight caches) 135
-constexpr int FK_SEG_COST_DBL = 7, FK_SEG_COST_ADD = 16, FK_SEG_COST_TABLE = 135;
+// costs in field multiplications (round 5, the co-Z form of g1.hpp mul_wnaf_coz): a doubling 7, a mixed addition 10, the table (one doubling, seven co-Z
+// additions, seven rescalings) 90
+constexpr int FK_SEG_COST_DBL = 7, FK_SEG_COST_ADD = 10, FK_SEG_COST_TABLE = 90;
 __global__ void __launch_bounds__(64) k_fk20_toom_seg(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const int* __restrict__ status, int n, int units, int K,
                                                        int base, uint4* __restrict__ seg) {
     const int idx = base + (int)blockIdx.x;
@@ -689,20 +698,18 @@ __global__ void __launch_bounds__(64) k_fk20_toom_seg(const uint32_t* __restrict
     if (sg == 0) {
         G1X p;
         f_load_xyzz(p, in + prow);
-        G1J run, two;
-        G1JC c, twoc;
-        G1D::jac_from_xyzz(run, p);
-        G1D::jac_cache(c, run);
-        seg_store_jc(unit, 0, lane, c);
-        G1D::jdbl(two, run);
-        G1D::jac_cache(twoc, two);
+        fp_t tx[8], ty[8], zc;
+        G1D::coz_odd_multiples(tx, ty, zc, p);
 #pragma unroll 1
-        for (int j = 1; j < 8; j++) {
-            G1D::jadd(run, run, twoc);
-            G1D::jac_cache(c, run);
-            seg_store_jc(unit, j, lane, c);
+        for (int j = 0; j < 8; j++) {
+            const fp_t* e[2] = {&tx[j], &ty[j]};
+            seg_store_fes<FK_SEG_ENTRY_Q, 2>(unit + (size_t)j * FK_SEG_ENTRY_Q * 64, lane, e);
         }
-        G1D::set_inf(acc);
+        const fp_t* z[1] = {&zc};
+        seg_store_fes<FK_SEG_ZC_Q, 1>(unit + (size_t)8 * FK_SEG_ENTRY_Q * 64, lane, z);
+        Fp::set_zero(acc.x);
+        Fp::set_zero(acc.y);
+        Fp::set_zero(acc.z);
     } else {
         seg_load_acc(acc, unit, lane);
     }
@@ -726,20 +733,32 @@ __global__ void __launch_bounds__(64) k_fk20_toom_seg(const uint32_t* __restrict
             const int d = (int)(int8_t)(half ? code >> 8 : code & 0xffu);
             if (d) {
                 cum += FK_SEG_COST_ADD;
+                const bool was_started = started;
                 started = true;
                 if (mine == 0) {
-                    G1JC q;
-                    seg_load_jc(q, unit, ((d < 0 ? -d : d) - 1) >> 1, lane);
+                    fp_t qx, qy;
+                    fp_t* e[2] = {&qx, &qy};
+                    seg_load_fes<FK_SEG_ENTRY_Q, 2>(e, unit + (size_t)(((d < 0 ? -d : d) - 1) >> 1) * FK_SEG_ENTRY_Q * 64, lane);
                     // second half: -phi(.) = (beta X, -Y); a negative digit flips the sign once more
-                    if (half) Fp::mul(q.x, q.x, beta);
-                    if ((d < 0) != (half != 0)) Fp::template neg<3>(q.y, q.y);   // 8p - Y (Y < 5.01p)
-                    G1D::jadd(acc, acc, q);
+                    if (half) Fp::mul(qx, qx, beta);
+                    if ((d < 0) != (half != 0)) Fp::template neg<2>(qy, qy);     // 4p - y (y < 3.01p)
+                    if (was_started) {
+                        G1D::jmadd_inc(acc, acc, qx, qy);
+                    } else {                                                      // the chain's first addition: the operand itself
+                        acc.x = qx;
+                        acc.y = qy;
+                        Fp::set_one(acc.z);
+                    }
                 }
             }
         }
     }
     if (sg == K - 1) {
         G1X r;
+        fp_t zc;
+        fp_t* z[1] = {&zc};
+        seg_load_fes<FK_SEG_ZC_Q, 1>(z, unit + (size_t)8 * FK_SEG_ENTRY_Q * 64, lane);
+        Fp::mul(acc.z, acc.z, zc);                                                // back from the table's isomorphic curve: (X', Y', Z' Z)
         G1D::jac_to_xyzz(r, acc);
         if (live) f_store_xyzz(out + prow, r);
     } else {

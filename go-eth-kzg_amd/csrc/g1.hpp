@@ -694,8 +694,9 @@ struct G1T {
         r.y = Y3;
         r.z = Z3;
     }
-    static KZ_HD void mul_wnaf_coz(XYZZ& r, const XYZZ& p_, const uint32_t* row, const fe& beta) {
-        fe tx[8], ty[8], lam[7], zc;
+    // the table of mul_wnaf_coz: (tx[j], ty[j]) = (2j + 1) P as affine points of E_zc (every entry with the Jacobian Z = zc)
+    static KZ_HD void coz_odd_multiples(fe tx[8], fe ty[8], fe& zc, const XYZZ& p_) {
+        fe lam[7];
         {
             XYZZ p = p_;
             opaque(p);
@@ -764,6 +765,10 @@ struct G1T {
                 F::mul(ty[j], ty[j], f3);
             }
         }
+    }
+    static KZ_HD void mul_wnaf_coz(XYZZ& r, const XYZZ& p, const uint32_t* row, const fe& beta) {
+        fe tx[8], ty[8], zc;
+        coz_odd_multiples(tx, ty, zc, p);
         Jac acc;
         F::set_zero(acc.x);
         F::set_zero(acc.y);

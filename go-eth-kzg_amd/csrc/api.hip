@@ -564,8 +564,8 @@ static void ctx_destroy_one(mkzg_ctx* c) {
     dev_free(c->d_tw_fwd); dev_free(c->d_tw_inv); dev_free(c->d_g1tw_fwd); dev_free(c->d_g1tw_inv);
     dev_free(c->d_monomial_aff); dev_free(c->d_pow7); dev_free(c->d_ipow7); dev_free(c->d_fk_t_aff); dev_free(c->d_fk_table);
     c->hash_forming.reset();
-    c->hash_prev.reset();
-    c->hash_prev2.reset();
+    for (auto& h : c->hash_hist) h.reset();
+    for (int i = 0; i < mkzg_ctx::NLANE; i++) if (c->lanes[i].tp_exec) { (void)hipGraphExecDestroy(c->lanes[i].tp_exec); c->lanes[i].tp_exec = nullptr; }
     for (auto& hs : c->hash_stream) if (hs) (void)hipStreamDestroy(hs);
     if (c->init_stream) (void)hipStreamDestroy(c->init_stream);
     delete c->pool;

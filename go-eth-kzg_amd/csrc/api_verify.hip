@@ -115,12 +115,20 @@ int draw_rlc_scalar(uint8_t r_le32[32]) { return getrandom(r_le32, 32, 0) == 32 
 // would hold the call's own queue, and with it whatever else HIP mapped there) and carries on in its own stream.
 // (A round that also validated its calls' points in one launch on a stream of its own was measured in round 4 and dropped -- DESIGN.md
 // Appendix A: the 1.3 ms chain runs in every call's own stream while the call waits for its round anyway.)
+// rounds in flight: THREE since round 5 (two until then).  *Measured* (tools/ab_r05_11.sh, 32 callers, one box, alternating): 2 in flight
+// 2.25-2.35 M blobs/s, 3: 2.40-2.45 M, 4: 2.35 M -- the rounds are what bounds the leg (rounds in flight x calls per round / 4 ms per
+// round), and a third one fills the gap between a round's end and its stream's next launch.  MKZG_HASH_IN_FLIGHT overrides (A/B aid).
+static int hash_in_flight() {
+    static const int v = [] { const char* e = getenv("MKZG_HASH_IN_FLIGHT"); const int n = e ? atoi(e) : 0; return n >= 1 && n <= mkzg_ctx::HASH_STREAMS_MAX ? n : 3; }();
+    return v;
+}
 static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, uint32_t* d_zrows, hipEvent_t ready, std::shared_ptr<HashRound>* out) {
     std::shared_ptr<HashRound> r, prev;
     bool leader = false;
     {
         std::unique_lock<std::mutex> lk(c->hash_mu);
-        for (auto& hs : c->hash_stream) {
+        for (int q = 0; q < hash_in_flight(); q++) {
+            hipStream_t& hs = c->hash_stream[q];
             if (hs) continue;
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -133,7 +141,7 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
         if (c->hash_forming && c->hash_forming->jobs.count >= SHA_MAX_JOBS) return MKZG_ERR_BAD_ARGS;     // cannot happen: one job per lane
         if (!c->hash_forming) {
             c->hash_forming = std::make_shared<HashRound>();
-            prev = c->hash_prev2;
+            prev = c->hash_hist[c->hash_rounds % (uint64_t)hash_in_flight()];      // the round that used the stream this one will take: hash_in_flight() rounds back
             leader = true;
         }
         r = c->hash_forming;
@@ -147,7 +155,7 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
         if (leader && prev) c->hash_cv.wait(lk, [&] { return prev->launched; });
     }
     if (leader) {
-        if (prev && prev->done) {                                            // the launch two rounds back has finished: its stream is free
+        if (prev && prev->done) {                                            // the launch that used this round's stream has finished: the stream is free
             // (a crowded context sleeps here too: hipEventSynchronize polls on this runtime, and one leader per round would keep a CPU spinning)
             if (wait_sleeping(c)) (void)wait_event_sleeping(prev->done);
             else (void)hipEventSynchronize(prev->done);
@@ -156,9 +164,9 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
         {
             std::lock_guard<std::mutex> g(c->hash_mu);
             c->hash_forming.reset();                                           // closed: later arrivals open the next round
-            c->hash_prev2 = c->hash_prev;
-            c->hash_prev = r;
-            hs = c->hash_stream[c->hash_rounds++ & 1];
+            const uint64_t slot = c->hash_rounds++ % (uint64_t)hash_in_flight();
+            c->hash_hist[slot] = r;
+            hs = c->hash_stream[slot];
         }
         int rc = MKZG_OK;
         if (hipEventCreateWithFlags(&r->done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { r->done = nullptr; rc = MKZG_ERR_HIP; }
@@ -188,6 +196,11 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
 #ifndef MKZG_LAT_VALIDATE_MODE
 #define MKZG_LAT_VALIDATE_MODE(n) 0         // the latency shape: a quad of lanes per point
 #endif
+// round 5's one bounded attempt at HIP graphs: off unless MKZG_TP_GRAPH=1
+static bool tp_graph_on() {
+    static const bool v = getenv("MKZG_TP_GRAPH") != nullptr && atoi(getenv("MKZG_TP_GRAPH")) != 0;
+    return v;
+}
 static bool throughput_shape(const mkzg_ctx* c) {
     if (c->opt_verify_shape >= 0) return c->opt_verify_shape == 1;
     return c->lanes_busy.load(std::memory_order_relaxed) >= 3;
@@ -221,7 +234,25 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
     // 5. one round trip: statuses, e, window sums
     int* h_st = (int*)L->h_v;
     uint32_t* h_ry = h_misc + V_MISC_WORDS + 16;
-    HIPCHK(hipMemcpyAsync(h_st, L->d_v_block, verdict_block_bytes(cap, sum_ry_on_host ? n : 0), hipMemcpyDeviceToHost, s));      // statuses, misc (and the r^i y_i words): ONE copy
+    {
+        const hipError_t ce = hipMemcpyAsync(h_st, L->d_v_block, verdict_block_bytes(cap, sum_ry_on_host ? n : 0), hipMemcpyDeviceToHost, s);      // statuses, misc (and the r^i y_i words): ONE copy
+        if (L->tp_capturing) {                  // MKZG_TP_GRAPH: what was captured since the evaluation kernel becomes this call's graph launch
+            L->tp_capturing = false;
+            hipGraph_t g = nullptr;
+            if (hipStreamEndCapture(s, &g) != hipSuccess || !g) { (void)hipGetLastError(); tl_hip_error = true; return MKZG_ERR_HIP; }
+            bool ok = false;
+            if (L->tp_exec) {
+                hipGraphNode_t bad = nullptr;
+                hipGraphExecUpdateResult res;
+                ok = hipGraphExecUpdate(L->tp_exec, g, &bad, &res) == hipSuccess;
+                if (!ok) { (void)hipGetLastError(); (void)hipGraphExecDestroy(L->tp_exec); L->tp_exec = nullptr; }
+            }
+            if (!ok) ok = hipGraphInstantiate(&L->tp_exec, g, nullptr, nullptr, 0) == hipSuccess;
+            (void)hipGraphDestroy(g);
+            if (!ok || hipGraphLaunch(L->tp_exec, s) != hipSuccess) { (void)hipGetLastError(); tl_hip_error = true; return MKZG_ERR_HIP; }
+        }
+        HIPCHK(ce);
+    }
     LANE_SYNC(c, L, s);                     // polls for a lone caller, asks and sleeps when the context is crowded (ctx.h)
     L->drained = true;                      // the side streams were joined into s by the caller; nothing of this call is left on the device
     if (with_blobs) {
@@ -365,6 +396,12 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             // evaluation's z-only rows came with the round's hash launch, the evaluation kernel's last lane leaves the blob's r^i, r^i z_i and
             // r^i y_i (the host adds the latter up), and ONE launch takes the three MSMs of kzg_verify.go:150,225,179
             const bool rows_ready = !d_z32;
+            if (tp_graph_on() && !c->profiling.load(std::memory_order_relaxed)) {
+                // the experiment: everything from here to the copy back is CAPTURED, not launched (verify_fold_tail ends the capture,
+                // updates the lane's executable graph with it and launches that)
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) L->tp_capturing = true;
+                else (void)hipGetLastError();
+            }
             KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s, rows_ready, r_words, exp_offset, L->d_v_s1,
                                                  L->d_v_s3, L->d_v_ry));
             tp_ry = true;

@@ -402,9 +402,12 @@ __global__ void __launch_bounds__(256) k_cell_rpowers(const RWords r_words8, uin
     if ((int)blockIdx.x < nb_cells) {
         const int k = blockIdx.x * 256 + t;
         if (k >= n) return;
-        fr_t rp;
+        fr_t rp, rp64, inv64;
         cell_rpower(rp, r, (uint32_t)k + exp_offset);
-        c_store_fr12(rp_rows + (size_t)k * 12, rp);
+        Fr::set(inv64, FR_INV_4096);
+        for (int sft = 0; sft < 6; sft++) FrC::add(inv64, inv64, inv64);     // 64 / 4096
+        c_fr_mul(rp64, rp, inv64);
+        c_store_fr12(rp_rows + (size_t)k * 12, rp64);                 // the interpolation's row: r^k / 64 (the inverse transform's scale rides along)
         fr_store_plain8(s1 + (size_t)k * 8, rp);
         const uint32_t c = (uint32_t)cell_idx[k] & 127u;
         fr_t hp, v;
@@ -443,61 +446,79 @@ __global__ void __launch_bounds__(256) k_cell_rpowers(const RWords r_words8, uin
         fr_store_plain8(weights8 + (size_t)row * 8, acc);
     }
 }
-// per cell: canonical check, coset IFFT-64 on the bit-reversed evaluations, times r^k, summed per
-// workgroup into partials[block][64]   (kzg_verify.go:50-66, coset_fft.go:55-70)
+// per cell: canonical check, coset IFFT-64 on the bit-reversed evaluations, times r^k / 64, summed per workgroup into
+// partials[block][64]   (kzg_verify.go:50-66, coset_fft.go:55-70).
+// Round 5 shape: TWO cells per pass of a single-wavefront workgroup.  A radix-2 stage of a 64-point transform is 32 butterflies, so one
+// cell left half the lanes idle through the six stage multiplications; lanes 0-31 now take cell A's butterflies and lanes 32-63 cell
+// B's.  The 32 stage twiddles w_64^-j sit in LDS (they were a global load inside every stage of every cell: a ~1 us stall in a chain of
+// six), and the 1/64 of the inverse transform rides in the power rows (k_cell_rpowers stores r^k / 64).  Per pair of cells 12 wavefront
+// multiplications instead of 20, six barriers instead of twelve.
 __global__ void __launch_bounds__(64) k_cell_interp(const uint8_t* __restrict__ cells, const uint64_t* __restrict__ cell_idx, const uint32_t* __restrict__ rp_rows, int n,
                                                     const uint32_t* __restrict__ tw_inv, uint32_t* __restrict__ partials, int* __restrict__ cell_status, uint32_t* __restrict__ interp8) {
-    __shared__ uint32_t sh[9 * 64];
-    const int lane = threadIdx.x;
-    fr_t acc, inv64;
+    __shared__ uint32_t sh[2][9 * 64];
+    __shared__ uint32_t tws[9 * 32];
+    const int lane = threadIdx.x, half = lane >> 5, l = lane & 31;
+    fr_t acc;
     Fr::set_zero(acc);
-    {
-        fr_t x;
-        Fr::set(x, FR_INV_4096);
-        for (int s = 0; s < 6; s++) FrC::add(x, x, x);           // 64/4096
-        inv64 = x;
+    if (lane < 32) {
+        fr_t w;
+        c_load_fr12(w, tw_inv + (size_t)(lane * 128) * 12);       // w_64^-lane = w_8192^(-128 lane)
+        lds_put<32>(tws, lane, w);
     }
-    for (int k = blockIdx.x; k < n; k += gridDim.x) {
-        uint32_t w[8];
-        c_load_be32(w, cells + (size_t)k * 2048 + (size_t)lane * 32);
-        const bool bad = Fr::words32_geq_mod(w);
-        if (__syncthreads_or(bad)) {
-            if (lane == 0) cell_status[k] = MKZG_ERR_NON_CANONICAL_SCALAR;
-            continue;
+    __syncthreads();
+    for (int k0 = blockIdx.x; k0 < n; k0 += 2 * (int)gridDim.x) {
+        const int k1 = k0 + (int)gridDim.x;
+        const bool has1 = k1 < n;
+        bool ok[2];
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            const int k = x ? k1 : k0;
+            if (x && !has1) { ok[1] = false; break; }
+            uint32_t w[8];
+            c_load_be32(w, cells + (size_t)k * 2048 + (size_t)lane * 32);
+            const bool bad = __ballot(Fr::words32_geq_mod(w)) != 0;      // one wavefront: a vote, no barrier
+            ok[x] = !bad;
+            if (lane == 0) cell_status[k] = bad ? MKZG_ERR_NON_CANONICAL_SCALAR : 0;
+            fr_t pl, m;
+            Fr::from_words32(pl, w);
+            Fr::from_plain(m, pl);
+            Fr::reduce_once(m, m);
+            lds_put<64>(sh[x], lane, m);
         }
-        if (lane == 0) cell_status[k] = 0;
-        fr_t pl, m;
-        Fr::from_words32(pl, w);
-        Fr::from_plain(m, pl);
-        Fr::reduce_once(m, m);
-        lds_put<64>(sh, lane, m);
         __syncthreads();
         // DIT with inverse twiddles: the cell is the bit-reversed natural-order input (kzg_verify.go:52)
-        for (int h = 1; h < 64; h <<= 1) {
-            if (lane < 32) {
-                const int kk = lane & (h - 1);
-                const int i0 = ((lane - kk) << 1) + kk, i1 = i0 + h;
+        if (half == 0 || has1) {
+            uint32_t* my = sh[half];
+#pragma unroll 1
+            for (int h = 1; h < 64; h <<= 1) {
+                const int kk = l & (h - 1);
+                const int i0 = ((l - kk) << 1) + kk, i1 = i0 + h;
                 fr_t a, bb, tw, tt;
-                lds_get<64>(a, sh, i0);
-                lds_get<64>(bb, sh, i1);
-                c_load_fr12(tw, tw_inv + (size_t)(kk * (32 / h) * 128) * 12);
+                lds_get<64>(a, my, i0);
+                lds_get<64>(bb, my, i1);
+                lds_get<32>(tw, tws, kk * (32 / h));
                 c_fr_mul(tt, bb, tw);
                 FrC::add(bb, a, tt);
                 FrC::sub(a, a, tt);
-                lds_put<64>(sh, i0, bb);
-                lds_put<64>(sh, i1, a);
+                lds_put<64>(my, i0, bb);                             // one wavefront: its LDS operations execute in program order, the barrier
+                lds_put<64>(my, i1, a);                              // below only keeps the compiler from moving them across stages
+                __builtin_amdgcn_wave_barrier();
             }
-            __syncthreads();
         }
-        fr_t v, hs, rp;
-        lds_get<64>(v, sh, lane);
-        const uint32_t c = (uint32_t)cell_idx[k] & 127u;
-        tw_any(hs, tw_inv, (uint32_t)lane * (__brev(c) >> 25));  // (h_c^-1)^lane
-        c_load_fr12(rp, rp_rows + (size_t)k * 12);
-        c_fr_mul(v, v, inv64);
-        c_fr_mul(v, v, hs);
-        c_fr_mul(v, v, rp);
-        FrC::add(acc, acc, v);
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 2; x++) {
+            if ((x && !has1) || !ok[x]) continue;
+            const int k = x ? k1 : k0;
+            fr_t v, hs, rp;
+            lds_get<64>(v, sh[x], lane);
+            const uint32_t c = (uint32_t)cell_idx[k] & 127u;
+            tw_any(hs, tw_inv, (uint32_t)lane * (__brev(c) >> 25));  // (h_c^-1)^lane
+            c_load_fr12(rp, rp_rows + (size_t)k * 12);               // r^k / 64
+            c_fr_mul(v, v, hs);
+            c_fr_mul(v, v, rp);
+            FrC::add(acc, acc, v);
+        }
         __syncthreads();
     }
     // interp[i] = the sum of all workgroups' partial sums, by whoever finishes last -- a launch of its own until round 5.  Two levels of

@@ -196,6 +196,10 @@ struct Lane {
     KernelTimer timer;
     double last_host_finish_us = 0;
     bool failed = false;                   // set by an error exit: the release then synchronises every stream of the lane
+    // the bounded HIP-graph experiment of round 5 (MKZG_TP_GRAPH=1, api_verify.hip): the throughput shape's launches behind the hash round
+    // captured per call and replayed through one executable graph per lane (hipGraphExecUpdate carries the call's r and sizes over)
+    hipGraphExec_t tp_exec = nullptr;
+    bool tp_capturing = false;
     bool drained = false;                  // set by a call that has waited for all its device work: the next owner need not wait for, or query, `done`
 };
 
@@ -223,8 +227,9 @@ struct mkzg_ctx {
     // ---- hash rounds (throughput shape of the blob verifier)
     std::mutex hash_mu;
     std::condition_variable hash_cv;
-    std::shared_ptr<HashRound> hash_forming, hash_prev, hash_prev2;   // the round being filled, the last two launched
-    hipStream_t hash_stream[2] = {nullptr, nullptr};                    // rounds alternate between them: two in flight
+    static constexpr int HASH_STREAMS_MAX = 4;
+    std::shared_ptr<HashRound> hash_forming, hash_hist[HASH_STREAMS_MAX];   // the round being filled; the last launched ones (ring by round number)
+    hipStream_t hash_stream[HASH_STREAMS_MAX] = {nullptr, nullptr, nullptr, nullptr};   // rounds take them in turn: hash_in_flight() of them are used
     uint64_t hash_rounds = 0;
     std::mutex mu;                         // lane hand-over only
     std::condition_variable cv;

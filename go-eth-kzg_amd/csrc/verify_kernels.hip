@@ -371,13 +371,20 @@ __device__ __forceinline__ void sha_challenge_block(const uint8_t* __restrict__ 
     if (a_side) store_fr12(z_out + (size_t)b * 12, z);
     if (zrows_out) eval_prep_rows(z, zrows_out + (size_t)b * EVT_ROWS * 12, a_side);
 }
+#ifndef MKZG_SHA_RESERVE
+#define MKZG_SHA_RESERVE_STMT
+#else
+#define MKZG_SHA_RESERVE_STMT asm volatile("" ::: MKZG_SHA_RESERVE);      // A/B aid (round 5): who may share a SIMD with the hash wavefronts, e.g. -DMKZG_SHA_RESERVE='"v175"'
+#endif
 __global__ void __launch_bounds__(256) k_challenge_sha256(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments48, int n, uint32_t* __restrict__ z_out,
                                                           uint32_t* __restrict__ zrows_out) {
+    MKZG_SHA_RESERVE_STMT
     sha_challenge_block(blobs, commitments48, n, z_out, (int)blockIdx.x, zrows_out);
 }
 // the challenges of SEVERAL calls in one launch (api_verify.hip, the hash rounds of the throughput shape): the chain is 2.7 ms long
 // whatever the number of blobs, and a launch holds its hardware queue for that long -- calls that arrive together share one
 __global__ void __launch_bounds__(256) k_challenge_sha256_jobs(ShaJobs jobs) {
+    MKZG_SHA_RESERVE_STMT
     int j = 0;
 #pragma unroll 1
     while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.first_block[j + 1]) j++;

@@ -465,10 +465,18 @@ def main():
     if dist_on:
         dist.barrier()
     if rank == 0 and not args.no_drop_in:
-        try:
-            in_proc = bench_multi_in_process(kzg, torch, min(torch.cuda.device_count(), 1 if shared_gpu else world))
-        except Exception as e:      # noqa: BLE001  (a leg that has never met real hardware must not cost the line)
-            in_proc = {"error": repr(e)[:300]}
+        n_dev = min(torch.cuda.device_count(), 1 if shared_gpu else world)
+        if n_dev < 2:
+            in_proc = bench_multi_in_process(kzg, torch, n_dev)
+        else:
+            # in a CHILD process with a time limit: a leg that has never met real multi-GPU hardware must not be able to cost the line
+            import subprocess
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--in-process-leg", str(n_dev)], capture_output=True, text=True, timeout=600)
+                got = [ln for ln in r.stdout.splitlines() if ln.startswith("IN_PROCESS ")]
+                in_proc = json.loads(got[-1][len("IN_PROCESS "):]) if got else {"error": (r.stderr or r.stdout)[-400:]}
+            except Exception as e:      # noqa: BLE001
+                in_proc = {"error": repr(e)[:300]}
         out.setdefault("multi_gpu", {})["in_process"] = in_proc
         line = json.dumps(out)
     if dist_on:
@@ -1602,5 +1610,20 @@ def cpu_baseline():
             "sample": f"{passes} passes over {n} GetRandBlob blobs, OpenMP over blobs with {threads} threads ({dt:.2f} s); 1 thread: {k1} blobs in 3 s"}
 
 
+def in_process_leg_main(n_dev):
+    """child of bench.py (rank 0, after every rank has closed its context): the one-process-over-all-devices form on its own"""
+    import torch
+    torch.cuda.init()
+    kzg = load_product()
+    try:
+        res = bench_multi_in_process(kzg, torch, n_dev)
+    except Exception as e:      # noqa: BLE001
+        res = {"error": repr(e)[:300]}
+    print("IN_PROCESS " + json.dumps(res), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--in-process-leg":
+        in_process_leg_main(int(sys.argv[2]))
+    else:
+        main()

@@ -212,6 +212,13 @@ bool lane_fork(Lane* L, hipStream_t s, hipStream_t side_a, hipStream_t side_b) {
     if (side_b && side_b != s && hipStreamWaitEvent(side_b, L->ev_fork, 0) != hipSuccess) tl_hip_error = true;
     return false;
 }
+std::atomic<long long> g_graph_launches{0}, g_graph_instantiations{0}, g_graph_fallbacks{0};
+// MKZG_TP_GRAPH=0 / 1 in the environment overrides the option (A/B aid)
+bool launch_graphs_on(const mkzg_ctx* c) {
+    static const int env = getenv("MKZG_TP_GRAPH") ? (atoi(getenv("MKZG_TP_GRAPH")) != 0 ? 1 : 0) : -1;
+    const bool on = env >= 0 ? env == 1 : c->opt_launch_graphs.load(std::memory_order_relaxed) != 0;
+    return on && !c->profiling.load(std::memory_order_relaxed);
+}
 bool wait_sleeping(const mkzg_ctx* c) {
     const int o = c->opt_host_wait.load(std::memory_order_relaxed);
     if (o >= 0) return o == 1;
@@ -405,13 +412,30 @@ static int commit_prepare(mkzg_ctx* c, Lane* L) {
 int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s) {
     int rc = commit_prepare(c, L);
     if (rc) return rc;
-    size_t done = 0;
-    while (done < n) {
-        const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
-        rc = commit_piece(c, L, d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, 0, d_out48n + done * 48, d_status + done, s);
-        if (rc) return rc;
-        done += chunk;
+    if (c->direct_bits_built) {
+        // whatever the pieces' shapes will need of the lane's workspace is allocated HERE: the launches below go out as one launch graph
+        // (ctx.h lane_graph_run), and a capture must not meet an allocation
+        for (size_t done = 0; done < n; done += (size_t)c->opt_max_batch) {
+            const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
+            DirectSlot slot = L->dslot;
+            direct_pick_shape(chunk, L->dslot_batch, &slot);
+            if ((size_t)chunk * (4096 / slot.k) > L->dslot_records) {
+                rc = ensure_lane_direct(c, L, (size_t)L->dslot_batch * 4096);
+                if (rc) return rc;
+            }
+        }
     }
+    rc = lane_graph_run(c, L, input_kind ? 2 : 1, s, [&]() -> int {
+        size_t done = 0;
+        while (done < n) {
+            const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
+            const int prc = commit_piece(c, L, d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, 0, d_out48n + done * 48, d_status + done, s);
+            if (prc) return prc;
+            done += chunk;
+        }
+        return MKZG_OK;
+    });
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     return MKZG_OK;
 }
@@ -565,7 +589,7 @@ static void ctx_destroy_one(mkzg_ctx* c) {
     dev_free(c->d_monomial_aff); dev_free(c->d_pow7); dev_free(c->d_ipow7); dev_free(c->d_fk_t_aff); dev_free(c->d_fk_table);
     c->hash_forming.reset();
     for (auto& h : c->hash_hist) h.reset();
-    for (int i = 0; i < mkzg_ctx::NLANE; i++) if (c->lanes[i].tp_exec) { (void)hipGraphExecDestroy(c->lanes[i].tp_exec); c->lanes[i].tp_exec = nullptr; }
+    for (int i = 0; i < mkzg_ctx::NLANE; i++) for (auto& ge : c->lanes[i].graph_exec) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
     for (auto& hs : c->hash_stream) if (hs) (void)hipStreamDestroy(hs);
     if (c->init_stream) (void)hipStreamDestroy(c->init_stream);
     delete c->pool;
@@ -859,6 +883,11 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         c->opt_verify_shape = (int)value;
         return MKZG_OK;
     }
+    if (!strcmp(key, "launch_graphs")) {
+        if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_launch_graphs = (int)value;
+        return MKZG_OK;
+    }
     if (!strcmp(key, "combine_single_calls")) {
         if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
         c->opt_combine = (int)value;
@@ -890,6 +919,10 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "host_sha")) *value = q->opt_host_sha;
     else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
     else if (!strcmp(key, "combine_single_calls")) *value = q->opt_combine;
+    else if (!strcmp(key, "launch_graphs")) *value = q->opt_launch_graphs;
+    else if (!strcmp(key, "graph_launches")) *value = (long)g_graph_launches.load();                 // process-wide diagnostics of lane_graph_run
+    else if (!strcmp(key, "graph_instantiations")) *value = (long)g_graph_instantiations.load();
+    else if (!strcmp(key, "graph_fallbacks")) *value = (long)g_graph_fallbacks.load();
     else if (!strcmp(key, "combined_calls")) {                                                  // single-item calls served as members of a group of two or more so far
         *value = 0;
         const std::vector<mkzg_ctx*> all = c->peers.empty() ? std::vector<mkzg_ctx*>{c} : c->peers;

@@ -196,11 +196,6 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
 #ifndef MKZG_LAT_VALIDATE_MODE
 #define MKZG_LAT_VALIDATE_MODE(n) 0         // the latency shape: a quad of lanes per point
 #endif
-// round 5's one bounded attempt at HIP graphs: off unless MKZG_TP_GRAPH=1
-static bool tp_graph_on() {
-    static const bool v = getenv("MKZG_TP_GRAPH") != nullptr && atoi(getenv("MKZG_TP_GRAPH")) != 0;
-    return v;
-}
 static bool throughput_shape(const mkzg_ctx* c) {
     if (c->opt_verify_shape >= 0) return c->opt_verify_shape == 1;
     return c->lanes_busy.load(std::memory_order_relaxed) >= 3;
@@ -227,32 +222,15 @@ struct CpuProfPrinter { ~CpuProfPrinter() {
 #define CPU_LAP(k) ((void)0)
 #endif
 // the end of every fold: one round trip (statuses, e, window sums), the reference's error precedence, Horner over the window sums
-static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int y_bad, hipStream_t s, VerifyFold* out, bool sum_ry_on_host = false) {
+// copy_enqueued: the caller has put the verdict block's copy on `s` already (inside its launch graph)
+static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int y_bad, hipStream_t s, VerifyFold* out, bool sum_ry_on_host = false, bool copy_enqueued = false) {
     const size_t cap = L->v_cap;
     uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * cap * sizeof(int));
     HIPCHK(hipGetLastError());
     // 5. one round trip: statuses, e, window sums
     int* h_st = (int*)L->h_v;
     uint32_t* h_ry = h_misc + V_MISC_WORDS + 16;
-    {
-        const hipError_t ce = hipMemcpyAsync(h_st, L->d_v_block, verdict_block_bytes(cap, sum_ry_on_host ? n : 0), hipMemcpyDeviceToHost, s);      // statuses, misc (and the r^i y_i words): ONE copy
-        if (L->tp_capturing) {                  // MKZG_TP_GRAPH: what was captured since the evaluation kernel becomes this call's graph launch
-            L->tp_capturing = false;
-            hipGraph_t g = nullptr;
-            if (hipStreamEndCapture(s, &g) != hipSuccess || !g) { (void)hipGetLastError(); tl_hip_error = true; return MKZG_ERR_HIP; }
-            bool ok = false;
-            if (L->tp_exec) {
-                hipGraphNode_t bad = nullptr;
-                hipGraphExecUpdateResult res;
-                ok = hipGraphExecUpdate(L->tp_exec, g, &bad, &res) == hipSuccess;
-                if (!ok) { (void)hipGetLastError(); (void)hipGraphExecDestroy(L->tp_exec); L->tp_exec = nullptr; }
-            }
-            if (!ok) ok = hipGraphInstantiate(&L->tp_exec, g, nullptr, nullptr, 0) == hipSuccess;
-            (void)hipGraphDestroy(g);
-            if (!ok || hipGraphLaunch(L->tp_exec, s) != hipSuccess) { (void)hipGetLastError(); tl_hip_error = true; return MKZG_ERR_HIP; }
-        }
-        HIPCHK(ce);
-    }
+    if (!copy_enqueued) HIPCHK(hipMemcpyAsync(h_st, L->d_v_block, verdict_block_bytes(cap, sum_ry_on_host ? n : 0), hipMemcpyDeviceToHost, s));      // statuses, misc (and the r^i y_i words): ONE copy
     LANE_SYNC(c, L, s);                     // polls for a lone caller, asks and sleeps when the context is crowded (ctx.h)
     L->drained = true;                      // the side streams were joined into s by the caller; nothing of this call is left on the device
     if (with_blobs) {
@@ -327,6 +305,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
     int vrc = 0;
     bool tp_ry = false;                         // the call's sum r^i y_i is added up on the host from L->d_v_ry (throughput shape)
+    bool tp_copy_enqueued = false;              // ... and the verdict block's copy back is on the stream already (throughput shape: part of its launch graph)
     // 1. decode + validate the points (serialization.go:108-115)
     //    on the side stream, beside the (longer, latency-bound) SHA-256 chain
     //    (throughput shape: on the call's own stream, ahead of the hash -- HIP multiplexes all streams of the process onto a few hardware
@@ -396,19 +375,22 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             // evaluation's z-only rows came with the round's hash launch, the evaluation kernel's last lane leaves the blob's r^i, r^i z_i and
             // r^i y_i (the host adds the latter up), and ONE launch takes the three MSMs of kzg_verify.go:150,225,179
             const bool rows_ready = !d_z32;
-            if (tp_graph_on() && !c->profiling.load(std::memory_order_relaxed)) {
-                // the experiment: everything from here to the copy back is CAPTURED, not launched (verify_fold_tail ends the capture,
-                // updates the lane's executable graph with it and launches that)
-                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) L->tp_capturing = true;
-                else (void)hipGetLastError();
-            }
-            KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s, rows_ready, r_words, exp_offset, L->d_v_s1,
-                                                 L->d_v_s3, L->d_v_ry));
-            tp_ry = true;
+            // (everything from here to the copy back is one fixed sequence on the call's stream: a launch graph, ctx.h lane_graph_run)
             const uint32_t* scal[3] = {L->d_v_s1, L->d_v_s1, L->d_v_s3};
             const uint32_t* pts[3] = {aff_q, aff_c, aff_q};
             const int njob[3] = {(int)n, (int)n, (int)n};
-            KT(KT_VMSM, s, vrc = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
+            rc = lane_graph_run(c, L, 0, s, [&]() -> int {
+                KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s, rows_ready, r_words, exp_offset, L->d_v_s1,
+                                                     L->d_v_s3, L->d_v_ry));
+                int v = 0;
+                KT(KT_VMSM, s, v = vmsm_windows_device(scal, pts, njob, 3, d_parts, d_wsum, s));
+                if (v) return MKZG_ERR_BAD_ARGS;
+                HIPCHK(hipMemcpyAsync(L->h_v, L->d_v_block, verdict_block_bytes(cap, n), hipMemcpyDeviceToHost, s));
+                return MKZG_OK;
+            });
+            if (rc) return rc;
+            tp_ry = true;
+            tp_copy_enqueued = true;
         } else if (d_z32) {
             // challenges from the host: the rows of z by a small kernel ahead, then as above
             KT(KT_EVAL_TREE, s, blob_eval_device(d_blobs, L->d_v_z, c->d_roots_brp, c->d_inv_roots_brp, (int)n, L->d_v_y, st_b, L->d_v_zrows, s, false, r_words, exp_offset, L->d_v_s1, L->d_v_s3,
@@ -450,7 +432,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     }
     if (vrc) return MKZG_ERR_BAD_ARGS;
     CPU_LAP(3);
-    return verify_fold_tail(c, L, n, d_blobs != nullptr, y_bad, s, out, tp_ry);
+    return verify_fold_tail(c, L, n, d_blobs != nullptr, y_bad, s, out, tp_ry, tp_copy_enqueued);
 }
 // kzg_verify.go:160-199: F = Cc - [e]G + D ; e(F, G2) e(-A, [alpha]G2) == 1
 int sd_verify_finish(mkzg_ctx* c, const VerifyFold& f) {

@@ -73,8 +73,10 @@ template <class T>
 static inline int dev_realloc_zero(T*& p, size_t bytes) {
     int rc = dev_realloc(p, bytes);
     if (rc) return rc;
-    HIPCHK(hipMemset(p, 0, bytes ? bytes : 16));
-    HIPCHK(hipStreamSynchronize(nullptr));
+    // (on the calling thread's own stream, not the legacy null stream: that one synchronises implicitly with every blocking stream of the
+    // process, which HIP refuses -- hipErrorStreamCaptureImplicit -- while another call's stream is being captured into its launch graph)
+    HIPCHK(hipMemsetAsync(p, 0, bytes ? bytes : 16, hipStreamPerThread));
+    HIPCHK(hipStreamSynchronize(hipStreamPerThread));
     return MKZG_OK;
 }
 template <class T>
@@ -196,10 +198,9 @@ struct Lane {
     KernelTimer timer;
     double last_host_finish_us = 0;
     bool failed = false;                   // set by an error exit: the release then synchronises every stream of the lane
-    // the bounded HIP-graph experiment of round 5 (MKZG_TP_GRAPH=1, api_verify.hip): the throughput shape's launches behind the hash round
-    // captured per call and replayed through one executable graph per lane (hipGraphExecUpdate carries the call's r and sizes over)
-    hipGraphExec_t tp_exec = nullptr;
-    bool tp_capturing = false;
+    // launch graphs (round 5, lane_graph_run below): a call's fixed sequence of launches behind its last host-side decision is captured
+    // and replayed through ONE executable graph per lane and slot; hipGraphExecUpdate carries the call's scalars and sizes over
+    hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};     // slot 0: the blob verifier's throughput shape behind its hash round; 1 / 2: a device-resident commitment batch over blobs / over quotient rows
     bool drained = false;                  // set by a call that has waited for all its device work: the next owner need not wait for, or query, `done`
 };
 
@@ -253,6 +254,7 @@ struct mkzg_ctx {
     kzg::Combiner<CommitCall> comb_commit;
     kzg::Combiner<CellsCall> comb_cells;
     kzg::Combiner<VerifyCall> comb_verify;
+    std::atomic<int> opt_launch_graphs{0};             // "launch_graphs": 1 replays fixed launch sequences through executable graphs (lane_graph_run), 0 (default, by measurement) launches one by one
     std::atomic<int> opt_combine{1};                   // "combine_single_calls": 1 (default) groups concurrent single-blob calls, 0 every call on its own
     std::atomic<int> opt_verify_shape{-1};             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip
     int opt_cells_chunk = 256;             // most blobs per launch set of a ComputeCellsAndKZGProofs batch (a lane's FK20 workspace grows to the pieces it has seen: 1.6 MB per blob)
@@ -343,6 +345,52 @@ bool wait_sleeping(const mkzg_ctx* c);
 int wait_event_sleeping(hipEvent_t ev);
 int lane_sync(mkzg_ctx* c, Lane* L, hipStream_t s);
 #define LANE_SYNC(c, L, s) do { const int ls__ = lane_sync(c, L, s); if (ls__) return ls__; } while (0)
+
+// LAUNCH GRAPHS.  `enqueue` puts a fixed sequence of kernels and copies on `s` (no host wait, no allocation, no stream other than s)
+// and returns 0 or an error.  With graphs on, the sequence is CAPTURED instead of launched, the lane's executable graph of that slot is
+// updated with the capture (same topology every call; the kernels' by-value arguments -- r, the exponents' offset, the sizes -- are
+// what changes) and launched: the packets of the whole sequence reach the hardware queue together instead of one API call at a time
+// between other threads' launches.  OFF by default (option "launch_graphs"): *measured* (round 5, 32 callers of the blob verifier, graphs
+// off / on alternating on one box each): 2.34 -> 2.52 M blobs/s on the first box (tools/profile_r05.sh), 2.26-2.31 -> 2.08 M on the
+// second (tools/ab_r05_14.sh), 2.12-2.27 against 2.04-2.23 M on the third (tools/ab_r05_15.sh: 1650 launches, 32 instantiations, no
+// fall-back); the headline's two launches per step 97.4 -> 95.7 k blobs/s.  No consistent gain: what binds the legs is queue time, which
+// a graph launch does not shorten.  Any failure of the capture machinery falls back to launching plainly (the
+// stub runtime of the sanitizer tests has no graphs at all); profiling runs plainly too (its events would be captured).
+bool launch_graphs_on(const mkzg_ctx* c);
+extern std::atomic<long long> g_graph_launches, g_graph_instantiations, g_graph_fallbacks;     // diagnostics ("graph_stats" options)
+template <class F>
+static inline int lane_graph_run(mkzg_ctx* c, Lane* L, int slot, hipStream_t s, F&& enqueue) {
+    if (!launch_graphs_on(c)) return enqueue();
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return enqueue(); }
+    const bool hip_err_before = tl_hip_error;
+    const int rc = enqueue();                                   // recorded, not run
+    hipGraph_t g = nullptr;
+    const hipError_t ee = hipStreamEndCapture(s, &g);
+    if (rc) {                                                   // the sequence itself reported an error: nothing was put on the stream
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        return rc;
+    }
+    bool ok = ee == hipSuccess && g != nullptr;
+    if (ok && L->graph_exec[slot]) {
+        hipGraphNode_t bad = nullptr;
+        hipGraphExecUpdateResult res;
+        if (hipGraphExecUpdate(L->graph_exec[slot], g, &bad, &res) != hipSuccess) {     // another topology (a size that takes other kernels): a new executable
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(L->graph_exec[slot]);
+            L->graph_exec[slot] = nullptr;
+        }
+    }
+    if (ok && !L->graph_exec[slot]) { ok = hipGraphInstantiate(&L->graph_exec[slot], g, nullptr, nullptr, 0) == hipSuccess; g_graph_instantiations++; }
+    if (g) (void)hipGraphDestroy(g);
+    if (ok) ok = hipGraphLaunch(L->graph_exec[slot], s) == hipSuccess;
+    if (ok) { g_graph_launches++; return MKZG_OK; }
+    g_graph_fallbacks++;
+    (void)hipGetLastError();
+    if (L->graph_exec[slot]) { (void)hipGraphExecDestroy(L->graph_exec[slot]); L->graph_exec[slot] = nullptr; }
+    tl_hip_error = hip_err_before;
+    return enqueue();                                           // plainly
+}
 #define KT(kind, s, call)                                         \
     do {                                                          \
         const bool kt_on__ = c->profiling.load(std::memory_order_relaxed); \

@@ -59,7 +59,7 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
     a->device = it->second;
     return hipSuccess;
 }
-// (the HIP-graph experiment of api_verify.hip is off unless MKZG_TP_GRAPH is set; the entry points only have to link)
+// (launch graphs, ctx.h lane_graph_run: this runtime has none -- every sequence falls back to plain launches, which is a tested path of its own)
 hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
 hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorNotSupported; }
 hipError_t hipGraphExecUpdate(hipGraphExec_t, hipGraph_t, hipGraphNode_t*, hipGraphExecUpdateResult*) { return hipErrorNotSupported; }
@@ -67,6 +67,7 @@ hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, cha
 hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
 hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t) { if (n) memset(dst, v, n); return hipSuccess; }
 hipError_t hipMemset(void* dst, int v, size_t n) { if (n) memset(dst, v, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(dst, src, n); return hipSuccess; }
 

@@ -68,7 +68,8 @@ def one():
         if trial:
             rates.append(K * (reps + 1) * N / (time.perf_counter() - t0))
     assert not errs, errs[0]
-    print("AB " + json.dumps({"lib": os.path.basename(kzg.LIB_PATH), "lone_ms_median": round(statistics.median(lone), 3), "sustained_blobs_per_s_median": round(statistics.median(rates)),
+    gs = {k: ctx.get_option(k) for k in ("graph_launches", "graph_instantiations", "graph_fallbacks")}
+    print("AB " + json.dumps({"graphs": gs, "lib": os.path.basename(kzg.LIB_PATH), "lone_ms_median": round(statistics.median(lone), 3), "sustained_blobs_per_s_median": round(statistics.median(rates)),
                               "sustained_each": [round(r) for r in rates]}), flush=True)
     ctx.close()
 

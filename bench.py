@@ -829,11 +829,16 @@ def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, se
     return out
 
 
-def bench_multi_in_process(kzg, torch, n_dev, B=256, N=1024, reps=4):
+def bench_multi_in_process(kzg, torch, n_dev, B=256, N=1024, reps=4, devices=None):
     """The form ONE Go process on a multi-GPU node would use (verify.go:152-169: one shared Context, many goroutines): a single context
     over n_dev devices (mkzg_ctx_new with n_dev ids, api_multi.hip), host-pointer batches cut into contiguous shards inside the library,
     the batch verifiers' per-device sums added in process -- no RCCL, no ranks.  Runs on rank 0 after every rank's own context is closed
     (the tables of both forms do not fit one GPU's HBM together).  Host-pointer batches of n_dev x the per-GPU sizes of the headline legs."""
+    if os.environ.get("BENCH_INPROC_DEVICES"):          # test aid for a 1-GPU box: e.g. "0,0" = two peers on the one GPU (tests/test_gpu_bench_multirank.py)
+        devices = [int(x) for x in os.environ["BENCH_INPROC_DEVICES"].split(",")]
+        n_dev = len(devices)
+        if os.environ.get("BENCH_INPROC_SIZES"):
+            B, N = (int(x) for x in os.environ["BENCH_INPROC_SIZES"].split(","))
     if n_dev < 2:
         return {"skipped": "one device (--gpus 1, or one device visible): the in-process multi-device context is the single-device context"}
     try:
@@ -842,8 +847,8 @@ def bench_multi_in_process(kzg, torch, n_dev, B=256, N=1024, reps=4):
         pass
     os.environ["MKZG_POOL_AFFINITY"] = "1"
     L = kzg.lib()
-    ctx = kzg.Context(devices=list(range(n_dev)))
-    out = {"devices": n_dev, "host_threads": int(ctx.get_option("host_threads") or 0)}
+    ctx = kzg.Context(devices=devices if devices is not None else list(range(n_dev)))
+    out = {"devices": n_dev, "device_ids": devices if devices is not None else list(range(n_dev)), "host_threads": int(ctx.get_option("host_threads") or 0)}
     try:
         torch.cuda.set_device(0)
         nb, nv = B * n_dev, N * n_dev

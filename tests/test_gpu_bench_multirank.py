@@ -95,3 +95,20 @@ def test_exchange_on_rccl_with_one_rank():
     le = v["library_exchange"]
     assert "error" not in le and le["blobs_per_s"] > 0 and le["exchange_us_per_call_this_rank"] > 0, le
     assert d["verify_metric"]["value"] == v["value"] and d["verify_metric"]["n_gpus"] == 1
+
+
+def test_in_process_multi_device_leg_on_one_gpu():
+    """bench.py's multi_gpu.in_process leg (ONE context over all the job's devices, the form a single Go process uses) has never met a
+    node with two GPUs: run its child process with devices = [0, 0] -- two peers on the one GPU -- at small sizes, so that the day an
+    8-GPU node appears the leg is not running for the first time"""
+    env = dict(os.environ, BENCH_INPROC_DEVICES="0,0", BENCH_INPROC_SIZES="32,64", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--in-process-leg", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    got = [ln for ln in r.stdout.splitlines() if ln.startswith("IN_PROCESS ")]
+    assert got, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(got[-1][len("IN_PROCESS "):])
+    assert "error" not in d, d
+    assert d["devices"] == 2 and d["blob_to_kzg_commitment_batch"]["blobs"] == 64 and d["blob_to_kzg_commitment_batch"]["blobs_per_s"] > 0
+    assert d["verify_blob_kzg_proof_batch"]["blobs"] == 128 and d["verify_blob_kzg_proof_batch"]["blobs_per_s"] > 0 and d["tables_on_own_device"] == 1

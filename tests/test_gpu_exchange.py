@@ -83,6 +83,19 @@ def test_cell_exchange_world_1(gpu_ctx, product, comm):
     assert L.mkzg_verify_cell_kzg_proof_batch_exchange(comm, cj, idx, arr, pj, n, 2 * n) == product.ERR_BATCH_LENGTH
     idx2 = (C.c_uint64 * n)(*([t[1] for t in tuples[:-1]] + [128]))
     assert L.mkzg_verify_cell_kzg_proof_batch_exchange(comm, cj, idx2, arr, pj, n, n) == product.ERR_INVALID_CELL_ID
+    # this rank's cells contiguous in HBM (round 5: mkzg_verify_cell_kzg_proof_batch_exchange_device)
+    import torch
+    d_cells = torch.frombuffer(bytearray(b"".join(t[2] for t in tuples)), dtype=torch.uint8).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    idx_p = C.cast(idx, C.c_void_p)
+    assert L.mkzg_verify_cell_kzg_proof_batch_exchange_device(comm, cj, idx_p, d_cells.data_ptr(), pj, n, n, st) == 0
+    assert L.mkzg_verify_cell_kzg_proof_batch_exchange_device(comm, cj, idx_p, d_cells.data_ptr(), bad, n, n, st) == VERIFY_FAILED
+    assert L.mkzg_verify_cell_kzg_proof_batch_exchange_device(comm, cj, idx_p, d_cells.data_ptr(), pj, n, n + 3, st) == product.ERR_BATCH_LENGTH
+    assert L.mkzg_verify_cell_kzg_proof_batch_exchange_device(comm, cj, C.cast(idx2, C.c_void_p), d_cells.data_ptr(), pj, n, n, st) == product.ERR_INVALID_CELL_ID
+    assert L.mkzg_verify_cell_kzg_proof_batch_exchange_device(comm, cj, idx_p, None, pj, n, n, st) == product.ERR_BAD_ARGS     # a rank-local argument error, through the collectives
+    d_cells[2048 * 5 + 64:2048 * 5 + 96] = torch.frombuffer(bytearray(R_MOD.to_bytes(32, "big")), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    assert L.mkzg_verify_cell_kzg_proof_batch_exchange_device(comm, cj, idx_p, d_cells.data_ptr(), pj, n, n, st) == 3                # a non-canonical cell: the reference's input error
 
 
 def test_wrapping_a_foreign_communicator_is_refused_without_one(gpu_ctx, product):

@@ -49,7 +49,7 @@ static void caller(mkzg_ctx* ctx, int id, int rounds, int my_device) {
     hipStream_t s;
     CHECK(hipStreamCreateWithPriority(&s, 0, id & 1 ? 0 : -1) == hipSuccess);
     for (int r = 0; r < rounds; r++) {
-        switch ((r + id) % 9) {
+        switch ((r + id) % 11) {
             case 0: CHECK(soft(mkzg_blob_to_kzg_commitment_batch(ctx, bp.data(), NB, out.data(), st.data()))); break;
             case 1: CHECK(soft(mkzg_verify_blob_kzg_proof_batch(ctx, bp.data(), cms.data(), prs.data(), NB, NB, NB))); break;
             case 2: CHECK(soft(mkzg_verify_blob_kzg_proof_batch_device(ctx, d_blobs, d_cm, d_pr, NB, s))); break;
@@ -58,6 +58,9 @@ static void caller(mkzg_ctx* ctx, int id, int rounds, int my_device) {
             case 5: CHECK(soft(mkzg_recover_cells_and_kzg_proofs(ctx, ids.data(), NC, cp.data(), NC, 0, cells.data(), proofs.data()))); break;
             case 6: CHECK(soft(mkzg_compute_blob_kzg_proof(ctx, bp[1], cms.data(), 0, out.data()))); break;
             case 7: CHECK(soft(mkzg_blob_to_kzg_commitment_batch_device(ctx, d_blobs, NB, d_out, d_st, s))); break;
+            // single-blob calls that meet on the context leave as one batch call (host_combine.hpp): leaders, members, the verifier's fallback
+            case 8: CHECK(soft(mkzg_blob_to_kzg_commitment(ctx, bp[r % NB], 0, out.data()))); break;
+            case 9: CHECK(soft(mkzg_verify_blob_kzg_proof(ctx, bp[r % NB], cms.data(), prs.data()))); break;
             default: CHECK(soft(mkzg_verify_kzg_proof(ctx, cms.data(), z.data(), y.data(), prs.data()))); break;
         }
         int dev = -1;

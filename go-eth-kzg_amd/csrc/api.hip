@@ -883,6 +883,11 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         c->opt_verify_shape = (int)value;
         return MKZG_OK;
     }
+    if (!strcmp(key, "deep_rounds")) {
+        if (value != 0 && value != 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_deep_rounds = (int)value;
+        return MKZG_OK;
+    }
     if (!strcmp(key, "launch_graphs")) {
         if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
         c->opt_launch_graphs = (int)value;
@@ -920,6 +925,7 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "verify_shape")) *value = q->opt_verify_shape;
     else if (!strcmp(key, "combine_single_calls")) *value = q->opt_combine;
     else if (!strcmp(key, "launch_graphs")) *value = q->opt_launch_graphs;
+    else if (!strcmp(key, "deep_rounds")) *value = q->opt_deep_rounds;
     else if (!strcmp(key, "graph_launches")) *value = (long)g_graph_launches.load();                 // process-wide diagnostics of lane_graph_run
     else if (!strcmp(key, "graph_instantiations")) *value = (long)g_graph_instantiations.load();
     else if (!strcmp(key, "graph_fallbacks")) *value = (long)g_graph_fallbacks.load();

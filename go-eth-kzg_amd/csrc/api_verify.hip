@@ -118,11 +118,55 @@ int draw_rlc_scalar(uint8_t r_le32[32]) { return getrandom(r_le32, 32, 0) == 32 
 // rounds in flight: THREE since round 5 (two until then).  *Measured* (tools/ab_r05_11.sh, 32 callers, one box, alternating): 2 in flight
 // 2.25-2.35 M blobs/s, 3: 2.40-2.45 M, 4: 2.35 M -- the rounds are what bounds the leg (rounds in flight x calls per round / 4 ms per
 // round), and a third one fills the gap between a round's end and its stream's next launch.  MKZG_HASH_IN_FLIGHT overrides (A/B aid).
+// FOUR with deep rounds (below: a round then holds its stream for the evaluation and the MSMs of its calls too; tools/ab_r05_27.sh, _28.sh:
+// 2.19 M with three, 2.21-2.25 M with four where plain rounds give 1.95-2.08 M with either) -- one per hardware queue of the streams' priority level.
 static int hash_in_flight() {
-    static const int v = [] { const char* e = getenv("MKZG_HASH_IN_FLIGHT"); const int n = e ? atoi(e) : 0; return n >= 1 && n <= mkzg_ctx::HASH_STREAMS_MAX ? n : 3; }();
+    static const int v = [] { const char* e = getenv("MKZG_HASH_IN_FLIGHT"); const int n = e ? atoi(e) : 0; return n >= 1 && n <= mkzg_ctx::HASH_STREAMS_MAX ? n : 4; }();
     return v;
 }
-static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, uint32_t* d_zrows, hipEvent_t ready, std::shared_ptr<HashRound>* out) {
+// DEEP ROUNDS (round 5).  A context runs ONE kernel at a time per hardware queue and has four queues per priority level for all its
+// streams (tools/ubench_streams.hip): behind its round a call used to put three more launches on its own stream --
+// evaluation, window sums, the copy back -- each of which waited its turn behind other calls' kernels and then had the queue, and a
+// fraction of the chip, to itself (192 wavefronts of window sums on 1024 SIMDs).  A call that can (device hash, r known at the call:
+// everything but the exchange forms) hands the round a DeepJob instead, and the round's leader enqueues behind the hash, on the round's
+// stream: ONE evaluation launch for all its calls (k_blob_eval_tree_jobs), a wait for every call's validation, ONE launch of all their
+// MSMs (k_vmsm_window_calls), their verdict copies.  The call waits for the round's end on the host and goes straight to its host finish.
+static bool deep_rounds_on(const mkzg_ctx* c) {
+    static const int env = getenv("MKZG_DEEP_ROUNDS") ? (atoi(getenv("MKZG_DEEP_ROUNDS")) != 0 ? 1 : 0) : -1;      // A/B aid
+    const bool on = env >= 0 ? env == 1 : c->opt_deep_rounds.load(std::memory_order_relaxed) != 0;
+    return on && !c->profiling.load(std::memory_order_relaxed);          // (the profile's per-kernel events bracket a call's own launches)
+}
+static int deep_round_launch(mkzg_ctx* c, HashRound& r, hipStream_t hs) {
+    int idx[SHA_MAX_JOBS], nd = 0;
+    for (int j = 0; j < r.jobs.count; j++) if (r.is_deep[j]) idx[nd++] = j;
+    for (int lo = 0; lo < nd; lo += DEEP_MAX_JOBS) {
+        const int cnt = std::min(DEEP_MAX_JOBS, nd - lo);
+        EvalJobs ev;
+        VmsmCalls vm;
+        ev.count = vm.count = cnt;
+        for (int q = 0; q < cnt; q++) {
+            const DeepJob& d = r.deep[idx[lo + q]];
+            ev.blobs[q] = d.blobs; ev.zrows[q] = d.zrows; ev.y_out[q] = d.y; ev.status[q] = d.st_b;
+            ev.s1[q] = d.s1; ev.s3[q] = d.s3; ev.ry[q] = d.ry;
+            memcpy(ev.r[q], d.r, 32);
+            ev.exp_offset[q] = d.exp_offset;
+            ev.n[q] = d.n;
+            vm.s1[q] = d.s1; vm.s3[q] = d.s3; vm.aff_q[q] = d.aff_q; vm.aff_c[q] = d.aff_c; vm.parts[q] = d.parts; vm.out[q] = d.wsum;
+            vm.n[q] = d.n;
+        }
+        blob_eval_jobs_device(ev, c->d_roots_brp, hs);
+        for (int q = 0; q < cnt; q++) HIPCHK(hipStreamWaitEvent(hs, r.deep[idx[lo + q]].validated, 0));
+        if (vmsm_calls_device(vm, hs)) return MKZG_ERR_BAD_ARGS;
+        HIPCHK(hipGetLastError());
+    }
+    for (int q = 0; q < nd; q++) {
+        const DeepJob& d = r.deep[idx[q]];
+        HIPCHK(hipMemcpyAsync(d.h_dst, d.d_src, d.copy_bytes, hipMemcpyDeviceToHost, hs));
+    }
+    return MKZG_OK;
+}
+static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d_commitments, int n, uint32_t* d_z, uint32_t* d_zrows, hipEvent_t ready, std::shared_ptr<HashRound>* out,
+                           const DeepJob* deep = nullptr) {
     std::shared_ptr<HashRound> r, prev;
     bool leader = false;
     {
@@ -152,10 +196,12 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
         r->jobs.zrows_out[j] = d_zrows;
         r->jobs.n[j] = n;
         r->ready[j] = ready;
+        r->is_deep[j] = deep != nullptr;
+        if (deep) r->deep[j] = *deep;
         if (leader && prev) c->hash_cv.wait(lk, [&] { return prev->launched; });
     }
     if (leader) {
-        if (prev && prev->done) {                                            // the launch that used this round's stream has finished: the stream is free
+        if (prev && prev->done) {                                            // everything the round that used this round's stream launched has finished: the stream is free
             // (a crowded context sleeps here too: hipEventSynchronize polls on this runtime, and one leader per round would keep a CPU spinning)
             if (wait_sleeping(c)) (void)wait_event_sleeping(prev->done);
             else (void)hipEventSynchronize(prev->done);
@@ -169,12 +215,19 @@ static int hash_round_join(mkzg_ctx* c, const uint8_t* d_blobs, const uint8_t* d
             hs = c->hash_stream[slot];
         }
         int rc = MKZG_OK;
+        bool any_deep = false, all_deep = true;
+        for (int j = 0; j < r->jobs.count; j++) { any_deep = any_deep || r->is_deep[j]; all_deep = all_deep && r->is_deep[j]; }
         if (hipEventCreateWithFlags(&r->done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { r->done = nullptr; rc = MKZG_ERR_HIP; }
+        // `hashed`: for the calls of a mixed round that carry on in their own streams (the exchange forms, whose r is still on its way)
+        if (!rc && any_deep && !all_deep && hipEventCreateWithFlags(&r->hashed, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { r->hashed = nullptr; rc = MKZG_ERR_HIP; }
         for (int j = 0; j < r->jobs.count && !rc; j++)
             if (r->ready[j] && hipStreamWaitEvent(hs, r->ready[j], 0) != hipSuccess) rc = MKZG_ERR_HIP;
         if (!rc) {
             challenge_jobs_device(r->jobs, hs);
-            if (hipGetLastError() != hipSuccess || hipEventRecord(r->done, hs) != hipSuccess) rc = MKZG_ERR_HIP;
+            if (hipGetLastError() != hipSuccess) rc = MKZG_ERR_HIP;
+            if (!rc && r->hashed && hipEventRecord(r->hashed, hs) != hipSuccess) rc = MKZG_ERR_HIP;
+            if (!rc && any_deep) rc = deep_round_launch(c, *r, hs);
+            if (hipEventRecord(r->done, hs) != hipSuccess && !rc) rc = MKZG_ERR_HIP;      // (recorded whatever happened: the stream's next round waits for it)
         }
         if (rc) (void)hipGetLastError();
         {
@@ -304,6 +357,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     uint32_t* d_wsum = L->d_v_misc + 16;
     const size_t parts_per_job = (size_t)VMSM_WINDOWS * VMSM_KMAX * 64, wsum_per_job = (size_t)VMSM_WINDOWS * 48;
     int vrc = 0;
+    bool deep = false;                          // the call's round launches what follows the hash (deep rounds)
     bool tp_ry = false;                         // the call's sum r^i y_i is added up on the host from L->d_v_ry (throughput shape)
     bool tp_copy_enqueued = false;              // ... and the verdict block's copy back is on the stream already (throughput shape: part of its launch graph)
     // 1. decode + validate the points (serialization.go:108-115)
@@ -343,13 +397,26 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
         } else if (tp) {
             std::shared_ptr<HashRound> round;                                // the hash of this call and of whoever else is waiting for one
             CPU_LAP(0);
+            DeepJob dj;
+            deep = !late && deep_rounds_on(c);                               // (r is known: not an exchange form still waiting for its collective)
+            if (deep) {
+                dj.validated = L->ev_join;                                   // recorded above, behind the validation on this call's stream
+                dj.blobs = d_blobs; dj.zrows = L->d_v_zrows; dj.y = L->d_v_y; dj.st_b = st_b;
+                dj.s1 = L->d_v_s1; dj.s3 = L->d_v_s3; dj.ry = L->d_v_ry;
+                memcpy(dj.r, r_words, 32);
+                dj.exp_offset = exp_offset;
+                dj.n = (int)n;
+                dj.aff_q = aff_q; dj.aff_c = aff_c; dj.parts = d_parts; dj.wsum = d_wsum;
+                dj.h_dst = L->h_v; dj.d_src = L->d_v_block; dj.copy_bytes = verdict_block_bytes(cap, n);
+            }
             // (the round's launch also leaves what the evaluation needs of each z alone: L->d_v_zrows)
-            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->d_v_zrows, s_idle ? nullptr : L->ev_fork, &round);   // ev_fork: recorded on s before any of this call's kernels
+            rc = hash_round_join(c, d_blobs, d_commitments, (int)n, L->d_v_z, L->d_v_zrows, s_idle ? nullptr : L->ev_fork, &round, deep ? &dj : nullptr);   // ev_fork: recorded on s before any of this call's kernels
             CPU_LAP(1);
-            if (round && round->done) {                                      // on the host: a device-side wait would hold the call's queue
+            hipEvent_t wait_for = round ? ((!deep && round->hashed) ? round->hashed : round->done) : nullptr;
+            if (wait_for) {                                                  // on the host: a device-side wait would hold the call's queue
                 int wr = MKZG_OK;
-                if (wait_sleeping(c)) wr = wait_event_sleeping(round->done);
-                else if (hipEventSynchronize(round->done) != hipSuccess) { (void)hipGetLastError(); wr = MKZG_ERR_HIP; }
+                if (wait_sleeping(c)) wr = wait_event_sleeping(wait_for);
+                else if (hipEventSynchronize(wait_for) != hipSuccess) { (void)hipGetLastError(); wr = MKZG_ERR_HIP; }
                 if (wr) {
                     // the round's kernels may still be writing this lane's challenges and rows: nobody gets the lane before the rounds' streams are idle
                     tl_hip_error = true;
@@ -370,7 +437,11 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
             HIPCHK(hipEventRecord(L->ev_join, s2));
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
-        if (tp) {
+        if (tp && deep) {
+            // the round has run this call's evaluation and MSMs and copied its verdict block back (deep rounds, above)
+            tp_ry = true;
+            tp_copy_enqueued = true;
+        } else if (tp) {
             // throughput shape: every launch is time on the call's hardware queue, which it shares with other calls' streams -- the
             // evaluation's z-only rows came with the round's hash launch, the evaluation kernel's last lane leaves the blob's r^i, r^i z_i and
             // r^i y_i (the host adds the latter up), and ONE launch takes the three MSMs of kzg_verify.go:150,225,179

@@ -205,13 +205,39 @@ struct Lane {
 };
 
 // One launch of the Fiat-Shamir hash kernel for all the calls that were waiting for one (api_verify.hip hash_round_join)
+// What a call of the blob verifier's throughput shape hands its round so that the ROUND carries on behind the hash (deep rounds,
+// api_verify.hip): the evaluation of its blobs with its share of the random linear combination, its three MSMs, its verdict block's
+// copy back -- on the round's stream, the first two as ONE launch each for all the round's calls.
+struct DeepJob {
+    hipEvent_t validated = nullptr;             // recorded on the call's stream behind the validation of its points (the MSMs read their affine rows)
+    const uint8_t* blobs = nullptr;
+    const uint32_t* zrows = nullptr;
+    uint32_t* y = nullptr;
+    int* st_b = nullptr;
+    uint32_t* s1 = nullptr;
+    uint32_t* s3 = nullptr;
+    uint32_t* ry = nullptr;
+    uint32_t r[8] = {};
+    uint32_t exp_offset = 0;
+    int n = 0;
+    const uint32_t* aff_q = nullptr;
+    const uint32_t* aff_c = nullptr;
+    uint32_t* parts = nullptr;
+    uint32_t* wsum = nullptr;
+    void* h_dst = nullptr;                      // the verdict block: device -> the lane's pinned mirror
+    const void* d_src = nullptr;
+    size_t copy_bytes = 0;
+};
 struct HashRound {
     kzg::ShaJobs jobs{};
     hipEvent_t ready[kzg::SHA_MAX_JOBS] = {};   // per job: its inputs are ready on the call's stream
-    hipEvent_t done = nullptr;                  // the launch has finished
+    DeepJob deep[kzg::SHA_MAX_JOBS];
+    bool is_deep[kzg::SHA_MAX_JOBS] = {};
+    hipEvent_t hashed = nullptr;                // the hash launch has finished (what a call that carries on in its own stream waits for)
+    hipEvent_t done = nullptr;                  // everything the round launched has finished
     bool launched = false;
     int rc = 0;
-    ~HashRound() { if (done) (void)hipEventDestroy(done); }
+    ~HashRound() { if (done) (void)hipEventDestroy(done); if (hashed) (void)hipEventDestroy(hashed); }
 };
 
 struct mkzg_ctx {
@@ -254,6 +280,7 @@ struct mkzg_ctx {
     kzg::Combiner<CommitCall> comb_commit;
     kzg::Combiner<CellsCall> comb_cells;
     kzg::Combiner<VerifyCall> comb_verify;
+    std::atomic<int> opt_deep_rounds{1};               // "deep_rounds": the blob verifier's hash rounds also launch their calls' evaluations and MSMs (one launch each per round) and copy the verdicts back; 0: every call carries on in its own stream
     std::atomic<int> opt_launch_graphs{0};             // "launch_graphs": 1 replays fixed launch sequences through executable graphs (lane_graph_run), 0 (default, by measurement) launches one by one
     std::atomic<int> opt_combine{1};                   // "combine_single_calls": 1 (default) groups concurrent single-blob calls, 0 every call on its own
     std::atomic<int> opt_verify_shape{-1};             // VerifyBlobKZGProofBatch: latency shape (0), throughput shape (1), by the calls in flight (-1); api_verify.hip

@@ -25,6 +25,36 @@ struct ShaJobs {
     int count;
 };
 void challenge_jobs_device(ShaJobs& jobs, hipStream_t s);
+// DEEP ROUNDS (api_verify.hip): what follows the challenges of a round's calls -- y = f(z) with the calls' shares of the random linear
+// combination, then their three MSMs each -- as ONE launch per step over up to DEEP_MAX_JOBS calls (kernel arguments: 1.7 KB / 1.0 KB)
+constexpr int DEEP_MAX_JOBS = 16;
+struct EvalJobs {
+    const uint8_t* blobs[DEEP_MAX_JOBS];
+    const uint32_t* zrows[DEEP_MAX_JOBS];       // from the round's hash launch (ShaJobs::zrows_out)
+    uint32_t* y_out[DEEP_MAX_JOBS];
+    int* status[DEEP_MAX_JOBS];
+    uint32_t* s1[DEEP_MAX_JOBS];                // r^i, r^i z_i (the MSMs' scalars), r^i y_i (for the host), 8 plain words per blob
+    uint32_t* s3[DEEP_MAX_JOBS];
+    uint32_t* ry[DEEP_MAX_JOBS];
+    uint32_t r[DEEP_MAX_JOBS][8];
+    uint32_t exp_offset[DEEP_MAX_JOBS];
+    int n[DEEP_MAX_JOBS];
+    int first_block[DEEP_MAX_JOBS];
+    int count;
+};
+struct VmsmCalls {
+    const uint32_t* s1[DEEP_MAX_JOBS];
+    const uint32_t* s3[DEEP_MAX_JOBS];
+    const uint32_t* aff_q[DEEP_MAX_JOBS];       // the call's proofs / commitments as affine rows
+    const uint32_t* aff_c[DEEP_MAX_JOBS];
+    uint32_t* parts[DEEP_MAX_JOBS];             // 3 x [32][VMSM_KMAX][64] words of slice sums (tickets zero)
+    uint32_t* out[DEEP_MAX_JOBS];               // 3 x [32][48] words
+    int n[DEEP_MAX_JOBS];
+    int k[DEEP_MAX_JOBS];
+    int count;
+};
+void blob_eval_jobs_device(EvalJobs& jobs, const uint32_t* d_roots, hipStream_t s);
+int vmsm_calls_device(VmsmCalls& calls, hipStream_t s);
 // d_zrows: n x blob_eval_scratch_words() words of scratch (what depends on z alone, from a one-lane-per-blob kernel ahead of the evaluation)
 size_t blob_eval_scratch_words();
 // rows_ready: d_zrows were written by the challenge launch already (ShaJobs::zrows_out, challenge_device's d_zrows).  h_r8 (HOST pointer to the eight words of r, may be

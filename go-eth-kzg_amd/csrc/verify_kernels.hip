@@ -542,12 +542,12 @@ __device__ __forceinline__ void evt_subtree(fr_t& out, int node, EvtCtx& cx) {
     }
 }
 template <int LOG>
-__global__ void __launch_bounds__(4096 >> LOG) k_blob_eval_tree(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ zrows, const uint32_t* __restrict__ roots_brp,
-                                                               uint32_t* __restrict__ y_out, int* __restrict__ status, const RlcOut rlc) {
+__device__ __forceinline__ void evt_blob_block(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ zrows, const uint32_t* __restrict__ roots_brp,
+                                               uint32_t* __restrict__ y_out, int* __restrict__ status, const RlcOut& rlc, const int b) {
     constexpr int T = 4096 >> LOG;
     __shared__ uint32_t sh[T * 9];
     __shared__ int sh_bad;
-    const int b = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     if (t == 0) sh_bad = 0;
     EvtCtx cx;
     cx.blob = blobs + (size_t)b * 131072;
@@ -595,6 +595,28 @@ __global__ void __launch_bounds__(4096 >> LOG) k_blob_eval_tree(const uint8_t* _
             if (rlc.s1) rlc_one_blob(rlc, b, z, y);
         }
     }
+}
+template <int LOG>
+__global__ void __launch_bounds__(4096 >> LOG) k_blob_eval_tree(const uint8_t* __restrict__ blobs, const uint32_t* __restrict__ zrows, const uint32_t* __restrict__ roots_brp,
+                                                               uint32_t* __restrict__ y_out, int* __restrict__ status, const RlcOut rlc) {
+    evt_blob_block<LOG>(blobs, zrows, roots_brp, y_out, status, rlc, (int)blockIdx.x);
+}
+// the evaluations of SEVERAL calls in one launch, behind their hash round on the round's stream (api_verify.hip, deep rounds): a context
+// runs one kernel at a time per hardware queue, so a call's own launch waits its turn behind other calls' kernels
+// and then fills the chip alone -- a round's worth of blobs in one launch does neither
+template <int LOG>
+__global__ void __launch_bounds__(4096 >> LOG) k_blob_eval_tree_jobs(const EvalJobs jobs, const uint32_t* __restrict__ roots_brp) {
+    int j = 0;
+#pragma unroll 1
+    while (j + 1 < jobs.count && (int)blockIdx.x >= jobs.first_block[j + 1]) j++;
+    RlcOut rlc;
+    rlc.s1 = jobs.s1[j];
+    rlc.s3 = jobs.s3[j];
+    rlc.ry = jobs.ry[j];
+    rlc.exp_offset = jobs.exp_offset[j];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rlc.r.w[i] = jobs.r[j][i];
+    evt_blob_block<LOG>(jobs.blobs[j], jobs.zrows[j], roots_brp, jobs.y_out[j], jobs.status[j], rlc, (int)blockIdx.x - jobs.first_block[j]);
 }
 
 // MODE 0: y_b = f_b(z_b)                                  -> y_out   (the per-lane Montgomery trick; kept for MODE 1 and as the A/B of the tree)
@@ -1119,18 +1141,18 @@ struct VmsmJobs { VmsmJob j[4]; int k[4]; };    // k: point-range slices per (jo
 #ifndef MKZG_VMSM_RESERVE
 #define MKZG_VMSM_RESERVE "a89"             // 256 + 90 registers: what the kernel held before round 5 (344) -- a challenge-hash wavefront (153) still fits beside it, a second chain does not
 #endif
-__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __restrict__ parts /* [msm][VNWIN][VMSM_KMAX][64] XYZZ */, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
+// one (window w, slice z of K) of ONE MSM; parts_m: that MSM's [VNWIN][VMSM_KMAX][64] slice sums (with the tickets), out_m: its [VNWIN][48] window sums
+__device__ __forceinline__ void vmsm_window_block(const VmsmJob& job, const int K, uint32_t* __restrict__ parts_m, uint32_t* __restrict__ out_m, const int w, const int z) {
     __shared__ uint32_t ent[VMAXN];
     __shared__ uint32_t hist[VNB + 1];
     __shared__ uint32_t cursor[VNB];
     __shared__ uint32_t xchg[2 * 56];
     __shared__ int last_flag;
-    asm volatile("" ::: MKZG_VMSM_RESERVE);
-    const int w = blockIdx.x, m = blockIdx.y, t = threadIdx.x, z = blockIdx.z;
-    if (z >= jobs.k[m]) return;
-    const int n_all = jobs.j[m].n, lo = (int)((long long)n_all * z / jobs.k[m]), hi = (int)((long long)n_all * (z + 1) / jobs.k[m]);
-    const uint32_t* sc = jobs.j[m].scalars + (size_t)lo * 8;
-    const uint32_t* pts = jobs.j[m].points + (size_t)lo * 32;
+    const int t = threadIdx.x;
+    if (z >= K) return;
+    const int n_all = job.n, lo = (int)((long long)n_all * z / K), hi = (int)((long long)n_all * (z + 1) / K);
+    const uint32_t* sc = job.scalars + (size_t)lo * 8;
+    const uint32_t* pts = job.points + (size_t)lo * 32;
     const int n = hi - lo;
     hist[t] = 0;
     if (t == 0) hist[VNB] = 0;
@@ -1203,12 +1225,12 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
             for (int i = 0; i < 14; i++) v.l[i] = q[i * stride];
         }
     };
-    const int lane = t & 63, wave = t >> 6, K = jobs.k[m];
+    const int lane = t & 63, wave = t >> 6;
     G1X Pf = acc;
     __syncthreads();                                        // every lane is through with ent[]
     uint32_t* snap = ent;                                   // [56][VNB]
-    uint32_t* mine = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + z) * 64;
-    uint32_t* ticket = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX) * 64 + 56;
+    uint32_t* mine = parts_m + ((size_t)w * VMSM_KMAX + z) * 64;
+    uint32_t* ticket = parts_m + ((size_t)w * VMSM_KMAX) * 64 + 56;
     int rounds = 14;
 #pragma unroll 1
     for (int round = 0; round < rounds; round++) {
@@ -1223,7 +1245,7 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
                 }
             } else if (t == 0) {                            // another slice's sum (published before the ticket we took: pub_ticket.hpp)
                 const int zz = round - 14 < z ? round - 14 : round - 13;
-                const uint32_t* o = parts + (((size_t)m * VNWIN + w) * VMSM_KMAX + zz) * 64;
+                const uint32_t* o = parts_m + ((size_t)w * VMSM_KMAX + zz) * 64;
 #pragma unroll
                 for (int i = 0; i < 56; i++) x[i] = pub_load(o + i);
             }
@@ -1260,7 +1282,7 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
         if (round >= 13) __syncthreads();                   // xchg is rewritten by the next round
     }
     if (t == 0) {                                           // canonical plain coordinates (all-zero = identity) for the host's Horner step
-        uint32_t* dst = out + ((size_t)m * VNWIN + w) * 48;
+        uint32_t* dst = out_m + (size_t)w * 48;
         const bool inf = g1x_is_inf(Pf);
         fp_t c;
         uint32_t ww[12];
@@ -1275,6 +1297,22 @@ __global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __
             for (int qq = 0; qq < 12; qq++) dst[12 * k + qq] = inf ? 0u : ww[qq];
         }
     }
+}
+__global__ void __launch_bounds__(VNB) k_vmsm_window(VmsmJobs jobs, uint32_t* __restrict__ parts /* [msm][VNWIN][VMSM_KMAX][64] XYZZ */, uint32_t* __restrict__ out /* [msm][VNWIN][48] */) {
+    asm volatile("" ::: MKZG_VMSM_RESERVE);
+    const int m = blockIdx.y;
+    vmsm_window_block(jobs.j[m], jobs.k[m], parts + (size_t)m * VNWIN * VMSM_KMAX * 64, out + (size_t)m * VNWIN * 48, (int)blockIdx.x, (int)blockIdx.z);
+}
+// the three MSMs of the blob verifier (kzg_verify.go:150,225,179: sum r^i Q_i, sum r^i C_i, sum r^i z_i Q_i) of SEVERAL calls in one launch
+// (deep rounds, api_verify.hip): grid (window, 3 x call, slice); every call brings its own scratch and output (its lane's verdict block)
+__global__ void __launch_bounds__(VNB) k_vmsm_window_calls(const VmsmCalls calls) {
+    asm volatile("" ::: MKZG_VMSM_RESERVE);
+    const int j = (int)blockIdx.y / 3, m = (int)blockIdx.y % 3;
+    VmsmJob job;
+    job.scalars = m == 2 ? calls.s3[j] : calls.s1[j];
+    job.points = m == 1 ? calls.aff_c[j] : calls.aff_q[j];
+    job.n = calls.n[j];
+    vmsm_window_block(job, calls.k[j], calls.parts[j] + (size_t)m * VNWIN * VMSM_KMAX * 64, calls.out[j] + (size_t)m * VNWIN * 48, (int)blockIdx.x, (int)blockIdx.z);
 }
 // The same, a QUAD of lanes per bucket (g1_quad.hpp): for the MSM a lone caller WAITS for -- sum r^i z_i Q_i of the blob batch verifier
 // can only start when the challenge hash has finished, and what it costs is the length of its dependent chain: the bucket walk and then
@@ -1544,6 +1582,25 @@ void challenge_jobs_device(ShaJobs& jobs, hipStream_t s) {
     if (blocks > 0) hipLaunchKernelGGL(k_challenge_sha256_jobs, dim3(blocks), dim3(256), 0, s, jobs);
 }
 size_t blob_eval_scratch_words() { return (size_t)EVT_ROWS * 12; }
+void blob_eval_jobs_device(EvalJobs& jobs, const uint32_t* d_roots, hipStream_t s) {
+    int blocks = 0;
+    for (int j = 0; j < jobs.count; j++) {
+        jobs.first_block[j] = blocks;
+        blocks += jobs.n[j];
+    }
+    if (blocks > 0) hipLaunchKernelGGL((k_blob_eval_tree_jobs<EVT_LOG>), dim3(blocks), dim3(4096 >> EVT_LOG), 0, s, jobs, d_roots);
+}
+int vmsm_calls_device(VmsmCalls& calls, hipStream_t s) {
+    int kmax = 1;
+    if (calls.count < 1 || calls.count > DEEP_MAX_JOBS) return -1;
+    for (int j = 0; j < calls.count; j++) {
+        if (calls.n[j] < 1 || calls.n[j] > VMAXN) return -1;
+        calls.k[j] = std::min(VMSM_KMAX, std::max(1, calls.n[j] / 2048));
+        kmax = std::max(kmax, calls.k[j]);
+    }
+    hipLaunchKernelGGL(k_vmsm_window_calls, dim3(VNWIN, 3 * calls.count, kmax), dim3(VNB), 0, s, calls);
+    return 0;
+}
 void blob_eval_device(const uint8_t* d_blobs, const uint32_t* d_z, const uint32_t* d_roots, const uint32_t* d_inv_roots, int n, uint32_t* d_y, int* d_status, uint32_t* d_zrows,
                       hipStream_t s, bool rows_ready, const uint32_t* h_r8, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_ry) {
 #ifdef MKZG_EVAL_LANE_TRICK

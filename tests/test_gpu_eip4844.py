@@ -446,13 +446,19 @@ def test_hash_rounds_many_callers(product, oracle_ctx):
             import traceback
             errors.append(traceback.format_exc())
 
-    for rep in range(2):
-        ts = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join(timeout=600)
-        assert not errors, errors[0]
+    # deep rounds (the default: the round also launches its calls' evaluations and MSMs, one launch each, and copies the verdicts back) and
+    # plain ones; 28 callers, so that rounds of more than DEEP_MAX_JOBS = 16 calls can form (two launches per step)
+    assert ctx.get_option("deep_rounds") == 1
+    for deep, callers in ((1, 12), (1, 28), (0, 12)):
+        assert ctx.set_option("deep_rounds", deep) == 0
+        for rep in range(2):
+            ts = [threading.Thread(target=worker, args=(k % 12,)) for k in range(callers)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join(timeout=600)
+            assert not errors, errors[0]
+    assert ctx.set_option("deep_rounds", 2) != 0
     ctx.close()
 
 

@@ -32,8 +32,15 @@ def main():
     torch.cuda.synchronize()
     cms, cells, proofs = d_cm.cpu().numpy().tobytes(), d_cells.cpu().numpy().tobytes(), d_proofs.cpu().numpy().tobytes()
     n = NB * 128
-    keep = [ctypes.create_string_buffer(cells[i * 2048:(i + 1) * 2048], 2048) for i in range(n)]
-    arr = (ctypes.c_char_p * n)(*[ctypes.cast(k, ctypes.c_char_p) for k in keep])
+    # every caller gets its OWN copies of the cells (CV_SHARED_CELLS=1: all callers read the same 16 MiB, which then live in the CPU's
+    # caches -- what this tool did until the end of round 5, and 10-15 % more than bench.py's leg with distinct cells reports)
+    shared = os.environ.get("CV_SHARED_CELLS") == "1"
+    kmax = 1 if shared else max([int(x) for x in os.environ["CV_CALLERS"].split(",")] if os.environ.get("CV_CALLERS") else [16])
+    keeps, arrs = [], []
+    for _ in range(kmax):
+        keep = [ctypes.create_string_buffer(cells[i * 2048:(i + 1) * 2048], 2048) for i in range(n)]
+        keeps.append(keep)
+        arrs.append((ctypes.c_char_p * n)(*[ctypes.cast(k, ctypes.c_char_p) for k in keep]))
     idx = (ctypes.c_uint64 * n)(*[i % 128 for i in range(n)])
     cj = b"".join(cms[48 * (i // 128):48 * (i // 128) + 48] for i in range(n))
     bad = bytearray(proofs)
@@ -55,6 +62,7 @@ def main():
                         assert L.mkzg_verify_cell_kzg_proof_batch_device(ctx._h, cj, ctypes.cast(idx, ctypes.c_void_p), ctypes.c_void_p(d_all.data_ptr()), proofs, n, ctypes.c_void_p(st.cuda_stream)) == 0
                     assert L.mkzg_verify_cell_kzg_proof_batch_device(ctx._h, cj, ctypes.cast(idx, ctypes.c_void_p), ctypes.c_void_p(d_all.data_ptr()), bad, n, ctypes.c_void_p(st.cuda_stream)) == 1
                     return
+                arr = arrs[k % len(arrs)]
                 for _ in range(reps):
                     assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, proofs, n) == 0
                 assert L.mkzg_verify_cell_kzg_proof_batch(ctx._h, cj, n, idx, n, arr, n, bad, n) == 1

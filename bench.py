@@ -1162,7 +1162,9 @@ def bench_verify(ctx, torch, dist, dist_on, dev, world, rank, args, d_blobs256, 
     if K > 1:
         # at N > 1 every rank runs this leg on ITS OWN batches at the same time (a node verifying many batches: no exchange -- the one
         # exchange step exists only where a single batch spans the GPUs, which is `single_call` / `strong_scaling`); the rates add up
-        reps = max(12, args.verify_steps)                # long enough to leave the ramp-up of the first hash rounds behind
+        # long enough to leave the start-up convoy behind (all callers start together; a round is 5-7 ms): *measured* (round 5, one box, tools/trace.py
+        # verify_inflight 32 N) 12 calls per caller 1.96-2.01 M blobs/s, 26: 2.21 M, 50: 2.22-2.26 M -- 30 + 1 calls per caller, ~0.45 s per trial
+        reps = max(30, args.verify_steps)
         errs = []
         # DISTINCT inputs: `--ring` sets of N (blob, commitment, proof) triples resident in HBM (8 x 134 MB: four times the Infinity
         # Cache), caller k verifies set k mod ring -- the algorithmic bytes of this leg really stream from HBM
@@ -1326,7 +1328,7 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
         # sustained: eight caller threads on the shared context (four until round 3: 17.2-17.7 k blobs/s against 18.6-18.8 k), each
         # pipelining calls of NB blobs on its own stream -- one call's latency-bound network of 686 scalar multiplications (two thirds
         # of the SIMDs, one wavefront each) runs beside another call's VALU-bound MSM
-        KC, reps = 8, 4
+        KC, reps = 8, 10                                 # (trials longer than the start-up convoy: ~0.3 s each)
         # every caller its own NB distinct blobs (and the proofs a serial call gives for them, to compare with)
         csets = []
         for k in range(KC):
@@ -1488,7 +1490,11 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
         badp = bytearray(proofs)
         badp[0:48] = proofs[48:96]
         badp = bytes(badp)
-        KV, reps = 12, 9                                 # measured (tools/bench_cellverify_inflight.py, one box, verdicts into pinned memory): 4 callers 8.5-9.5, 8: 7.4-9.8, 12: 8.9, 16: 8.3, 24: 8.4 M cells/s
+        # KV: measured (tools/bench_cellverify_inflight.py, one box, verdicts into pinned memory): 4 callers 8.5-9.5, 8: 7.4-9.8, 12: 8.9, 16: 8.3, 24: 8.4 M cells/s
+        # reps: all callers start together and move in step for their first calls (twelve gathers, then twelve uploads, ...): *measured* (round 5, one box, distinct cells
+        # per caller) 9 calls per caller 9.3-9.8 M cells/s with trials of 8.9-12.2, 30 calls 10.8-10.9 M (10.5-11.5), 60 calls 11.5 M (11.3-11.6) -- a SUSTAINED rate needs
+        # trials longer than the start-up convoy: 36 + 1 calls per caller, ~0.35 s per trial
+        KV, reps = 12, 36
         errs = []
         # every caller its own NB x 128 (commitment, index, cell, proof) tuples in host memory (12 x 17.6 MB)
         vsets = [(cj, arr, proofs, badp, keep)]

@@ -110,12 +110,12 @@ int draw_rlc_scalar(uint8_t r_le32[32]) { return getrandom(r_le32, 32, 0) == 32 
 // queue for 3 ms at a time and a context verified ~0.65 M blobs/s however many callers it had.  So calls that find other calls in
 // flight do not launch the hash themselves: they join the ROUND that is forming.  The first caller to find no round forming opens one
 // and leads it: it waits until the round before the previous one has finished (on the host; whoever arrives meanwhile joins), closes
-// the round and launches ONE kernel over all its jobs on one of the context's two hash streams (rounds alternate, two are in flight)
+// the round and launches ONE kernel over all its jobs on one of the context's hash streams (rounds take them in turn: hash_in_flight() are in flight)
 // -- streams of the lowest priority, so that no other stream of the process shares their queues.  Everyone then waits for the round on the host (the call is synchronous anyway; a device-side wait
 // would hold the call's own queue, and with it whatever else HIP mapped there) and carries on in its own stream.
 // (A round that also validated its calls' points in one launch on a stream of its own was measured in round 4 and dropped -- DESIGN.md
 // Appendix A: the 1.3 ms chain runs in every call's own stream while the call waits for its round anyway.)
-// rounds in flight: THREE since round 5 (two until then).  *Measured* (tools/ab_r05_11.sh, 32 callers, one box, alternating): 2 in flight
+// rounds in flight: three since round 5's first session (two until then), four with deep rounds (below).  *Measured* (tools/ab_r05_11.sh, 32 callers, one box, alternating): 2 in flight
 // 2.25-2.35 M blobs/s, 3: 2.40-2.45 M, 4: 2.35 M -- the rounds are what bounds the leg (rounds in flight x calls per round / 4 ms per
 // round), and a third one fills the gap between a round's end and its stream's next launch.  MKZG_HASH_IN_FLIGHT overrides (A/B aid).
 // FOUR with deep rounds (below: a round then holds its stream for the evaluation and the MSMs of its calls too; tools/ab_r05_27.sh, _28.sh:

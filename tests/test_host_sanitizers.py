@@ -53,6 +53,16 @@ def test_host_pool_under_tsan():
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
 
 
+def test_call_combiner_under_tsan():
+    """go-eth-kzg_amd/csrc/host_combine.hpp alone: every item processed once by its group's leader, at most max_running() groups in flight,
+    a lone caller is a group of one"""
+    exe = os.path.join(SHIM_DIR, "combiner_stress_tsan")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-o", exe, os.path.join(SHIM_DIR, "combiner_stress.cpp")])
+    r = subprocess.run([exe], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+
+
 def test_host_layer_on_stub_device_under_tsan():
     """ten caller threads on one context (one of them changing options and reading the profile all the while), four on a context of the
     device they are NOT on, six on a two-device context: no runtime error, tables on their own device, the callers' current device

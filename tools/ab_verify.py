@@ -22,7 +22,7 @@ def one():
     torch.cuda.init()
     kzg = bench.load_product()
     ctx = kzg.Context(device=0)
-    N, K, reps = 1024, int(os.environ.get("AB_CALLERS", "32")), 12
+    N, K, reps = 1024, int(os.environ.get("AB_CALLERS", "32")), int(os.environ.get("AB_REPS", "30"))      # (12 calls per caller until round 5: inside the start-up convoy)
     st = torch.cuda.current_stream().cuda_stream
     sets = []
     for q in range(8):

@@ -351,6 +351,35 @@ static const size_t CELL_PIECE = VMSM_MAX_N;       // cells per fold (the variab
 // caller's stream)
 static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, const uint64_t* cell_indices, const uint8_t* const* cells, const uint8_t* d_cells,
                            const uint8_t* proofs48n, size_t n, uint32_t exp_offset, const uint32_t r_words_in[8], hipStream_t s, CellFold* out, RlcLate* late = nullptr) {
+    size_t first_nil = n;
+    if (!d_cells) for (size_t i = 0; i < n; i++) if (!cells[i]) { first_nil = i; break; }
+    int rc = ensure_verify_ws(L, n);
+    if (!rc) rc = ensure_cv_ws(L, d_cells ? 0 : n, n);
+    if (!rc) rc = ensure_staging(L, 1, (d_cells ? 0 : n * 2048) + n * 48 + n * 48 + n * 12 + 64);      // (rows: at most n of them)
+    if (rc) return rc;
+    // The cells (n x 2 KiB behind scattered host pointers) are gathered into the pinned staging area by the host pool -- all chunks' tasks
+    // queued at once, FIRST THING in the call (round 5: the timeline of a lone call showed its first upload 0.22 ms after its start, behind
+    // the commitments' deduplication and seven API calls of this thread; `tools/ab_r05_38.sh`): the pool runs ahead while this thread
+    // deduplicates, uploads the small arrays and launches the points' kernels, and waits for chunk k only when it gets there.
+    const size_t CH = 2048;
+    const size_t nch = d_cells ? 0 : (n + CH - 1) / CH;
+    const int TPC = n >= 256 ? 4 : 1;
+    std::vector<Countdown> left(nch);
+    for (auto& a : left) a.set(TPC);
+    Countdown all_left((int)nch * TPC);
+    const std::function<void(int)> gather = [&](int t) {
+        const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(n, lo + CH), per = (hi - lo + TPC - 1) / TPC, q = (size_t)(t % TPC);
+        for (size_t i = lo + q * per; i < std::min(hi, lo + (q + 1) * per); i++) {
+            if (cells[i]) copy_to_staging(L->h_stage + i * 2048, cells[i], 2048);
+            else memset(L->h_stage + i * 2048, 0, 2048);           // stands in for nil entries (reported after the device work)
+        }
+        left[k].arrive();
+    };
+    struct GatherJoin {                        // the tasks reference this frame: every way out waits for them
+        mkzg_ctx* c; Countdown* all; bool started;
+        ~GatherJoin() { if (started) c->pool->wait(*all); }
+    } gather_join{c, &all_left, false};
+    if (nch) { c->pool->run_async((int)nch * TPC, gather, &all_left); gather_join.started = true; }
     // deduplicateKZGCommitments (api_eip7594.go:238-265); per piece -- the sum over rows is linear, so pieces need not agree on the rows
     std::unordered_map<std::string, uint32_t> seen;
     std::vector<uint32_t> row_idx(n);
@@ -367,12 +396,6 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
         row_idx[i] = it->second;
     }
     const size_t n_rows = seen.size();
-    size_t first_nil = n;
-    if (!d_cells) for (size_t i = 0; i < n; i++) if (!cells[i]) { first_nil = i; break; }
-    int rc = ensure_verify_ws(L, n);
-    if (!rc) rc = ensure_cv_ws(L, d_cells ? 0 : n, n);
-    if (!rc) rc = ensure_staging(L, 1, (d_cells ? 0 : n * 2048) + n_rows * 48 + n * 48 + n * 12 + 64);
-    if (rc) return rc;
     const size_t cap = L->v_cap;
     uint32_t* h_misc = (uint32_t*)(L->h_v + 3 * cap * sizeof(int));
     // uploads, part 1: the points (small) -- their validation starts on the side stream before the 2 KiB cells are staged.  Everything
@@ -432,35 +455,11 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     }
     KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, d_cidx, d_ridx, nullptr, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp, L->d_v_s1, L->d_v_s3,
                                                        L->d_cv_weights, L->d_cv_partials, L->d_cv_interp, d_cv_st, s, 1));
-    // uploads, part 2: the cells (n x 2 KiB, scattered host pointers) are gathered into the pinned staging area by the host pool running
-    // AHEAD of this thread -- all chunks' tasks queued at once -- while the GPU validates the points; this thread waits for chunk k only
-    // and puts its copy in flight
-    if (!d_cells) {
-        const size_t CH = 2048;
-        const size_t nch = (n + CH - 1) / CH;
-        const int TPC = n >= 256 ? 4 : 1;
-        std::vector<Countdown> left(nch);
-        for (auto& a : left) a.set(TPC);
-        Countdown all_left((int)nch * TPC);
-        const std::function<void(int)> gather = [&](int t) {
-            const size_t k = (size_t)(t / TPC), lo = k * CH, hi = std::min(n, lo + CH), per = (hi - lo + TPC - 1) / TPC, q = (size_t)(t % TPC);
-            for (size_t i = lo + q * per; i < std::min(hi, lo + (q + 1) * per); i++) {
-                if (cells[i]) copy_to_staging(L->h_stage + i * 2048, cells[i], 2048);
-                else memset(L->h_stage + i * 2048, 0, 2048);           // stands in for nil entries (reported after the device work)
-            }
-            left[k].arrive();
-        };
-        c->pool->run_async((int)nch * TPC, gather, &all_left);
-        int urc = [&]() -> int {
-            for (size_t k = 0; k < nch; k++) {
-                const size_t lo = k * CH, hi = std::min(n, lo + CH);
-                c->pool->wait(left[k]);
-                HIPCHK(hipMemcpyAsync(L->d_cv_cells + lo * 2048, L->h_stage + lo * 2048, (hi - lo) * 2048, hipMemcpyHostToDevice, s));
-            }
-            return MKZG_OK;
-        }();
-        c->pool->wait(all_left);                  // the tasks reference this frame
-        if (urc) return urc;
+    // uploads, part 2: the cells, chunk by chunk as the pool (started at the top of the call) signs them off
+    for (size_t k = 0; k < nch; k++) {
+        const size_t lo = k * CH, hi = std::min(n, lo + CH);
+        c->pool->wait(left[k]);
+        HIPCHK(hipMemcpyAsync(L->d_cv_cells + lo * 2048, L->h_stage + lo * 2048, (hi - lo) * 2048, hipMemcpyHostToDevice, s));
     }
     // scalars, second part: the interpolation reads the cells
     KT(KT_CELL_SCALARS, s, cell_verify_scalars_device(r_words, exp_offset, d_cidx, d_ridx, d_cells ? d_cells : L->d_cv_cells, (int)n, (int)n_rows, c->d_tw_fwd, c->d_tw_inv, L->d_cv_rp,

@@ -27,13 +27,29 @@ def _run(extra_env, launcher, gpus=2, sizes=("32", "32", "3")):
         del env["BENCH_SHARE_GPU"]
     args = ["--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--repeats", "2", "--batch", sizes[0], "--direct-bits", "12", "--verify-batch", sizes[1], "--verify-steps", "1",
             "--cell-blobs", sizes[2], "--no-cpu-baseline"]
-    cmd = launcher + [os.path.join(ROOT, "bench.py")] + args
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    assert r.stdout.strip().splitlines()[-1] == lines[0], "the JSON line must be the last line on stdout (RCCL / gloo print banners there too)"
-    return json.loads(lines[0])
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        cmd = launcher + [os.path.join(ROOT, "bench.py")] + args + ["--detail-out", detail]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        assert r.stdout.strip().splitlines()[-1] == lines[0], "the JSON line must be the last line on stdout (RCCL / gloo print banners there too)"
+        # the stdout line is the COMPACT one (round 5's 21.6 KB line came back from the driver unparsed): the contract's keys, roofline, one
+        # figure per leg; the whole record is in the detail file and on stderr
+        c = json.loads(lines[0])
+        assert len(lines[0]) < 6000, len(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "legs", "detail"):
+            assert k in c, k
+        assert c["roofline"]["bound"] == "hbm" and c["roofline"]["peak"] == 8000.0 and "frac" in c["roofline"] and "workload" in c["config"]
+        with open(detail) as fh:
+            d = json.loads(fh.read())
+        assert d["value"] == c["value"] and d["n_gpus"] == c["n_gpus"] and d["ms_per_step"] == c["ms_per_step"]
+        assert c["legs"].get("verify_blob_batch_1024.sustained_blobs_per_s") == d["verify_blob_kzg_proof_batch"]["sustained"]["blobs_per_s"]
+        on_err = [ln for ln in r.stderr.splitlines() if ln.startswith("BENCH_DETAIL ")]
+        assert len(on_err) == 1 and json.loads(on_err[0][len("BENCH_DETAIL "):]) == d
+        return d
 
 
 def _check(d, n=2, cell_blobs=3):

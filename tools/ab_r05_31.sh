@@ -10,8 +10,8 @@ v=d["eip7594"]["verify_cell_kzg_proof_batch"]
 print(sys.argv[2], "headline", d["value"], "cell verifier lone", v["ms_per_call_median"], "sustained", v["sustained"]["cells_per_s"], v["sustained"]["cells_per_s_each_trial"], "cpus", v["sustained"]["host_cpus_busy"])
 PY
 }
-timeout 600 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-drop-in --verify-batch 0 --cell-blobs 64 > $O/b31_A.json 2>/dev/null < /dev/null; show $O/b31_A.json A
-timeout 900 python3 bench.py --no-cpu-baseline > $O/b31_B.json 2>/dev/null < /dev/null; show $O/b31_B.json B
-timeout 600 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-drop-in --verify-batch 0 --cell-blobs 64 > $O/b31_C.json 2>/dev/null < /dev/null; show $O/b31_C.json C
-timeout 900 python3 bench.py --no-cpu-baseline --no-drop-in > $O/b31_D.json 2>/dev/null < /dev/null; show $O/b31_D.json D
-timeout 900 python3 bench.py --no-cpu-baseline --verify-batch 0 > $O/b31_E.json 2>/dev/null < /dev/null; show $O/b31_E.json E
+timeout 600 python3 bench.py --full-line --steps 2 --warmup 1 --no-cpu-baseline --no-drop-in --verify-batch 0 --cell-blobs 64 > $O/b31_A.json 2>/dev/null < /dev/null; show $O/b31_A.json A
+timeout 900 python3 bench.py --full-line --no-cpu-baseline > $O/b31_B.json 2>/dev/null < /dev/null; show $O/b31_B.json B
+timeout 600 python3 bench.py --full-line --steps 2 --warmup 1 --no-cpu-baseline --no-drop-in --verify-batch 0 --cell-blobs 64 > $O/b31_C.json 2>/dev/null < /dev/null; show $O/b31_C.json C
+timeout 900 python3 bench.py --full-line --no-cpu-baseline --no-drop-in > $O/b31_D.json 2>/dev/null < /dev/null; show $O/b31_D.json D
+timeout 900 python3 bench.py --full-line --no-cpu-baseline --verify-batch 0 > $O/b31_E.json 2>/dev/null < /dev/null; show $O/b31_E.json E

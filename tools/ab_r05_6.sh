@@ -10,7 +10,7 @@ for v in "r04 $R04" "new $NEW" "r04 $R04" "new $NEW"; do set -- $v
   MI355KZG_LIB=$2 SWEEP_NB=256 SWEEP_SIZES=1,16,33,48,64,65,128,193,256 timeout 300 python3 tools/sweep_cells.py >> $O/ab_fk20_6.txt 2>&1 < /dev/null
 done
 grep -v amdgpu.ids $O/ab_fk20_6.txt
-timeout 900 python bench.py > $O/bench6.json 2> $O/bench6.err < /dev/null
+timeout 900 python bench.py --full-line > $O/bench6.json 2> $O/bench6.err < /dev/null
 tail -c 2500 $O/bench6.err
 python3 - <<'PY'
 import json

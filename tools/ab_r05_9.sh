@@ -9,7 +9,7 @@ for v in "r04 $R04" "new $NEW"; do set -- $v
   MI355KZG_LIB=$2 SWEEP_NB=256 SWEEP_SIZES=64,65,96,128,160,192,256 timeout 300 python3 tools/sweep_cells.py >> $O/ab_fk20_9.txt 2>&1 < /dev/null
 done
 grep -v amdgpu.ids $O/ab_fk20_9.txt | cut -c1-200
-timeout 900 python bench.py > $O/bench9.json 2> $O/bench9.err < /dev/null
+timeout 900 python bench.py --full-line > $O/bench9.json 2> $O/bench9.err < /dev/null
 tail -c 1500 $O/bench9.err
 python3 - <<'PY'
 import json

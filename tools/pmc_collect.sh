@@ -21,7 +21,7 @@ PASSES=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_I
 if [ -n "${PMC_PASSES:-}" ]; then IFS=";" read -r -a PASSES <<< "$PMC_PASSES"; fi
 i=0
 for p in "${PASSES[@]}"; do
-  timeout -k 5 ${PASS_TIMEOUT:-120} rocprofv3 --pmc $p -d $OUT/pass$i --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-drop-in --cell-blobs 0 --verify-batch 0 --streams 1 --no-big-cells "$@" > $OUT/pass$i.log 2>&1 || { echo "pass $i ($p) failed"; grep -m2 -i "error\|exceeds" $OUT/pass$i.log; }
+  timeout -k 5 ${PASS_TIMEOUT:-120} rocprofv3 --pmc $p -d $OUT/pass$i --output-format csv -- python3 bench.py --full-line --steps 2 --warmup 1 --no-cpu-baseline --no-drop-in --cell-blobs 0 --verify-batch 0 --streams 1 --no-big-cells "$@" > $OUT/pass$i.log 2>&1 || { echo "pass $i ($p) failed"; grep -m2 -i "error\|exceeds" $OUT/pass$i.log; }
   i=$((i+1))
 done
 python3 tools/pmc_summarize.py $OUT gpurun_out/${TAG}

@@ -20,12 +20,12 @@ rm -rf gpurun_out/pmc_r05v gpurun_out/pmc_r05t gpurun_out/pmc_r05e
 python3 tools/pmc_merge.py profiles/r05_traffic.json @profiles/r05_traffic.json verify=gpurun_out/r05v_traffic.json verify_tp=gpurun_out/r05t_traffic.json eip7594=gpurun_out/r05e_traffic.json
 cp profiles/r05_traffic.json $O/r05_traffic.json
 # 3. kernel stats of the headline command (one stream: the launch alone, what roofline.frac is quoted on) and of the default line
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_commit -o ks -- python3 bench.py --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-drop-in --cell-blobs 0 --verify-batch 0 > $O/bench_commit_only.json 2> $O/bench_commit_only.err < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_commit -o ks -- python3 bench.py --full-line --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-drop-in --cell-blobs 0 --verify-batch 0 > $O/bench_commit_only.json 2> $O/bench_commit_only.err < /dev/null
 cp $(find $O/ks_commit -name '*kernel_stats.csv' | head -1) $O/bench_commit_only_kernel_stats.csv; rm -rf $O/ks_commit
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_default -o ks -- python3 bench.py > $O/bench_default_profiled.json 2> $O/bench_default_profiled.err < /dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_default -o ks -- python3 bench.py --full-line > $O/bench_default_profiled.json 2> $O/bench_default_profiled.err < /dev/null
 cp $(find $O/ks_default -name '*kernel_stats.csv' | head -1) $O/bench_default_kernel_stats.csv; rm -rf $O/ks_default
 # 4. the default line, unprofiled: THE line
-timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err < /dev/null
+timeout 900 python3 bench.py --full-line > $O/bench_default.json 2> $O/bench_default.err < /dev/null
 tail -c 600 $O/bench_default.err
 # 5. busy summaries of the two sustained verifier legs
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr_v -o tr -- python3 tools/trace.py verify_inflight 32 10 > $O/verify_sustained_trace.txt 2>&1 < /dev/null

@@ -13,7 +13,7 @@ rm -rf gpurun_out/pmc_r05v gpurun_out/pmc_r05t gpurun_out/pmc_r05e
 python3 tools/pmc_merge.py profiles/r05_traffic.json @profiles/r05_traffic.json verify=gpurun_out/r05v_traffic.json verify_tp=gpurun_out/r05t_traffic.json eip7594=gpurun_out/r05e_traffic.json
 cp profiles/r05_traffic.json $O/r05_traffic.json
 cp gpurun_out/r05v_pmc_summary.csv gpurun_out/r05t_pmc_summary.csv gpurun_out/r05e_pmc_summary.csv $O/ 2>/dev/null
-timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err < /dev/null
+timeout 900 python3 bench.py --full-line > $O/bench_default.json 2> $O/bench_default.err < /dev/null
 tail -c 400 $O/bench_default.err
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/tr_v -o tr -- python3 tools/trace.py verify_inflight 32 10 > $O/verify_sustained_trace.txt 2>&1 < /dev/null
 python3 tools/trace.py busy $O/tr_v > $O/verify_sustained_busy.txt 2>&1; rm -rf $O/tr_v

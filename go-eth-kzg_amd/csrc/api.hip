@@ -88,6 +88,9 @@ static void free_lane_plan(Lane* L) {
 }
 static void free_lane_direct(Lane* L) {
     dev_free(L->dslot.d_parts); dev_free(L->dslot.d_bad);
+#ifdef MKZG_AFFINE_PAIRS
+    dev_free(L->dslot.d_prefix);
+#endif
     L->dslot_batch = 0;
     L->dslot_records = 0;
 }
@@ -362,11 +365,22 @@ static int ensure_lane_plan(mkzg_ctx* c, Lane* L) {
 // buffer once (hipFree waits for the lane's earlier, possibly still running, calls).
 static int ensure_lane_direct(mkzg_ctx* c, Lane* L, size_t need_records = 0) {
     const size_t base = (size_t)c->opt_max_batch * 512;
+#ifdef MKZG_AFFINE_PAIRS
+    const bool pairs = c->opt_affine_pairs.load(std::memory_order_relaxed) != 0 && c->direct_bits_built == 15;
+    if (L->dslot_batch >= c->opt_max_batch && L->dslot.d_parts && L->dslot_records >= std::max(base, need_records) && pairs == (L->dslot.d_prefix != nullptr)) return MKZG_OK;
+#else
     if (L->dslot_batch >= c->opt_max_batch && L->dslot.d_parts && L->dslot_records >= std::max(base, need_records)) return MKZG_OK;
+#endif
     const size_t records = std::max(std::max(base, need_records), L->dslot_batch >= c->opt_max_batch ? L->dslot_records : (size_t)0);
     free_lane_direct(L);
     HIPCHK(hipMalloc(&L->dslot.d_parts, records * 256));
     HIPCHK(hipMalloc(&L->dslot.d_bad, direct_bad_bytes(c->opt_max_batch)));
+#ifdef MKZG_AFFINE_PAIRS
+    if (pairs && hipMalloc(&L->dslot.d_prefix, direct_prefix_bytes(c->opt_max_batch)) != hipSuccess) {
+        (void)hipGetLastError();                 // no room for the pair kernel's scratch (6 MB per blob of max_batch): the plain accumulate kernel runs
+        L->dslot.d_prefix = nullptr;
+    }
+#endif
     L->dslot_batch = c->opt_max_batch;
     L->dslot_records = records;
     return MKZG_OK;
@@ -860,6 +874,15 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         c->opt_host_zero_copy = (int)value;
         return MKZG_OK;
     }
+#ifdef MKZG_AFFINE_PAIRS
+    if (!strcmp(key, "commit_affine_pairs")) {   // A/B builds only
+        if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
+        lanes_quiesce(c);                        // lanes pick the scratch up (or drop it) at their next commitment call
+        c->opt_affine_pairs = (int)value;
+        lanes_resume(c);
+        return MKZG_OK;
+    }
+#endif
     if (!strcmp(key, "host_sha")) {
         if (value < -1 || value > 1) return MKZG_ERR_BAD_ARGS;
         c->opt_host_sha = (int)value;
@@ -939,6 +962,9 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "debug_serial")) *value = q->opt_debug_serial;
     else if (!strcmp(key, "cpu_share")) *value = q->cpu_share;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
+#ifdef MKZG_AFFINE_PAIRS
+    else if (!strcmp(key, "commit_affine_pairs")) *value = q->opt_affine_pairs;
+#endif
     else if (!strcmp(key, "devices")) *value = c->peers.empty() ? 1 : (long)c->peers.size();
     else if (!strcmp(key, "tables_on_own_device")) {
         // diagnostic: 1 when every shared table built so far lives on the device of the (per-device) context that owns it

@@ -272,6 +272,9 @@ struct mkzg_ctx {
     int opt_fk20_bits = 12;                // widest FK20 direct table to try: 13 (86 GB), 12 (47 GB), 11 (25.8 GB), 8 (4.3 GB); narrower ones are the fallback
     std::atomic<int> opt_host_chunk{128};              // blobs per chunk of the host-pointer commitment pipeline (measured: tools/bench_host_path.py)
     std::atomic<int> opt_host_gather_tasks{16};        // gather tasks per chunk of the host-pointer commitment pipeline (measured, tools/sweep_host_commit.py: 3.37 ms per 256 blobs with 16, 3.55 with 4)
+#ifdef MKZG_AFFINE_PAIRS
+    std::atomic<int> opt_affine_pairs{0};              // A/B builds only (experiments/commit_pairs_kernels.hip): adjacent windows of a scalar added in affine coordinates first
+#endif
     std::atomic<int> opt_host_zero_copy{1};            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
     // single-item calls of the reference API served in groups through the batch paths when several are in flight (host_combine.hpp)
     struct CommitCall { const uint8_t* blob; uint8_t* out48; int rc; };

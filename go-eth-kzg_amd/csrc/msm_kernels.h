@@ -80,10 +80,17 @@ struct DirectSlot {
     int k = 8;                 // scalars per lane of the accumulate kernel (8, 4, 2, 1): 4096 / k partial sums per blob; see direct_pick_shape
     int serial = 1;            // 1: the finish kernel sums the 4096 / (64 k) records of a lane serially; 0: two butterfly folds first (calls of few blobs)
     int fin_quad = 1;          // serial form: the finish on four wavefronts per blob with a quad of lanes per record column (shorter chain, 2.1x the instructions)
+#ifdef MKZG_AFFINE_PAIRS
+    uint4* d_prefix = nullptr; // A/B builds with experiments/commit_pairs_kernels.hip: scratch of the pair kernel (direct_prefix_bytes per blob of max_batch), else null
+#endif
 };
 void direct_pick_shape(int n, int max_batch, DirectSlot* slot);
 size_t direct_parts_bytes(int max_batch);
 size_t direct_bad_bytes(int max_batch);
+#ifdef MKZG_AFFINE_PAIRS
+size_t direct_prefix_bytes(int max_batch);                 // experiments/commit_pairs_kernels.hip
+void commit_direct_acc_pairs_launch(int input_kind, dim3 grid, hipStream_t s, const uint8_t* d_scalars, size_t stride, const uint32_t* d_direct, const DirectSlot& ws);
+#endif
 DirectSlot direct_slot_offset(const DirectSlot& ws, int off);
 double valu_calibrate_device(hipStream_t s);   // sustained v_mad_u64_u32 wave-instructions per second on this GPU
 void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, hipStream_t s, KernelTimer* kt);

@@ -750,7 +750,7 @@ def source_hash(files):
     return h.hexdigest()[:16]
 
 
-PMC_SOURCES = {"commit": ["msm_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "modinv30.hpp"],
+PMC_SOURCES = {"commit": ["msm_kernels.hip", "msm_device.hpp", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "modinv30.hpp"],
                "verify": ["verify_kernels.hip", "cells_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp", "pub_ticket.hpp"],
                "eip7594": ["fk20_kernels.hip", "recover_kernels.hip", "cells_kernels.hip", "verify_kernels.hip", "g1.hpp", "g1_quad.hpp", "mont29.hpp", "g1_decode.hpp", "pub_ticket.hpp"]}
 

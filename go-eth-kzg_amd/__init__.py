@@ -34,7 +34,7 @@ ERR_BAD_ARGS = 17
 ERR_HIP = 100
 
 EXPORTED_SYMBOLS = [
-    "mkzg_ctx_new", "mkzg_ctx_free", "mkzg_ctx_set_option", "mkzg_ctx_get_option",
+    "mkzg_ctx_new", "mkzg_ctx_free", "mkzg_ctx_prepare", "mkzg_ctx_set_option", "mkzg_ctx_get_option",
     "mkzg_blob_to_kzg_commitment", "mkzg_blob_to_kzg_commitment_batch", "mkzg_blob_to_kzg_commitment_batch_device",
     "mkzg_commit_lagrange", "mkzg_profile_enable", "mkzg_profile_read", "mkzg_version",
     "mkzg_compute_kzg_proof", "mkzg_compute_blob_kzg_proof", "mkzg_compute_blob_kzg_proof_batch_device",
@@ -69,6 +69,8 @@ def lib():
         L.mkzg_ctx_free.argtypes = [vp]
         L.mkzg_ctx_free.restype = None
         L.mkzg_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+        L.mkzg_ctx_prepare.argtypes = [vp, C.c_uint]
+        L.mkzg_ctx_prepare.restype = C.c_int
         L.mkzg_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long)]
         L.mkzg_blob_to_kzg_commitment.argtypes = [vp, C.c_char_p, i32, C.c_char_p]
         L.mkzg_blob_to_kzg_commitment_batch.argtypes = [vp, C.POINTER(C.c_char_p), sz, C.c_char_p, C.POINTER(i32)]
@@ -153,6 +155,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def prepare(self, what=3):
+        """mkzg_ctx_prepare: build the big tables now (1 commitments, 2 cells / recovery, 3 both) as NewContext4096 does at construction (api.go:90-149)"""
+        return self._L.mkzg_ctx_prepare(self._h, C.c_uint(what))
 
     def set_option(self, key, value):
         return self._L.mkzg_ctx_set_option(self._h, key.encode(), int(value))

@@ -583,6 +583,26 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
 extern "C" {
 
 const char* mkzg_version(void) { return "mi355kzg 0.2 (gfx950)"; }
+// NewContext4096's precomputation (api.go:90-149) on request: see the header
+int mkzg_ctx_prepare(mkzg_ctx* c, unsigned what) {
+    if (!c || (what & ~MKZG_PREPARE_ALL)) return MKZG_ERR_BAD_ARGS;
+    const std::vector<mkzg_ctx*> all = c->peers.empty() ? std::vector<mkzg_ctx*>{c} : c->peers;
+    for (mkzg_ctx* p : all) {
+        LaneGuard G(p);                                  // a call like any other: option changes that rebuild a table wait for it (lanes_quiesce)
+        if (what & MKZG_PREPARE_COMMIT) {
+            int rc = MKZG_OK;
+            if (p->opt_direct_bits && !p->direct_bits_built && !p->direct_failed) rc = ensure_direct(p);
+            if (!rc && !p->direct_bits_built && p->commit_table_c.load(std::memory_order_acquire) != p->opt_c) rc = ensure_commit_table(p);
+            if (rc) return rc;
+        }
+        if (what & MKZG_PREPARE_CELLS) {
+            int rc = ensure_fk20_tables(p);             // twiddles and the monomial SRS on its way
+            if (!rc) rc = ensure_rec_tables(p);
+            if (rc) return rc;
+        }
+    }
+    return MKZG_OK;
+}
 int mkzg_valu_calibrate(mkzg_ctx* c, double* wave_instr_per_s) {
     if (!c || !wave_instr_per_s) return MKZG_ERR_BAD_ARGS;
     if (!c->peers.empty()) c = c->peers[0];

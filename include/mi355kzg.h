@@ -73,6 +73,18 @@ typedef struct mkzg_ctx mkzg_ctx;
  * per rank and use the _partial / _finish entry points below (DESIGN.md "multi-GPU"). */
 int mkzg_ctx_new(const char* trusted_setup_json, size_t len, const int* device_ids, int n_dev, mkzg_ctx** out);
 void mkzg_ctx_free(mkzg_ctx* ctx);
+/* The reference's NewContext4096 does ALL of its precomputation at construction (api.go:90-149: commit key, FK20 tables through
+ * fk20.NewFK20 at api.go:137, the recovery domain), so the first call on a Go Context costs what every later one does.  Here the big
+ * tables are built by the first call that needs them (0.27 s for the 146 GB commitment table, 0.47 s for the FK20 table), so that a
+ * context which only ever verifies does not pin 193 GB of HBM.  A caller that wants the reference's behaviour calls this once after
+ * mkzg_ctx_new (and after any option that sizes the tables): `what` is a mask of MKZG_PREPARE_COMMIT (the commitment MSM's table as
+ * "commit_direct_bits" / "msm_window" ask for it, degrading as documented there), MKZG_PREPARE_CELLS (NTT twiddles, the monomial SRS,
+ * the FK20 window table, the recovery tables).  Every device of a multi-device context is prepared.  Idempotent; calls in flight on the
+ * context are not disturbed. */
+#define MKZG_PREPARE_COMMIT 1u
+#define MKZG_PREPARE_CELLS 2u
+#define MKZG_PREPARE_ALL 3u
+int mkzg_ctx_prepare(mkzg_ctx* ctx, unsigned what);
 /* Tuning knobs.  Changing one waits for the calls in flight on the context.
  *   "msm_window"          11..13: window width of the bucket method
  *   "max_batch"           blobs per launch of the commitment kernels (workspace size)

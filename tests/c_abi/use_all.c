@@ -22,7 +22,7 @@ static any_fn all_symbols[] = {
     (any_fn)mkzg_recover_cells_and_kzg_proofs, (any_fn)mkzg_recover_cells_and_kzg_proofs_batch, (any_fn)mkzg_recover_cells, (any_fn)mkzg_profile_enable, (any_fn)mkzg_profile_read,
     (any_fn)mkzg_last_host_finish_us, (any_fn)mkzg_valu_calibrate, (any_fn)mkzg_msm_g1, (any_fn)mkzg_version, (any_fn)mkzg_evaluate_blobs_device, (any_fn)mkzg_recover_cells_and_kzg_proofs_batch_device, (any_fn)mkzg_verify_cell_kzg_proof_batch_device, (any_fn)mkzg_verify_cell_kzg_proof_batch_partial_device, (any_fn)mkzg_comm_unique_id, (any_fn)mkzg_comm_init, (any_fn)mkzg_comm_from_nccl, (any_fn)mkzg_comm_free,
     (any_fn)mkzg_comm_last_exchange_us, (any_fn)mkzg_verify_blob_kzg_proof_batch_exchange, (any_fn)mkzg_verify_blob_kzg_proof_batch_exchange_device,
-    (any_fn)mkzg_verify_cell_kzg_proof_batch_exchange, (any_fn)mkzg_verify_cell_kzg_proof_batch_exchange_device,
+    (any_fn)mkzg_verify_cell_kzg_proof_batch_exchange, (any_fn)mkzg_verify_cell_kzg_proof_batch_exchange_device, (any_fn)mkzg_ctx_prepare,
 };
 
 static char* slurp(const char* path, long* len) {
@@ -54,6 +54,8 @@ int main(int argc, char** argv) {
     if (rc == MKZG_ERR_HIP) { printf("no HIP device: mkzg_ctx_new -> MKZG_ERR_HIP (no fallback)\n"); return 0; }
     if (rc != MKZG_OK) { printf("mkzg_ctx_new -> %d\n", rc); return 1; }
     int all = 1;
+    all &= report("mkzg_ctx_prepare(bad mask)", mkzg_ctx_prepare(ctx, 8u), MKZG_ERR_BAD_ARGS, 1);
+    all &= report("mkzg_ctx_prepare(commit)", mkzg_ctx_prepare(ctx, MKZG_PREPARE_COMMIT), MKZG_OK, 1);
     static uint8_t zero[MKZG_BYTES_PER_BLOB];           /* the zero polynomial commits to the identity: c0 00 .. 00 */
     uint8_t out[48], proof[48];
     rc = mkzg_blob_to_kzg_commitment(ctx, zero, 0, out);

@@ -81,7 +81,8 @@ static void caller(mkzg_ctx* ctx, int id, int rounds, int my_device) {
 static void tuner(mkzg_ctx* ctx, std::atomic<bool>* stop) {
     int i = 0;
     while (!stop->load()) {
-        switch (i++ % 7) {
+        switch (i++ % 8) {
+            case 7: CHECK(mkzg_ctx_prepare(ctx, 1u + (unsigned)(i % 3)) == MKZG_OK); break;      // tables up front, beside the calls that build them lazily and the options that drop them
             case 0: CHECK(mkzg_ctx_set_option(ctx, "lanes", 3 + i % 13) == MKZG_OK); break;
             case 1: CHECK(mkzg_ctx_set_option(ctx, "trim", 1) == MKZG_OK); break;
             case 2: CHECK(mkzg_ctx_set_option(ctx, "verify_shape", (i % 3) - 1) == MKZG_OK); break;

@@ -391,7 +391,8 @@ static int ensure_lane_direct(mkzg_ctx* c, Lane* L, size_t need_records = 0) {
 // 1: 12-word Montgomery Fr rows (quotient polynomials of the proof path).  The caller holds lane L; pieces of max_batch items
 // run back to back on s through the lane's one workspace.  ws_off: first workspace item to use (chunks of one call that run on
 // different streams take disjoint item ranges; n + ws_off <= max_batch then).
-static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, int n, int ws_off, uint8_t* d_out48n, int* d_status, hipStream_t s) {
+static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, int n, int ws_off, uint8_t* d_out48n, int* d_status, hipStream_t s,
+                        uint32_t* d_raw = nullptr) {
     KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
     if (c->direct_bits_built) {
         DirectSlot slot = L->dslot;
@@ -404,7 +405,7 @@ static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t s
         }
         slot.fin_quad = L->others_active == 0;                          // nobody else on the GPU: the short finish; else the cheap one (it hides behind the next call)
         const DirectSlot ws = direct_slot_offset(slot, ws_off);
-        commit_direct_device(c->direct_bits_built, c->d_direct, ws, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt);
+        commit_direct_device(c->direct_bits_built, c->d_direct, ws, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt, d_raw);
     } else {
         const CommitPlan pl = commit_plan_offset(L->plan, ws_off);
         commit_batch_device(pl, d_scalars, stride_bytes, input_kind, n, d_out48n, d_status, s, kt);
@@ -423,9 +424,12 @@ static int commit_prepare(mkzg_ctx* c, Lane* L) {
     }
     return ensure_lane_plan(c, L);
 }
-int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s) {
+// d_raw (direct table only, one piece): the sums as XYZZ limb words, 64 words per item, for commit_host_finish instead of compressed bytes in d_out48n
+int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s,
+                          uint32_t* d_raw) {
     int rc = commit_prepare(c, L);
     if (rc) return rc;
+    if (d_raw && (!c->direct_bits_built || n > (size_t)c->opt_max_batch)) return MKZG_ERR_BAD_ARGS;
     if (c->direct_bits_built) {
         // whatever the pieces' shapes will need of the lane's workspace is allocated HERE: the launches below go out as one launch graph
         // (ctx.h lane_graph_run), and a capture must not meet an allocation
@@ -443,7 +447,7 @@ int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t
         size_t done = 0;
         while (done < n) {
             const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
-            const int prc = commit_piece(c, L, d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, 0, d_out48n + done * 48, d_status + done, s);
+            const int prc = commit_piece(c, L, d_scalars + done * stride_bytes, stride_bytes, input_kind, chunk, 0, d_out48n + done * 48, d_status + done, s, d_raw);
             if (prc) return prc;
             done += chunk;
         }
@@ -468,6 +472,7 @@ int ensure_staging(Lane* L, size_t n_items, size_t in_bytes_per_item) {
         if (rc) return rc;
         L->d_blobs_bytes = need;
     }
+    n_items = std::max<size_t>(n_items, 16);                  // the few-blob entry points park XYZZ sums (256 B per item) where the compressed points go
     if (L->d_out_items < n_items) {
         L->d_out_items = 0;
         int rc = dev_realloc(L->d_out, n_items * 48);
@@ -484,6 +489,21 @@ int ensure_staging(Lane* L, size_t n_items, size_t in_bytes_per_item) {
     return MKZG_OK;
 }
 
+// XYZZ limb words of a sum (as k_commit_direct_fin leaves them with `raw`) -> the 48 compressed bytes: g1.hpp's to_affine (one divsteps
+// inversion) and the zcash compression (serialization.go:98-100), the device's own templates compiled for the host
+constexpr size_t HOST_FIN_MAX = 4;
+void commit_host_finish(const uint32_t* w56, uint8_t out48[48]) {
+    G1X acc;
+    for (int i = 0; i < 14; i++) { acc.x.l[i] = w56[i]; acc.y.l[i] = w56[14 + i]; acc.zz.l[i] = w56[28 + i]; acc.zzz.l[i] = w56[42 + i]; }
+    G1Aff a;
+    g1x_to_affine(a, acc);
+    uint32_t w12[12];
+    g1_compress_words(w12, a);
+    for (int i = 0; i < 12; i++) {
+        const uint32_t v = __builtin_bswap32(w12[i]);
+        memcpy(out48 + 4 * i, &v, 4);
+    }
+}
 // Host-pointer commitments, one piece of at most max_batch blobs.  The blobs (Go's []*Blob: scattered, pageable) are gathered into the
 // lane's pinned staging area by the host pool, which runs AHEAD of the calling thread: the gather tasks of all chunks are queued at
 // once, the caller waits for chunk k's tasks only and issues chunk k's device work while chunks k + 1.. are still being gathered.
@@ -507,6 +527,10 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
         if (dslot.serial) dslot.k = 8;                                  // the chunks' launches fill the chip together: eight scalars per lane
         dslot.fin_quad = L->others_active == 0;
     }
+    // A FEW blobs (the single-blob entry point, small groups of the call combiner): the caller waits for a one-wavefront finish kernel
+    // whose inversion + compression are an ~90 us dependent chain; the same conversion takes the calling thread ~8 us per blob (the limb
+    // code of g1.hpp / mont29.hpp compiles for the host), so the kernel leaves the XYZZ sums and the host finishes them.
+    const bool host_fin = direct && n <= HOST_FIN_MAX && c->opt_host_fin.load(std::memory_order_relaxed) != 0 && n * 256 <= L->d_out_items * 48 && n * 256 <= L->h_out_items * 48;
     KernelTimer* kt = c->profiling.load(std::memory_order_relaxed) ? &L->timer : nullptr;
     const size_t CH = (size_t)std::max(1, c->opt_host_chunk.load(std::memory_order_relaxed));
     hipStream_t copy = L->side, cs[4] = {L->stream, L->side2, L->aux[0], L->aux[1]};
@@ -564,9 +588,9 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
             HIPCHK(hipEventRecord(L->ev_cs[0], copy));
             HIPCHK(hipStreamWaitEvent(L->stream, L->ev_cs[0], 0));
         }
-        if (direct) commit_direct_fin_device(dslot, (int)n, L->d_out, L->d_status, L->stream, kt);
+        if (direct) commit_direct_fin_device(dslot, (int)n, L->d_out, L->d_status, L->stream, kt, host_fin ? reinterpret_cast<uint32_t*>(L->d_out) : nullptr);
         else (void)commit_piece(c, L, L->d_blobs, MKZG_BYTES_PER_BLOB, 0, (int)n, 0, L->d_out, L->d_status, L->stream);      // bucket method: no buffer to grow
-        HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, n * 48, hipMemcpyDeviceToHost, L->stream));
+        HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, host_fin ? n * 256 : n * 48, hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipMemcpyAsync(L->h_out + L->h_out_items * 48, L->d_status, n * sizeof(int), hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipGetLastError());
         LANE_SYNC(c, L, L->stream);
@@ -575,8 +599,15 @@ static int commit_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, 
     }();
     drain();
     if (rc) return rc;
-    memcpy(out48n, L->h_out, n * 48);
     memcpy(st_out, L->h_out + L->h_out_items * 48, n * sizeof(int));
+    if (host_fin) {
+        for (size_t i = 0; i < n; i++) {
+            if (st_out[i]) { memset(out48n + 48 * i, 0, 48); continue; }
+            commit_host_finish(reinterpret_cast<const uint32_t*>(L->h_out + 256 * i), out48n + 48 * i);
+        }
+    } else {
+        memcpy(out48n, L->h_out, n * 48);
+    }
     return MKZG_OK;
 }
 
@@ -903,6 +934,11 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         return MKZG_OK;
     }
 #endif
+    if (!strcmp(key, "host_fin")) {
+        if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_host_fin = (int)value;
+        return MKZG_OK;
+    }
     if (!strcmp(key, "host_sha")) {
         if (value < -1 || value > 1) return MKZG_ERR_BAD_ARGS;
         c->opt_host_sha = (int)value;
@@ -982,6 +1018,7 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "debug_serial")) *value = q->opt_debug_serial;
     else if (!strcmp(key, "cpu_share")) *value = q->cpu_share;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
+    else if (!strcmp(key, "host_fin")) *value = q->opt_host_fin;
 #ifdef MKZG_AFFINE_PAIRS
     else if (!strcmp(key, "commit_affine_pairs")) *value = q->opt_affine_pairs;
 #endif

@@ -275,6 +275,7 @@ struct mkzg_ctx {
 #ifdef MKZG_AFFINE_PAIRS
     std::atomic<int> opt_affine_pairs{0};              // A/B builds only (experiments/commit_pairs_kernels.hip): adjacent windows of a scalar added in affine coordinates first
 #endif
+    std::atomic<int> opt_host_fin{1};                  // host-pointer commitments of up to four blobs: the kernel leaves XYZZ sums, the calling thread inverts and compresses
     std::atomic<int> opt_host_zero_copy{1};            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
     // single-item calls of the reference API served in groups through the batch paths when several are in flight (host_combine.hpp)
     struct CommitCall { const uint8_t* blob; uint8_t* out48; int rc; };
@@ -457,7 +458,11 @@ int ensure_cells_ws(Lane* L, size_t n);
 int ensure_fk20_ws(Lane* L, size_t n);
 void free_lane(Lane* L);
 // commitments of n polynomials in Lagrange form (api.hip); the caller holds lane L and runs on stream s
-int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s);
+int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s,
+                          uint32_t* d_raw = nullptr);
+void commit_host_finish(const uint32_t* w56, uint8_t out48[48]);      // api.hip: XYZZ limb words of a sum -> 48 compressed bytes on the calling thread
+// the single-item proof entry points' switch: sums come back as XYZZ words (direct table built, option host_fin on)
+inline bool host_fin_one(const mkzg_ctx* c) { return c->direct_bits_built != 0 && c->opt_host_fin.load(std::memory_order_relaxed) != 0; }
 // device a pointer lives on (-1: not a device pointer)
 int pointer_device(const void* p);
 mkzg_ctx* ctx_for_pointer(mkzg_ctx* c, const void* p);

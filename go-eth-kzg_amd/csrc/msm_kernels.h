@@ -94,8 +94,9 @@ void commit_direct_acc_pairs_launch(int input_kind, dim3 grid, hipStream_t s, co
 DirectSlot direct_slot_offset(const DirectSlot& ws, int off);
 double valu_calibrate_device(hipStream_t s);   // sustained v_mad_u64_u32 wave-instructions per second on this GPU
 void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, hipStream_t s, KernelTimer* kt);
-void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt);
+// d_raw (may be null): n x 64 words that receive the sums as XYZZ limb words instead of d_out48 receiving compressed bytes (the caller converts on the host)
+void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt, uint32_t* d_raw = nullptr);
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48,
-                          int* d_status, hipStream_t s, KernelTimer* kt);
+                          int* d_status, hipStream_t s, KernelTimer* kt, uint32_t* d_raw = nullptr);
 
 }  // namespace kzg

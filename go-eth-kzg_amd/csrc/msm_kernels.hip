@@ -726,9 +726,12 @@ __global__ void __launch_bounds__(64, 2) k_commit_direct_sum8(uint32_t* __restri
 // affine and writes the compressed commitment.  Tiny and latency-bound: it runs beside the next accumulate kernel.
 // folded (K < 8): the blob's nblk / 4 records sit 256 apart (two rounds of k_commit_direct_fold16), a quad of lanes per record;
 // quads beyond them start from the identity.
+// raw (may be null): leave the blob's sum as it is -- 56 limb words X, Y, ZZ, ZZZ at raw + 64 b -- instead of the 48 compressed bytes: the
+// host-pointer entry points of a few blobs convert and compress on the HOST (api.hip commit_host_piece): the inversion is an ~80 us chain
+// for one wavefront and ~5 us for the calling thread, which waits for this kernel anyway.
 __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __restrict__ parts, const int* __restrict__ bad_flags, uint8_t* __restrict__ out48,
                                                           int* __restrict__ status, int blob_blocks /* 64-record blocks per blob = accumulate workgroups */,
-                                                          int nblk /* blocks to sum (the first ones) */, int folded) {
+                                                          int nblk /* blocks to sum (the first ones) */, int folded, uint32_t* __restrict__ raw) {
     const int b = blockIdx.x, lane = threadIdx.x;
     int anybad = 0;
     for (int q = 0; q < blob_blocks; q++) anybad |= bad_flags[b * DBAD + q];
@@ -759,6 +762,13 @@ __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __r
     for (int m = folded ? 0 : 32; m >= 1; m >>= 1) {
         shfl_xor_xyzz(o, acc, m);
         g1x_add(acc, acc, o);
+    }
+    if (raw) {
+        if (lane == 0) {
+            status[b] = 0;
+            store_xyzz(raw + (size_t)b * 64, acc);
+        }
+        return;
     }
     // after the xor butterfly every lane holds the sum: all of them run the inversion and the compression (a wavefront with one
     // active lane issues slower on gfx950, see fk20_kernels.hip FULL_WAVES), lane 0 stores
@@ -1031,7 +1041,7 @@ void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot&
     }
     if (kt) kt->end(KT_COMMIT_DIRECT, s);
 }
-void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt) {
+void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt, uint32_t* d_raw) {
     if (n <= 0) return;
     if (kt) kt->begin(KT_COMMIT_DIRECT_FIN, s);
     const int blocks = 4096 / (ws.k * DTA);
@@ -1040,14 +1050,14 @@ void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int
         hipLaunchKernelGGL(k_commit_direct_sum8, dim3(blocks / 8, n), dim3(64), 0, s, ws.d_parts, blocks);
         nblk = blocks / 8;
     }
-    if (ws.serial && ws.fin_quad) hipLaunchKernelGGL(k_commit_direct_fin_quad, dim3(n), dim3(256), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, blocks, nblk);
-    else hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, blocks, nblk, ws.serial ? 0 : 1);
+    if (ws.serial && ws.fin_quad && !d_raw) hipLaunchKernelGGL(k_commit_direct_fin_quad, dim3(n), dim3(256), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, blocks, nblk);
+    else hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, blocks, nblk, ws.serial ? 0 : 1, d_raw);
     if (kt) kt->end(KT_COMMIT_DIRECT_FIN, s);
 }
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status,
-                          hipStream_t s, KernelTimer* kt) {
+                          hipStream_t s, KernelTimer* kt, uint32_t* d_raw) {
     commit_direct_acc_device(c, d_direct, ws, d_scalars, stride, input_kind, n, s, kt);
-    commit_direct_fin_device(ws, n, d_out48, d_status, s, kt);
+    commit_direct_fin_device(ws, n, d_out48, d_status, s, kt, d_raw);
 }
 void commit_plan_sizes(int c, int max_batch, CommitPlanSizes* sz) {
     const int nwin = (255 + c - 1) / c, nb = 1 << (c - 1);

@@ -120,6 +120,9 @@ int mkzg_ctx_prepare(mkzg_ctx* ctx, unsigned what);
  *                         to the pieces it has seen, 1.6 MB per blob)
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
+ *   "host_fin"            1 (default): host-pointer commitment calls of up to four blobs (the single-blob entry point, small groups of
+ *                         the call combiner) get the sum's projective coordinates back and convert + compress on the calling thread (~8 us
+ *                         per blob) instead of waiting for the one-wavefront inversion on the device (~90 us); 0: the device finishes
  *   "host_sha"            host-pointer verifiers: Fiat-Shamir challenges hashed by the host pool while the blobs upload (1),
  *                         on the device after the upload (0), library's choice (-1, default: a call that is alone on the context hashes on
  *                         the host -- pairs of transcripts interleaved per core, 35 us each, under the chunked upload, the device taking

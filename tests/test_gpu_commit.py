@@ -321,3 +321,59 @@ def test_every_documented_option_reads_back_and_sets(product):
     for key in ("commit_direct_bits_effective", "fk20_bits_effective", "devices", "host_threads", "cpu_share", "tables_on_own_device", "pool_node_cpus"):
         assert ctx.get_option(key) is not None, key
     ctx.close()
+
+
+def test_host_finish_of_few_blob_calls(product, oracle_ctx, vectors):
+    """option host_fin (default 1): host-pointer commitment calls of up to four blobs and the single-proof entry points get the sum's XYZZ
+    coordinates back and invert + compress on the calling thread (api.hip commit_host_finish: the device's own limb templates compiled for
+    the host) instead of waiting for the device's one-wavefront finish.  Same bytes and codes either way: the consensus vectors, the
+    identity (zero blob, constant polynomial), a non-canonical blob among four, five blobs (the device's finish), ComputeKZGProof at a
+    point of the domain.  Reference: prove.go:13-33,85-111 -> serialization.go:98-100."""
+    from conftest import BadHex
+    R_MOD = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    ctx = product.Context()
+    try:
+        assert ctx.set_option("commit_direct_bits", 12) == 0                    # 24 GB: runs beside the other modules' contexts
+        assert ctx.get_option("host_fin") == 1 and ctx.set_option("host_fin", 2) == 17
+        blobs = [rand_blob(900 + i) for i in range(3)] + [bytes(131072), (9).to_bytes(32, "big") * 4096]
+        bad = bytearray(blobs[0])
+        bad[64:96] = R_MOD.to_bytes(32, "big")
+        bad = bytes(bad)
+        exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
+        z_dom = (1).to_bytes(32, "big")                                          # omega^0
+        z_any = (0x1234567).to_bytes(32, "big")
+        got = {}
+        for hf in (1, 0, 1):
+            assert ctx.set_option("host_fin", hf) == 0 and ctx.get_option("host_fin") == hf
+            res = []
+            for b, e in zip(blobs, exp):
+                rc, cm = ctx.BlobToKZGCommitment(b)
+                assert rc == 0 and cm == e
+            rc, outs, st = ctx.BlobToKZGCommitmentBatch([blobs[0], bad, blobs[3], blobs[1]])          # four: host finish, one item rejected
+            assert rc == 3 and st == [0, 3, 0, 0] and outs[0] == exp[0] and outs[2] == exp[3] and outs[3] == exp[1]
+            rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs)                                        # five: the device's finish whatever the option
+            assert rc == 0 and outs == exp and st == [0] * 5
+            assert ctx.BlobToKZGCommitment(bad)[0] == 3
+            for b, e in zip(blobs[:2] + blobs[3:], exp[:2] + exp[3:]):
+                res.append(ctx.ComputeBlobKZGProof(b, e))
+                res.append(ctx.ComputeKZGProof(b, z_dom))
+                res.append(ctx.ComputeKZGProof(b, z_any))
+                assert res[-3][0] == 0 and res[-3][1] == oracle_ctx.compute_blob_kzg_proof(b, e)[1]
+                assert res[-2] == tuple(oracle_ctx.compute_kzg_proof(b, z_dom)) and res[-1] == tuple(oracle_ctx.compute_kzg_proof(b, z_any))
+            assert ctx.ComputeKZGProof(bad, z_any)[0] == 3
+            got[hf] = res
+            n_ok = 0
+            for c in vectors.cases("compute_kzg_proof"):
+                blob, z, e = vectors.val(c["input"]["blob"]), vectors.val(c["input"]["z"]), vectors.val(c["output"])
+                if any(isinstance(v, BadHex) for v in (blob, z)) or len(blob) != 131072 or len(z) != 32:
+                    continue
+                rc, pr, y = ctx.ComputeKZGProof(blob, z)
+                if e is None:
+                    assert rc != 0, c["name"]
+                else:
+                    assert rc == 0 and pr == e[0] and y == e[1], c["name"]
+                    n_ok += 1
+            assert n_ok > 30
+        assert got[0] == got[1]
+    finally:
+        ctx.close()

@@ -397,7 +397,7 @@ static int commit_piece(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t s
     if (c->direct_bits_built) {
         DirectSlot slot = L->dslot;
         if (!ws_off) direct_pick_shape(n, L->dslot_batch, &slot);        // a call of few blobs spreads each over more lanes
-        if ((size_t)(n + ws_off) * (4096 / slot.k) > L->dslot_records) {
+        if ((size_t)(n + ws_off) * (4096 / slot.k) * slot.wsplit > L->dslot_records) {
             int rc = ensure_lane_direct(c, L, (size_t)L->dslot_batch * 4096);
             if (rc) return rc;
             slot.d_parts = L->dslot.d_parts;
@@ -437,7 +437,7 @@ int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t
             const int chunk = (int)std::min<size_t>(n - done, (size_t)c->opt_max_batch);
             DirectSlot slot = L->dslot;
             direct_pick_shape(chunk, L->dslot_batch, &slot);
-            if ((size_t)chunk * (4096 / slot.k) > L->dslot_records) {
+            if ((size_t)chunk * (4096 / slot.k) * slot.wsplit > L->dslot_records) {
                 rc = ensure_lane_direct(c, L, (size_t)L->dslot_batch * 4096);
                 if (rc) return rc;
             }

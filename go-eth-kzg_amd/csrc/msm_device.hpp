@@ -93,7 +93,7 @@ struct Recode {
 #endif
 constexpr int DTA = MKZG_DTA; // threads per accumulate workgroup, 8 points per lane (64: single-wave workgroups, any free wave slot takes one)
 constexpr int DPARTS = 4096;  // lane accumulators per blob (64-word XYZZ records) of the one-scalar-per-lane shapes: 1 MB per blob (a lane's buffer grows to it on demand, api.hip ensure_lane_direct)
-constexpr int DBAD = 4096 / DTA;   // stride of a blob's bad-scalar flags (one per accumulate workgroup, at most 4096 / DTA of them)
+constexpr int DBAD = 2 * 4096 / DTA;   // stride of a blob's bad-scalar flags (one per accumulate workgroup, at most 2 * 4096 / DTA of them: the window-split shape)
 static_assert(DTA == 64, "the partial-sum layout (64 parts per accumulate workgroup, folded by one wavefront) assumes single-wave workgroups");
 
 }  // namespace kzg

@@ -78,6 +78,7 @@ struct DirectSlot {
     uint32_t* d_parts = nullptr;
     int* d_bad = nullptr;
     int k = 8;                 // scalars per lane of the accumulate kernel (8, 4, 2, 1): 4096 / k partial sums per blob; see direct_pick_shape
+    int wsplit = 1;            // 2 (k == 1, up to eight blobs): a pair of lanes per scalar, lower / upper windows; 8192 partial sums per blob
     int serial = 1;            // 1: the finish kernel sums the 4096 / (64 k) records of a lane serially; 0: two butterfly folds first (calls of few blobs)
     int fin_quad = 1;          // serial form: the finish on four wavefronts per blob with a quad of lanes per record column (shorter chain, 2.1x the instructions)
 #ifdef MKZG_AFFINE_PAIRS

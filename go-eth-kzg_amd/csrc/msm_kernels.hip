@@ -597,12 +597,18 @@ __device__ __forceinline__ void shfl_xor_xyzz(G1X& r, const G1X& a, int m) {
 // the 12 run on a quad of lanes each.  When C divides 255 the signed recoding has no spare top window; scalars with bit 254
 // set are replaced by r - s (top digit then <= 2^(C-1)) and every digit sign is flipped.
 template <int C, int INPUT_KIND>     // INPUT_KIND 0: 32-byte big-endian scalars (blobs); 1: 12-word Montgomery Fr rows (quotient polynomials)
+// wsplit 2 (K = 1, calls of up to eight blobs: the caller waits for this chain): a PAIR of lanes per scalar, lane 2q the lower ceil(NWIN / 2)
+// windows, lane 2q + 1 the upper ones (after running the recoding's carry through the lower ones): 9 dependent additions instead of 17
+// on twice the wavefronts (128 per blob); the two records of a scalar are added by the first fold launch (k_commit_direct_fold16 `pairs`).
 __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __restrict__ scalars, size_t scalar_stride_bytes, const uint32_t* __restrict__ direct,
-                                                            uint32_t* __restrict__ parts, int* __restrict__ bad_flags, int K) {
+                                                            uint32_t* __restrict__ parts, int* __restrict__ bad_flags, int K, int wsplit) {
     using RC = Recode<C>;
     constexpr bool TIGHT = (C * RC::NWIN < 256);
     __shared__ __attribute__((aligned(16))) uint32_t rowbuf[(DTA / 64) * 8 * 256];     // 32 KB: one table row per lane
     const int half = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63;
+    const int part = wsplit == 2 ? (t & 1) : 0;
+    const int NS = wsplit == 2 ? (RC::NWIN + 1) / 2 : RC::NWIN;      // windows of this lane: [j0, min(j0 + NS, NWIN))
+    const int j0 = part * NS;
     __shared__ uint32_t scal[8 * DTA];              // this lane's scalar, word-major: the window position is wave-uniform
     uint32_t* wb = rowbuf + (t >> 6) * (8 * 256);
     bool bad = false;
@@ -610,7 +616,7 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
     g1x_set_inf(acc);
 #pragma unroll 1
     for (int k = 0; k < K; k++) {
-        const int i = (half * K + k) * DTA + t;
+        const int i = wsplit == 2 ? half * (DTA / 2) + (t >> 1) : (half * K + k) * DTA + t;
         uint32_t w[8];
         if (INPUT_KIND == 0) {
             load_scalar_be(w, scalars + (size_t)b * scalar_stride_bytes + (size_t)i * 32);
@@ -641,9 +647,17 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
 #pragma unroll
         for (int q = 0; q < 8; q++) scal[q * DTA + t] = w[q];
         int carry = 0;
+#pragma unroll 1
+        for (int jj = 0; jj < j0; jj++) {                // the upper half's carry-in: the recoding of the windows below, nothing added
+            const int bit = C * jj, wi = bit >> 5, off = bit & 31;
+            const uint32_t lo = scal[wi * DTA + t], hi = scal[(wi < 7 ? wi + 1 : 7) * DTA + t];
+            const uint32_t v = (uint32_t)((((uint64_t)(wi < 7 ? hi : 0u) << 32) | lo) >> off);
+            carry = ((int)(v & ((1u << C) - 1)) + carry) > RC::NBUCKET ? 1 : 0;
+        }
         bool cur = false, cneg = false;
 #pragma unroll 1
-        for (int j = 0; j <= RC::NWIN; j++) {
+        for (int sl = 0; sl <= NS; sl++) {
+            const int j = j0 + sl;
             G1Aff p;
             p.inf = 1;
             if (cur) {
@@ -662,7 +676,7 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
                 asm volatile("" : "+v"(p.inf));
             }
             bool nxt = false, nneg = false;
-            if (j < RC::NWIN) {
+            if (sl < NS && j < RC::NWIN) {
                 const int bit = C * j, wi = bit >> 5, off = bit & 31;
                 const uint32_t lo = scal[wi * DTA + t], hi = scal[(wi < 7 ? wi + 1 : 7) * DTA + t];
                 const uint32_t v = (uint32_t)((((uint64_t)(wi < 7 ? hi : 0u) << 32) | lo) >> off);
@@ -695,11 +709,16 @@ __global__ void __launch_bounds__(DTA, 2) k_commit_direct_acc(const uint8_t* __r
 // Fold (K < 8, calls of few blobs: somebody waits for this chain): 16 records per wavefront, a QUAD of lanes per record (g1_quad.hpp
 // xadd_quad: an addition four products deep instead of fourteen), xor butterfly over the 16 quads, the sum left in the first record.
 // Two launches take a blob's 4096 / K records (stride 1) to 4096 / 16K (stride 16) to 4096 / 256K (stride 256) for the finish kernel.
-__global__ void __launch_bounds__(64, 2) k_commit_direct_fold16(uint32_t* __restrict__ parts, int per_blob /* records of a blob, in units of `stride` */, int stride) {
+// pairs (the window-split shape's first launch): a wavefront takes 32 records, every quad adds its two first (a scalar's lower and upper windows)
+__global__ void __launch_bounds__(64, 2) k_commit_direct_fold16(uint32_t* __restrict__ parts, int per_blob /* records of a blob, in units of `stride` */, int stride, int pairs) {
     const QuadRole qr(threadIdx.x);
-    const size_t base = (size_t)blockIdx.y * per_blob * stride + (size_t)blockIdx.x * 16 * stride;
+    const size_t base = (size_t)blockIdx.y * per_blob * stride + (size_t)blockIdx.x * (16 << pairs) * stride;
     G1X acc, o;
-    load_xyzz(acc, parts + (base + (size_t)(threadIdx.x >> 2) * stride) * 64);
+    load_xyzz(acc, parts + (base + ((size_t)(threadIdx.x >> 2) << pairs) * stride) * 64);
+    if (pairs) {
+        load_xyzz(o, parts + (base + (((size_t)(threadIdx.x >> 2) << 1) + 1) * stride) * 64);
+        xadd_quad(acc, o, qr);
+    }
 #pragma unroll 1
     for (int m = 32; m >= 4; m >>= 1) {
         shfl_xor_xyzz(o, acc, m);
@@ -741,10 +760,10 @@ __global__ void __launch_bounds__(64, 2) k_commit_direct_fin(const uint32_t* __r
     }
     G1X acc, o;
     const size_t base = (size_t)b * blob_blocks * 64;
-    if (folded) {
+    if (folded) {                                    // = the stride of the records the folds left: 256, or 512 behind the window-split shape
         const QuadRole qr(lane);
         g1x_set_inf(acc);
-        if ((lane >> 2) < nblk / 4) load_xyzz(acc, parts + (base + (size_t)(lane >> 2) * 256) * 64);
+        if ((lane >> 2) < nblk / 4) load_xyzz(acc, parts + (base + (size_t)(lane >> 2) * folded) * 64);
 #pragma unroll 1
         for (int m = 32; m >= 4; m >>= 1) {
             shfl_xor_xyzz(o, acc, m);
@@ -968,7 +987,7 @@ size_t direct_parts_bytes(int max_batch) { return (size_t)max_batch * DPARTS * 6
 size_t direct_bad_bytes(int max_batch) { return (size_t)max_batch * DBAD * sizeof(int); }
 DirectSlot direct_slot_offset(const DirectSlot& ws, int off) {
     DirectSlot o = ws;
-    o.d_parts = ws.d_parts + (size_t)off * (4096 / ws.k) * 64;
+    o.d_parts = ws.d_parts + (size_t)off * (4096 / ws.k) * ws.wsplit * 64;
     o.d_bad = ws.d_bad + (size_t)off * DBAD;
 #ifdef MKZG_AFFINE_PAIRS
     if (ws.d_prefix) o.d_prefix = ws.d_prefix + (size_t)off * (direct_prefix_bytes(1) / sizeof(uint4));
@@ -988,8 +1007,15 @@ DirectSlot direct_slot_offset(const DirectSlot& ws, int off) {
 void direct_pick_shape(int n, int max_batch, DirectSlot* slot) {
     slot->k = 8;
     slot->serial = 1;
+    slot->wsplit = 1;
     for (int k = 1; k < 8; k *= 2)      // within the 512 records per blob of max_batch that every lane's buffer starts with
-        if ((size_t)n * (4096 / k) <= (size_t)max_batch * 512 && n * (4096 / k) / 64 <= 2048) { slot->k = k; slot->serial = 0; return; }
+        if ((size_t)n * (4096 / k) <= (size_t)max_batch * 512 && n * (4096 / k) / 64 <= 2048) {
+            slot->k = k;
+            slot->serial = 0;
+            // up to eight blobs: a pair of lanes per scalar (128 wavefronts per blob, one per SIMD at eight blobs): 9 dependent additions instead of 17
+            if (k == 1 && n <= 8 && (size_t)n * 8192 <= (size_t)max_batch * 512) slot->wsplit = 2;
+            return;
+        }
     if (n > 128 && n < 256 && (size_t)n * 4096 <= (size_t)max_batch * DPARTS) slot->k = 1;
     // pieces above 256 blobs (max_batch raised by the caller): eight scalars per lane cost whole rounds of 2048 wavefronts (2.75 ms each),
     // one scalar per lane costs 10.8 us per blob + 0.3 ms -- e.g. 300 blobs: two rounds = 5.5 ms against 3.5 ms
@@ -1019,10 +1045,10 @@ static void launch_direct_acc(int c, dim3 grid, hipStream_t s, const uint8_t* d_
     }
 #endif
     switch (c) {
-        case 12: hipLaunchKernelGGL((k_commit_direct_acc<12, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k); break;
-        case 13: hipLaunchKernelGGL((k_commit_direct_acc<13, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k); break;
-        case 14: hipLaunchKernelGGL((k_commit_direct_acc<14, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k); break;
-        default: hipLaunchKernelGGL((k_commit_direct_acc<15, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k); break;
+        case 12: hipLaunchKernelGGL((k_commit_direct_acc<12, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k, ws.wsplit); break;
+        case 13: hipLaunchKernelGGL((k_commit_direct_acc<13, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k, ws.wsplit); break;
+        case 14: hipLaunchKernelGGL((k_commit_direct_acc<14, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k, ws.wsplit); break;
+        default: hipLaunchKernelGGL((k_commit_direct_acc<15, KIND>), grid, dim3(DTA), 0, s, d_scalars, stride, d_direct, ws.d_parts, ws.d_bad, ws.k, ws.wsplit); break;
     }
 }
 // the two halves of a direct-table commitment: accumulate (VALU-bound, one single-wave workgroup per 512 scalars) and finish
@@ -1031,27 +1057,30 @@ static void launch_direct_acc(int c, dim3 grid, hipStream_t s, const uint8_t* d_
 void commit_direct_acc_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, hipStream_t s, KernelTimer* kt) {
     if (n <= 0) return;
     if (kt) kt->begin(KT_COMMIT_DIRECT, s);
-    const dim3 grid(4096 / (ws.k * DTA), n);
+    const dim3 grid(4096 / (ws.k * DTA) * ws.wsplit, n);
     if (input_kind == 0) launch_direct_acc<0>(c, grid, s, d_scalars, stride, d_direct, ws);
     else launch_direct_acc<1>(c, grid, s, d_scalars, stride, d_direct, ws);
-    if (!ws.serial) {
+    if (!ws.serial && ws.wsplit == 2) {                   // 8192 records per blob: pairs + 16 -> 256 at stride 32 -> 16 at stride 512
+        hipLaunchKernelGGL(k_commit_direct_fold16, dim3(256, n), dim3(64), 0, s, ws.d_parts, 8192, 1, 1);
+        hipLaunchKernelGGL(k_commit_direct_fold16, dim3(16, n), dim3(64), 0, s, ws.d_parts, 256, 32, 0);
+    } else if (!ws.serial) {
         const int pp = 4096 / ws.k;                       // records per blob: 4096, 2048, 1024 -> / 16 -> / 256
-        hipLaunchKernelGGL(k_commit_direct_fold16, dim3(pp / 16, n), dim3(64), 0, s, ws.d_parts, pp, 1);
-        hipLaunchKernelGGL(k_commit_direct_fold16, dim3(pp / 256, n), dim3(64), 0, s, ws.d_parts, pp / 16, 16);
+        hipLaunchKernelGGL(k_commit_direct_fold16, dim3(pp / 16, n), dim3(64), 0, s, ws.d_parts, pp, 1, 0);
+        hipLaunchKernelGGL(k_commit_direct_fold16, dim3(pp / 256, n), dim3(64), 0, s, ws.d_parts, pp / 16, 16, 0);
     }
     if (kt) kt->end(KT_COMMIT_DIRECT, s);
 }
 void commit_direct_fin_device(const DirectSlot& ws, int n, uint8_t* d_out48, int* d_status, hipStream_t s, KernelTimer* kt, uint32_t* d_raw) {
     if (n <= 0) return;
     if (kt) kt->begin(KT_COMMIT_DIRECT_FIN, s);
-    const int blocks = 4096 / (ws.k * DTA);
-    int nblk = blocks;
+    const int blocks = 4096 / (ws.k * DTA) * ws.wsplit;   // accumulate workgroups per blob: bad-scalar flags, 64-record blocks
+    int nblk = blocks / ws.wsplit;                        // (folded shapes: four times the records the folds left)
     if (ws.serial && blocks > 8) {
         hipLaunchKernelGGL(k_commit_direct_sum8, dim3(blocks / 8, n), dim3(64), 0, s, ws.d_parts, blocks);
         nblk = blocks / 8;
     }
     if (ws.serial && ws.fin_quad && !d_raw) hipLaunchKernelGGL(k_commit_direct_fin_quad, dim3(n), dim3(256), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, blocks, nblk);
-    else hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, blocks, nblk, ws.serial ? 0 : 1, d_raw);
+    else hipLaunchKernelGGL(k_commit_direct_fin, dim3(n), dim3(64), 0, s, ws.d_parts, ws.d_bad, d_out48, d_status, blocks, nblk, ws.serial ? 0 : 256 * ws.wsplit, d_raw);
     if (kt) kt->end(KT_COMMIT_DIRECT_FIN, s);
 }
 void commit_direct_device(int c, const uint32_t* d_direct, const DirectSlot& ws, const uint8_t* d_scalars, size_t stride, int input_kind, int n, uint8_t* d_out48, int* d_status,

@@ -127,8 +127,8 @@ def test_direct_table_mode(product, oracle_ctx, bits):
 
 def test_direct_table_lane_shapes(product, oracle_ctx):
     """The direct-table commitment spreads a blob over 512 lanes (8 scalars each) in a full batch and over 1024, 2048 or 4096 lanes
-    in calls of fewer blobs (msm_kernels.hip direct_pick_shape: 1..32 blobs -> 1 scalar per lane, ..64 -> 2, ..128 -> 4; 129..255 -> 1 with a
-    serial sum instead of the butterflies), with a fold of
+    in calls of fewer blobs (msm_kernels.hip direct_pick_shape: 1..8 blobs -> a PAIR of lanes per scalar, lower and upper windows, 9..32 -> 1
+    scalar per lane, ..64 -> 2, ..128 -> 4; 129..255 -> 1 with a serial sum instead of the butterflies), with a fold of
     the partial sums in between: every shape gives the oracle's bytes, an invalid blob is reported at its index."""
     import torch
     torch.cuda.init()
@@ -136,7 +136,7 @@ def test_direct_table_lane_shapes(product, oracle_ctx):
     exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in distinct]
     ctx = product.Context()
     assert ctx.set_option("commit_direct_bits", 12) == 0
-    for n in (1, 2, 20, 32, 33, 64, 65, 128, 129, 200, 255, 300):
+    for n in (1, 2, 8, 9, 20, 32, 33, 64, 65, 128, 129, 200, 255, 300, 3):      # 1..8: a pair of lanes per scalar (lower / upper windows); the last 3 with max_batch 320
         if n == 300:
             assert ctx.set_option("max_batch", 320) == 0          # one piece above 256 blobs: one scalar per lane again (a full round + 352 wavefronts otherwise)
         blobs = [distinct[i % 6] for i in range(n)]
@@ -164,6 +164,27 @@ def test_direct_table_lane_shapes(product, oracle_ctx):
             else:
                 assert st_d[i] == 0 and out_b[48 * i:48 * i + 48] == exp[i % 6], (n, i)
     ctx.close()
+
+
+def test_few_blob_shapes_with_a_small_workspace(product, oracle_ctx):
+    """max_batch 8: the lane's buffer starts with 8 x 512 records, so a single blob (8192 records in the window-split shape) takes the
+    one-lane-per-scalar shape and eight blobs grow the buffer: same bytes, with and without the host finish"""
+    blobs = [rand_blob(770 + i) for i in range(8)]
+    exp = [oracle_ctx.blob_to_kzg_commitment(b)[1] for b in blobs]
+    ctx = product.Context()
+    try:
+        assert ctx.set_option("commit_direct_bits", 12) == 0 and ctx.set_option("max_batch", 8) == 0
+        for hf in (1, 0):
+            assert ctx.set_option("host_fin", hf) == 0
+            for n in (1, 3, 4, 5, 8):
+                rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs[:n])
+                assert rc == 0 and outs == exp[:n] and st == [0] * n, (hf, n)
+        assert ctx.set_option("max_batch", 16) == 0                           # 16 x 512 = 8192 records: one blob fits the split shape, two do not
+        for n in (1, 2, 8):
+            rc, outs, st = ctx.BlobToKZGCommitmentBatch(blobs[:n])
+            assert rc == 0 and outs == exp[:n], n
+    finally:
+        ctx.close()
 
 
 def test_options_and_calibration(product, oracle_ctx):

@@ -934,6 +934,11 @@ static int set_option_one(mkzg_ctx* c, const char* key, long value) {
         return MKZG_OK;
     }
 #endif
+    if (!strcmp(key, "host_validate")) {
+        if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
+        c->opt_host_validate = (int)value;
+        return MKZG_OK;
+    }
     if (!strcmp(key, "host_fin")) {
         if (value < 0 || value > 1) return MKZG_ERR_BAD_ARGS;
         c->opt_host_fin = (int)value;
@@ -1019,6 +1024,7 @@ int mkzg_ctx_get_option(mkzg_ctx* c, const char* key, long* value) {
     else if (!strcmp(key, "cpu_share")) *value = q->cpu_share;
     else if (!strcmp(key, "host_zero_copy")) *value = q->opt_host_zero_copy;
     else if (!strcmp(key, "host_fin")) *value = q->opt_host_fin;
+    else if (!strcmp(key, "host_validate")) *value = q->opt_host_validate;
 #ifdef MKZG_AFFINE_PAIRS
     else if (!strcmp(key, "commit_affine_pairs")) *value = q->opt_affine_pairs;
 #endif

@@ -14,6 +14,7 @@
 #include <functional>
 #include <thread>
 #include "ctx.h"
+#include "host_validate.hpp"
 #include "api_multi.h"
 #include "host_sha256.hpp"
 
@@ -318,8 +319,22 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
     L->last_host_finish_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
     return MKZG_OK;
 }
+// The single-proof entry points' two points (VerifyKZGProof, VerifyBlobKZGProof: verify.go:12-83) validated on the HOST (host_validate.hpp:
+// ~45 us per point on one core where a quad of GPU lanes takes 0.64 ms for the same dependent chain), the proof's on a pool thread beside
+// the commitment's on this one; one small launch puts the records and status words where the validation kernel leaves them.
+static void host_validate_pair(mkzg_ctx* c, const uint8_t* c48, const uint8_t* q48, uint32_t* aff_c, int* st_c, uint32_t* aff_q, int* st_q, hipStream_t s2) {
+    G1RowPair rp;
+    Countdown cd(1);
+    const std::function<void(int)> task = [&](int) { rp.st[1] = g1h_validate_row(q48, rp.row[1]); };
+    c->pool->run_async(1, task, &cd);
+    rp.st[0] = g1h_validate_row(c48, rp.row[0]);
+    c->pool->wait(cd);
+    g1_put_rows_device(rp, aff_c, st_c, aff_q, st_q, s2);
+}
+static bool host_validate_on(const mkzg_ctx* c) { return c->opt_host_validate.load(std::memory_order_relaxed) != 0; }
 static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
-                       uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out, RlcLate* late = nullptr) {
+                       uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out, RlcLate* late = nullptr,
+                       const uint8_t* h_c48 = nullptr, const uint8_t* h_q48 = nullptr /* n == 1: the two points on the host, for host_validate_pair */) {
     if (n == 0 || n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
     int rc = ensure_verify_ws(L, n);
     if (rc) return rc;
@@ -367,7 +382,8 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     //    context with eight calls in flight had two of them progressing; one stream per call keeps one queue per call)
     hipStream_t s2 = tp ? s : lane_side_stream(L, s);
     const bool s_idle = lane_fork(L, s, s2);
-    KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
+    if (n == 1 && h_c48 && h_q48 && !tp && !late && host_validate_on(c)) host_validate_pair(c, h_c48, h_q48, aff_c, st_c, aff_q, st_q, s2);
+    else KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
     if (d_blobs) {
         //    ... and, for blobs, the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
         //    (throughput shape: none of that -- the three MSMs go out as ONE launch after the challenge, see below)
@@ -711,7 +727,8 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
             HIPCHK(hipMemcpyAsync(L->d_v_raw, h_pts, m * 48, hipMemcpyHostToDevice, s2));
             HIPCHK(hipMemcpyAsync(L->d_v_raw + cap * 48, h_pts + m * 48, m * 48, hipMemcpyHostToDevice, s2));
             if (n_dev) HIPCHK(hipEventRecord(L->ev_decoded, s2));                  // the commitments are up: the device's share of the hash may read them
-            KT(KT_SUBGROUP, s2, g1_validate2_device(L->d_v_raw, (int)m, aff_c, st_c, L->d_v_raw + cap * 48, (int)m, aff_q, st_q, s2, MKZG_LAT_VALIDATE_MODE(m)));
+            if (m == 1 && !late && host_validate_on(c)) host_validate_pair(c, commitments48n, proofs48n, aff_c, st_c, aff_q, st_q, s2);
+            else KT(KT_SUBGROUP, s2, g1_validate2_device(L->d_v_raw, (int)m, aff_c, st_c, L->d_v_raw + cap * 48, (int)m, aff_q, st_q, s2, MKZG_LAT_VALIDATE_MODE(m)));
             if (early_msm) {
                 KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)m, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
                 const uint32_t* scal[2] = {L->d_v_s1, L->d_v_s1};
@@ -832,7 +849,8 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
         c->pool->wait(all_left);                      // the tasks reference this frame
         if (rc) return rc;
         if (hsha) HIPCHK(hipMemcpyAsync(d_z, h_z, m * 32, hipMemcpyHostToDevice, s));
-        rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out, late);
+        rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out, late,
+                         m == 1 ? commitments48n : nullptr, m == 1 ? proofs48n : nullptr);
     }
     if (first_nil < m) {
         // the reference deserialises commitment i and proof i before blob i, so a nil blob only surfaces after their checks: an error
@@ -1017,7 +1035,7 @@ int mkzg_verify_kzg_proof(mkzg_ctx* c, const uint8_t commitment48[48], const uin
     HIPCHK(hipMemcpyAsync(L->d_v_raw, L->h_stage + 64, 48, hipMemcpyHostToDevice, G.s));
     HIPCHK(hipMemcpyAsync(L->d_v_raw + L->v_cap * 48, L->h_stage + 112, 48, hipMemcpyHostToDevice, G.s));
     VerifyFold f;
-    rc = verify_fold(c, L, nullptr, L->d_blobs, L->d_blobs + 32, L->d_v_raw, L->d_v_raw + L->v_cap * 48, 1, 0, r, G.s, &f);
+    rc = verify_fold(c, L, nullptr, L->d_blobs, L->d_blobs + 32, L->d_v_raw, L->d_v_raw + L->v_cap * 48, 1, 0, r, G.s, &f, nullptr, commitment48, proof48);
     if (rc) return G.fail(rc);
     return timed_finish(c, L, f);
 }
@@ -1027,7 +1045,8 @@ int mkzg_verify_kzg_proof(mkzg_ctx* c, const uint8_t commitment48[48], const uin
 // status[i] receives the per-item code; proofs of failed items are undefined.
 // d_z32: the challenges when the caller hashed the transcripts on the host (n x 32 B big-endian, canonical), else nullptr.
 static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_commitments48, size_t n, uint8_t* d_proofs48, int* d_status, hipStream_t s,
-                                      const uint8_t* d_z32 = nullptr, uint32_t* d_raw = nullptr /* n == 1: the proof as XYZZ words for commit_host_finish */) {
+                                      const uint8_t* d_z32 = nullptr, uint32_t* d_raw = nullptr /* n == 1: the proof as XYZZ words for commit_host_finish */,
+                                      const uint8_t* h_cm48 = nullptr /* n == 1: the commitment's bytes on the host */) {
     // Slices of up to 4096 proofs.  Per slice the latency-bound stages run ONCE over the whole slice -- Fiat-Shamir challenges
     // (a 2050-compression chain per blob whatever the count) on the caller's stream, commitment decoding + subgroup checks on the
     // side stream -- and only the quotient + MSM stage is cut into max_batch pieces (its workspace is 196 KB per blob).
@@ -1045,7 +1064,8 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         // commitment must be a valid subgroup point (prove.go:56-62)
         hipStream_t s2 = lane_side_stream(L, s);
         lane_fork(L, s, s2);
-        g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, s2);
+        int h_st_cm = -1;                                  // n == 1 with the commitment's bytes on the host: its status from host_validate.hpp (below)
+        if (!(n == 1 && h_cm48 && host_validate_on(c))) g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, s2);
         HIPCHK(hipEventRecord(L->ev_join, s2));
         if (d_z32) scalars_to_fr_device(d_z32 + done * 32, (int)slice, L->d_q_z, L->d_v_stx, s);
         else KT(KT_SHA256, s, challenge_device(blobs, cms, (int)slice, L->d_q_z, s));
@@ -1063,8 +1083,14 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         int* stb = (int*)L->h_v;
         int* stc = stb + L->v_cap;
         HIPCHK(hipMemcpyAsync(stb, st_blob, slice * sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(stc, st_cm, slice * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (n == 1 && h_cm48 && host_validate_on(c)) {     // the one commitment's checks on this thread while the quotient and its MSM run
+            uint32_t row[32];
+            h_st_cm = g1h_validate_row(h_cm48, row);
+        } else {
+            HIPCHK(hipMemcpyAsync(stc, st_cm, slice * sizeof(int), hipMemcpyDeviceToHost, s));
+        }
         LANE_SYNC(c, L, s);
+        if (h_st_cm >= 0) stc[0] = h_st_cm;
         bool any = false;
         for (size_t i = 0; i < slice; i++) { stb[i] = stb[i] ? stb[i] : stc[i]; any = any || stb[i]; }
         if (any) HIPCHK(hipMemcpyAsync(d_status + done, stb, slice * sizeof(int), hipMemcpyHostToDevice, s));
@@ -1099,7 +1125,7 @@ int mkzg_compute_blob_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t 
     // exist for that (a first call builds it inside compute_blob_proofs_device and takes the device's finish)
     const bool hfin = host_fin_one(c);
     rc = compute_blob_proofs_device(c, L, L->d_blobs, L->d_blobs + MKZG_BYTES_PER_BLOB, 1, L->d_out, L->d_status, G.s, hsha ? L->d_blobs + MKZG_BYTES_PER_BLOB + 64 : nullptr,
-                                    hfin ? reinterpret_cast<uint32_t*>(L->d_out) : nullptr);
+                                    hfin ? reinterpret_cast<uint32_t*>(L->d_out) : nullptr, commitment48);
     if (rc) return G.fail(rc);
     HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, hfin ? 256 : 48, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(L->h_out + 256, L->d_status, sizeof(int), hipMemcpyDeviceToHost, G.s));

@@ -276,6 +276,7 @@ struct mkzg_ctx {
     std::atomic<int> opt_affine_pairs{0};              // A/B builds only (experiments/commit_pairs_kernels.hip): adjacent windows of a scalar added in affine coordinates first
 #endif
     std::atomic<int> opt_host_fin{1};                  // host-pointer commitments of up to four blobs: the kernel leaves XYZZ sums, the calling thread inverts and compresses
+    std::atomic<int> opt_host_validate{1};             // single-proof entry points: their one or two points are decoded and subgroup-tested on the calling thread (host_validate.hpp)
     std::atomic<int> opt_host_zero_copy{1};            // host-pointer commitments: the accumulate kernel reads the pinned staging area itself (1) or a device copy (0)
     // single-item calls of the reference API served in groups through the batch paths when several are in flight (host_combine.hpp)
     struct CommitCall { const uint8_t* blob; uint8_t* out48; int rc; };

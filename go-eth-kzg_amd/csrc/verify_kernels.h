@@ -71,6 +71,13 @@ void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint
 // decode (gnark SetBytes checks) + subgroup test of two arrays of compressed points in one launch: affine rows and status words out
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
                          int mode = 0 /* 0: decode + subgroup test (a lane quad per point); 1: decode only; 2: subgroup test only, verdicts to d_st_*; 3: as 0, one lane per point */);
+// Two affine records and their status words, validated on the HOST (host_validate.hpp: the single-proof entry points), into the places where
+// g1_validate2_device leaves them for n_a = n_b = 1 -- by value in the kernel arguments: no staging buffer, no copy kernel that reads host memory
+struct G1RowPair {
+    uint32_t row[2][32];
+    int st[2];
+};
+void g1_put_rows_device(const G1RowPair& rp, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b, hipStream_t s);
 // r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)
 // h_r8: HOST pointer to the eight words of r
 void rlc_scalars_device(const uint32_t* h_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,

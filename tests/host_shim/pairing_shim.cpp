@@ -1,6 +1,7 @@
 // tests/host_shim/pairing_shim.cpp -- exposes the product's HOST pairing / G1 code
 // (go-eth-kzg_amd/csrc/host_pairing.hpp, host_g1.hpp) to Python for CPU-side unit tests.
 #include "../../go-eth-kzg_amd/csrc/host_g1.hpp"
+#include "../../go-eth-kzg_amd/csrc/host_validate.hpp"
 using namespace kzg;
 extern "C" {
 // prod e(P_i, Q_i) == 1 ?  P: n x 48 B compressed, Q: n x 96 B compressed.  -1 on decode error.
@@ -240,5 +241,16 @@ int shim_hostfp_mul_adx_check(int n, uint64_t seed) {
     (void)n; (void)seed;
     return -1;
 #endif
+}
+// host_validate.hpp: status of one compressed point and its affine record (32 words) as the kernels consume it
+int shim_g1_validate_row(const uint8_t* in48, uint32_t* row32) { return g1h_validate_row(in48, row32); }
+// the record back to compressed bytes through the device's limb templates compiled for the host (round trip of the conversion)
+void shim_row_compress(const uint32_t* row32, uint8_t* out48) {
+    G1Aff a;
+    for (int i = 0; i < 14; i++) { a.x.l[i] = row32[i]; a.y.l[i] = row32[14 + i]; }
+    a.inf = row32[28];
+    uint32_t w12[12];
+    g1_compress_words(w12, a);
+    for (int i = 0; i < 12; i++) { const uint32_t v = __builtin_bswap32(w12[i]); memcpy(out48 + 4 * i, &v, 4); }
 }
 }

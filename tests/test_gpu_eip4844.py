@@ -50,16 +50,21 @@ def test_compute_kzg_proof(vectors, gpu_ctx):
     assert n_ok > 30
 
 
-@pytest.fixture(params=[(-1, -1), (0, 0), (1, 1), (0, 1)], ids=["defaults", "sha_device-latency_shape", "sha_host-throughput_shape", "sha_device-throughput_shape"])
+@pytest.fixture(params=[(-1, -1, 1), (0, 0, 1), (1, 1, 1), (0, 1, 1), (-1, -1, 0), (0, 0, 0)],
+                ids=["defaults", "sha_device-latency_shape", "sha_host-throughput_shape", "sha_device-throughput_shape", "device_validation", "sha_device-latency_shape-device_validation"])
 def hash_place(request, gpu_ctx):
     """Where the Fiat-Shamir transcript is hashed (option host_sha: by default the host pool takes small calls and the device large
     ones) and which shape the verifier takes (option verify_shape: inverse NTT + Horner and quad subgroup tests for a lone call,
     barycentric evaluation and one lane per point when several calls share the chip): the vectors run under each setting."""
     assert gpu_ctx.set_option("host_sha", request.param[0]) == 0
     assert gpu_ctx.set_option("verify_shape", request.param[1]) == 0
+    # option host_validate (round 6, default 1): the single-proof entry points decode and subgroup-test their points on the calling thread
+    # (host_validate.hpp); 0 = the device's kernels as for batches.  Same codes either way: the vectors' invalid points run under both
+    assert gpu_ctx.set_option("host_validate", request.param[2]) == 0 and gpu_ctx.get_option("host_validate") == request.param[2]
     yield gpu_ctx
     assert gpu_ctx.set_option("host_sha", -1) == 0
     assert gpu_ctx.set_option("verify_shape", -1) == 0
+    assert gpu_ctx.set_option("host_validate", 1) == 0
 
 
 def test_compute_blob_kzg_proof(vectors, hash_place):
@@ -112,10 +117,16 @@ def test_points_outside_the_subgroup(gpu_ctx):
             outside.append((x, y))
     good = compress(ec_mul(5, (G1X, G1Y)))
     z, y32 = (3).to_bytes(32, "big"), (4).to_bytes(32, "big")
-    for pt in outside:
-        assert ec_mul(R, pt) is not None
-        assert gpu_ctx.VerifyKZGProof(compress(pt), z, y32, good) == NOT_IN_SUBGROUP, pt
-        assert gpu_ctx.VerifyKZGProof(good, z, y32, compress(pt)) == NOT_IN_SUBGROUP, pt
+    for hv in (0, 1):                                           # the device's kernel, then the calling thread's host_validate.hpp
+        assert gpu_ctx.set_option("host_validate", hv) == 0
+        for pt in outside:
+            assert ec_mul(R, pt) is not None
+            assert gpu_ctx.VerifyKZGProof(compress(pt), z, y32, good) == NOT_IN_SUBGROUP, pt
+            assert gpu_ctx.VerifyKZGProof(good, z, y32, compress(pt)) == NOT_IN_SUBGROUP, pt
+        blob0 = rand_blob(6)
+        assert gpu_ctx.ComputeBlobKZGProof(blob0, compress(outside[3]))[0] == NOT_IN_SUBGROUP
+        assert gpu_ctx.VerifyBlobKZGProof(blob0, compress(outside[4]), good) == NOT_IN_SUBGROUP
+        assert gpu_ctx.VerifyBlobKZGProof(blob0, good, compress(outside[5])) == NOT_IN_SUBGROUP
     H_COF = 0x396c8c005555e1568c00aaab0000aaab
     for pt in outside[2:5]:
         q = ec_mul(H_COF, pt)

@@ -18,7 +18,7 @@ X = -0xD201000000010000
 @pytest.fixture(scope="module")
 def shim():
     from conftest import build_host_shim
-    return C.CDLL(build_host_shim("pairing", ("host_pairing.hpp", "host_cyclo_ifma.hpp", "host_field.hpp", "host_g1.hpp", "host_pool.hpp", "g1.hpp", "mont29.hpp", "constants29.h")))
+    return C.CDLL(build_host_shim("pairing", ("host_pairing.hpp", "host_cyclo_ifma.hpp", "host_field.hpp", "host_g1.hpp", "host_validate.hpp", "host_pool.hpp", "g1.hpp", "mont29.hpp", "constants29.h")))
 
 
 @pytest.fixture(scope="module")
@@ -133,3 +133,56 @@ def test_miller_loop_segments_multiply_to_the_whole_loop(shim, setup):
     g1, g2 = setup
     for i, j in ((1, 0), (5, 3), (0, 7), (9, 9)):
         assert shim.shim_miller_segments_check(g1[i], g2[j]) == 0, (i, j)
+
+
+def test_host_point_validation_matches_oracle(shim, setup):
+    """host_validate.hpp g1h_validate_row (gnark SetBytes on the calling thread for the single-proof entry points, reference
+    serialization.go:108-115): the status of every kind of encoding equals the oracle's deserialisation -- trusted-setup points, multiples
+    of the generator, the identity, bad flag combinations, x >= p, x not on the curve, curve points OUTSIDE the r-torsion (orders with
+    small factors among them), both sign bits -- and the affine record it leaves compresses back to the input (the 29-bit-limb conversion)."""
+    import random
+    import sys
+    sys.path.insert(0, ROOT)
+    import oracle
+    g1, _ = setup
+    rng = random.Random(11)
+    cases = list(g1[:8]) + [oracle.g1_gen_mul(k) for k in (1, 2, 3, R - 1, 0x1234567890abcdef, rng.randrange(R))]
+    cases.append(bytes([0xc0] + [0] * 47))                                  # identity
+    cases.append(bytes([0xc0] + [0] * 46 + [1]))                            # identity flag with payload
+    cases.append(bytes([0xe0] + [0] * 47))                                  # all three flags
+    cases.append(bytes([0x40] + [0] * 47))                                  # not compressed
+    cases.append(bytes(48))                                                 # no flags
+    cases.append(bytes([0x9f] + [0xff] * 47))                               # x >= p
+    cases.append(bytes([0x80]) + (P - 1).to_bytes(48, "big")[1:])           # x = p - 1 with the flag byte
+    # curve points that are (almost surely) not in the subgroup, and x values that are not on the curve, with either sign bit
+    n_out = n_off = 0
+    x = 5
+    while n_out < 12 or n_off < 6:
+        x += 1
+        rhs = (x * x * x + 4) % P
+        on = pow(rhs, (P - 1) // 2, P) == 1
+        for sign in (0x80, 0xa0):
+            b = bytearray(x.to_bytes(48, "big"))
+            b[0] |= sign
+            cases.append(bytes(b))
+        n_out += on
+        n_off += not on
+    # a point of order 3: (0, 2) -- x = 0
+    cases.append(bytes([0x80] + [0] * 47))
+    cases.append(bytes([0xa0] + [0] * 47))
+    shim.shim_g1_validate_row.restype = C.c_int
+    seen = set()
+    for enc in cases:
+        row = (C.c_uint32 * 32)()
+        got = shim.shim_g1_validate_row(enc, row)
+        want = oracle.g1_validate(enc)
+        assert got == want, (enc.hex(), got, want)
+        seen.add(got)
+        if got in (0, 13) and not (enc[0] & 0x40):
+            out = C.create_string_buffer(48)
+            shim.shim_row_compress(row, out)
+            assert out.raw == enc, enc.hex()
+            assert row[28] == 0
+        else:
+            assert row[28] == 1 and not any(row[i] for i in range(28))
+    assert seen == {0, 11, 12, 13}

@@ -319,22 +319,25 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
     L->last_host_finish_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_h0).count();
     return MKZG_OK;
 }
-// The single-proof entry points' two points (VerifyKZGProof, VerifyBlobKZGProof: verify.go:12-83) validated on the HOST (host_validate.hpp:
-// ~45 us per point on one core where a quad of GPU lanes takes 0.64 ms for the same dependent chain), the proof's on a pool thread beside
-// the commitment's on this one; one small launch puts the records and status words where the validation kernel leaves them.
-static void host_validate_pair(mkzg_ctx* c, const uint8_t* c48, const uint8_t* q48, uint32_t* aff_c, int* st_c, uint32_t* aff_q, int* st_q, hipStream_t s2) {
-    G1RowPair rp;
-    Countdown cd(1);
-    const std::function<void(int)> task = [&](int) { rp.st[1] = g1h_validate_row(q48, rp.row[1]); };
-    c->pool->run_async(1, task, &cd);
-    rp.st[0] = g1h_validate_row(c48, rp.row[0]);
-    c->pool->wait(cd);
+// The points of the single-proof entry points (VerifyKZGProof, VerifyBlobKZGProof: verify.go:12-83) and of batches of up to G1_ROWS_MAX
+// items -- a block's blobs, what a consensus client hands VerifyBlobKZGProofBatch (verify.go:88-143) -- validated on the HOST
+// (host_validate.hpp: ~45 us per point on one core where a quad of GPU lanes takes 0.64 ms for the same dependent chain, however few the
+// points), one task per point on the pool and this thread; one small launch puts the records and status words where the validation
+// kernel leaves them.
+static void host_validate_points(mkzg_ctx* c, const uint8_t* c48n, const uint8_t* q48n, size_t n, uint32_t* aff_c, int* st_c, uint32_t* aff_q, int* st_q, hipStream_t s2) {
+    G1Rows rp;
+    rp.n = (int)n;
+    const std::function<void(int)> task = [&](int t) {
+        const uint8_t* src = (size_t)t < n ? c48n + 48 * (size_t)t : q48n + 48 * ((size_t)t - n);
+        rp.st[t] = g1h_validate_row(src, rp.row[t]);
+    };
+    c->pool->parallel(2 * (int)n, task);
     g1_put_rows_device(rp, aff_c, st_c, aff_q, st_q, s2);
 }
-static bool host_validate_on(const mkzg_ctx* c) { return c->opt_host_validate.load(std::memory_order_relaxed) != 0; }
+static bool host_validate_on(const mkzg_ctx* c, size_t n) { return n <= (size_t)G1_ROWS_MAX && c->opt_host_validate.load(std::memory_order_relaxed) != 0; }
 static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
                        uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out, RlcLate* late = nullptr,
-                       const uint8_t* h_c48 = nullptr, const uint8_t* h_q48 = nullptr /* n == 1: the two points on the host, for host_validate_pair */) {
+                       const uint8_t* h_c48 = nullptr, const uint8_t* h_q48 = nullptr /* the points' bytes on the host (n x 48 each), for host_validate_points */) {
     if (n == 0 || n > (size_t)VMSM_MAX_N) return MKZG_ERR_BAD_ARGS;
     int rc = ensure_verify_ws(L, n);
     if (rc) return rc;
@@ -382,7 +385,7 @@ static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8
     //    context with eight calls in flight had two of them progressing; one stream per call keeps one queue per call)
     hipStream_t s2 = tp ? s : lane_side_stream(L, s);
     const bool s_idle = lane_fork(L, s, s2);
-    if (n == 1 && h_c48 && h_q48 && !tp && !late && host_validate_on(c)) host_validate_pair(c, h_c48, h_q48, aff_c, st_c, aff_q, st_q, s2);
+    if (h_c48 && h_q48 && !tp && !late && host_validate_on(c, n)) host_validate_points(c, h_c48, h_q48, n, aff_c, st_c, aff_q, st_q, s2);
     else KT(KT_SUBGROUP, s2, g1_validate2_device(d_commitments, (int)n, aff_c, st_c, d_proofs, (int)n, aff_q, st_q, s2, tp ? MKZG_TP_VALIDATE_MODE : MKZG_LAT_VALIDATE_MODE(n)));
     if (d_blobs) {
         //    ... and, for blobs, the powers of r and the two MSMs that use nothing else (sum r^i Q_i, sum r^i C_i: kzg_verify.go:150,225)
@@ -727,7 +730,7 @@ static int fold_host_pipelined(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs
             HIPCHK(hipMemcpyAsync(L->d_v_raw, h_pts, m * 48, hipMemcpyHostToDevice, s2));
             HIPCHK(hipMemcpyAsync(L->d_v_raw + cap * 48, h_pts + m * 48, m * 48, hipMemcpyHostToDevice, s2));
             if (n_dev) HIPCHK(hipEventRecord(L->ev_decoded, s2));                  // the commitments are up: the device's share of the hash may read them
-            if (m == 1 && !late && host_validate_on(c)) host_validate_pair(c, commitments48n, proofs48n, aff_c, st_c, aff_q, st_q, s2);
+            if (!late && host_validate_on(c, m)) host_validate_points(c, commitments48n, proofs48n, m, aff_c, st_c, aff_q, st_q, s2);
             else KT(KT_SUBGROUP, s2, g1_validate2_device(L->d_v_raw, (int)m, aff_c, st_c, L->d_v_raw + cap * 48, (int)m, aff_q, st_q, s2, MKZG_LAT_VALIDATE_MODE(m)));
             if (early_msm) {
                 KT(KT_RLC, s2, rlc_scalars_device(r_words, nullptr, nullptr, (int)m, exp_offset, L->d_v_s1, nullptr, nullptr, 1, s2));
@@ -850,7 +853,7 @@ static int fold_host_piece(mkzg_ctx* c, Lane* L, const uint8_t* const* blobs, co
         if (rc) return rc;
         if (hsha) HIPCHK(hipMemcpyAsync(d_z, h_z, m * 32, hipMemcpyHostToDevice, s));
         rc = verify_fold(c, L, L->d_blobs, hsha ? d_z : nullptr, nullptr, L->d_v_raw, L->d_v_raw + L->v_cap * 48, m, exp_offset, r_le32, s, out, late,
-                         m == 1 ? commitments48n : nullptr, m == 1 ? proofs48n : nullptr);
+                         commitments48n, proofs48n);
     }
     if (first_nil < m) {
         // the reference deserialises commitment i and proof i before blob i, so a nil blob only surfaces after their checks: an error
@@ -1065,7 +1068,7 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         hipStream_t s2 = lane_side_stream(L, s);
         lane_fork(L, s, s2);
         int h_st_cm = -1;                                  // n == 1 with the commitment's bytes on the host: its status from host_validate.hpp (below)
-        if (!(n == 1 && h_cm48 && host_validate_on(c))) g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, s2);
+        if (!(n == 1 && h_cm48 && host_validate_on(c, 1))) g1_validate2_device(cms, (int)slice, L->d_v_aff, st_cm, nullptr, 0, nullptr, nullptr, s2);
         HIPCHK(hipEventRecord(L->ev_join, s2));
         if (d_z32) scalars_to_fr_device(d_z32 + done * 32, (int)slice, L->d_q_z, L->d_v_stx, s);
         else KT(KT_SHA256, s, challenge_device(blobs, cms, (int)slice, L->d_q_z, s));
@@ -1083,7 +1086,7 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         int* stb = (int*)L->h_v;
         int* stc = stb + L->v_cap;
         HIPCHK(hipMemcpyAsync(stb, st_blob, slice * sizeof(int), hipMemcpyDeviceToHost, s));
-        if (n == 1 && h_cm48 && host_validate_on(c)) {     // the one commitment's checks on this thread while the quotient and its MSM run
+        if (n == 1 && h_cm48 && host_validate_on(c, 1)) {  // the one commitment's checks on this thread while the quotient and its MSM run
             uint32_t row[32];
             h_st_cm = g1h_validate_row(h_cm48, row);
         } else {

@@ -1626,15 +1626,16 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
 void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint32_t* d_y, const int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_poly_eval, dim3(n), dim3(256), 0, s, d_coeffs, d_z, d_status, d_y);
 }
-__global__ void __launch_bounds__(64) k_g1_put_rows(const G1RowPair rp, uint32_t* __restrict__ aff_a, int* __restrict__ st_a, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
-    const int t = threadIdx.x;
-    if (t < 32) aff_a[t] = rp.row[0][t];
-    else aff_b[t - 32] = rp.row[1][t - 32];
-    if (t == 0) st_a[0] = rp.st[0];
-    if (t == 32) st_b[0] = rp.st[1];
+__global__ void __launch_bounds__(2 * G1_ROWS_MAX * 32) k_g1_put_rows(const G1Rows rp, uint32_t* __restrict__ aff_a, int* __restrict__ st_a, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
+    const int pt = threadIdx.x >> 5, w = threadIdx.x & 31;
+    if (pt >= 2 * rp.n) return;
+    const bool b = pt >= rp.n;
+    const int i = b ? pt - rp.n : pt;
+    (b ? aff_b : aff_a)[i * 32 + w] = rp.row[pt][w];
+    if (w == 0) (b ? st_b : st_a)[i] = rp.st[pt];
 }
-void g1_put_rows_device(const G1RowPair& rp, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b, hipStream_t s) {
-    hipLaunchKernelGGL(k_g1_put_rows, dim3(1), dim3(64), 0, s, rp, d_aff_a, d_st_a, d_aff_b, d_st_b);
+void g1_put_rows_device(const G1Rows& rp, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b, hipStream_t s) {
+    hipLaunchKernelGGL(k_g1_put_rows, dim3(1), dim3(2 * G1_ROWS_MAX * 32), 0, s, rp, d_aff_a, d_st_a, d_aff_b, d_st_b);
 }
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
                          int mode) {

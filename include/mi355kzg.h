@@ -120,10 +120,11 @@ int mkzg_ctx_prepare(mkzg_ctx* ctx, unsigned what);
  *                         to the pieces it has seen, 1.6 MB per blob)
  *   "host_zero_copy"      1 (default): the commitment kernel reads the gathered blobs straight from pinned host memory over PCIe
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
- *   "host_validate"       1 (default): the single-proof entry points (VerifyKZGProof, VerifyBlobKZGProof, ComputeBlobKZGProof) decode and
- *                         subgroup-test their one or two points on the calling thread and one pool thread (~45 us per point; same checks,
- *                         same codes) instead of waiting for the device's chain (0.64 ms on a quad of lanes); 0: the device validates.
- *                         Batches always validate on the device
+ *   "host_validate"       1 (default): the single-proof entry points (VerifyKZGProof, VerifyBlobKZGProof, ComputeBlobKZGProof) and host-pointer
+ *                         VerifyBlobKZGProofBatch calls of up to twelve items (a block carries at most nine blobs: EIP-7691) decode and subgroup-test their points on
+ *                         the calling thread and the host pool (~45 us per point; same checks, same codes) instead of waiting for the
+ *                         device's chain (0.64 ms on a quad of lanes however few the points); 0: the device validates.
+ *                         Larger batches and the device-pointer forms always validate on the device
  *   "host_fin"            1 (default): host-pointer commitment calls of up to four blobs (the single-blob entry point, small groups of
  *                         the call combiner) get the sum's projective coordinates back and convert + compress on the calling thread (~8 us
  *                         per blob) instead of waiting for the one-wavefront inversion on the device (~90 us); 0: the device finishes

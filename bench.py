@@ -324,6 +324,7 @@ def main():
 
     single = None
     if rank == 0 and world == 1 and not dist_on and not args.no_drop_in and args.verify_batch > 0 and args.cell_blobs > 0:
+        drop_in["single_calls_ms"] = bench_single_calls(ctx, host_blobs)
         single = bench_single_blob_callers(ctx, kzg, torch)
         assert ctx.set_option("combine_single_calls", 0) == 0            # for the record: every call on its own, as until round 5
         alone = bench_single_blob_callers(ctx, kzg, torch, callers=(32,))
@@ -556,6 +557,11 @@ def compact_line(out, detail_path):
             ("verify_cell_batch_8192.device_cells_ms", "eip7594.verify_cell_kzg_proof_batch.device_cells.ms_per_call_median"),
             ("verify_cell_batch_8192.sustained_cells_per_s", "eip7594.verify_cell_kzg_proof_batch.sustained.cells_per_s"),
             ("recover_cells_and_proofs_64.ms_per_call", "eip7594.recover_cells_and_kzg_proofs.ms_per_batch"),
+            ("single_call_ms.BlobToKZGCommitment", "drop_in.single_calls_ms.BlobToKZGCommitment"),
+            ("single_call_ms.ComputeBlobKZGProof", "drop_in.single_calls_ms.ComputeBlobKZGProof"),
+            ("single_call_ms.VerifyBlobKZGProof", "drop_in.single_calls_ms.VerifyBlobKZGProof"),
+            ("single_call_ms.VerifyBlobKZGProofBatch_6", "drop_in.single_calls_ms.VerifyBlobKZGProofBatch_6"),
+            ("single_call_ms.ComputeCellsAndKZGProofs", "drop_in.single_calls_ms.ComputeCellsAndKZGProofs"),
             ("single_blob_callers_32.commit_blobs_per_s", "drop_in.single_blob_callers.blob_to_kzg_commitment.callers_32.blobs_per_s"),
             ("single_blob_callers_32.cells_blobs_per_s", "drop_in.single_blob_callers.compute_cells_and_kzg_proofs.callers_32.blobs_per_s"),
             ("single_blob_callers_32.verify_blobs_per_s", "drop_in.single_blob_callers.verify_blob_kzg_proof.callers_32.blobs_per_s"),
@@ -830,6 +836,47 @@ def bench_drop_in(ctx, kzg, host_blobs, d_expect):
             "device_resident_one_synchronous_caller": {"ms_per_call": round(dtd * 1e3, 3), "blobs_per_s": round(n / dtd, 1)},
             "one_caller_over_device_resident": round(dtd / dt1, 3), "two_callers_over_device_resident": round(dtd / dt2, 3),
             "note": "PCIe inclusive: pageable host blobs in (gathered into pinned staging chunk by chunk), host bytes out"}
+
+
+def bench_single_calls(ctx, host_blobs, reps=30):
+    """The reference's API as its tests and clients call it -- ONE item per call, host pointers in, host bytes out, one caller
+    (prove.go:13-111, verify.go:12-143, api_eip7594.go:28-52,144-214) -- latency in ms, median of `reps` calls each; the block-sized
+    VerifyBlobKZGProofBatch (6 and 9 blobs: EIP-4844 / EIP-7691) beside the single-proof forms.  Results checked against each other
+    (the proofs verify, a swapped proof does not)."""
+    b = host_blobs[:9]
+    cms = [ctx.BlobToKZGCommitment(x)[1] for x in b]
+    prs = [ctx.ComputeBlobKZGProof(x, c)[1] for x, c in zip(b, cms)]
+    z = (0x5eed).to_bytes(32, "big")
+    rc, pz, y = ctx.ComputeKZGProof(b[0], z)
+    assert rc == 0 and ctx.VerifyKZGProof(cms[0], z, y, pz) == 0 and ctx.VerifyBlobKZGProof(b[0], cms[0], prs[0]) == 0 and ctx.VerifyBlobKZGProof(b[0], cms[0], prs[1]) == 1
+    assert ctx.VerifyBlobKZGProofBatch(b, cms, prs) == 0 and ctx.VerifyBlobKZGProofBatch(b, cms, prs[1:] + prs[:1]) == 1
+    rc, cells, proofs = ctx.ComputeCellsAndKZGProofs(b[0])
+    assert rc == 0
+    half = list(range(0, 128, 2))
+    calls = {"BlobToKZGCommitment": lambda: ctx.BlobToKZGCommitment(b[0]),
+             "ComputeKZGProof": lambda: ctx.ComputeKZGProof(b[0], z),
+             "ComputeBlobKZGProof": lambda: ctx.ComputeBlobKZGProof(b[0], cms[0]),
+             "VerifyKZGProof": lambda: ctx.VerifyKZGProof(cms[0], z, y, pz),
+             "VerifyBlobKZGProof": lambda: ctx.VerifyBlobKZGProof(b[0], cms[0], prs[0]),
+             "VerifyBlobKZGProofBatch_6": lambda: ctx.VerifyBlobKZGProofBatch(b[:6], cms[:6], prs[:6]),
+             "VerifyBlobKZGProofBatch_9": lambda: ctx.VerifyBlobKZGProofBatch(b, cms, prs),
+             "ComputeCellsAndKZGProofs": lambda: ctx.ComputeCellsAndKZGProofs(b[0]),
+             "VerifyCellKZGProofBatch_128": lambda: ctx.VerifyCellKZGProofBatch([cms[0]] * 128, list(range(128)), cells, proofs),
+             "RecoverCellsAndComputeKZGProofs": lambda: ctx.RecoverCellsAndComputeKZGProofs(half, [cells[i] for i in half])}
+    out = {}
+    for name, fn in calls.items():
+        fn()
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out[name] = round(ts[len(ts) // 2] * 1e3, 3)
+    out["note"] = ("ms per call, median of %d, one caller, host pointers through the ctypes binding (its marshalling included); options host_fin / host_validate "
+                   "at their defaults: the one resulting point and the few input points of these calls are finished / validated on the calling thread" % reps)
+    return out
 
 
 def bench_single_blob_callers(ctx, kzg, torch, callers=(8, 32), per_thread=4, seconds=0.35, kinds=None, wrong_every=0):

@@ -7,6 +7,15 @@ export TMPDIR=/tmp
 O=gpurun_out/r06p; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q -x -p no:cacheprovider < /dev/null > $O/tests_full.txt 2>&1
 grep -E "passed|failed|error" $O/tests_full.txt | tail -3
+# PMC passes of every leg on the final kernel sources (one bench configuration per leg: tools/pmc_collect.sh), merged into profiles/r06_traffic.json
+PASS_TIMEOUT=150 bash tools/pmc_collect.sh r06c > $O/pmc_c.log 2>&1 < /dev/null
+PASS_TIMEOUT=150 bash tools/pmc_collect.sh r06v --verify-batch 1024 --verify-inflight 1 --no-strong > $O/pmc_v.log 2>&1 < /dev/null
+PMC_GRIDS="k_g1_validate=4096" PASS_TIMEOUT=150 bash tools/pmc_collect.sh r06t --verify-batch 1024 --verify-inflight 1 --no-strong --verify-shape 1 > $O/pmc_t.log 2>&1 < /dev/null
+PASS_TIMEOUT=200 bash tools/pmc_collect.sh r06e --cell-blobs 64 > $O/pmc_e.log 2>&1 < /dev/null
+rm -rf gpurun_out/pmc_r06c gpurun_out/pmc_r06v gpurun_out/pmc_r06t gpurun_out/pmc_r06e
+python3 tools/pmc_merge.py profiles/r06_traffic.json commit=gpurun_out/r06c_traffic.json verify=gpurun_out/r06v_traffic.json verify_tp=gpurun_out/r06t_traffic.json eip7594=gpurun_out/r06e_traffic.json
+cp profiles/r06_traffic.json $O/r06_traffic.json
+cp gpurun_out/r06c_pmc_summary.csv gpurun_out/r06v_pmc_summary.csv gpurun_out/r06t_pmc_summary.csv gpurun_out/r06e_pmc_summary.csv $O/ 2>/dev/null
 timeout 900 python3 bench.py --steps 20 --warmup 5 --detail-out $O/bench_default_detail.json > $O/bench_default.json 2> $O/bench_default.err < /dev/null
 wc -c $O/bench_default.json; tail -c 300 $O/bench_default.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_commit -o ks -- python3 bench.py --full-line --steps 20 --warmup 3 --streams 1 --no-cpu-baseline --no-drop-in --cell-blobs 0 --verify-batch 0 --detail-out /tmp/d1.json > $O/bench_commit_only.json 2> $O/bench_commit_only.err < /dev/null

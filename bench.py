@@ -1404,21 +1404,24 @@ def bench_eip7594(ctx, kzg, torch, dist, dist_on, dev, world, rank, args, hw):
     assert ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st) == 0      # builds the FK20 table
     torch.cuda.synchronize()
     assert int(d_st.abs().sum().item()) == 0
-    steps = 3
+    steps = 5
     out = {}
+    ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st)        # a second warm call: the lane's workspaces at their size
+    torch.cuda.synchronize()
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
+    each = []
+    for _ in range(steps):                     # every call timed on its own: the leg's figure is the MEDIAN (one call in five that meets a hiccup used to move a mean of three by 20 %)
+        t0 = time.perf_counter()
         ctx.compute_cells_and_kzg_proofs_batch_device(d_blobs.data_ptr(), NB, d_cells.data_ptr(), d_proofs.data_ptr(), d_st.data_ptr(), st)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize()
+        each.append(time.perf_counter() - t0)
+    dt = sorted(each)[steps // 2]
     prof = ctx.profile_read(reset=True)
     kern = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
     roof, valu = leg_roofline(kern, 399360 * NB, hw, pmc_valid_for_size=full_size and ctx.get_option("fk20_bits_effective") == 12, leg="eip7594")
     out["compute_cells_and_kzg_proofs"] = {"blobs_per_gpu": NB, "fk20_table_bits": ctx.get_option("fk20_bits_effective"), "ms_per_batch": round(dt * 1e3, 3), "blobs_per_s_per_gpu": round(NB / dt, 1),
-                                           "kernels_ms": kern, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3), "roofline": roof, "valu": valu}
+                                           "ms_each_call": [round(t * 1e3, 3) for t in each], "kernels_ms": kern, "algorithmic_GBps": round(399360 * NB / dt / 1e9, 3), "roofline": roof, "valu": valu}
     ctx.profile_enable(False)
     if solo:
         # the sizes a block carries (6 blobs today, up to 48 planned): one synchronous caller, ms per call

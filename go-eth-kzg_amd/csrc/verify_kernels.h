@@ -79,6 +79,7 @@ struct G1Rows {
     uint32_t row[2 * G1_ROWS_MAX][32];      // [0, n): array a (commitments), [n, 2n): array b (proofs)
     int st[2 * G1_ROWS_MAX];
     int n;
+    int first;                              // index of the chunk's first item in the arrays (larger sets go out in chunks of G1_ROWS_MAX items)
 };
 void g1_put_rows_device(const G1Rows& rp, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b, hipStream_t s);
 // r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)

@@ -1630,7 +1630,7 @@ __global__ void __launch_bounds__(2 * G1_ROWS_MAX * 32) k_g1_put_rows(const G1Ro
     const int pt = threadIdx.x >> 5, w = threadIdx.x & 31;
     if (pt >= 2 * rp.n) return;
     const bool b = pt >= rp.n;
-    const int i = b ? pt - rp.n : pt;
+    const int i = rp.first + (b ? pt - rp.n : pt);
     (b ? aff_b : aff_a)[i * 32 + w] = rp.row[pt][w];
     if (w == 0) (b ? st_b : st_a)[i] = rp.st[pt];
 }

@@ -15,7 +15,7 @@ def main():
     torch.cuda.init()
     kzg = load_product()
     ctx = kzg.Context()
-    blobs = [rand_blob(50 + i) for i in range(16)]
+    blobs = [rand_blob(50 + i) for i in range(48)]
     cms = [ctx.BlobToKZGCommitment(b)[1] for b in blobs]
     prs = [ctx.ComputeBlobKZGProof(b, c)[1] for b, c in zip(blobs, cms)]
     z = (99).to_bytes(32, "big")
@@ -36,7 +36,7 @@ def main():
             r = {"VerifyKZGProof": timeit(lambda: ctx.VerifyKZGProof(cms[0], z, y, pz)),
                  "VerifyBlobKZGProof": timeit(lambda: ctx.VerifyBlobKZGProof(blobs[0], cms[0], prs[0])),
                  "ComputeBlobKZGProof": timeit(lambda: ctx.ComputeBlobKZGProof(blobs[0], cms[0]))}
-            for n in (2, 6, 8, 9, 16):
+            for n in (2, 6, 9, 16, 32, 33, 48):
                 assert ctx.VerifyBlobKZGProofBatch(blobs[:n], cms[:n], prs[:n]) == 0
                 bad = list(prs[:n])
                 bad[n - 1] = prs[0] if n > 1 else prs[1]

@@ -11,6 +11,7 @@
 #include <thread>
 #include <unordered_map>
 #include "ctx.h"
+#include "host_validate_dev.hpp"
 #include "api_multi.h"
 
 static const size_t V_MISC_WORDS_C = 16 + 4 * VMSM_WINDOWS * 48;
@@ -431,6 +432,15 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     int* sub_rows = d_cv_st + cap;
     int* sub_q = d_cv_st + 2 * cap;
     lane_fork(L, s, s2, s3);
+    // Calls of a few cells -- a column sidecar is ONE cell of every blob of the block, a custody set a few columns (EIP-7594) -- wait for
+    // nothing but the points' chain: 0.7 ms on the device however few the points, ~45 us per point on a host core.  Up to
+    // HOST_VALIDATE_MAX_POINTS points are decoded and subgroup-tested on the host pool and this thread (host_validate.hpp, option
+    // host_validate) and go to the device as records; the verdict arrays are the kernels'.
+    if (!late && n + n_rows <= HOST_VALIDATE_MAX_POINTS && c->opt_host_validate.load(std::memory_order_relaxed) != 0) {
+        host_validate_arrays(c->pool, rows.data(), n_rows, proofs48n, n, aff_rows, st_rows, aff_q, st_q, s2, sub_rows, sub_q);
+        HIPCHK(hipEventRecord(L->ev_decoded, s2));
+        HIPCHK(hipEventRecord(L->ev_join, s2));
+    } else {
     KT(KT_DECOMPRESS, s2, g1_validate2_device(d_rows, (int)n_rows, aff_rows, st_rows, d_proofs, (int)n, aff_q, st_q, s2, 1));
     HIPCHK(hipEventRecord(L->ev_decoded, s2));
     // the r-torsion test: a quad of lanes per point for calls of few cells (its 0.75 ms chain is what such a call waits for); one lane per
@@ -439,6 +449,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     const int sub_mode = MKZG_CV_SUBGROUP_WIDE_FROM > 0 && n + n_rows >= (size_t)MKZG_CV_SUBGROUP_WIDE_FROM ? 4 : 2;
     KT(KT_SUBGROUP, s3, g1_validate2_device(d_rows, (int)n_rows, nullptr, sub_rows, d_proofs, (int)n, nullptr, sub_q, s3, sub_mode));
     HIPCHK(hipEventRecord(L->ev_join, s3));
+    }
     // scalars, first part: r^k, r^k h_k^64 and the rows' weights need the indices only -- in the call's queue AHEAD of the cells' upload, where
     // they run while the host still gathers (A/B with twelve callers: 9.4 against 8.6-9.3 M cells/s)
     // (r still on its way from a collective, RlcLate: the points' chains are running by now; the cells' gather below does not overlap the

@@ -14,7 +14,7 @@
 #include <functional>
 #include <thread>
 #include "ctx.h"
-#include "host_validate.hpp"
+#include "host_validate_dev.hpp"
 #include "api_multi.h"
 #include "host_sha256.hpp"
 
@@ -324,25 +324,10 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
 // (host_validate.hpp: ~45 us per point on one core where a quad of GPU lanes takes 0.64 ms for the same dependent chain, however few the
 // points), one task per point on the pool and this thread; one small launch puts the records and status words where the validation
 // kernel leaves them.
-constexpr size_t HOST_VALIDATE_MAX = 32;          // items: 64 points = four rounds of sixteen pool threads, ~0.2 ms against the device's 0.64-0.7 ms chain
 static void host_validate_points(mkzg_ctx* c, const uint8_t* c48n, const uint8_t* q48n, size_t n, uint32_t* aff_c, int* st_c, uint32_t* aff_q, int* st_q, hipStream_t s2) {
-    constexpr size_t CH = (size_t)G1_ROWS_MAX;
-    G1Rows rp[(HOST_VALIDATE_MAX + CH - 1) / CH];
-    const std::function<void(int)> task = [&](int t) {
-        const bool q = (size_t)t >= n;
-        const size_t i = q ? (size_t)t - n : (size_t)t, k = i / CH, j = i % CH, m = std::min(CH, n - k * CH);
-        G1Rows& r = rp[k];
-        const size_t slot = q ? m + j : j;
-        r.st[slot] = g1h_validate_row((q ? q48n : c48n) + 48 * i, r.row[slot]);
-    };
-    c->pool->parallel(2 * (int)n, task);
-    for (size_t k = 0; k * CH < n; k++) {
-        rp[k].n = (int)std::min(CH, n - k * CH);
-        rp[k].first = (int)(k * CH);
-        g1_put_rows_device(rp[k], aff_c, st_c, aff_q, st_q, s2);
-    }
+    host_validate_arrays(c->pool, c48n, n, q48n, n, aff_c, st_c, aff_q, st_q, s2);
 }
-static bool host_validate_on(const mkzg_ctx* c, size_t n) { return n <= HOST_VALIDATE_MAX && c->opt_host_validate.load(std::memory_order_relaxed) != 0; }
+static bool host_validate_on(const mkzg_ctx* c, size_t n) { return 2 * n <= HOST_VALIDATE_MAX_POINTS && c->opt_host_validate.load(std::memory_order_relaxed) != 0; }
 static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
                        uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out, RlcLate* late = nullptr,
                        const uint8_t* h_c48 = nullptr, const uint8_t* h_q48 = nullptr /* the points' bytes on the host (n x 48 each), for host_validate_points */) {

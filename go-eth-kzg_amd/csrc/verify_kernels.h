@@ -71,17 +71,20 @@ void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint
 // decode (gnark SetBytes checks) + subgroup test of two arrays of compressed points in one launch: affine rows and status words out
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
                          int mode = 0 /* 0: decode + subgroup test (a lane quad per point); 1: decode only; 2: subgroup test only, verdicts to d_st_*; 3: as 0, one lane per point */);
-// The affine records and status words of up to G1_ROWS_MAX + G1_ROWS_MAX points validated on the HOST (host_validate.hpp: the single-proof
-// entry points and batches of a few items), into the places where g1_validate2_device leaves them for n_a = n_b = n -- by value in the
-// kernel arguments (2.1 KB): no staging buffer, no copy kernel that reads host memory
-constexpr int G1_ROWS_MAX = 12;     // 9 = the most blobs a block carries (EIP-7691); 24 records = 3 KB of kernel arguments
+// The affine records and status words of up to G1_ROWS_MAX points validated on the HOST (host_validate.hpp: the single-proof entry points
+// and the verifiers' calls of a few items), into the places where g1_validate2_device leaves them -- by value in the kernel arguments
+// (3.3 KB): no staging buffer, no copy kernel that reads host memory.  A chunk holds na records of array a (the blob verifier's
+// commitments, the cell verifier's distinct commitments) from index first_a on, then nb records of array b (the proofs) from first_b on;
+// larger sets go out as several chunks.  st: the decoding status (0, MKZG_ERR_G1_BAD_ENCODING, MKZG_ERR_G1_NOT_ON_CURVE); sub: 0 or
+// MKZG_ERR_G1_NOT_IN_SUBGROUP.  With d_sub_* null the two are one status word as k_g1_validate<0> writes it (decoding error first).
+constexpr int G1_ROWS_MAX = 24;      // records per chunk
 struct G1Rows {
-    uint32_t row[2 * G1_ROWS_MAX][32];      // [0, n): array a (commitments), [n, 2n): array b (proofs)
-    int st[2 * G1_ROWS_MAX];
-    int n;
-    int first;                              // index of the chunk's first item in the arrays (larger sets go out in chunks of G1_ROWS_MAX items)
+    uint32_t row[G1_ROWS_MAX][32];
+    int st[G1_ROWS_MAX];
+    int sub[G1_ROWS_MAX];
+    int na, nb, first_a, first_b;
 };
-void g1_put_rows_device(const G1Rows& rp, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b, hipStream_t s);
+void g1_put_rows_device(const G1Rows& rp, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b, hipStream_t s, int* d_sub_a = nullptr, int* d_sub_b = nullptr);
 // r^(exp_offset + i) for i < n (exp_offset: global index of the shard's first proof)
 // h_r8: HOST pointer to the eight words of r
 void rlc_scalars_device(const uint32_t* h_r8, const uint32_t* d_z, const uint32_t* d_y, int n, uint32_t exp_offset, uint32_t* d_s1, uint32_t* d_s3, uint32_t* d_e,

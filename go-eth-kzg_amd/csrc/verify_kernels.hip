@@ -1626,16 +1626,25 @@ void blob_quotient_device(const uint8_t* d_blobs, const uint32_t* d_z, const uin
 void poly_eval_device(const uint32_t* d_coeffs, const uint32_t* d_z, int n, uint32_t* d_y, const int* d_status, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(k_poly_eval, dim3(n), dim3(256), 0, s, d_coeffs, d_z, d_status, d_y);
 }
-__global__ void __launch_bounds__(2 * G1_ROWS_MAX * 32) k_g1_put_rows(const G1Rows rp, uint32_t* __restrict__ aff_a, int* __restrict__ st_a, uint32_t* __restrict__ aff_b, int* __restrict__ st_b) {
+__global__ void __launch_bounds__(G1_ROWS_MAX * 32) k_g1_put_rows(const G1Rows rp, uint32_t* __restrict__ aff_a, int* __restrict__ st_a, uint32_t* __restrict__ aff_b, int* __restrict__ st_b,
+                                                                  int* __restrict__ sub_a, int* __restrict__ sub_b) {
     const int pt = threadIdx.x >> 5, w = threadIdx.x & 31;
-    if (pt >= 2 * rp.n) return;
-    const bool b = pt >= rp.n;
-    const int i = rp.first + (b ? pt - rp.n : pt);
+    if (pt >= rp.na + rp.nb) return;
+    const bool b = pt >= rp.na;
+    const int i = b ? rp.first_b + pt - rp.na : rp.first_a + pt;
     (b ? aff_b : aff_a)[i * 32 + w] = rp.row[pt][w];
-    if (w == 0) (b ? st_b : st_a)[i] = rp.st[pt];
+    if (w == 0) {
+        int* sub = b ? sub_b : sub_a;
+        if (sub) {
+            (b ? st_b : st_a)[i] = rp.st[pt];
+            sub[i] = rp.sub[pt];
+        } else {
+            (b ? st_b : st_a)[i] = rp.st[pt] ? rp.st[pt] : rp.sub[pt];
+        }
+    }
 }
-void g1_put_rows_device(const G1Rows& rp, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b, hipStream_t s) {
-    hipLaunchKernelGGL(k_g1_put_rows, dim3(1), dim3(2 * G1_ROWS_MAX * 32), 0, s, rp, d_aff_a, d_st_a, d_aff_b, d_st_b);
+void g1_put_rows_device(const G1Rows& rp, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b, hipStream_t s, int* d_sub_a, int* d_sub_b) {
+    hipLaunchKernelGGL(k_g1_put_rows, dim3(1), dim3(G1_ROWS_MAX * 32), 0, s, rp, d_aff_a, d_st_a, d_aff_b, d_st_b, d_sub_a, d_sub_b);
 }
 void g1_validate2_device(const uint8_t* d_in48_a, int n_a, uint32_t* d_aff_a, int* d_st_a, const uint8_t* d_in48_b, int n_b, uint32_t* d_aff_b, int* d_st_b, hipStream_t s,
                          int mode) {

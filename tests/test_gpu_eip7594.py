@@ -71,15 +71,74 @@ def _check_verifier(rc, expected, name):
         assert rc == 1, f"{name}: expected reject, got rc={rc}"
 
 
-def test_verify_cell_kzg_proof_batch_vectors(vectors, gpu_ctx):
-    for c in vectors.cases("verify_cell_kzg_proof_batch"):
-        i = c["input"]
-        cms, idx, cells, prs = (vectors.val(i[k]) for k in ("commitments", "cell_indices", "cells", "proofs"))
-        exp = vectors.val(c["output"])
-        if _bad(*cms, *cells, *prs) or any(len(x) != 48 for x in cms) or any(len(x) != 2048 for x in cells) or any(len(x) != 48 for x in prs):
-            assert exp is None
-            continue
-        _check_verifier(gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs), exp, c["name"])
+@pytest.mark.parametrize("host_validate", [1, 0], ids=["host_validation", "device_validation"])
+def test_verify_cell_kzg_proof_batch_vectors(vectors, gpu_ctx, host_validate):
+    """option host_validate (round 6, default 1): calls whose distinct commitments + proofs are at most 64 points decode and subgroup-test
+    them on the host pool (host_validate.hpp; a column sidecar is one cell of every blob of the block), larger ones and option 0 on the
+    device -- the 30 vectors (invalid commitments and proofs among them) under both"""
+    assert gpu_ctx.set_option("host_validate", host_validate) == 0
+    try:
+        for c in vectors.cases("verify_cell_kzg_proof_batch"):
+            i = c["input"]
+            cms, idx, cells, prs = (vectors.val(i[k]) for k in ("commitments", "cell_indices", "cells", "proofs"))
+            exp = vectors.val(c["output"])
+            if _bad(*cms, *cells, *prs) or any(len(x) != 48 for x in cms) or any(len(x) != 2048 for x in cells) or any(len(x) != 48 for x in prs):
+                assert exp is None
+                continue
+            _check_verifier(gpu_ctx.VerifyCellKZGProofBatch(cms, idx, cells, prs), exp, c["name"])
+    finally:
+        assert gpu_ctx.set_option("host_validate", 1) == 0
+
+
+def test_small_cell_batches_under_both_validations(gpu_ctx):
+    """Column-sidecar-sized calls (EIP-7594: one cell of each of a block's 6 / 9 blobs; 8 columns of them; 63 + 1 and 64 + 1 points, the
+    boundary of the host validation): accept, reject a swapped proof, and answer a curve point outside the r-torsion -- as a proof and as a
+    commitment -- with the decoder's error, identically with the points validated on the host and on the device.  Reference:
+    api_eip7594.go:163-214, serialization.go:108-115."""
+    from test_gpu_commit import rand_blob
+    from test_mont29_host import P, R, ec_mul, compress
+    blobs = [rand_blob(6100 + i) for i in range(3)]
+    data = []
+    for b in blobs:
+        rc, cm = gpu_ctx.BlobToKZGCommitment(b)
+        rc2, cells, proofs = gpu_ctx.ComputeCellsAndKZGProofs(b)
+        assert rc == 0 and rc2 == 0
+        data.append((cm, cells, proofs))
+    x = 3
+    while True:
+        x += 1
+        rhs = (x * x * x + 4) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P == rhs and ec_mul(R, (x, y)) is not None:
+            break
+    outside = compress((x, y))
+
+    def batch(n_blobs, cols):
+        c, idx, ce, pr = [], [], [], []
+        for col in cols:
+            for b in range(n_blobs):
+                c.append(data[b][0]); idx.append(col); ce.append(data[b][1][col]); pr.append(data[b][2][col])
+        return c, idx, ce, pr
+
+    shapes = [batch(3, [9]), batch(3, list(range(0, 128, 16))), batch(1, list(range(63))), batch(1, list(range(64))), batch(3, list(range(21))), batch(3, list(range(22)))]
+    results = {}
+    for hv in (1, 0):
+        assert gpu_ctx.set_option("host_validate", hv) == 0
+        res = []
+        for c, idx, ce, pr in shapes:
+            res.append(gpu_ctx.VerifyCellKZGProofBatch(c, idx, ce, pr))
+            res.append(gpu_ctx.VerifyCellKZGProofBatch(c, idx, ce, pr[1:] + pr[:1]))
+            bad = list(pr)
+            bad[len(bad) // 2] = outside
+            res.append(gpu_ctx.VerifyCellKZGProofBatch(c, idx, ce, bad))
+            badc = list(c)
+            badc[-1] = outside
+            res.append(gpu_ctx.VerifyCellKZGProofBatch(badc, idx, ce, pr))
+        results[hv] = res
+    assert gpu_ctx.set_option("host_validate", 1) == 0
+    assert results[1] == results[0], (results[1], results[0])
+    for k in range(len(shapes)):
+        assert results[1][4 * k: 4 * k + 4] == [0, 1, 13, 13], (k, results[1][4 * k: 4 * k + 4])
 
 
 def test_verify_cell_kzg_proof_batch_vectors_device_cells(vectors, gpu_ctx):

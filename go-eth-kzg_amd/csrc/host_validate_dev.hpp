@@ -11,13 +11,14 @@ namespace kzg {
 
 // na + nb points (two arrays of 48-byte encodings) validated on the pool and the calling thread, one task per point, and handed to the device
 // in chunks of G1_ROWS_MAX records (verify_kernels.h G1Rows / g1_put_rows_device).  d_sub_*: see g1_put_rows_device.
-constexpr size_t HOST_VALIDATE_MAX_POINTS = 64;          // four rounds of sixteen pool threads, ~0.2 ms against the device's 0.64-0.7 ms chain
+constexpr size_t HOST_VALIDATE_MAX_POINTS = 64;          // blob verifier: four rounds of sixteen pool threads, ~0.2 ms against the device's 0.64-0.7 ms chain
+constexpr size_t HOST_VALIDATE_MAX_CELL_POINTS = 96;     // cell verifier (A/B, tools/lat_cellverify.py: 81 points 1.28 -> 1.17 ms, 129 points 1.30 -> 1.36-1.55): eight columns of nine blobs
 template <class Pool>
 inline void host_validate_arrays(Pool* pool, const uint8_t* a48n, size_t na, const uint8_t* b48n, size_t nb, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b,
                                  hipStream_t s, int* d_sub_a = nullptr, int* d_sub_b = nullptr) {
     constexpr size_t CH = (size_t)G1_ROWS_MAX;
     const size_t total = na + nb;
-    G1Rows rp[(HOST_VALIDATE_MAX_POINTS + CH - 1) / CH];
+    G1Rows rp[(HOST_VALIDATE_MAX_CELL_POINTS + CH - 1) / CH];
     const std::function<void(int)> task = [&](int t) {           // point t of the concatenation a | b sits in chunk t / CH, slot t % CH
         const size_t k = (size_t)t / CH, slot = (size_t)t % CH;
         const uint8_t* src = (size_t)t < na ? a48n + 48 * (size_t)t : b48n + 48 * ((size_t)t - na);

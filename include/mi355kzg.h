@@ -122,7 +122,7 @@ int mkzg_ctx_prepare(mkzg_ctx* ctx, unsigned what);
  *                         (2 KB per wavefront per 17 group additions); 0: an explicit copy to HBM precedes each chunk's kernel
  *   "host_validate"       1 (default): the single-proof entry points (VerifyKZGProof, VerifyBlobKZGProof, ComputeBlobKZGProof) and host-pointer
  *                         VerifyBlobKZGProofBatch calls of up to 32 items (a block carries at most nine blobs: EIP-7691) and VerifyCellKZGProofBatch calls of up to
- *                         64 points (distinct commitments + proofs: a column sidecar is one cell of every blob of the block) decode and subgroup-test their points on
+ *                         96 points (distinct commitments + proofs: a column sidecar is one cell of every blob of the block) decode and subgroup-test their points on
  *                         the calling thread and the host pool (~45 us per point; same checks, same codes) instead of waiting for the
  *                         device's chain (0.64 ms on a quad of lanes however few the points); 0: the device validates.
  *                         Larger batches and the device-pointer forms always validate on the device

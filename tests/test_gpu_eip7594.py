@@ -73,7 +73,7 @@ def _check_verifier(rc, expected, name):
 
 @pytest.mark.parametrize("host_validate", [1, 0], ids=["host_validation", "device_validation"])
 def test_verify_cell_kzg_proof_batch_vectors(vectors, gpu_ctx, host_validate):
-    """option host_validate (round 6, default 1): calls whose distinct commitments + proofs are at most 64 points decode and subgroup-test
+    """option host_validate (round 6, default 1): calls whose distinct commitments + proofs are at most 96 points decode and subgroup-test
     them on the host pool (host_validate.hpp; a column sidecar is one cell of every blob of the block), larger ones and option 0 on the
     device -- the 30 vectors (invalid commitments and proofs among them) under both"""
     assert gpu_ctx.set_option("host_validate", host_validate) == 0
@@ -91,7 +91,7 @@ def test_verify_cell_kzg_proof_batch_vectors(vectors, gpu_ctx, host_validate):
 
 
 def test_small_cell_batches_under_both_validations(gpu_ctx):
-    """Column-sidecar-sized calls (EIP-7594: one cell of each of a block's 6 / 9 blobs; 8 columns of them; 63 + 1 and 64 + 1 points, the
+    """Column-sidecar-sized calls (EIP-7594: one cell of each of a block's 6 / 9 blobs; 8 columns of them; 95 + 1 and 96 + 1 points, the
     boundary of the host validation): accept, reject a swapped proof, and answer a curve point outside the r-torsion -- as a proof and as a
     commitment -- with the decoder's error, identically with the points validated on the host and on the device.  Reference:
     api_eip7594.go:163-214, serialization.go:108-115."""
@@ -120,7 +120,7 @@ def test_small_cell_batches_under_both_validations(gpu_ctx):
                 c.append(data[b][0]); idx.append(col); ce.append(data[b][1][col]); pr.append(data[b][2][col])
         return c, idx, ce, pr
 
-    shapes = [batch(3, [9]), batch(3, list(range(0, 128, 16))), batch(1, list(range(63))), batch(1, list(range(64))), batch(3, list(range(21))), batch(3, list(range(22)))]
+    shapes = [batch(3, [9]), batch(3, list(range(0, 128, 16))), batch(1, list(range(95))), batch(1, list(range(96))), batch(3, list(range(31))), batch(3, list(range(32)))]
     results = {}
     for hv in (1, 0):
         assert gpu_ctx.set_option("host_validate", hv) == 0

@@ -424,12 +424,15 @@ static int commit_prepare(mkzg_ctx* c, Lane* L) {
     }
     return ensure_lane_plan(c, L);
 }
-// d_raw (direct table only, one piece): the sums as XYZZ limb words, 64 words per item, for commit_host_finish instead of compressed bytes in d_out48n
+// d_raw (a request; *raw_used says whether it was granted): the sums as XYZZ limb words, 64 words per item, for commit_host_finish instead of compressed bytes in d_out48n
 int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s,
-                          uint32_t* d_raw) {
+                          uint32_t* d_raw, bool* raw_used) {
     int rc = commit_prepare(c, L);
     if (rc) return rc;
-    if (d_raw && (!c->direct_bits_built || n > (size_t)c->opt_max_batch)) return MKZG_ERR_BAD_ARGS;
+    // decided HERE, behind commit_prepare (the table's state is read under the ordering its builder's mutex gives): XYZZ words instead of
+    // compressed bytes only through the direct table, for one piece, with option host_fin on
+    if (d_raw && !(c->direct_bits_built && n <= (size_t)c->opt_max_batch && c->opt_host_fin.load(std::memory_order_relaxed) != 0)) d_raw = nullptr;
+    if (raw_used) *raw_used = d_raw != nullptr;
     if (c->direct_bits_built) {
         // whatever the pieces' shapes will need of the lane's workspace is allocated HERE: the launches below go out as one launch graph
         // (ctx.h lane_graph_run), and a capture must not meet an allocation

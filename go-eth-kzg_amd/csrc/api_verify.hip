@@ -1041,8 +1041,8 @@ int mkzg_verify_kzg_proof(mkzg_ctx* c, const uint8_t commitment48[48], const uin
 // status[i] receives the per-item code; proofs of failed items are undefined.
 // d_z32: the challenges when the caller hashed the transcripts on the host (n x 32 B big-endian, canonical), else nullptr.
 static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_commitments48, size_t n, uint8_t* d_proofs48, int* d_status, hipStream_t s,
-                                      const uint8_t* d_z32 = nullptr, uint32_t* d_raw = nullptr /* n == 1: the proof as XYZZ words for commit_host_finish */,
-                                      const uint8_t* h_cm48 = nullptr /* n == 1: the commitment's bytes on the host */) {
+                                      const uint8_t* d_z32 = nullptr, uint32_t* d_raw = nullptr /* n == 1: ask for the proof as XYZZ words for commit_host_finish */,
+                                      bool* raw_used = nullptr, const uint8_t* h_cm48 = nullptr /* n == 1: the commitment's bytes on the host */) {
     // Slices of up to 4096 proofs.  Per slice the latency-bound stages run ONCE over the whole slice -- Fiat-Shamir challenges
     // (a 2050-compression chain per blob whatever the count) on the caller's stream, commitment decoding + subgroup checks on the
     // side stream -- and only the quotient + MSM stage is cut into max_batch pieces (its workspace is 196 KB per blob).
@@ -1069,7 +1069,7 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
             const size_t chunk = std::min<size_t>(slice - off, (size_t)c->opt_max_batch);
             KT(KT_QUOTIENT, s, blob_quotient_device(blobs + off * MKZG_BYTES_PER_BLOB, L->d_q_z + off * 12, c->d_roots_brp, c->d_inv_roots_brp, (int)chunk, L->d_q_y + off * 12,
                                                     L->d_quot, st_blob + off, s));
-            rc = commit_scalars_device(c, L, (const uint8_t*)L->d_quot, (size_t)4096 * 48, 1, chunk, d_proofs48 + (done + off) * 48, d_status + done + off, s, n == 1 ? d_raw : nullptr);
+            rc = commit_scalars_device(c, L, (const uint8_t*)L->d_quot, (size_t)4096 * 48, 1, chunk, d_proofs48 + (done + off) * 48, d_status + done + off, s, n == 1 ? d_raw : nullptr, n == 1 ? raw_used : nullptr);
             if (rc) return rc;
         }
         HIPCHK(hipStreamWaitEvent(s, L->ev_join, 0));
@@ -1117,11 +1117,11 @@ int mkzg_compute_blob_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t 
     const bool hsha = use_host_sha(c, 1);                      // one transcript: ~70 us on this thread instead of the 2.7 ms device chain
     if (hsha) host_compute_challenge(L->h_stage + MKZG_BYTES_PER_BLOB + 64, L->h_stage, commitment48);
     HIPCHK(hipMemcpyAsync(L->d_blobs, L->h_stage, MKZG_BYTES_PER_BLOB + 96, hipMemcpyHostToDevice, G.s));
-    // the proof's inversion + compression on this thread instead of an ~90 us one-wavefront chain (api.hip commit_host_finish); the table must
-    // exist for that (a first call builds it inside compute_blob_proofs_device and takes the device's finish)
-    const bool hfin = host_fin_one(c);
+    // the proof's inversion + compression on this thread instead of an ~90 us one-wavefront chain (api.hip commit_host_finish) when the direct
+    // table serves the call (commit_scalars_device says so)
+    bool hfin = false;
     rc = compute_blob_proofs_device(c, L, L->d_blobs, L->d_blobs + MKZG_BYTES_PER_BLOB, 1, L->d_out, L->d_status, G.s, hsha ? L->d_blobs + MKZG_BYTES_PER_BLOB + 64 : nullptr,
-                                    hfin ? reinterpret_cast<uint32_t*>(L->d_out) : nullptr, commitment48);
+                                    reinterpret_cast<uint32_t*>(L->d_out), &hfin, commitment48);
     if (rc) return G.fail(rc);
     HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, hfin ? 256 : 48, hipMemcpyDeviceToHost, G.s));
     HIPCHK(hipMemcpyAsync(L->h_out + 256, L->d_status, sizeof(int), hipMemcpyDeviceToHost, G.s));
@@ -1153,8 +1153,8 @@ int mkzg_compute_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t z32[3
     int* st_z = L->d_q_st + L->q_cap;
     scalars_to_fr_device(L->d_blobs + MKZG_BYTES_PER_BLOB, 1, L->d_q_z, st_z, s);
     blob_quotient_device(L->d_blobs, L->d_q_z, c->d_roots_brp, c->d_inv_roots_brp, 1, L->d_q_y, L->d_quot, L->d_q_st, s);
-    const bool hfin = host_fin_one(c);                             // as in mkzg_compute_blob_kzg_proof
-    rc = commit_scalars_device(c, L, (const uint8_t*)L->d_quot, (size_t)4096 * 48, 1, 1, L->d_out, L->d_status, s, hfin ? reinterpret_cast<uint32_t*>(L->d_out) : nullptr);
+    bool hfin = false;                                             // as in mkzg_compute_blob_kzg_proof
+    rc = commit_scalars_device(c, L, (const uint8_t*)L->d_quot, (size_t)4096 * 48, 1, 1, L->d_out, L->d_status, s, reinterpret_cast<uint32_t*>(L->d_out), &hfin);
     if (rc) return G.fail(rc);
     fr_to_scalars_device(L->d_q_y, 1, L->d_blobs + MKZG_BYTES_PER_BLOB + 64, s);
     HIPCHK(hipGetLastError());

@@ -460,10 +460,8 @@ int ensure_fk20_ws(Lane* L, size_t n);
 void free_lane(Lane* L);
 // commitments of n polynomials in Lagrange form (api.hip); the caller holds lane L and runs on stream s
 int commit_scalars_device(mkzg_ctx* c, Lane* L, const uint8_t* d_scalars, size_t stride_bytes, int input_kind, size_t n, uint8_t* d_out48n, int* d_status, hipStream_t s,
-                          uint32_t* d_raw = nullptr);
+                          uint32_t* d_raw = nullptr, bool* raw_used = nullptr);
 void commit_host_finish(const uint32_t* w56, uint8_t out48[48]);      // api.hip: XYZZ limb words of a sum -> 48 compressed bytes on the calling thread
-// the single-item proof entry points' switch: sums come back as XYZZ words (direct table built, option host_fin on)
-inline bool host_fin_one(const mkzg_ctx* c) { return c->direct_bits_built != 0 && c->opt_host_fin.load(std::memory_order_relaxed) != 0; }
 // device a pointer lives on (-1: not a device pointer)
 int pointer_device(const void* p);
 mkzg_ctx* ctx_for_pointer(mkzg_ctx* c, const void* p);

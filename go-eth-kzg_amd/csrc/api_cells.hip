@@ -436,7 +436,7 @@ static int cell_fold_piece(mkzg_ctx* c, Lane* L, const uint8_t* commitments48n, 
     // nothing but the points' chain: 0.7 ms on the device however few the points, ~45 us per point on a host core.  Up to
     // HOST_VALIDATE_MAX_POINTS points are decoded and subgroup-tested on the host pool and this thread (host_validate.hpp, option
     // host_validate) and go to the device as records; the verdict arrays are the kernels'.
-    if (!late && n + n_rows <= HOST_VALIDATE_MAX_CELL_POINTS && c->opt_host_validate.load(std::memory_order_relaxed) != 0) {
+    if (!late && c->opt_host_validate.load(std::memory_order_relaxed) != 0 && host_validate_pays(n + n_rows, c->pool ? c->pool->size() : 0, HOST_VALIDATE_MAX_CELL_POINTS)) {
         host_validate_arrays(c->pool, rows.data(), n_rows, proofs48n, n, aff_rows, st_rows, aff_q, st_q, s2, sub_rows, sub_q);
         HIPCHK(hipEventRecord(L->ev_decoded, s2));
         HIPCHK(hipEventRecord(L->ev_join, s2));

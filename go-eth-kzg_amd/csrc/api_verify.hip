@@ -327,7 +327,9 @@ static int verify_fold_tail(mkzg_ctx* c, Lane* L, size_t n, bool with_blobs, int
 static void host_validate_points(mkzg_ctx* c, const uint8_t* c48n, const uint8_t* q48n, size_t n, uint32_t* aff_c, int* st_c, uint32_t* aff_q, int* st_q, hipStream_t s2) {
     host_validate_arrays(c->pool, c48n, n, q48n, n, aff_c, st_c, aff_q, st_q, s2);
 }
-static bool host_validate_on(const mkzg_ctx* c, size_t n) { return 2 * n <= HOST_VALIDATE_MAX_POINTS && c->opt_host_validate.load(std::memory_order_relaxed) != 0; }
+static bool host_validate_on(const mkzg_ctx* c, size_t n) {
+    return c->opt_host_validate.load(std::memory_order_relaxed) != 0 && host_validate_pays(2 * n, c->pool ? c->pool->size() : 0, HOST_VALIDATE_MAX_POINTS);
+}
 static int verify_fold(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_z32, const uint8_t* d_y32, const uint8_t* d_commitments, const uint8_t* d_proofs, size_t n,
                        uint32_t exp_offset, const uint8_t* r_le32, hipStream_t s, VerifyFold* out, RlcLate* late = nullptr,
                        const uint8_t* h_c48 = nullptr, const uint8_t* h_q48 = nullptr /* the points' bytes on the host (n x 48 each), for host_validate_points */) {

@@ -13,6 +13,11 @@ namespace kzg {
 // in chunks of G1_ROWS_MAX records (verify_kernels.h G1Rows / g1_put_rows_device).  d_sub_*: see g1_put_rows_device.
 constexpr size_t HOST_VALIDATE_MAX_POINTS = 64;          // blob verifier: four rounds of sixteen pool threads, ~0.2 ms against the device's 0.64-0.7 ms chain
 constexpr size_t HOST_VALIDATE_MAX_CELL_POINTS = 96;     // cell verifier (A/B, tools/lat_cellverify.py: 81 points 1.28 -> 1.17 ms, 129 points 1.30 -> 1.36-1.55): eight columns of nine blobs
+// Does the host pay?  ~45 us per point spread over the pool's workers and the caller must stay under the device's ~0.6 ms chain with room
+// to spare: a rank of an 8-GPU job on a 16-CPU quota has ONE worker (16 points), a lone context on the same box fifteen.
+inline bool host_validate_pays(size_t points, int pool_workers, size_t cap) {
+    return points <= cap && points <= (size_t)8 * (size_t)(pool_workers + 1);      // measured with MKZG_HOST_THREADS=2: 12 points 1.36 against 1.58 ms, 18 points 1.64 against 1.58
+}
 template <class Pool>
 inline void host_validate_arrays(Pool* pool, const uint8_t* a48n, size_t na, const uint8_t* b48n, size_t nb, uint32_t* d_aff_a, int* d_st_a, uint32_t* d_aff_b, int* d_st_b,
                                  hipStream_t s, int* d_sub_a = nullptr, int* d_sub_b = nullptr) {

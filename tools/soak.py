@@ -185,7 +185,7 @@ def main():
                 elif kind == "option" and k == 0 and rng.random() < 0.3:
                     # options that change routing, flipped while every other thread is in flight (same bytes and verdicts whatever the value)
                     key, vals = rng.choice((("combine_single_calls", (0, 1)), ("deep_rounds", (0, 1)), ("host_sha", (-1, 0, 1)), ("verify_shape", (-1, 0, 1)), ("host_zero_copy", (0, 1)),
-                                            ("fk20_segments", (0, 1)), ("host_wait", (-1, 0))))
+                                            ("fk20_segments", (0, 1)), ("host_wait", (-1, 0)), ("host_fin", (0, 1)), ("host_validate", (0, 1))))
                     assert ctx.set_option(key, rng.choice(vals)) == 0, key
                 else:
                     continue

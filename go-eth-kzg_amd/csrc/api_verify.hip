@@ -1044,7 +1044,9 @@ int mkzg_verify_kzg_proof(mkzg_ctx* c, const uint8_t commitment48[48], const uin
 // d_z32: the challenges when the caller hashed the transcripts on the host (n x 32 B big-endian, canonical), else nullptr.
 static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blobs, const uint8_t* d_commitments48, size_t n, uint8_t* d_proofs48, int* d_status, hipStream_t s,
                                       const uint8_t* d_z32 = nullptr, uint32_t* d_raw = nullptr /* n == 1: ask for the proof as XYZZ words for commit_host_finish */,
-                                      bool* raw_used = nullptr, const uint8_t* h_cm48 = nullptr /* n == 1: the commitment's bytes on the host */) {
+                                      bool* raw_used = nullptr, const uint8_t* h_cm48 = nullptr /* n == 1: the commitment's bytes on the host */,
+                                      int* h_st_cm_out = nullptr /* n == 1 and the commitment validated on the host: its status goes HERE and the caller, who syncs
+                                                                    anyway for the proof, merges it with the blob's (L->d_q_st[0]): no sync of this function's own */) {
     // Slices of up to 4096 proofs.  Per slice the latency-bound stages run ONCE over the whole slice -- Fiat-Shamir challenges
     // (a 2050-compression chain per blob whatever the count) on the caller's stream, commitment decoding + subgroup checks on the
     // side stream -- and only the quotient + MSM stage is cut into max_batch pieces (its workspace is 196 KB per blob).
@@ -1080,6 +1082,11 @@ static int compute_blob_proofs_device(mkzg_ctx* c, Lane* L, const uint8_t* d_blo
         // (into the lane's pinned area: a copy into pageable memory blocks and polls inside the runtime until the stream gets there)
         int* stb = (int*)L->h_v;
         int* stc = stb + L->v_cap;
+        if (n == 1 && h_cm48 && h_st_cm_out && host_validate_on(c, 1)) {      // the single-proof entry point: everything comes back with ITS one copy + sync
+            uint32_t row[32];
+            *h_st_cm_out = g1h_validate_row(h_cm48, row);                     // on this thread while the quotient and its MSM run
+            return MKZG_OK;
+        }
         HIPCHK(hipMemcpyAsync(stb, st_blob, slice * sizeof(int), hipMemcpyDeviceToHost, s));
         if (n == 1 && h_cm48 && host_validate_on(c, 1)) {  // the one commitment's checks on this thread while the quotient and its MSM run
             uint32_t row[32];
@@ -1122,15 +1129,17 @@ int mkzg_compute_blob_kzg_proof(mkzg_ctx* c, const uint8_t* blob, const uint8_t 
     // the proof's inversion + compression on this thread instead of an ~90 us one-wavefront chain (api.hip commit_host_finish) when the direct
     // table serves the call (commit_scalars_device says so)
     bool hfin = false;
+    int st_cm_host = -1;                                           // >= 0: the commitment was validated on this thread (compute_blob_proofs_device did not sync)
     rc = compute_blob_proofs_device(c, L, L->d_blobs, L->d_blobs + MKZG_BYTES_PER_BLOB, 1, L->d_out, L->d_status, G.s, hsha ? L->d_blobs + MKZG_BYTES_PER_BLOB + 64 : nullptr,
-                                    reinterpret_cast<uint32_t*>(L->d_out), &hfin, commitment48);
+                                    reinterpret_cast<uint32_t*>(L->d_out), &hfin, commitment48, &st_cm_host);
     if (rc) return G.fail(rc);
     HIPCHK(hipMemcpyAsync(L->h_out, L->d_out, hfin ? 256 : 48, hipMemcpyDeviceToHost, G.s));
-    HIPCHK(hipMemcpyAsync(L->h_out + 256, L->d_status, sizeof(int), hipMemcpyDeviceToHost, G.s));
+    HIPCHK(hipMemcpyAsync(L->h_out + 256, st_cm_host >= 0 ? L->d_q_st : L->d_status, sizeof(int), hipMemcpyDeviceToHost, G.s));
     LANE_SYNC(c, G.L, G.s);
     L->drained = true;
     int st = 0;
-    memcpy(&st, L->h_out + 256, sizeof(int));
+    memcpy(&st, L->h_out + 256, sizeof(int));                      // the merged status, or (host-validated commitment) the blob's: blob error first, then the commitment's (prove.go:49-62)
+    if (!st && st_cm_host > 0) st = st_cm_host;
     if (st) return st;
     if (hfin) commit_host_finish(reinterpret_cast<const uint32_t*>(L->h_out), out48);
     else memcpy(out48, L->h_out, 48);
